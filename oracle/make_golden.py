@@ -1,0 +1,300 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference, via oracle/ref_harness.py) on seeded inputs.  Runs only in the build container
+(the reference is not present on the GPU box); the .npz files are committed and travel.
+
+    python oracle/make_golden.py            # regenerate everything
+
+The reference code is never edited: where an intermediate value is needed (minibatch permutation,
+Gaussian noise draws) the script wraps ``torch.randperm`` / ``torch.distributions.utils._standard_normal``
+with recorders that return the original results untouched.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def _np(x):
+    return x.detach().cpu().numpy().copy() if isinstance(x, torch.Tensor) else np.array(x)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_discount_cumsum():
+    """Known-answer vectors of the reference's own unit test (tests/test_utils.py:95-115) plus the
+    function evaluated on random data."""
+    from omnisafe.utils.math import discount_cumsum
+
+    out = {}
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])
+    for g in (0.9, 0.99, 0.999):
+        out[f'kat_{g}'] = _np(discount_cumsum(x, g))
+    rng = np.random.default_rng(0)
+    xr = rng.standard_normal(257).astype(np.float32)
+    out['x_rand'] = xr
+    out['y_rand_0.9405'] = _np(discount_cumsum(torch.from_numpy(xr.copy()), 0.99 * 0.95))
+    np.savez(os.path.join(OUT, 'discount_cumsum.npz'), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _ragged_schedule(rng, T, N):
+    """Random path boundaries: kind 0 none, 1 terminated (bootstrap 0), 2 truncated (bootstrap v);
+    last step always ends the path (epoch end)."""
+    kind = rng.choice([0, 1, 2], size=(T, N), p=[0.8, 0.1, 0.1]).astype(np.int32)
+    kind[-1, :] = 2
+    kind[:, 0] = 0  # env 0: a single path spanning the whole epoch
+    kind[-1, 0] = 2
+    if N > 1:
+        kind[:, 1] = 1  # env 1: every step is its own path (length-1 paths)
+    return kind
+
+
+def gen_buffer():
+    """VectorOnPolicyBuffer.store / finish_path / get on ragged paths, all estimators."""
+    from gymnasium.spaces import Box
+    from omnisafe.common.buffer import VectorOnPolicyBuffer
+
+    T, N, D_o, D_a = 24, 6, 5, 2
+    rng = np.random.default_rng(1)
+    inp = {
+        'obs': rng.standard_normal((T, N, D_o)).astype(np.float32),
+        'act': rng.standard_normal((T, N, D_a)).astype(np.float32),
+        'reward': rng.standard_normal((T, N)).astype(np.float32),
+        'cost': (rng.random((T, N)) < 0.3).astype(np.float32),
+        'value_r': rng.standard_normal((T, N)).astype(np.float32),
+        'value_c': rng.standard_normal((T, N)).astype(np.float32),
+        'logp': rng.standard_normal((T, N)).astype(np.float32),
+    }
+    kind = _ragged_schedule(rng, T, N)
+    boot_r = np.where(kind == 2, rng.standard_normal((T, N)), 0.0).astype(np.float32)
+    boot_c = np.where(kind == 2, rng.standard_normal((T, N)), 0.0).astype(np.float32)
+    out = dict(inp, path_end=(kind != 0).astype(np.uint8), boot_r=boot_r, boot_c=boot_c,
+               gamma=0.99, lam=0.95, lam_c=0.9)
+    for est in ('gae', 'gae-rtg', 'plain'):
+        for pc in (0.0, 0.3):
+            buf = VectorOnPolicyBuffer(
+                obs_space=Box(-np.inf, np.inf, (D_o,)), act_space=Box(-1, 1, (D_a,)), size=T,
+                gamma=0.99, lam=0.95, lam_c=0.9, advantage_estimator=est, penalty_coefficient=pc,
+                standardized_adv_r=True, standardized_adv_c=True, num_envs=N)
+            for t in range(T):
+                buf.store(**{k: torch.from_numpy(v[t].copy()) for k, v in inp.items()})
+                for n in range(N):
+                    if kind[t, n]:
+                        buf.finish_path(torch.tensor([boot_r[t, n]]), torch.tensor([boot_c[t, n]]), n)
+            # raw (un-standardised) per-env arrays, env-major, before get() resets pointers
+            raw = {k: np.concatenate([_np(b.data[k]) for b in buf.buffers])
+                   for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c', 'discounted_ret')}
+            data = buf.get()
+            tag = f'{est}_pc{pc}'
+            for k, v in raw.items():
+                out[f'{tag}/raw/{k}'] = v
+            for k, v in data.items():
+                out[f'{tag}/get/{k}'] = _np(v)
+    np.savez(os.path.join(OUT, 'buffer.npz'), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_normalizer():
+    from omnisafe.common.normalizer import Normalizer
+
+    rng = np.random.default_rng(2)
+    D = 7
+    norm = Normalizer((D,), clip=5)
+    out = {}
+    batches = [rng.standard_normal((n, D)).astype(np.float32) * s + m
+               for n, s, m in ((1, 1.0, 0.0), (4, 2.0, 1.0), (3, 0.5, -2.0), (16, 10.0, 0.0), (2, 1e-4, 3.0))]
+    for i, b in enumerate(batches):
+        y = norm.normalize(torch.from_numpy(b.copy()))
+        out[f'in{i}'] = b
+        out[f'out{i}'] = _np(y)
+        out[f'mean{i}'] = _np(norm._mean)
+        out[f'sumsq{i}'] = _np(norm._sumsq)
+        out[f'var{i}'] = _np(norm._var)
+        out[f'std{i}'] = _np(norm._std)
+        out[f'count{i}'] = np.int64(int(norm._count))
+    out['n_batches'] = len(batches)
+    np.savez(os.path.join(OUT, 'normalizer.npz'), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Recorder:
+    """Spy on torch.randperm and on the standard-normal draws of torch.distributions."""
+
+    def __init__(self):
+        self.perms, self.normals = [], []
+
+    def __enter__(self):
+        import torch.distributions.normal as tdn
+
+        self._rp, self._sn, self._tdn = torch.randperm, tdn._standard_normal, tdn
+
+        def randperm(*a, **k):
+            r = self._rp(*a, **k)
+            self.perms.append(r.clone())
+            return r
+
+        def std_normal(*a, **k):
+            r = self._sn(*a, **k)
+            self.normals.append(r.clone())
+            return r
+
+        torch.randperm = randperm
+        tdn._standard_normal = std_normal
+        return self
+
+    def __exit__(self, *exc):
+        torch.randperm = self._rp
+        self._tdn._standard_normal = self._sn
+
+
+def _state(module):
+    return {k: _np(v).copy() for k, v in module.state_dict().items()}
+
+
+def _make_algo(algo, env_id, n_envs, steps_per_epoch, horizon, extra_algo=None, seed=0):
+    import omnisafe
+
+    ref_harness.register_synth_env()
+    d = tempfile.mkdtemp()
+    cfg = {
+        'seed': seed,
+        'train_cfgs': {'total_steps': steps_per_epoch * 4, 'vector_env_nums': n_envs,
+                       'torch_threads': 8, 'device': 'cpu'},
+        'algo_cfgs': dict({'steps_per_epoch': steps_per_epoch}, **(extra_algo or {})),
+        'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d},
+        'env_cfgs': {'horizon': horizon},
+    }
+    agent = omnisafe.Agent(algo, env_id, custom_cfgs=cfg)
+    return agent.agent
+
+
+def gen_actor_critic_step():
+    """ConstraintActorCritic.step with recorded noise."""
+    algo = _make_algo('PPOLag', 'SynthPointGoal1-v0', 4, 64, 8)
+    ac = algo._actor_critic
+    rng = np.random.default_rng(3)
+    obs = rng.standard_normal((37, 60)).astype(np.float32)
+    with _Recorder() as rec:
+        torch.manual_seed(11)
+        act, v_r, v_c, logp = ac.step(torch.from_numpy(obs.copy()))
+    act_det, _, _, logp_det = ac.step(torch.from_numpy(obs.copy()), deterministic=True)
+    out = {'obs': obs, 'eps': _np(rec.normals[0]), 'act': _np(act), 'value_r': _np(v_r),
+           'value_c': _np(v_c), 'logp': _np(logp), 'act_det': _np(act_det),
+           'logp_det': _np(logp_det)}
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'{net}/{k}'] = v
+    np.savez(os.path.join(OUT, 'actor_critic_step.npz'), **out)
+
+
+def _snapshot_buffer_raw(buf):
+    keys = ('obs', 'act', 'reward', 'cost', 'value_r', 'value_c', 'logp', 'adv_r', 'adv_c',
+            'target_value_r', 'target_value_c', 'discounted_ret')
+    return {k: np.stack([_np(b.data[k]) for b in buf.buffers], axis=1) for k in keys}  # (T, N, ...)
+
+
+def gen_rollout_and_ppolag_update():
+    """One reference epoch on the synthetic env: rollout (recorded env outputs + noise) -> buffer ->
+    PPOLag._update (recorded permutations) -> post-update parameters."""
+    N, T, horizon = 4, 40, 16
+    algo = _make_algo('PPOLag', 'SynthPointGoal1-v0', N, N * T, horizon,
+                      extra_algo={'update_iters': 3, 'batch_size': 64, 'kl_early_stop': False})
+    ac = algo._actor_critic
+    out = {'N': N, 'T': T, 'horizon': horizon}
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'init/{net}/{k}'] = v
+
+    # record what the raw env hands to the wrapper chain
+    env_core = algo._env._env
+    while hasattr(env_core, '_env'):
+        env_core = env_core._env
+    steps = []
+    orig_step, orig_reset = env_core.step, env_core.reset
+
+    def spy_step(action):
+        r = orig_step(action)
+        obs, reward, cost, term, trunc, info = r
+        steps.append({'action': _np(action).copy(), 'obs': _np(obs).copy(), 'reward': _np(reward).copy(),
+                      'cost': _np(cost).copy(), 'terminated': _np(term).copy(),
+                      'truncated': _np(trunc).copy(),
+                      'final_obs': (_np(info['final_observation']).copy()
+                                    if 'final_observation' in info else np.zeros_like(_np(obs)))})
+        return r
+
+    resets = []
+
+    def spy_reset(*a, **k):
+        r = orig_reset(*a, **k)
+        resets.append(_np(r[0]).copy())
+        return r
+
+    env_core.step, env_core.reset = spy_step, spy_reset
+    with _Recorder() as rec:
+        torch.manual_seed(5)
+        algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+    env_core.step, env_core.reset = orig_step, orig_reset
+    out['rollout/reset_obs'] = resets[-1]
+    for k in steps[0]:
+        out[f'rollout/{k}'] = np.stack([s[k] for s in steps])
+    vec_eps = [e for e in rec.normals if e.dim() == 2]
+    assert len(vec_eps) == T
+    out['rollout/eps'] = np.stack([_np(e) for e in vec_eps])
+    raw = _snapshot_buffer_raw(algo._buf)
+    for k, v in raw.items():
+        out[f'buffer/{k}'] = v
+    norm = algo._env.save()['obs_normalizer']
+    for k in ('_mean', '_sumsq', '_var', '_std', '_count'):
+        out[f'rollout/norm{k}'] = _np(getattr(norm, k))
+    out['rollout/ep_cost_window'] = np.asarray(list(algo._logger._data['Metrics/EpCost']), np.float32)
+    out['rollout/ep_ret_window'] = np.asarray(list(algo._logger._data['Metrics/EpRet']), np.float32)
+    out['rollout/ep_len_window'] = np.asarray(list(algo._logger._data['Metrics/EpLen']), np.float32)
+    out['rollout/value_r_log_mean'] = np.float32(np.mean(algo._logger._data['Value/reward']))
+
+    # ---- update
+    out['update/lambda_before'] = _np(algo._lagrange.lagrangian_multiplier)
+    out['update/Jc'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])
+    with _Recorder() as rec:
+        torch.manual_seed(7)
+        algo._update()
+    out['update/lambda_after'] = _np(algo._lagrange.lagrangian_multiplier)
+    # RandomSampler.__iter__ (torch/utils/data/sampler.py) calls randperm twice per pass: the full
+    # permutation that is consumed, then one whose slice [:num_samples % n] is empty.  Keep the first.
+    assert len(rec.perms) == 2 * 3
+    out['update/perms'] = np.stack([_np(p) for p in rec.perms[::2]])
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'post/{net}/{k}'] = v
+    lg = algo._logger._data
+    for key, name in (('Loss/Loss_pi', 'loss_pi'), ('Loss/Loss_reward_critic', 'loss_r'),
+                      ('Loss/Loss_cost_critic', 'loss_c'), ('Train/PolicyRatio', 'ratio_mean'),
+                      ('Train/Entropy', 'entropy'), ('Train/KL', 'kl'), ('Train/StopIter', 'stop_iter'),
+                      ('Value/Adv', 'value_adv')):
+        out[f'update/{name}'] = np.asarray(list(lg[key]), np.float32)
+    np.savez(os.path.join(OUT, 'ppolag_epoch.npz'), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_harness.import_reference()
+    torch.set_num_threads(1)  # deterministic reductions
+    gen_discount_cumsum()
+    gen_buffer()
+    gen_normalizer()
+    gen_actor_critic_step()
+    gen_rollout_and_ppolag_update()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()

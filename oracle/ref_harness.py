@@ -1,0 +1,245 @@
+"""TEST INFRASTRUCTURE ONLY -- lets the *unmodified* reference (PKU-Alignment/omnisafe at
+/root/reference) execute in the build container so it can pin the oracle and generate golden vectors.
+
+Nothing in the product (``omnisafe_amd/``) imports this file.  It is used by
+``oracle/make_golden.py`` (fixture generator, runs only where /root/reference exists) and by the
+``-m "not gpu"`` tests that cross-check ``oracle/np_oracle.py`` against the live reference when it is
+present.  /root/reference does not exist on the GPU box; every user of this module must skip there.
+
+What it does:
+  1. appends a meta-path finder that fabricates empty stand-in modules for the reference's third-party
+     imports that are not installed here (gymnasium, safety_gymnasium, wandb, tensorboard, ...).  Real
+     packages win when present because the finder is *appended*.
+  2. pre-seeds ``torch.utils.tensorboard`` with a no-op ``SummaryWriter``
+     (reference omnisafe/common/logger.py:49 imports it unconditionally).
+  3. puts /root/reference on sys.path.
+  4. ``register_synth_env()`` registers a synthetic vector CMDP (zero-cost stand-in for
+     Safety-Gymnasium, same distributions as omnisafe_amd's device env: obs ~ N(0,1)^D_o,
+     reward ~ N(0,1), cost ~ Bernoulli(p), truncation every ``horizon`` steps).
+"""
+from __future__ import annotations
+
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get('OMNISAFE_REFERENCE_ROOT', '/root/reference')
+
+_STUB_PREFIXES = (
+    'gymnasium', 'safety_gymnasium', 'wandb', 'tensorboard', 'pytorch_lightning', 'moviepy',
+    'seaborn', 'gdown', 'cvxopt', 'gpytorch', 'qpth', 'isaacgym', 'metadrive', 'matplotlib',
+    'gymnasium_robotics', 'mujoco', 'tensorboardX',
+)
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'omnisafe'))
+
+
+class _Box:
+    """Tiny stand-in for gymnasium.spaces.Box (only .low/.high/.shape/.dtype/.sample are used on the
+    hot path: reference omnisafe/common/buffer/base.py:73-80, omnisafe/envs/wrapper.py:451-480)."""
+
+    def __init__(self, low, high, shape=None, dtype=None, seed=None):
+        import numpy as np
+
+        if shape is None:
+            shape = np.asarray(low).shape
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype) if dtype is not None else np.dtype('float32')
+        self.low = np.broadcast_to(np.asarray(low, dtype=self.dtype), self.shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=self.dtype), self.shape).copy()
+
+    def sample(self):
+        import numpy as np
+
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+
+class _Discrete:
+    def __init__(self, n, seed=None, start=0):
+        self.n = int(n)
+        self.shape = ()
+
+    def sample(self):
+        import numpy as np
+
+        return int(np.random.randint(self.n))
+
+
+class _StubModule(types.ModuleType):
+    __path__: list = []
+
+    def __getattr__(self, name):
+        if name.startswith('__') and name.endswith('__'):
+            raise AttributeError(name)
+        if name == 'Box':
+            value = _Box
+        elif name == 'Discrete':
+            value = _Discrete
+        else:
+            value = type(name, (object,), {'__init__': lambda self, *a, **k: None})
+        setattr(self, name, value)
+        return value
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split('.')[0] in _STUB_PREFIXES:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        mod = _StubModule(spec.name)
+        mod.__path__ = []
+        return mod
+
+    def exec_module(self, module):
+        return None
+
+
+_installed = False
+
+
+def install() -> None:
+    """Make ``import omnisafe`` resolve to the unmodified reference."""
+    global _installed
+    if _installed:
+        return
+    if not reference_available():
+        raise RuntimeError(f'reference not found at {REFERENCE_ROOT}')
+    sys.meta_path.append(_StubFinder())
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tbw = types.ModuleType('torch.utils.tensorboard.writer')
+
+    class SummaryWriter:  # no-op
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def flush(self):
+            pass
+
+        def close(self):
+            pass
+
+    tb.SummaryWriter = SummaryWriter
+    tbw.SummaryWriter = SummaryWriter
+    tb.writer = tbw
+    sys.modules.setdefault('torch.utils.tensorboard', tb)
+    sys.modules.setdefault('torch.utils.tensorboard.writer', tbw)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import gymnasium.spaces  # noqa: F401  (resolve the stub *submodule* first, Appendix B item 4)
+
+    _installed = True
+
+
+def import_reference():
+    install()
+    import omnisafe  # noqa: F401
+
+    return omnisafe
+
+
+_SYNTH_REGISTERED = False
+
+
+def register_synth_env():
+    """Register ``Synth{D_o}x{D_a}-v0`` style ids with the reference's env registry.
+
+    Env id grammar: ``SynthPointGoal1-v0`` (60/2), ``SynthCarGoal1-v0`` (72/2), ``SynthAnt-v0`` (27/8),
+    ``SynthHumanoid-v0`` (376/17), ``SynthTiny-v0`` (6/2).  ``env_cfgs`` understood: horizon, cost_p.
+    """
+    global _SYNTH_REGISTERED
+    install()
+    import torch
+    from omnisafe.envs.core import CMDP, env_register
+    from gymnasium.spaces import Box
+
+    if _SYNTH_REGISTERED:
+        return
+    dims = {
+        'SynthPointGoal1-v0': (60, 2),
+        'SynthCarGoal1-v0': (72, 2),
+        'SynthAnt-v0': (27, 8),
+        'SynthHumanoid-v0': (376, 17),
+        'SynthTiny-v0': (6, 2),
+    }
+
+    @env_register
+    class SynthRefEnv(CMDP):  # pylint: disable=too-many-instance-attributes
+        _support_envs = list(dims)
+        need_auto_reset_wrapper = False
+        need_time_limit_wrapper = False
+        need_evaluation = False
+
+        def __init__(self, env_id, num_envs=1, device=torch.device('cpu'), **kwargs):
+            super().__init__(env_id)
+            self._num_envs = num_envs
+            self._device = torch.device(device)
+            d_o, d_a = dims[env_id]
+            self._d_o, self._d_a = d_o, d_a
+            self._horizon = int(kwargs.get('horizon', 1000))
+            self._cost_p = float(kwargs.get('cost_p', 0.05))
+            self._observation_space = Box(-float('inf'), float('inf'), (d_o,))
+            self._action_space = Box(-1.0, 1.0, (d_a,))
+            self._metadata = {}
+            self._gen = torch.Generator(device='cpu')
+            self._gen.manual_seed(0)
+            self._steps = torch.zeros(num_envs, dtype=torch.int64)
+
+        @property
+        def max_episode_steps(self):
+            return self._horizon
+
+        def _obs(self):
+            return torch.randn(self._num_envs, self._d_o, generator=self._gen).to(self._device)
+
+        def set_seed(self, seed):
+            self._gen.manual_seed(int(seed))
+
+        def reset(self, seed=None, options=None):
+            if seed is not None:
+                self.set_seed(seed)
+            self._steps.zero_()
+            obs = self._obs()
+            if self._num_envs == 1:
+                obs = obs[0]
+            return obs, {}
+
+        def step(self, action):
+            n = self._num_envs
+            obs = self._obs()
+            reward = torch.randn(n, generator=self._gen).to(self._device)
+            cost = (torch.rand(n, generator=self._gen) < self._cost_p).float().to(self._device)
+            self._steps += 1
+            truncated = self._steps >= self._horizon
+            terminated = torch.zeros(n, dtype=torch.bool)
+            info = {}
+            if bool(truncated.any()):
+                info['final_observation'] = obs.clone()
+                info['_final_observation'] = truncated.clone()
+                fresh = self._obs()
+                obs = torch.where(truncated[:, None].to(self._device), fresh, obs)
+                self._steps[truncated] = 0
+            if n == 1:
+                return (obs[0], reward[0], cost[0], terminated[0].to(self._device),
+                        truncated[0].to(self._device),
+                        {k: (v[0] if k == 'final_observation' else v) for k, v in info.items()})
+            return obs, reward, cost, terminated.to(self._device), truncated.to(self._device), info
+
+        def render(self):
+            return None
+
+        def close(self):
+            return None
+
+    _SYNTH_REGISTERED = True
+    return SynthRefEnv

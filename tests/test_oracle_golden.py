@@ -1,0 +1,167 @@
+"""CPU tests: the oracle (oracle/np_oracle.py) against golden vectors produced by the unmodified
+reference (oracle/make_golden.py) and against the reference's own known-answer tests."""
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+
+# ---- reference's own KATs: tests/test_utils.py:95-115 (hard-coded fp64 answers) ---------------
+KAT = {
+    0.9: [11.4265, 11.585, 10.65, 8.5, 5.0],
+    0.99: [14.604476, 13.741895, 11.8605, 8.95, 5.0],
+    0.999: [14.96004, 13.974015, 11.985985, 8.995, 5.0],
+}
+
+
+@pytest.mark.parametrize('g', [0.9, 0.99, 0.999])
+def test_discount_cumsum_reference_kat(g):
+    y = O.discount_cumsum(np.array([1, 2, 3, 4, 5], np.float32), g)
+    assert np.allclose(y, KAT[g], rtol=1e-5, atol=1e-8)
+
+
+def test_discount_cumsum_golden(golden):
+    gd = golden('discount_cumsum.npz')
+    for g in (0.9, 0.99, 0.999):
+        y = O.discount_cumsum(np.array([1, 2, 3, 4, 5], np.float32), g)
+        assert np.array_equal(y, gd[f'kat_{g}'])
+    y = O.discount_cumsum(gd['x_rand'], 0.99 * 0.95)
+    assert np.array_equal(y, gd['y_rand_0.9405'])  # bit-exact fp64
+
+
+# ---- CPO case ids: reference tests/test_policy.py:55-74 ----------------------------------------
+@pytest.mark.parametrize('b,c,q,r,s,case', [
+    ([1., 1.], -1., 1., 1., 1., 3),       # ep_costs<0, B<0
+    ([1., 1.], -0.01, 1., 1., 1., 2),     # ep_costs<0, B>=0
+    ([1., 1.], 0.01, 1., 1., 1., 1),      # ep_costs>=0, B>=0
+    ([1., 1.], 1., 1., 1., 1., 0),        # ep_costs>=0, B<0
+    ([1e-4, 1e-4], -1., 1., 1., 1., 4),   # tiny cost gradient
+])
+def test_cpo_case_ids(b, c, q, r, s, case):
+    oc, A, B = O.cpo_determine_case(torch.tensor(b), torch.tensor(c), torch.tensor(q),
+                                    torch.tensor(r), torch.tensor(s), target_kl=0.01)
+    assert oc == case
+
+
+# ---- buffer / GAE ----------------------------------------------------------------------------
+@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain'])
+@pytest.mark.parametrize('pc', [0.0, 0.3])
+def test_gae_bit_exact_vs_reference(golden, est, pc):
+    g = golden('buffer.npz')
+    args = (g['reward'], g['cost'], g['value_r'], g['value_c'], g['path_end'], g['boot_r'],
+            g['boot_c'], float(g['gamma']), float(g['lam']), float(g['lam_c']), pc, est)
+    tm = O.gae_time_major(*args)
+    pp = O.gae_per_path(*args)
+    tag = f'{est}_pc{pc}'
+    for ok, gk in (('adv_r', 'adv_r'), ('adv_c', 'adv_c'), ('tgt_r', 'target_value_r'),
+                   ('tgt_c', 'target_value_c'), ('disc_ret', 'discounted_ret')):
+        ref = g[f'{tag}/raw/{gk}']
+        assert np.array_equal(O.env_major(pp[ok]), ref), (ok, 'per-path')
+        assert np.array_equal(O.env_major(tm[ok]), ref), (ok, 'time-major')
+
+
+def test_buffer_get_vs_reference(golden):
+    g = golden('buffer.npz')
+    tm = O.gae_time_major(g['reward'], g['cost'], g['value_r'], g['value_c'], g['path_end'],
+                          g['boot_r'], g['boot_c'], 0.99, 0.95, 0.9)
+    a_r, a_c, _ = O.buffer_get(tm['adv_r'], tm['adv_c'])
+    assert np.array_equal(a_r, g['gae_pc0.0/get/adv_r'])
+    assert np.array_equal(a_c, g['gae_pc0.0/get/adv_c'])
+    for k in ('obs', 'act', 'logp'):
+        assert np.array_equal(O.env_major(g[k]), g[f'gae_pc0.0/get/{k}'])
+
+
+# ---- normaliser ------------------------------------------------------------------------------
+def test_normalizer_vs_reference(golden):
+    g = golden('normalizer.npz')
+    norm = O.Normalizer((7,), clip=5)
+    for i in range(int(g['n_batches'])):
+        y = norm.normalize(torch.from_numpy(g[f'in{i}'].copy()))
+        assert np.array_equal(y.numpy(), g[f'out{i}']), i
+        assert np.array_equal(norm.mean.numpy(), g[f'mean{i}'])
+        assert np.array_equal(norm.sumsq.numpy(), g[f'sumsq{i}'])
+        assert np.array_equal(norm.std.numpy(), g[f'std{i}'], equal_nan=True)  # count==1 -> 0/0
+        assert norm.count == int(g[f'count{i}'])
+
+
+# ---- actor-critic step -----------------------------------------------------------------------
+def load_ac(g, prefix, obs_dim=60, act_dim=2, **kw):
+    ac = O.ActorCritic(obs_dim, act_dim, **kw)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        sd = {k[len(prefix) + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
+              if k.startswith(f'{prefix}{net}/')}
+        getattr(ac, net).load_state_dict(sd)
+    return ac
+
+
+def test_actor_critic_step_vs_reference(golden):
+    g = golden('actor_critic_step.npz')
+    ac = load_ac(g, '')
+    act, v_r, v_c, logp = ac.step(torch.from_numpy(g['obs']), eps=torch.from_numpy(g['eps']))
+    assert np.array_equal(act.numpy(), g['act'])
+    assert np.array_equal(v_r.numpy(), g['value_r'])
+    assert np.array_equal(v_c.numpy(), g['value_c'])
+    assert np.array_equal(logp.numpy(), g['logp'])
+    a_det, _, _, lp_det = ac.step(torch.from_numpy(g['obs']), deterministic=True)
+    assert np.array_equal(a_det.numpy(), g['act_det'])
+    assert np.array_equal(lp_det.numpy(), g['logp_det'])
+    # parameter order is log_std first (checkpoint key order of the reference)
+    assert [k for k, _ in ac.actor.named_parameters()][0] == 'log_std'
+
+
+# ---- whole epoch: rollout on the recorded trace, then PPOLag update ---------------------------
+def _trace(g):
+    return {'reset_obs': g['rollout/reset_obs'], 'obs': g['rollout/obs'], 'reward': g['rollout/reward'],
+            'cost': g['rollout/cost'], 'terminated': g['rollout/terminated'],
+            'truncated': g['rollout/truncated'], 'final_obs': g['rollout/final_obs'],
+            'eps': g['rollout/eps']}
+
+
+def test_rollout_vs_reference(golden):
+    g = golden('ppolag_epoch.npz')
+    torch.set_num_threads(1)
+    ac = load_ac(g, 'init/')
+    norm = O.Normalizer((60,), clip=5)
+    buf, gae, aux = O.rollout_on_trace(ac, norm, _trace(g))
+    for k in ('obs', 'act', 'reward', 'cost', 'value_r', 'value_c', 'logp'):
+        assert np.array_equal(buf[k], g[f'buffer/{k}']), k
+    for ok, gk in (('adv_r', 'adv_r'), ('adv_c', 'adv_c'), ('tgt_r', 'target_value_r'),
+                   ('tgt_c', 'target_value_c'), ('disc_ret', 'discounted_ret')):
+        assert np.array_equal(gae[ok], g[f'buffer/{gk}']), ok
+    assert np.array_equal(norm.mean.numpy(), g['rollout/norm_mean'])
+    assert np.array_equal(norm.std.numpy(), g['rollout/norm_std'])
+    assert norm.count == int(g['rollout/norm_count'])
+    assert np.array_equal(aux['episodes'][:, 0], g['rollout/ep_ret_window'])
+    assert np.array_equal(aux['episodes'][:, 1], g['rollout/ep_cost_window'])
+    assert np.array_equal(aux['episodes'][:, 2], g['rollout/ep_len_window'])
+
+
+def _update_data(g):
+    a_r, a_c, _ = O.buffer_get(g['buffer/adv_r'], g['buffer/adv_c'])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    return {'obs': t(O.env_major(g['buffer/obs'])), 'act': t(O.env_major(g['buffer/act'])),
+            'logp': t(O.env_major(g['buffer/logp'])),
+            'target_value_r': t(O.env_major(g['buffer/target_value_r'])),
+            'target_value_c': t(O.env_major(g['buffer/target_value_c'])),
+            'adv_r': t(a_r), 'adv_c': t(a_c)}
+
+
+def test_ppolag_update_vs_reference(golden):
+    g = golden('ppolag_epoch.npz')
+    torch.set_num_threads(1)
+    ac = load_ac(g, 'init/')
+    lag = O.Lagrange(cost_limit=25.0, lagrangian_multiplier_init=0.001, lambda_lr=0.035)
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['update/lambda_before']
+    lag.update_lagrange_multiplier(float(g['update/Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['update/lambda_after']
+    stats = O.ppolag_update(ac, _update_data(g), lag.lagrangian_multiplier.item(), g['update/perms'],
+                            batch_size=64, update_iters=3, kl_early_stop=False)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'post/{net}/{k}']), (net, k)
+    assert np.allclose(stats['loss_pi'], g['update/loss_pi'], rtol=0, atol=0)
+    assert np.allclose(stats['loss_r'], g['update/loss_r'], rtol=0, atol=0)
+    assert np.allclose(stats['loss_c'], g['update/loss_c'], rtol=0, atol=0)
+    assert np.float32(stats['kl']) == g['update/kl'][-1]
+    assert stats['stop_iter'] == int(g['update/stop_iter'][-1])
