@@ -1,0 +1,83 @@
+"""ctypes binding of libomnisafe_amd.so -- the C-ABI boundary (include/omnisafe_amd.h).
+
+There is NO CPU fallback: if the library (or a GPU) is missing the product fails loudly here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+_LIB = None
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+c_ptr = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/omnisafe_amd.h one to one.
+_I, _L, _F, _D, _P = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p
+SIGNATURES: dict[str, tuple] = {
+    'osa_strerror': (C.c_char_p, [_I]),
+    'osa_version': (_I, []),
+    'osa_build_arch': (C.c_char_p, []),
+    'osa_buffer_store_step': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I,
+                                   _P, _P, _P, _P, _P, _P]),
+    'osa_gae_scan': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
+    'osa_reduce_ws_bytes': (C.c_size_t, []),
+    'osa_adv_stats_phase1': (_I, [_P, _P, _L, _P, _P, _P]),
+    'osa_adv_stats_phase2': (_I, [_P, _L, _P, _P, _P]),
+    'osa_buffer_get': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I,
+                            _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
+class OsaError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(require_gpu: bool = False):
+    """Load (building if necessary) the shared library and declare every prototype."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            try:
+                _build.build_library(verbose=False)
+            except Exception as exc:  # pragma: no cover
+                raise OsaError(
+                    f'libomnisafe_amd.so is missing and could not be built ({exc}); '
+                    'run `python -m omnisafe_amd.build` -- there is no CPU fallback') from exc
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    if require_gpu and not torch.cuda.is_available():
+        raise OsaError('omnisafe_amd needs an AMD GPU visible to torch (ROCm); there is no CPU fallback')
+    return _LIB
+
+
+def check(code: int, what: str = '') -> None:
+    if code != 0:
+        msg = load().osa_strerror(code).decode()
+        raise OsaError(f'{what or "libomnisafe_amd"} failed: {msg} ({code})')
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, 'omnisafe_amd kernels take device tensors'
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream, so kernels order with torch ops and RCCL."""
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,200 @@
+"""HBM-resident VectorOnPolicyBuffer.
+
+Mirror of the reference interface (omnisafe/common/buffer/vector_onpolicy_buffer.py:54-138 and
+onpolicy_buffer.py:84-238): same constructor arguments, ``store(**data)``, ``finish_path(last_value_r,
+last_value_c, idx)`` and ``get() -> dict`` with the same 8 keys in the same env-major order, same
+exception types.  The reference keeps N independent Python buffers and runs three fp64 Python loops
+per path; here the rollout lives in one time-major (T, N, .) block of HBM and every path of every env
+is finished by ONE launch of the HIP backward-scan kernel (osa_gae_scan), followed by a two-phase
+statistics reduction and a fused standardise+transpose (osa_buffer_get).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .spaces import is_box
+
+_EST = {'gae': 0, 'gae-rtg': 1, 'plain': 2}
+
+
+class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
+    """Time-major device buffer for ``num_envs`` vectorised environments x ``size`` steps."""
+
+    def __init__(  # pylint: disable=too-many-arguments
+        self,
+        obs_space,
+        act_space,
+        size: int,
+        gamma: float,
+        lam: float,
+        lam_c: float,
+        advantage_estimator: str,
+        penalty_coefficient: float,
+        standardized_adv_r: bool,
+        standardized_adv_c: bool,
+        num_envs: int = 1,
+        device: torch.device | str = 'cuda:0',
+    ) -> None:
+        if num_envs < 1:
+            raise ValueError('num_envs must be greater than 0.')  # vector_onpolicy_buffer.py:74-75
+        if not is_box(obs_space) or not is_box(act_space):
+            raise NotImplementedError  # buffer/base.py:73-80 (Box only)
+        if advantage_estimator == 'vtrace':
+            raise NotImplementedError('vtrace is not implemented in omnisafe_amd (SURVEY 8f-4)')
+        if advantage_estimator not in _EST:
+            raise NotImplementedError  # onpolicy_buffer.py:333-334
+        self._lib = _lib.load(require_gpu=True)
+        self._device = torch.device(device)
+        self._num_buffers = int(num_envs)
+        self._size = int(size)
+        self._gamma, self._lam, self._lam_c = float(gamma), float(lam), float(lam_c)
+        self._estimator = _EST[advantage_estimator]
+        self._penalty_coefficient = float(penalty_coefficient)
+        self._standardized_adv_r = bool(standardized_adv_r)
+        self._standardized_adv_c = bool(standardized_adv_c)
+        self._obs_dim = int(obs_space.shape[0])
+        self._act_dim = int(act_space.shape[0])
+        T, N, dev = self._size, self._num_buffers, self._device
+        f32 = dict(dtype=torch.float32, device=dev)
+        # time-major rollout storage (a4: BaseBuffer/OnPolicyBuffer.__init__ allocations)
+        self.data: dict[str, torch.Tensor] = {
+            'obs': torch.zeros(T, N, self._obs_dim, **f32),
+            'act': torch.zeros(T, N, self._act_dim, **f32),
+        }
+        for k in ('reward', 'cost', 'value_r', 'value_c', 'logp', 'adv_r', 'adv_c', 'target_value_r',
+                  'target_value_c', 'discounted_ret', 'boot_r', 'boot_c'):
+            self.data[k] = torch.zeros(T, N, **f32)
+        self.data['path_end'] = torch.zeros(T, N, dtype=torch.uint8, device=dev)
+        # env-major staging returned by get()
+        M = T * N
+        self._out = {
+            'obs': torch.empty(M, self._obs_dim, **f32),
+            'act': torch.empty(M, self._act_dim, **f32),
+        }
+        for k in ('logp', 'target_value_r', 'target_value_c', 'adv_r', 'adv_c', 'discounted_ret'):
+            self._out[k] = torch.empty(M, **f32)
+        self._stats = torch.zeros(8, dtype=torch.float64, device=dev)
+        self._ws = torch.empty(self._lib.osa_reduce_ws_bytes() // 8, dtype=torch.float64, device=dev)
+        self.ptr = 0
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def num_buffers(self) -> int:
+        return self._num_buffers
+
+    @property
+    def size(self) -> int:
+        return self._size
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def standardized_adv_r(self) -> bool:
+        return self._standardized_adv_r
+
+    @property
+    def standardized_adv_c(self) -> bool:
+        return self._standardized_adv_c
+
+    @property
+    def stats(self) -> torch.Tensor:
+        """Device statistics [sum_r, sum_c, n, sumsq_r, mean_r, mean_c, std_r, -] of the last get()."""
+        return self._stats
+
+    # ------------------------------------------------------------------ store / finish_path
+    def row(self, key: str, t: int | None = None) -> torch.Tensor:
+        """Row ``t`` (default: the current write row) of a time-major array -- producers may write into
+        it directly instead of calling :meth:`store`."""
+        return self.data[key][self.ptr if t is None else t]
+
+    def advance(self) -> None:
+        """Advance the write pointer after a producer filled ``row(...)`` in place."""
+        assert self.ptr < self._size, 'No more space in the buffer!'
+        self.ptr += 1
+
+    def store(self, **data: torch.Tensor) -> None:
+        """Store one vector step (reference keys: obs, act, reward, cost, value_r, value_c, logp)."""
+        assert self.ptr < self._size, 'No more space in the buffer!'  # onpolicy_buffer.py:143
+        d = {k: v.to(self._device, torch.float32).contiguous() for k, v in data.items()}
+        N = self._num_buffers
+        obs = d['obs'].reshape(N, self._obs_dim)
+        act = d['act'].reshape(N, self._act_dim)
+        b = self.data
+        _lib.check(self._lib.osa_buffer_store_step(
+            self.ptr, N, self._obs_dim, self._act_dim, _lib.ptr(obs), self._obs_dim, _lib.ptr(act),
+            self._act_dim, _lib.ptr(d['reward'].reshape(N)), _lib.ptr(d['cost'].reshape(N)),
+            _lib.ptr(d['value_r'].reshape(N)), _lib.ptr(d['value_c'].reshape(N)),
+            _lib.ptr(d['logp'].reshape(N)), _lib.ptr(b['obs']), self._obs_dim, _lib.ptr(b['act']),
+            self._act_dim, _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']),
+            _lib.ptr(b['value_c']), _lib.ptr(b['logp']), _lib.stream_ptr()), 'osa_buffer_store_step')
+        self.ptr += 1
+
+    def finish_path(self, last_value_r: torch.Tensor | None = None,
+                    last_value_c: torch.Tensor | None = None, idx: int = 0) -> None:
+        """Reference-compatible per-env call: ends env ``idx``'s current path after the last stored
+        step with the given bootstrap values (defaults 0).  No arithmetic happens here -- the whole
+        buffer is scanned once in :meth:`get`.  Vector callers should use :meth:`finish_paths`."""
+        t = self.ptr - 1
+        assert t >= 0, 'finish_path() before any store()'
+        self.data['path_end'][t, idx] = 1
+        for key, val in (('boot_r', last_value_r), ('boot_c', last_value_c)):
+            if val is None:
+                self.data[key][t, idx] = 0.0
+            else:
+                self.data[key][t, idx] = torch.as_tensor(val, dtype=torch.float32).reshape(-1)[0].to(
+                    self._device, non_blocking=True)
+
+    def finish_paths(self, mask: torch.Tensor, last_value_r: torch.Tensor,
+                     last_value_c: torch.Tensor) -> None:
+        """Vector form: ends the path of every env with ``mask[n]`` after the last stored step."""
+        t = self.ptr - 1
+        assert t >= 0, 'finish_paths() before any store()'
+        m = mask.to(self._device).bool()
+        self.data['path_end'][t] = m.to(torch.uint8)
+        self.data['boot_r'][t] = torch.where(m, last_value_r.to(self._device, torch.float32), 0.0)
+        self.data['boot_c'][t] = torch.where(m, last_value_c.to(self._device, torch.float32), 0.0)
+
+    # ------------------------------------------------------------------ get
+    def compute_advantages(self) -> None:
+        """K5: one backward scan over the (T, N) buffer (osa_gae_scan)."""
+        b, T, N = self.data, self._size, self._num_buffers
+        _lib.check(self._lib.osa_gae_scan(
+            _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),
+            _lib.ptr(b['path_end']), _lib.ptr(b['boot_r']), _lib.ptr(b['boot_c']), T, N, self._gamma,
+            self._lam, self._lam_c, self._penalty_coefficient, self._estimator, _lib.ptr(b['adv_r']),
+            _lib.ptr(b['adv_c']), _lib.ptr(b['target_value_r']), _lib.ptr(b['target_value_c']),
+            _lib.ptr(b['discounted_ret']), _lib.stream_ptr()), 'osa_gae_scan')
+
+    def get(self) -> dict[str, torch.Tensor]:
+        """Finish all paths, standardise, and return the env-major batch (reference key set)."""
+        from . import distributed as dist
+
+        b, T, N = self.data, self._size, self._num_buffers
+        M = T * N
+        st = _lib.stream_ptr()
+        self.compute_advantages()
+        _lib.check(self._lib.osa_adv_stats_phase1(_lib.ptr(b['adv_r']), _lib.ptr(b['adv_c']), M,
+                                                  _lib.ptr(self._ws), _lib.ptr(self._stats), st),
+                   'osa_adv_stats_phase1')
+        if dist.world_size() > 1:
+            dist.all_reduce_sum_(self._stats[0:3])
+        _lib.check(self._lib.osa_adv_stats_phase2(_lib.ptr(b['adv_r']), M, _lib.ptr(self._ws),
+                                                  _lib.ptr(self._stats), st), 'osa_adv_stats_phase2')
+        if dist.world_size() > 1:
+            dist.all_reduce_sum_(self._stats[3:4])
+        o = self._out
+        _lib.check(self._lib.osa_buffer_get(
+            T, N, self._obs_dim, self._act_dim, _lib.ptr(b['obs']), self._obs_dim, _lib.ptr(b['act']),
+            self._act_dim, _lib.ptr(b['logp']), _lib.ptr(b['target_value_r']),
+            _lib.ptr(b['target_value_c']), _lib.ptr(b['adv_r']), _lib.ptr(b['adv_c']),
+            _lib.ptr(b['discounted_ret']), _lib.ptr(self._stats), int(self._standardized_adv_r),
+            int(self._standardized_adv_c), _lib.ptr(o['obs']), self._obs_dim, _lib.ptr(o['act']),
+            self._act_dim, _lib.ptr(o['logp']), _lib.ptr(o['target_value_r']),
+            _lib.ptr(o['target_value_c']), _lib.ptr(o['adv_r']), _lib.ptr(o['adv_c']),
+            _lib.ptr(o['discounted_ret']), st), 'osa_buffer_get')
+        self.ptr = 0
+        self.data['path_end'].zero_()
+        return dict(o)

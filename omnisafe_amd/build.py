@@ -1,0 +1,69 @@
+"""Builds libomnisafe_amd.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m omnisafe_amd.build            # rebuild if any source is newer than the library
+
+The library is git-ignored but travels to the GPU box with the working tree.  hipcc cross-compiles
+without a GPU, so this also runs in the (GPU-less) build container.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIB_DIR = os.path.join(PKG, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libomnisafe_amd.so')
+ARCH = 'gfx950'
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (need ROCm >= 7.0)')
+
+
+def sources() -> list[str]:
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    lib_m = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(
+        os.path.join(os.path.dirname(PKG), 'include', '*.h'))
+    return any(os.path.getmtime(d) > lib_m for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + '.o')
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src),
+                *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))),
+                *(os.path.getmtime(h) for h in glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))):
+            cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
+                   '-Wall', '-Wno-unused-function']
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB_PATH, *objs]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv)
+    print(LIB_PATH)

@@ -1,0 +1,393 @@
+// Rollout-buffer kernels: store (K4), dual reward+cost GAE backward scan (K5), advantage statistics
+// and env-major get() (K6).  HBM-bound byte work: coalesced along the env axis n of the time-major
+// (T, N) layout, float64 recurrences exactly as the reference (see include/omnisafe_amd.h).
+#include "osa_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K4  store one vector step into row t
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_store_step_kernel(
+    int N, int obs_dim, int act_dim, const float* __restrict__ obs, int ld_os,
+    const float* __restrict__ act, int ld_as, const float* __restrict__ reward,
+    const float* __restrict__ cost, const float* __restrict__ value_r,
+    const float* __restrict__ value_c, const float* __restrict__ logp, float* __restrict__ b_obs,
+    int ld_ob, float* __restrict__ b_act, int ld_ab, float* __restrict__ b_reward,
+    float* __restrict__ b_cost, float* __restrict__ b_value_r, float* __restrict__ b_value_c,
+    float* __restrict__ b_logp) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_obs = (long)N * obs_dim, n_act = (long)N * act_dim;
+  if (gid < n_obs) {
+    const int n = (int)(gid / obs_dim), d = (int)(gid % obs_dim);
+    b_obs[(long)n * ld_ob + d] = obs[(long)n * ld_os + d];
+  }
+  if (gid < n_act) {
+    const int n = (int)(gid / act_dim), d = (int)(gid % act_dim);
+    b_act[(long)n * ld_ab + d] = act[(long)n * ld_as + d];
+  }
+  if (gid < N) {
+    b_reward[gid] = reward[gid];
+    b_cost[gid] = cost[gid];
+    b_value_r[gid] = value_r[gid];
+    b_value_c[gid] = value_c[gid];
+    b_logp[gid] = logp[gid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  dual GAE backward scan.  One lane per env; each wave reads 64 consecutive envs of row t
+// (256 B coalesced per array).  The time axis is walked in chunks of U steps whose loads are all
+// issued before the (sequential, float64) recurrence consumes them, so HBM latency is paid once per
+// chunk instead of once per step.
+// ------------------------------------------------------------------------------------------------
+template <int EST, int U>
+__global__ __launch_bounds__(256) void osa_gae_scan_kernel(
+    const float* __restrict__ reward, const float* __restrict__ cost,
+    const float* __restrict__ value_r, const float* __restrict__ value_c,
+    const uint8_t* __restrict__ path_end, const float* __restrict__ boot_r,
+    const float* __restrict__ boot_c, int T, int N, float g32, double d_g, double d_r, double d_c,
+    float pc, float* __restrict__ adv_r, float* __restrict__ adv_c, float* __restrict__ tgt_r,
+    float* __restrict__ tgt_c, float* __restrict__ disc_ret) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float nv_r = 0.f, nv_c = 0.f;
+  double a_r = 0.0, a_c = 0.0, ret = 0.0, rtg_r = 0.0, rtg_c = 0.0;
+  for (int t0 = T - 1; t0 >= 0; t0 -= U) {
+    float r[U], c[U], vr[U], vc[U], br[U], bc[U];
+    uint8_t e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 - u;
+      if (t >= 0) {
+        const long i = (long)t * N + n;
+        r[u] = reward[i];
+        c[u] = cost[i];
+        vr[u] = value_r[i];
+        vc[u] = value_c[i];
+        e[u] = path_end[i];
+        br[u] = e[u] ? boot_r[i] : 0.f;
+        bc[u] = e[u] ? boot_c[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 - u;
+      if (t < 0) break;
+      if (e[u]) {  // a path ends after step t: re-seed every carry with the bootstrap
+        nv_r = br[u];
+        nv_c = bc[u];
+        a_r = 0.0;
+        a_c = 0.0;
+        ret = (double)br[u];
+        const float pb = pc * bc[u];
+        rtg_r = (double)(br[u] - pb);
+        rtg_c = (double)bc[u];
+      }
+      const float pcost = pc * c[u];
+      const float r_pen = r[u] - pcost;
+      const float gr = g32 * nv_r;
+      const float gc = g32 * nv_c;
+      const float sr = r_pen + gr;
+      const float sc = c[u] + gc;
+      const float delta_r = sr - vr[u];
+      const float delta_c = sc - vc[u];
+      const double m0 = d_g * ret;
+      ret = (double)r[u] + m0;
+      double out_ar, out_ac, out_tr, out_tc;
+      if (EST != OSA_EST_GAE) {
+        const double m1 = d_g * rtg_r;
+        rtg_r = (double)r_pen + m1;
+        const double m2 = d_g * rtg_c;
+        rtg_c = (double)c[u] + m2;
+      }
+      if (EST == OSA_EST_PLAIN) {
+        out_ar = (double)delta_r;
+        out_ac = (double)delta_c;
+      } else {
+        const double m3 = d_r * a_r;
+        a_r = (double)delta_r + m3;
+        const double m4 = d_c * a_c;
+        a_c = (double)delta_c + m4;
+        out_ar = a_r;
+        out_ac = a_c;
+      }
+      if (EST == OSA_EST_GAE) {
+        out_tr = out_ar + (double)vr[u];
+        out_tc = out_ac + (double)vc[u];
+      } else {
+        out_tr = rtg_r;
+        out_tc = rtg_c;
+      }
+      const long i = (long)t * N + n;
+      adv_r[i] = (float)out_ar;
+      adv_c[i] = (float)out_ac;
+      tgt_r[i] = (float)out_tr;
+      tgt_c[i] = (float)out_tc;
+      disc_ret[i] = (float)ret;
+      nv_r = vr[u];
+      nv_c = vc[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  statistics: deterministic two-stage float64 reductions
+// ------------------------------------------------------------------------------------------------
+#define OSA_RED_BLOCKS 512
+#define OSA_RED_THREADS 256
+
+__global__ __launch_bounds__(OSA_RED_THREADS) void osa_sum2_partial_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, long M, double* __restrict__ ws) {
+  __shared__ double red[17];
+  double sa = 0.0, sb = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+    sa += (double)a[i];
+    sb += (double)b[i];
+  }
+  sa = osa_block_sum<OSA_RED_THREADS>(sa, red);
+  sb = osa_block_sum<OSA_RED_THREADS>(sb, red);
+  if (threadIdx.x == 0) {
+    ws[2 * blockIdx.x] = sa;
+    ws[2 * blockIdx.x + 1] = sb;
+  }
+}
+
+__global__ __launch_bounds__(OSA_RED_THREADS) void osa_sum2_final_kernel(
+    const double* __restrict__ ws, int nblk, long M, double* __restrict__ stats) {
+  __shared__ double red[17];
+  double sa = 0.0, sb = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += OSA_RED_THREADS) {
+    sa += ws[2 * i];
+    sb += ws[2 * i + 1];
+  }
+  sa = osa_block_sum<OSA_RED_THREADS>(sa, red);
+  sb = osa_block_sum<OSA_RED_THREADS>(sb, red);
+  if (threadIdx.x == 0) {
+    stats[0] = sa;
+    stats[1] = sb;
+    stats[2] = (double)M;
+  }
+}
+
+__global__ __launch_bounds__(OSA_RED_THREADS) void osa_sumsq_partial_kernel(
+    const float* __restrict__ a, long M, const double* __restrict__ stats,
+    double* __restrict__ ws) {
+#pragma clang fp contract(off)
+  __shared__ double red[17];
+  // float32 mean exactly as the reference forms it: float32 sum / n (distributed.py:384)
+  const float mean = (float)stats[0] / (float)stats[2];
+  double s = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+    const float d = a[i] - mean;
+    const float q = d * d;
+    s += (double)q;
+  }
+  s = osa_block_sum<OSA_RED_THREADS>(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(OSA_RED_THREADS) void osa_sumsq_final_kernel(
+    const double* __restrict__ ws, int nblk, double* __restrict__ stats) {
+  __shared__ double red[17];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += OSA_RED_THREADS) s += ws[i];
+  s = osa_block_sum<OSA_RED_THREADS>(s, red);
+  if (threadIdx.x == 0) {
+    stats[3] = s;
+    stats[4] = (double)((float)stats[0] / (float)stats[2]);
+    stats[5] = (double)((float)stats[1] / (float)stats[2]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  get(): (T, N) -> (N*T) transposition through a 64x64 LDS tile, standardisation fused
+// ------------------------------------------------------------------------------------------------
+struct OsaGetScalars {
+  const float* src[6];
+  float* dst[6];
+  int op[6];  // 0 copy, 1 (x - mean_r)/(std_r + 1e-8), 2 x - mean_c
+};
+
+__global__ __launch_bounds__(256) void osa_get_scalars_kernel(OsaGetScalars p, int T, int N,
+                                                              double* __restrict__ stats) {
+#pragma clang fp contract(off)
+  __shared__ float tile[64][65];
+  const int n0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const float mean_r = (float)stats[4], mean_c = (float)stats[5];
+  const float std_r = sqrtf((float)stats[3] / (float)stats[2]);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stats[6] = (double)std_r;
+  const float denom = std_r + 1e-8f;
+  for (int k = 0; k < 6; ++k) {
+    const float* __restrict__ src = p.src[k];
+    float* __restrict__ dst = p.dst[k];
+    if (src == nullptr || dst == nullptr) continue;
+    const int op = p.op[k];
+    __syncthreads();
+    for (int tt = ty; tt < 64; tt += 4) {
+      const int t = t0 + tt, n = n0 + tx;
+      if (t < T && n < N) {
+        float v = src[(long)t * N + n];
+        if (op == 1) v = (v - mean_r) / denom;
+        else if (op == 2) v = v - mean_c;
+        tile[tt][tx] = v;
+      }
+    }
+    __syncthreads();
+    for (int nn = ty; nn < 64; nn += 4) {
+      const int n = n0 + nn, t = t0 + tx;
+      if (t < T && n < N) dst[(long)n * T + t] = tile[tx][nn];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void osa_get_rows_kernel(const float* __restrict__ src, int ld_src,
+                                                           float* __restrict__ dst, int ld_dst,
+                                                           int T, int N, int dim) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * N * dim;
+  if (gid >= total) return;
+  const long row = gid / dim;  // env-major sample index i = n*T + t
+  const int d = (int)(gid - row * dim);
+  const int n = (int)(row / T), t = (int)(row - (long)n * T);
+  dst[row * ld_dst + d] = src[((long)t * N + n) * ld_src + d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* osa_strerror(int code) {
+  switch (code) {
+    case OSA_OK: return "ok";
+    case OSA_EINVAL: return "invalid argument";
+    case OSA_EHIP: return "HIP runtime error";
+    case OSA_EUNSUPPORTED: return "not implemented in libomnisafe_amd";
+    default: return "unknown error";
+  }
+}
+int osa_version(void) { return 1; }
+const char* osa_build_arch(void) { return "gfx950"; }
+
+int osa_buffer_store_step(int t, int N, int obs_dim, int act_dim, const float* obs, int ld_obs_src,
+                          const float* act, int ld_act_src, const float* reward, const float* cost,
+                          const float* value_r, const float* value_c, const float* logp,
+                          float* buf_obs, int ld_obs_buf, float* buf_act, int ld_act_buf,
+                          float* buf_reward, float* buf_cost, float* buf_value_r, float* buf_value_c,
+                          float* buf_logp, void* stream) {
+  OSA_REQUIRE(t >= 0 && N > 0 && obs_dim > 0 && act_dim > 0);
+  OSA_REQUIRE(obs && act && reward && cost && value_r && value_c && logp);
+  OSA_REQUIRE(buf_obs && buf_act && buf_reward && buf_cost && buf_value_r && buf_value_c && buf_logp);
+  OSA_REQUIRE(ld_obs_src >= obs_dim && ld_obs_buf >= obs_dim && ld_act_src >= act_dim &&
+              ld_act_buf >= act_dim);
+  const long row = (long)t * N;
+  const long work = (long)N * (obs_dim > act_dim ? obs_dim : act_dim);
+  const int blocks = (int)((work + 255) / 256);
+  hipLaunchKernelGGL(osa_store_step_kernel, dim3(blocks), dim3(256), 0, osa_stream(stream), N,
+                     obs_dim, act_dim, obs, ld_obs_src, act, ld_act_src, reward, cost, value_r,
+                     value_c, logp, buf_obs + row * ld_obs_buf, ld_obs_buf,
+                     buf_act + row * ld_act_buf, ld_act_buf, buf_reward + row, buf_cost + row,
+                     buf_value_r + row, buf_value_c + row, buf_logp + row);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_gae_scan(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                 const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
+                 double gamma, double lam, double lam_c, float penalty_coef, int estimator,
+                 float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
+                 float* discounted_ret, void* stream) {
+  OSA_REQUIRE(T > 0 && N > 0);
+  OSA_REQUIRE(reward && cost && value_r && value_c && path_end && boot_r && boot_c);
+  OSA_REQUIRE(adv_r && adv_c && target_value_r && target_value_c && discounted_ret);
+  if (estimator < OSA_EST_GAE || estimator > OSA_EST_PLAIN) return OSA_EUNSUPPORTED;
+  const float g32 = (float)gamma;  // gamma * float32 tensor: the scalar is rounded to float32
+  const double d_g = gamma, d_r = gamma * lam, d_c = gamma * lam_c;  // python-float products
+  const int threads = N >= 256 ? 256 : 64;
+  const int blocks = (N + threads - 1) / threads;
+  constexpr int U = 8;
+#define OSA_GAE_LAUNCH(E)                                                                         \
+  hipLaunchKernelGGL((osa_gae_scan_kernel<E, U>), dim3(blocks), dim3(threads), 0,                 \
+                     osa_stream(stream), reward, cost, value_r, value_c, path_end, boot_r, boot_c, \
+                     T, N, g32, d_g, d_r, d_c, penalty_coef, adv_r, adv_c, target_value_r,        \
+                     target_value_c, discounted_ret)
+  if (estimator == OSA_EST_GAE) OSA_GAE_LAUNCH(OSA_EST_GAE);
+  else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_LAUNCH(OSA_EST_GAE_RTG);
+  else OSA_GAE_LAUNCH(OSA_EST_PLAIN);
+#undef OSA_GAE_LAUNCH
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+size_t osa_reduce_ws_bytes(void) { return (size_t)OSA_RED_BLOCKS * 2 * sizeof(double); }
+
+static int osa_red_blocks(long M) {
+  long b = (M + (long)OSA_RED_THREADS * 4 - 1) / ((long)OSA_RED_THREADS * 4);
+  if (b < 1) b = 1;
+  if (b > OSA_RED_BLOCKS) b = OSA_RED_BLOCKS;
+  return (int)b;
+}
+
+int osa_adv_stats_phase1(const float* adv_r, const float* adv_c, long M, double* ws, double* stats,
+                         void* stream) {
+  OSA_REQUIRE(adv_r && adv_c && ws && stats && M > 0);
+  const int nblk = osa_red_blocks(M);
+  hipLaunchKernelGGL(osa_sum2_partial_kernel, dim3(nblk), dim3(OSA_RED_THREADS), 0,
+                     osa_stream(stream), adv_r, adv_c, M, ws);
+  hipLaunchKernelGGL(osa_sum2_final_kernel, dim3(1), dim3(OSA_RED_THREADS), 0, osa_stream(stream),
+                     ws, nblk, M, stats);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_adv_stats_phase2(const float* adv_r, long M, double* ws, double* stats, void* stream) {
+  OSA_REQUIRE(adv_r && ws && stats && M > 0);
+  const int nblk = osa_red_blocks(M);
+  hipLaunchKernelGGL(osa_sumsq_partial_kernel, dim3(nblk), dim3(OSA_RED_THREADS), 0,
+                     osa_stream(stream), adv_r, M, stats, ws);
+  hipLaunchKernelGGL(osa_sumsq_final_kernel, dim3(1), dim3(OSA_RED_THREADS), 0, osa_stream(stream),
+                     ws, nblk, stats);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_buffer_get(int T, int N, int obs_dim, int act_dim, const float* obs, int ld_obs,
+                   const float* act, int ld_act, const float* logp, const float* target_value_r,
+                   const float* target_value_c, const float* adv_r, const float* adv_c,
+                   const float* discounted_ret, double* stats, int standardize_r, int standardize_c,
+                   float* out_obs, int ld_out_obs, float* out_act, int ld_out_act, float* out_logp,
+                   float* out_target_value_r, float* out_target_value_c, float* out_adv_r,
+                   float* out_adv_c, float* out_discounted_ret, void* stream) {
+  OSA_REQUIRE(T > 0 && N > 0 && stats);
+  OsaGetScalars p;
+  const float* srcs[6] = {logp, target_value_r, target_value_c, adv_r, adv_c, discounted_ret};
+  float* dsts[6] = {out_logp, out_target_value_r, out_target_value_c, out_adv_r, out_adv_c,
+                    out_discounted_ret};
+  const int ops[6] = {0, 0, 0, standardize_r ? 1 : 0, standardize_c ? 2 : 0, 0};
+  for (int k = 0; k < 6; ++k) {
+    p.src[k] = srcs[k];
+    p.dst[k] = dsts[k];
+    p.op[k] = ops[k];
+  }
+  hipLaunchKernelGGL(osa_get_scalars_kernel, dim3((N + 63) / 64, (T + 63) / 64), dim3(256), 0,
+                     osa_stream(stream), p, T, N, stats);
+  if (obs && out_obs) {
+    OSA_REQUIRE(obs_dim > 0 && ld_obs >= obs_dim && ld_out_obs >= obs_dim);
+    const long total = (long)T * N * obs_dim;
+    hipLaunchKernelGGL(osa_get_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       osa_stream(stream), obs, ld_obs, out_obs, ld_out_obs, T, N, obs_dim);
+  }
+  if (act && out_act) {
+    OSA_REQUIRE(act_dim > 0 && ld_act >= act_dim && ld_out_act >= act_dim);
+    const long total = (long)T * N * act_dim;
+    hipLaunchKernelGGL(osa_get_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       osa_stream(stream), act, ld_act, out_act, ld_out_act, T, N, act_dim);
+  }
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+}  // extern "C"

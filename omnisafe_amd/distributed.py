@@ -1,0 +1,84 @@
+"""Data-parallel communication for the hot path: one process per GPU, torch.distributed with the
+``nccl`` backend (= RCCL over xGMI on ROCm) on device tensors, ``gloo`` on CPU tensors (tests).
+
+Replaces the collective call sites of omnisafe/utils/distributed.py:142-393 (C1-C5 in SURVEY.md 2.2).
+The reference issues one blocking all-reduce per parameter tensor (avg_grads, :193-198: 19 messages per
+minibatch for three nets); here every exchange is ONE flat buffer:
+  * gradients of pi, V_r, V_c of one optimiser step   -> all_reduce_avg_(flat)      (C1)
+  * Fisher-vector product                              -> all_reduce_avg_(flat)      (C2)
+  * scalar KL / loss statistics packed in one vector   -> all_reduce_avg_(vec)       (C3)
+  * advantage / episode statistics [sum, n, sumsq]     -> all_reduce_sum_(vec)       (C4)
+  * initial parameters                                 -> broadcast_(flat, src=0)    (C5)
+All payloads here are <= a few hundred KB, i.e. latency-bound on xGMI (7 point-to-point links per
+GPU): fewer, fused messages matter, ring bandwidth does not.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if is_initialized() else 0
+
+
+def init_from_env(device: torch.device | str | None = None) -> bool:
+    """Join the process group described by torchrun's environment (RANK/WORLD_SIZE/MASTER_*), as the
+    reference does in setup_distributed (omnisafe/utils/distributed.py:59-104).  Returns True when
+    running with world_size > 1."""
+    if is_initialized():
+        return world_size() > 1
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1:
+        return False
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    use_gpu = device is not None and torch.device(device).type == 'cuda'
+    if use_gpu:
+        torch.cuda.set_device(torch.device(device))
+    kwargs = {}
+    if use_gpu:
+        kwargs['device_id'] = torch.device(device)
+    dist.init_process_group(backend='nccl' if use_gpu else 'gloo', **kwargs)
+    return True
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if world_size() > 1:
+        if not t.is_contiguous():
+            tmp = t.contiguous()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            t.copy_(tmp)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_avg_(t: torch.Tensor) -> torch.Tensor:
+    """SUM then divide by world size (avg_grads / avg_tensor semantics, distributed.py:160-198)."""
+    ws = world_size()
+    if ws > 1:
+        all_reduce_sum_(t)
+        t.div_(ws)
+    return t
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def barrier() -> None:
+    if world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,155 @@
+"""GPU parity: HIP rollout buffer (store / GAE scan / get) vs the oracle and the reference's golden
+vectors.  GAE outputs must be BIT-EXACT (float64 recurrence restated op for op); the standardised
+advantages are compared at rtol 1e-5 (the reference reduces in float32 pairwise order, the kernels in
+float64 -- SURVEY.md 8c)."""
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _mk(T, N, D_o, D_a, est='gae', pc=0.0, lam_c=0.9):
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from omnisafe_amd.spaces import Box
+
+    return VectorOnPolicyBuffer(Box(-np.inf, np.inf, (D_o,)), Box(-1, 1, (D_a,)), size=T, gamma=0.99,
+                                lam=0.95, lam_c=lam_c, advantage_estimator=est,
+                                penalty_coefficient=pc, standardized_adv_r=True,
+                                standardized_adv_c=True, num_envs=N, device=DEV)
+
+
+def _fill(buf, g_in, path_end, boot_r, boot_c, vector_finish=True):
+    T, N = g_in['reward'].shape
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    for t in range(T):
+        buf.store(**{k: dev(v[t]) for k, v in g_in.items()})
+        if vector_finish:
+            buf.finish_paths(dev(path_end[t]), dev(boot_r[t]), dev(boot_c[t]))
+        else:
+            for n in range(N):
+                if path_end[t, n]:
+                    buf.finish_path(torch.tensor([boot_r[t, n]]), torch.tensor([boot_c[t, n]]), n)
+
+
+IN_KEYS = ('obs', 'act', 'reward', 'cost', 'value_r', 'value_c', 'logp')
+
+
+@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain'])
+@pytest.mark.parametrize('pc', [0.0, 0.3])
+@pytest.mark.parametrize('vector_finish', [True, False])
+def test_golden_buffer(golden, est, pc, vector_finish):
+    g = golden('buffer.npz')
+    T, N = g['reward'].shape
+    buf = _mk(T, N, g['obs'].shape[2], g['act'].shape[2], est, pc)
+    _fill(buf, {k: g[k] for k in IN_KEYS}, g['path_end'], g['boot_r'], g['boot_c'], vector_finish)
+    buf.compute_advantages()
+    tag = f'{est}_pc{pc}'
+    for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c', 'discounted_ret'):
+        got = O.env_major(buf.data[k].cpu().numpy())
+        assert np.array_equal(got, g[f'{tag}/raw/{k}']), k  # bit-exact vs the reference
+    data = buf.get()
+    assert set(data) == {'obs', 'act', 'target_value_r', 'adv_r', 'logp', 'discounted_ret', 'adv_c',
+                         'target_value_c'}
+    for k in ('obs', 'act', 'logp', 'target_value_r', 'target_value_c', 'discounted_ret'):
+        assert np.array_equal(data[k].cpu().numpy(), g[f'{tag}/get/{k}']), k
+    np.testing.assert_allclose(data['adv_r'].cpu().numpy(), g[f'{tag}/get/adv_r'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(data['adv_c'].cpu().numpy(), g[f'{tag}/get/adv_c'], rtol=1e-5, atol=1e-6)
+    assert buf.ptr == 0
+
+
+def _random_case(rng, T, N, D_o=3, D_a=2, p_end=0.05):
+    g_in = {
+        'obs': rng.standard_normal((T, N, D_o)).astype(np.float32),
+        'act': rng.standard_normal((T, N, D_a)).astype(np.float32),
+        'reward': rng.standard_normal((T, N)).astype(np.float32),
+        'cost': (rng.random((T, N)) < 0.05).astype(np.float32),
+        'value_r': rng.standard_normal((T, N)).astype(np.float32),
+        'value_c': rng.standard_normal((T, N)).astype(np.float32),
+        'logp': rng.standard_normal((T, N)).astype(np.float32),
+    }
+    kind = rng.choice([0, 1, 2], size=(T, N), p=[1 - 2 * p_end, p_end, p_end])
+    kind[-1] = 2
+    boot_r = np.where(kind == 2, rng.standard_normal((T, N)), 0).astype(np.float32)
+    boot_c = np.where(kind == 2, rng.standard_normal((T, N)), 0).astype(np.float32)
+    return g_in, (kind != 0).astype(np.uint8), boot_r, boot_c
+
+
+@pytest.mark.parametrize('T,N', [(16, 4096), (1, 64), (7, 1), (257, 300), (1000, 4), (64, 16384)])
+def test_gae_vs_oracle_sizes(T, N):
+    """Oracle (vectorised numpy restatement, pinned to the reference) at BASELINE sizes and ragged /
+    degenerate shapes: single step, single env, T not a multiple of the scan chunk, N not a
+    multiple of the wave."""
+    rng = np.random.default_rng(T * 1000 + N)
+    g_in, pe, br, bc = _random_case(rng, T, N)
+    buf = _mk(T, N, 3, 2, lam_c=0.95)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    for k in IN_KEYS:
+        buf.data[k].copy_(dev(g_in[k]))
+    buf.data['path_end'].copy_(dev(pe))
+    buf.data['boot_r'].copy_(dev(br))
+    buf.data['boot_c'].copy_(dev(bc))
+    buf.ptr = T
+    ref = O.gae_time_major(g_in['reward'], g_in['cost'], g_in['value_r'], g_in['value_c'], pe, br, bc,
+                           0.99, 0.95, 0.95)
+    data = buf.get()
+    for ok, bk in (('adv_r', 'adv_r'), ('adv_c', 'adv_c'), ('tgt_r', 'target_value_r'),
+                   ('tgt_c', 'target_value_c'), ('disc_ret', 'discounted_ret')):
+        assert np.array_equal(buf.data[bk].cpu().numpy(), ref[ok]), ok
+    a_r, a_c, (mean_r, std_r, mean_c) = O.buffer_get(ref['adv_r'], ref['adv_c'])
+    np.testing.assert_allclose(data['adv_r'].cpu().numpy(), a_r, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(data['adv_c'].cpu().numpy(), a_c, rtol=2e-5, atol=2e-6)
+    st = buf.stats.cpu().numpy()
+    assert st[2] == T * N
+    np.testing.assert_allclose(st[4], mean_r, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st[6], std_r, rtol=1e-5)
+    assert np.array_equal(data['obs'].cpu().numpy(), O.env_major(g_in['obs']))
+    assert np.array_equal(data['target_value_r'].cpu().numpy(), O.env_major(ref['tgt_r']))
+    # size-independent properties of get(): zero-mean / unit-variance reward advantages,
+    # zero-mean cost advantages
+    x = data['adv_r'].double()
+    assert abs(float(x.mean())) < 1e-4
+    if T * N > 1:
+        assert abs(float(x.pow(2).mean().sqrt()) - 1.0) < 1e-3
+    assert abs(float(data['adv_c'].double().mean())) < 1e-4
+
+
+def test_gae_linearity_full_size():
+    """Size-independent property at the BASELINE size (N=4096, T=16): with values and bootstraps zero,
+    GAE is linear in the reward stream: adv(a*r) = a*adv(r) for a power-of-two a (exact in fp)."""
+    T, N = 16, 4096
+    rng = np.random.default_rng(0)
+    g_in, pe, br, bc = _random_case(rng, T, N)
+    outs = []
+    for scale in (1.0, 4.0):
+        buf = _mk(T, N, 3, 2)
+        buf.data['reward'].copy_(torch.from_numpy(g_in['reward'] * np.float32(scale)).to(DEV))
+        buf.data['path_end'].copy_(torch.from_numpy(pe).to(DEV))
+        buf.ptr = T
+        buf.compute_advantages()
+        outs.append(buf.data['adv_r'].cpu().numpy())
+    assert np.array_equal(outs[0] * np.float32(4.0), outs[1])
+
+
+def test_errors():
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from omnisafe_amd.spaces import Box
+
+    box = Box(-1, 1, (2,))
+    with pytest.raises(ValueError):
+        VectorOnPolicyBuffer(box, box, 4, .99, .95, .95, 'gae', 0.0, True, True, num_envs=0, device=DEV)
+    with pytest.raises(NotImplementedError):
+        VectorOnPolicyBuffer(object(), box, 4, .99, .95, .95, 'gae', 0.0, True, True, 1, DEV)
+    with pytest.raises(NotImplementedError):
+        VectorOnPolicyBuffer(box, box, 4, .99, .95, .95, 'bogus', 0.0, True, True, 1, DEV)
+    buf = VectorOnPolicyBuffer(box, box, 1, .99, .95, .95, 'gae', 0.0, True, True, 1, DEV)
+    z = torch.zeros(1, device=DEV)
+    step = dict(obs=torch.zeros(1, 2, device=DEV), act=torch.zeros(1, 2, device=DEV), reward=z, cost=z,
+                value_r=z, value_c=z, logp=z)
+    buf.store(**step)
+    with pytest.raises(AssertionError):
+        buf.store(**step)
