@@ -99,6 +99,89 @@ int osa_buffer_get(int T, int N, int obs_dim, int act_dim,
                    float* out_target_value_r, float* out_target_value_c, float* out_adv_r,
                    float* out_adv_c, float* out_discounted_ret, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Actor-critic networks (replaces the torch modules + optimisers of
+ * omnisafe/models/actor_critic/{actor_critic,constraint_actor_critic}.py on this path)
+ *
+ * Three MLPs obs_dim -> hidden -> hidden -> {act_dim | 1 | 1} with tanh (omnisafe/utils/model.py:73-111,
+ * hidden_sizes [64, 64] = every on-policy YAML default).  Each network's parameters, Adam moments and
+ * gradients live in one PADDED float32 block of P floats described by osa_mlp_layout:
+ *   W1 [H][INP] | b1 [H] | W2 [H][H] | b2 [H] | W3 [OUTP][H] | b3 [OUTP] | log_std [OUTP]
+ * (INP/OUTP = obs_dim / max(act_dim,1) rounded up to 16; padding is zero and stays zero).  The three
+ * blocks are stored back to back: params[3][P] = actor, reward critic, cost critic.  Conversion to
+ * the reference's state_dict tensors / flat-parameter order (omnisafe/utils/tools.py:35-129) is an
+ * index map built from osa_mlp_layout on the host.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out12 = {INP, OUTP, oW1, ob1, oW2, ob2, oW3, ob3, oLS, P, H, KB} (offsets in floats). */
+int osa_mlp_layout(int obs_dim, int act_dim, int hidden, int* out12);
+
+/* ConstraintActorCritic.step (constraint_actor_critic.py:102-109; GaussianLearningActor.predict /
+ * log_prob gaussian_learning_actor.py:81-129; VCritic.forward v_critic.py:89-92) for N observation
+ * rows: act = mean + exp(log_std) * eps (or mean if deterministic), logp = sum_d Normal.log_prob,
+ * value_r, value_c.  eps: optional external standard-normal noise [N][act_dim] (parity tests);
+ * when NULL the kernel draws Philox4x32-10 + Box-Muller normals keyed by (seed, offset, row, dim).
+ * nets_mask: bit0 actor, bit1 reward critic, bit2 cost critic (bootstrap calls need critics only).
+ * Any output pointer may be NULL.  mean_out optionally receives the distribution mean. */
+int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
+                    int ld_obs, int N, const float* eps, unsigned long long seed,
+                    unsigned long long offset, int deterministic, int nets_mask, float* act,
+                    int ld_act, float* value_r, float* value_c, float* logp, float* mean_out,
+                    int ld_mean, void* stream);
+
+/* Hyper-parameters of one optimiser step; field names follow algo_cfgs / model_cfgs of
+ * omnisafe/configs/on-policy/PPOLag.yaml. */
+typedef struct osa_ppo_hparams {
+  float clip;             /* algo_cfgs.clip */
+  float entropy_coef;     /* algo_cfgs.entropy_coef */
+  float critic_norm_coef; /* algo_cfgs.critic_norm_coef */
+  float max_grad_norm;    /* algo_cfgs.max_grad_norm */
+  float lr_actor;         /* model_cfgs.actor.lr x LinearLR factor of the current epoch */
+  float lr_critic;        /* model_cfgs.critic.lr */
+  float beta1, beta2, adam_eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+  int use_critic_norm;    /* algo_cfgs.use_critic_norm */
+  int use_max_grad_norm;  /* algo_cfgs.use_max_grad_norm */
+  int use_cost;           /* algo_cfgs.use_cost */
+} osa_ppo_hparams;
+
+/* One minibatch step of PolicyGradient._update's inner loop for all three networks in one launch:
+ * _update_reward_critic / _update_cost_critic (omnisafe/algorithms/on_policy/base/policy_gradient.py:
+ * 428-445, 468-485: MSE + critic_norm_coef * sum p^2, clip_grad_norm_, Adam) and _update_actor
+ * (:514-524) with PPOLag's surrogate advantage (adv_r - lambda adv_c)/(1 + lambda)
+ * (naive_lagrange/ppo_lag.py:101-102) and loss_kind 0 = PPO clipped loss (base/ppo.py:66-78) or
+ * 1 = plain ratio * adv (policy_gradient.py:574-578).  Data arrays are the ENV-MAJOR tensors of
+ * osa_buffer_get; idx[B] selects the minibatch rows (NULL = rows 0..B-1); *lagrange is a device scalar.
+ * mode 0: gradient + local clip + Adam;  1: gradient + local clip (caller all-reduces grads[3][P]
+ * and calls osa_adam_apply -- clip-then-average order of policy_gradient.py:437-442);  2: raw grads.
+ * B <= 64*max_blocks rows are processed by ceil(B/64) workgroups per network (ws: at least
+ * osa_minibatch_ws_floats floats when more than one is used).  step_stats[16] receives
+ *   [0] mse_r [1] mse_c [2] loss_pi [3] mean ratio [4] entropy [5] sum p^2 (V_r) [6] sum p^2 (V_c)
+ *   [7] |g_pi| [8] |g_Vr| [9] |g_Vc|   (logged Loss_*_critic = mse + critic_norm_coef * sum p^2). */
+size_t osa_minibatch_ws_floats(int obs_dim, int act_dim, int hidden, int max_blocks);
+int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
+                      float* adam_v, int* adam_step, float* grads, const float* obs, int ld_obs,
+                      const float* act, int ld_act, const float* logp, const float* target_value_r,
+                      const float* target_value_c, const float* adv_r, const float* adv_c,
+                      const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
+                      int loss_kind, int mode, int nets_mask, int max_blocks, float* ws,
+                      float* step_stats, void* stream);
+
+/* Adam step on already clipped (and, for world_size > 1, all-reduce-averaged) gradients. */
+int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                   int* adam_step, float* grads, const osa_ppo_hparams* hp, int nets_mask,
+                   void* stream);
+
+/* Full-batch actor forward over M env-major rows.  With old_mean == NULL it only snapshots the
+ * distribution mean into mean_out (old_distribution = actor(obs), policy_gradient.py:357).  Otherwise
+ * it evaluates KL(old || new) of torch.distributions.kl._kl_normal_normal: reduce_mode 0 =
+ * .sum(-1).mean() (policy_gradient.py:383-389), 1 = .mean() over all M x act_dim elements
+ * (natural_pg.py:95, trpo.py:113, cpo.py:133); the scalar lands in *kl_out (device).
+ * ws: at least 1024 doubles. */
+int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params, const float* obs,
+                 int ld_obs, long M, const float* old_mean, int ld_old, const float* old_log_std,
+                 int reduce_mode, float* mean_out, int ld_mean, double* ws, float* kl_out,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ c_f32p = C.c_void_p  # device pointers travel as integers
 c_ptr = C.c_void_p
 
 # name -> (restype, argtypes); mirrors include/omnisafe_amd.h one to one.
-_I, _L, _F, _D, _P = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p
+_I, _L, _F, _D, _P, _U = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p, C.c_ulonglong
 SIGNATURES: dict[str, tuple] = {
     'osa_strerror': (C.c_char_p, [_I]),
     'osa_version': (_I, []),
@@ -30,6 +30,14 @@ SIGNATURES: dict[str, tuple] = {
     'osa_adv_stats_phase2': (_I, [_P, _L, _P, _P, _P]),
     'osa_buffer_get': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                             _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'osa_mlp_layout': (_I, [_I, _I, _I, _P]),
+    'osa_policy_step': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _I, _I, _P, _I, _P, _P, _P, _P, _I,
+                             _P]),
+    'osa_minibatch_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_ppo_minibatch': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
+                               _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'osa_actor_kl': (_I, [_I, _I, _I, _P, _P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
 }
 
 

@@ -1,0 +1,189 @@
+// Device building blocks for the actor-critic MLPs (Linear-tanh-Linear-tanh-Linear, reference
+// omnisafe/utils/model.py:103-111) on gfx950 matrix cores.
+//
+// Everything is exact float32: v_mfma_f32_16x16x4_f32 is bit-for-bit an fmaf chain at the f32 vector
+// rate (157 TFLOP/s peak), so results differ from the reference's CPU sgemm only by summation order.
+//
+// Orientation.  All products are computed TRANSPOSED: H^T[out x samples] = W[out x in] . X^T[in x
+// samples].  With that choice the accumulator fragment of one layer IS the B-operand fragment of the
+// next layer, register for register, so activations never leave VGPRs between layers:
+//   MFMA 16x16x4:  A-frag lane l holds A[i = l&15][k = l>>4],  B-frag lane l holds B[k = l>>4][j = l&15],
+//                  D-frag lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3.
+// Within one 16-wide K block we permute K so that MFMA step s (0..3) of lane group g = l>>4 consumes
+// k = 4g + s.  A-fragments are then 4 CONTIGUOUS floats of a weight row (one 16-byte load), and the
+// D-fragment of the previous layer (rows 4g + r of lane group g) is exactly the 4 steps of the next
+// layer's B-fragment.  ("S layout": lane = sample, registers = 4 consecutive features.)
+//
+// Weight gradients contract over samples instead of features and need the transposed ("F layout":
+// lane = feature, registers = 4 consecutive samples) fragments; those go through LDS once.
+#pragma once
+#include "osa_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define OSA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Padded parameter block of one network (all offsets in floats, multiples of 16 -> 64-byte aligned):
+//   W1 [H][INP] | b1 [H] | W2 [H][H] | b2 [H] | W3 [OUTP][H] | b3 [OUTP] | log_std [OUTP]
+// INP = obs_dim rounded up to 16, OUTP = max(act_dim, 1) rounded up to 16.  Padding entries are zero
+// and stay zero (their gradients are identically zero).  The same block shape is used for the actor
+// and both critics (critics use row 0 of W3 / b3[0]; their log_std slot is unused).
+struct OsaNet {
+  int obs_dim, act_dim, H, INP, OUTP, KB;
+  int oW1, ob1, oW2, ob2, oW3, ob3, oLS, P;
+};
+
+__host__ __device__ inline OsaNet osa_make_net(int obs_dim, int act_dim, int H) {
+  OsaNet n;
+  n.obs_dim = obs_dim;
+  n.act_dim = act_dim;
+  n.H = H;
+  n.INP = (obs_dim + 15) / 16 * 16;
+  n.OUTP = ((act_dim > 1 ? act_dim : 1) + 15) / 16 * 16;
+  n.KB = n.INP / 16;
+  n.oW1 = 0;
+  n.ob1 = n.oW1 + H * n.INP;
+  n.oW2 = n.ob1 + H;
+  n.ob2 = n.oW2 + H * H;
+  n.oW3 = n.ob2 + H;
+  n.ob3 = n.oW3 + n.OUTP * H;
+  n.oLS = n.ob3 + n.OUTP;
+  n.P = n.oLS + n.OUTP;
+  return n;
+}
+
+__device__ __forceinline__ f32x4 osa_tanh4(f32x4 v) {
+  f32x4 r;
+  r.x = tanhf(v.x);
+  r.y = tanhf(v.y);
+  r.z = tanhf(v.z);
+  r.w = tanhf(v.w);
+  return r;
+}
+
+// X fragment (S layout): 4 consecutive input features [col0, col0+4) of this lane's sample row.
+// `row` may be nullptr (masked sample) -> zeros.  vec_ok: rows are 16-byte aligned and ld % 4 == 0.
+__device__ __forceinline__ f32x4 osa_load_x(const float* __restrict__ row, int col0, int obs_dim,
+                                            int ld, bool vec_ok) {
+  f32x4 x = {0.f, 0.f, 0.f, 0.f};
+  if (row == nullptr || col0 >= obs_dim) return x;
+  if (vec_ok && col0 + 4 <= ld) {
+    x = *reinterpret_cast<const f32x4*>(row + col0);
+    if (col0 + 1 >= obs_dim) x.y = 0.f;
+    if (col0 + 2 >= obs_dim) x.z = 0.f;
+    if (col0 + 3 >= obs_dim) x.w = 0.f;
+  } else {
+    x.x = row[col0];
+    if (col0 + 1 < obs_dim) x.y = row[col0 + 1];
+    if (col0 + 2 < obs_dim) x.z = row[col0 + 2];
+    if (col0 + 3 < obs_dim) x.w = row[col0 + 3];
+  }
+  return x;
+}
+
+// Forward pass of one network for the 16 samples owned by this wave.
+//   xrow : this lane's sample row (lane l -> sample l&15), nullptr if masked
+//   h1,h2: hidden activations, S layout, HT tiles of 16 features
+//   out  : output pre-activations, S layout, OT tiles (row 4g+r of tile o = output 16o+4g+r)
+template <int HT, int OT>
+__device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* __restrict__ p,
+                                                const float* __restrict__ xrow, int ld, bool vec_ok,
+                                                f32x4 (&h1)[HT], f32x4 (&h2)[HT], f32x4 (&out)[OT]) {
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int H = nd.H, INP = nd.INP;
+  const float* __restrict__ W1 = p + nd.oW1;
+  const float* __restrict__ W2 = p + nd.oW2;
+  const float* __restrict__ W3 = p + nd.oW3;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(p + nd.ob1 + 16 * t + 4 * g);
+  for (int kb = 0; kb < nd.KB; ++kb) {
+    const f32x4 x = osa_load_x(xrow, 16 * kb + 4 * g, nd.obs_dim, ld, vec_ok);
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 16 * kb + 4 * g);
+      h1[t] = OSA_MFMA(w.x, x.x, h1[t]);
+      h1[t] = OSA_MFMA(w.y, x.y, h1[t]);
+      h1[t] = OSA_MFMA(w.z, x.z, h1[t]);
+      h1[t] = OSA_MFMA(w.w, x.w, h1[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h1[t] = osa_tanh4(h1[t]);
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(p + nd.ob2 + 16 * t + 4 * g);
+#pragma unroll
+  for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (16 * t + i) * H + 16 * kb + 4 * g);
+      h2[t] = OSA_MFMA(w.x, h1[kb].x, h2[t]);
+      h2[t] = OSA_MFMA(w.y, h1[kb].y, h2[t]);
+      h2[t] = OSA_MFMA(w.z, h1[kb].z, h2[t]);
+      h2[t] = OSA_MFMA(w.w, h1[kb].w, h2[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h2[t] = osa_tanh4(h2[t]);
+#pragma unroll
+  for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(p + nd.ob3 + 16 * o + 4 * g);
+#pragma unroll
+  for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W3 + (16 * o + i) * H + 16 * kb + 4 * g);
+      out[o] = OSA_MFMA(w.x, h2[kb].x, out[o]);
+      out[o] = OSA_MFMA(w.y, h2[kb].y, out[o]);
+      out[o] = OSA_MFMA(w.z, h2[kb].z, out[o]);
+      out[o] = OSA_MFMA(w.w, h2[kb].w, out[o]);
+    }
+  }
+}
+
+// Sum over the 4 lane groups g (same sample j in lanes j, j+16, j+32, j+48).
+__device__ __forceinline__ float osa_sum_over_groups(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ---- Philox4x32-10 counter-based generator + Box-Muller (device-resident rollout noise) ------------
+__device__ __forceinline__ void osa_philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0;
+  c[1] = n1;
+  c[2] = n2;
+  c[3] = n3;
+}
+__device__ __forceinline__ void osa_philox(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo,
+                                           uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi,
+                   (uint32_t)(ctr_hi >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    osa_philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0];
+  out[1] = c[1];
+  out[2] = c[2];
+  out[3] = c[3];
+}
+__device__ __forceinline__ float osa_u01(uint32_t x) {  // (0, 1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+// two independent standard normals from two 32-bit words
+__device__ __forceinline__ void osa_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = osa_u01(a), u2 = osa_u01(b);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.28318530717958647692f * u2, &s, &c);
+  n0 = r * c;
+  n1 = r * s;
+}

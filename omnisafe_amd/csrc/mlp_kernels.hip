@@ -1,0 +1,737 @@
+// Actor-critic kernels on gfx950 matrix cores: rollout policy step (K1), PPO-Lag minibatch
+// forward/backward + gradient-norm clip + Adam (K9/K10), full-batch KL (K11).
+// See mlp_device.h for the fragment algebra.  One workgroup = 256 threads = 4 waves = 64 samples;
+// blockIdx.y selects the network (0 actor, 1 reward critic, 2 cost critic) so the three
+// independent networks of ConstraintActorCritic run concurrently in one launch.
+#include "mlp_device.h"
+
+#define OSA_SLD 68  // LDS leading dimension (floats) of the [feature][sample] transposed tiles
+#define OSA_NSTAT 16
+
+struct OsaHp {  // mirrors osa_ppo_hparams in include/omnisafe_amd.h
+  float clip, entropy_coef, critic_norm_coef, max_grad_norm;
+  float lr_actor, lr_critic, beta1, beta2, adam_eps;
+  int use_critic_norm, use_max_grad_norm, use_cost;
+};
+
+struct OsaMbArgs {
+  OsaNet nd;
+  float* params;   // [3][P]
+  float* adam_m;   // [3][P]
+  float* adam_v;   // [3][P]
+  int* adam_step;  // [3]
+  float* grads;    // [3][P]
+  const float* obs;
+  int ld_obs;
+  const float* act;
+  int ld_act;
+  const float* logp;
+  const float* tgt_r;
+  const float* tgt_c;
+  const float* adv_r;
+  const float* adv_c;
+  const long* idx;  // [B] sample rows, nullptr = identity
+  int B;
+  const float* lagrange;  // device scalar
+  OsaHp hp;
+  int mode;      // 0: grad + clip + Adam; 1: grad + clip only (all-reduce follows); 2: grad only
+  int nblk;      // row blocks per network
+  float* slabs;  // [3][nblk][P + OSA_NSTAT] partial gradients when nblk > 1
+  float* stats;  // [OSA_NSTAT] statistics of this optimiser step
+  int loss_kind; // 0 PPO clipped surrogate (base/ppo.py:66-78), 1 plain ratio*adv (policy_gradient.py:574)
+  int nets_mask; // bit0 actor, bit1 reward critic, bit2 cost critic
+};
+
+// ------------------------------------------------------------------------------------------------
+// K1  rollout policy step
+// ------------------------------------------------------------------------------------------------
+template <int HT, int OT>
+__global__ __launch_bounds__(256) void osa_policy_step_kernel(
+    OsaNet nd, const float* __restrict__ params, const float* __restrict__ obs, int ld, int N,
+    const float* __restrict__ eps, unsigned long long seed, unsigned long long offset,
+    int deterministic, int nets_mask, float* __restrict__ act, int ld_act,
+    float* __restrict__ value_r, float* __restrict__ value_c, float* __restrict__ logp,
+    float* __restrict__ mean_out, int ld_mean) {
+  const int net = blockIdx.y;
+  if (!((nets_mask >> net) & 1)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 64 + 16 * wave + j;
+  const bool valid = row < N;
+  const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+  const float* p = params + (long)net * nd.P;
+  f32x4 h1[HT], h2[HT], out[OT];
+  osa_mlp_forward<HT, OT>(nd, p, valid ? obs + row * ld : nullptr, ld, vec_ok, h1, h2, out);
+  if (net == 0) {
+    float lp = 0.f;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 16 * o + 4 * g + r;
+        if (d < nd.act_dim && valid) {
+          const float mu = out[o][r];
+          const float sd = expf(p[nd.oLS + d]);
+          float a = mu;
+          if (!deterministic) {
+            float e;
+            if (eps != nullptr) {
+              e = eps[row * nd.act_dim + d];
+            } else {
+              uint32_t w[4];
+              osa_philox(seed, offset, (unsigned long long)row * nd.act_dim + d, w);
+              float e1;
+              osa_box_muller(w[0], w[1], e, e1);
+            }
+            a = mu + e * sd;  // Normal.rsample: loc + eps * scale
+          }
+          if (act) act[row * ld_act + d] = a;
+          if (mean_out) mean_out[row * ld_mean + d] = mu;
+          // Normal.log_prob: -((v - loc)^2) / (2 var) - log(scale) - log(sqrt(2 pi))
+          const float z = a - mu;
+          lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+        }
+      }
+    }
+    lp = osa_sum_over_groups(lp);
+    if (g == 0 && valid && logp) logp[row] = lp;
+  } else {
+    float* __restrict__ dst = (net == 1) ? value_r : value_c;
+    if (g == 0 && valid && dst) dst[row] = out[0][0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9/K10  minibatch forward + backward (+ fused clip / Adam when one row block covers the batch)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float osa_block_sum_f(float v, float* red) {
+  // deterministic block-wide float sum (any multiple-of-64 block size up to 1024); result to all
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = osa_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    red[16] = s;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// Gradient finalisation for one network, executed by one whole workgroup:
+//   critic: g += 2*coef*p (the `param.pow(2).sum() * coef` term, policy_gradient.py:431-433)
+//   total_norm = ||g||_2; g *= min(1, max_norm / (total_norm + 1e-6))   (clip_grad_norm_, :437-441)
+//   Adam (torch.optim.Adam single-tensor step, bias-corrected), actor_critic.py:91-113
+// Reads/writes grads[net] in place.  mode 0: clip + Adam, 1: clip only, 2: nothing (raw grads),
+// 3: Adam only (gradients already clipped and averaged across ranks).
+__device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
+  const OsaNet& nd = a.nd;
+  const int P = nd.P;
+  float* __restrict__ p = a.params + (long)net * P;
+  float* __restrict__ gbuf = a.grads + (long)net * P;
+  const bool critic = net != 0;
+  const int mode = a.mode;
+  if (mode != 3) {
+    const bool l2 = critic && a.hp.use_critic_norm;
+    const float c2 = 2.f * a.hp.critic_norm_coef;
+    float gsq = 0.f, psq = 0.f;
+    for (int e = threadIdx.x; e < P; e += blockDim.x) {
+      float gv = gbuf[e];
+      const float pv = p[e];
+      if (critic && e >= nd.oLS) {  // critics have no log_std; keep the slot inert
+        gv = 0.f;
+      } else {
+        if (l2) gv += c2 * pv;
+        if (critic) psq += pv * pv;
+      }
+      gsq += gv * gv;
+      gbuf[e] = gv;
+    }
+    gsq = osa_block_sum_f(gsq, red);
+    psq = osa_block_sum_f(psq, red);
+    const float total_norm = sqrtf(gsq);
+    if (threadIdx.x == 0) {
+      a.stats[7 + net] = total_norm;
+      if (critic) a.stats[4 + net] = psq;  // [5] reward critic, [6] cost critic
+    }
+    if (mode == 2) return;
+    if (a.hp.use_max_grad_norm) {
+      float coef = a.hp.max_grad_norm / (total_norm + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+      for (int e = threadIdx.x; e < P; e += blockDim.x) gbuf[e] *= coef;
+    }
+    if (mode == 1) return;
+    __syncthreads();
+  }
+  // ---- Adam
+  const int step = a.adam_step[net] + 1;
+  const double b1 = a.hp.beta1, b2 = a.hp.beta2;
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, eps = a.hp.adam_eps;
+  float* __restrict__ m = a.adam_m + (long)net * P;
+  float* __restrict__ v = a.adam_v + (long)net * P;
+  for (int e = threadIdx.x; e < P; e += blockDim.x) {
+    const float gv = gbuf[e];
+    float mv = m[e], vv = v[e];
+    mv = mv + (gv - mv) * (1.f - beta1);              // exp_avg.lerp_(grad, 1 - beta1)
+    vv = vv * beta2 + (1.f - beta2) * gv * gv;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
+    p[e] = p[e] - step_size * (mv / denom);           // param.addcdiv_(exp_avg, denom, -step_size)
+    m[e] = mv;
+    v[e] = vv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.adam_step[net] = step;
+}
+
+template <int HT, int OT>
+__global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const OsaNet& nd = a.nd;
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  const int H = nd.H, INP = nd.INP, OUTP = nd.OUTP, P = nd.P;
+  float* sH1 = reinterpret_cast<float*>(smem_raw);    // [H][SLD]
+  float* sH2 = sH1 + H * OSA_SLD;                     // [H][SLD]
+  float* sZ1 = sH2 + H * OSA_SLD;                     // [H][SLD]  dL/d(pre-activation 1)
+  float* sZ2 = sZ1 + H * OSA_SLD;                     // [H][SLD]
+  float* sDO = sZ2 + H * OSA_SLD;                     // [OUTP][SLD]  dL/d(output)
+  float* sDL = sDO + OUTP * OSA_SLD;                  // [OUTP][SLD]  per-sample dL/d(log_std)
+  float* red = sDL + OUTP * OSA_SLD;                  // [32]
+  long* sIdx = reinterpret_cast<long*>(red + 32);     // [64] sample row or -1
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int i = j;  // the same lane bits index weight rows (A operand) and samples (B operand)
+  const float* __restrict__ p = a.params + (long)net * P;
+  const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
+  const float invB = 1.f / (float)a.B;
+  float* __restrict__ gout =
+      (a.nblk > 1) ? a.slabs + ((long)net * a.nblk + blockIdx.x) * (P + OSA_NSTAT) : a.grads + (long)net * P;
+  float lam = 0.f;
+  if (net == 0 && a.lagrange) lam = *a.lagrange;
+
+  float loss_acc = 0.f, ratio_acc = 0.f;  // per-lane partial sums over this block's chunks
+  const int nchunk = (a.B + 63) / 64;
+  bool first = true;
+  for (int chunk = blockIdx.x; chunk < nchunk; chunk += a.nblk, first = false) {
+    const int pos = chunk * 64 + 16 * wave + j;
+    const bool valid = pos < a.B;
+    const long row = valid ? (a.idx ? a.idx[pos] : (long)pos) : -1;
+    __syncthreads();  // previous chunk's LDS fully consumed
+    if (g == 0) sIdx[16 * wave + j] = row;
+
+    f32x4 h1[HT], h2[HT], out[OT];
+    osa_mlp_forward<HT, OT>(nd, p, valid ? a.obs + row * a.ld_obs : nullptr, a.ld_obs, vec_ok, h1, h2,
+                            out);
+    // ---- loss and dL/d(out), S layout
+    f32x4 dO[OT], dLS[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (net == 0) {
+      float lp = 0.f;
+      f32x4 zv[OT], ivar[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * o + 4 * g + r;
+          zv[o][r] = 0.f;
+          ivar[o][r] = 0.f;
+          if (d < nd.act_dim && valid) {
+            const float sd = expf(p[nd.oLS + d]);
+            const float var = sd * sd;
+            const float z = a.act[row * a.ld_act + d] - out[o][r];
+            zv[o][r] = z;
+            ivar[o][r] = 1.f / var;
+            lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+          }
+        }
+      }
+      lp = osa_sum_over_groups(lp);
+      if (valid) {
+        const float ratio = expf(lp - a.logp[row]);
+        // PPOLag surrogate advantage (ppo_lag.py:101-102)
+        const float adv = (a.adv_r[row] - lam * a.adv_c[row]) / (1.f + lam);
+        float dratio, li;
+        if (a.loss_kind == 0) {
+          const float lo = 1.f - a.hp.clip, hi = 1.f + a.hp.clip;
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float s1 = ratio * adv, s2 = rc * adv;
+          const bool inrange = ratio >= lo && ratio <= hi;
+          li = -fminf(s1, s2);
+          dratio = (s1 < s2 || inrange) ? -adv : 0.f;
+        } else {
+          li = -(ratio * adv);
+          dratio = -adv;
+        }
+        const float dlogp = dratio * ratio * invB;
+        if (g == 0) {
+          loss_acc += li;
+          ratio_acc += ratio;
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = zv[o][r], iv = ivar[o][r];
+            // d logp / d mu = z / var ; d logp / d log_std = z^2 / var - 1
+            dO[o][r] = dlogp * z * iv;
+            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) : 0.f;
+          }
+        }
+      }
+    } else if (valid) {
+      const float tgt = (net == 1 ? a.tgt_r : a.tgt_c)[row];
+      const float diff = out[0][0] - tgt;
+      if (g == 0) {
+        loss_acc += diff * diff;
+        dO[0][0] = 2.f * diff * invB;
+      }
+    }
+    // ---- backward through the hidden layers (S layout, activations stay in registers)
+    const float* __restrict__ W2 = p + nd.oW2;
+    const float* __restrict__ W3 = p + nd.oW3;
+    f32x4 z2[HT], z1[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
+          const float w = W3[(16 * o + 4 * g + s) * H + 16 * t + i];
+          acc = OSA_MFMA(w, dO[o][s], acc);
+        }
+      }
+      z2[t] = acc * (1.f - h2[t] * h2[t]);  // tanh'
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+          const float w = W2[(16 * kb + 4 * g + s) * H + 16 * t + i];
+          acc = OSA_MFMA(w, z2[kb][s], acc);
+        }
+      }
+      z1[t] = acc * (1.f - h1[t] * h1[t]);
+    }
+    // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f*SLD + c]
+    const int c = 16 * wave + j;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * g + r;
+        sH1[f * OSA_SLD + c] = h1[t][r];
+        sH2[f * OSA_SLD + c] = h2[t][r];
+        sZ1[f * OSA_SLD + c] = z1[t][r];
+        sZ2[f * OSA_SLD + c] = z2[t][r];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * o + 4 * g + r;
+        sDO[f * OSA_SLD + c] = dO[o][r];
+        sDL[f * OSA_SLD + c] = dLS[o][r];
+      }
+    }
+    __syncthreads();
+    // ---- weight gradients: contraction over the 64 samples of the chunk.
+    // D tile: lane (cc = l&15, g) holds dW[row 4g + r][col cc].
+    const int cc = j;
+    {  // dW2 row-tile `wave`, all HT column tiles;  dW1 row-tile `wave`, all KB column tiles
+      f32x4 a2[4], a1[4];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
+        a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
+      }
+      if (wave < HT) {
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+            const f32x4 b =
+                *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * OSA_SLD + 16 * sb + 4 * g);
+            acc = OSA_MFMA(a2[sb].x, b.x, acc);
+            acc = OSA_MFMA(a2[sb].y, b.y, acc);
+            acc = OSA_MFMA(a2[sb].z, b.z, acc);
+            acc = OSA_MFMA(a2[sb].w, b.w, acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = gout + nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+            *dst = first ? acc[r] : *dst + acc[r];
+          }
+        }
+        for (int kb = 0; kb < nd.KB; ++kb) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const int col = 16 * kb + cc;
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {  // B[k = sample 16sb+4g+s][j = input feature col]
+              const long rr = sIdx[16 * sb + 4 * g + s];
+              const float x = (rr >= 0 && col < nd.obs_dim) ? a.obs[rr * a.ld_obs + col] : 0.f;
+              acc = OSA_MFMA(a1[sb][s], x, acc);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = gout + nd.oW1 + (long)(16 * wave + 4 * g + r) * INP + col;
+            *dst = first ? acc[r] : *dst + acc[r];
+          }
+        }
+      }
+    }
+    // dW3: output tiles o x column tile `wave`
+    if (wave < HT) {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const f32x4 av =
+              *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * OSA_SLD + 16 * sb + 4 * g);
+          const f32x4 b =
+              *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
+          acc = OSA_MFMA(av.x, b.x, acc);
+          acc = OSA_MFMA(av.y, b.y, acc);
+          acc = OSA_MFMA(av.z, b.z, acc);
+          acc = OSA_MFMA(av.w, b.w, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = gout + nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+          *dst = first ? acc[r] : *dst + acc[r];
+        }
+      }
+    }
+    // bias / log_std gradients: one thread per feature sums its LDS row over the 64 samples
+    {
+      const int tid = threadIdx.x;
+      const float* srow = nullptr;
+      float* dst = nullptr;
+      if (tid < H) {
+        srow = sZ1 + tid * OSA_SLD;
+        dst = gout + nd.ob1 + tid;
+      } else if (tid < 2 * H) {
+        srow = sZ2 + (tid - H) * OSA_SLD;
+        dst = gout + nd.ob2 + (tid - H);
+      } else if (tid < 2 * H + OUTP) {
+        srow = sDO + (tid - 2 * H) * OSA_SLD;
+        dst = gout + nd.ob3 + (tid - 2 * H);
+      } else if (tid < 2 * H + 2 * OUTP) {
+        srow = sDL + (tid - 2 * H - OUTP) * OSA_SLD;
+        dst = gout + nd.oLS + (tid - 2 * H - OUTP);
+      }
+      if (dst) {
+        float s = 0.f;
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) s += srow[k];
+        *dst = first ? s : *dst + s;
+      }
+    }
+  }  // chunks
+  // ---- block-level loss statistics (deterministic order)
+  __syncthreads();
+  const float loss_sum = osa_block_sum_f(loss_acc, red);
+  const float ratio_sum = osa_block_sum_f(ratio_acc, red);
+  if (a.nblk > 1) {
+    if (threadIdx.x == 0) {
+      gout[P + 0] = loss_sum;
+      gout[P + 1] = ratio_sum;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    if (net == 0) {
+      float ent = 0.f;
+      for (int d = 0; d < nd.act_dim; ++d) ent += 1.41893853320467274178f + p[nd.oLS + d];
+      ent /= (float)nd.act_dim;
+      a.stats[2] = loss_sum * invB - a.hp.entropy_coef * ent;
+      a.stats[3] = ratio_sum * invB;
+      a.stats[4] = ent;
+    } else {
+      a.stats[net - 1] = loss_sum * invB;
+    }
+  }
+  if (net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < nd.act_dim)
+    gout[nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)nd.act_dim;
+  __syncthreads();
+  osa_finalize_net(a, net, red);
+}
+
+// Sum the per-block partial slabs into grads[net] (large-batch path), then finalize in a second launch.
+__global__ __launch_bounds__(256) void osa_slab_reduce_kernel(OsaMbArgs a) {
+  const OsaNet& nd = a.nd;
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = nd.P + OSA_NSTAT;
+  if (e >= W) return;
+  const float* s = a.slabs + (long)net * a.nblk * W + e;
+  float acc = 0.f;
+  for (int b = 0; b < a.nblk; ++b) acc += s[(long)b * W];
+  if (e < nd.P) {
+    a.grads[(long)net * nd.P + e] = acc;
+  } else {
+    const int k = e - nd.P;
+    const float invB = 1.f / (float)a.B;
+    if (net == 0) {
+      if (k == 0 || k == 1) {
+        // loss needs the entropy term; log_std is read directly
+        if (k == 0) {
+          float ent = 0.f;
+          const float* p = a.params;
+          for (int d = 0; d < nd.act_dim; ++d) ent += 1.41893853320467274178f + p[nd.oLS + d];
+          ent /= (float)nd.act_dim;
+          a.stats[2] = acc * invB - a.hp.entropy_coef * ent;
+          a.stats[4] = ent;
+        } else {
+          a.stats[3] = acc * invB;
+        }
+      }
+    } else if (k == 0) {
+      a.stats[net - 1] = acc * invB;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void osa_finalize_kernel(OsaMbArgs a, int add_entropy_grad) {
+  __shared__ float red[32];
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  if (add_entropy_grad && net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < a.nd.act_dim)
+    a.grads[a.nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)a.nd.act_dim;
+  __syncthreads();
+  osa_finalize_net(a, net, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11  full-batch KL(old || new), policy_gradient.py:383-389: kl_divergence(..).sum(-1).mean()
+//      (reduce_mode 0) or .mean() over all M x D_a elements (reduce_mode 1: natural_pg.py:95,
+//      trpo.py:113, cpo.py:133).  Also snapshots the mean (old distribution) when mean_out != null.
+// ------------------------------------------------------------------------------------------------
+template <int HT, int OT>
+__global__ __launch_bounds__(256) void osa_actor_kl_kernel(
+    OsaNet nd, const float* __restrict__ params, const float* __restrict__ obs, int ld, long M,
+    const float* __restrict__ old_mean, int ld_old, const float* __restrict__ old_log_std,
+    float* __restrict__ mean_out, int ld_mean, double* __restrict__ ws) {
+  __shared__ double red[17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+  double acc = 0.0;
+  for (long base = (long)blockIdx.x * 64; base < M; base += (long)gridDim.x * 64) {
+    const long row = base + 16 * wave + j;
+    const bool valid = row < M;
+    f32x4 h1[HT], h2[HT], out[OT];
+    osa_mlp_forward<HT, OT>(nd, params, valid ? obs + row * ld : nullptr, ld, vec_ok, h1, h2, out);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 16 * o + 4 * g + r;
+        if (d < nd.act_dim && valid) {
+          const float mu = out[o][r];
+          if (mean_out) mean_out[row * ld_mean + d] = mu;
+          if (old_mean) {
+            // torch _kl_normal_normal: 0.5 * (var_ratio + t1 - 1 - log(var_ratio))
+            const float ps = expf(old_log_std[d]), qs = expf(params[nd.oLS + d]);
+            const float vr = (ps / qs) * (ps / qs);
+            const float t1 = ((old_mean[row * ld_old + d] - mu) / qs);
+            acc += (double)(0.5f * (vr + t1 * t1 - 1.f - logf(vr)));
+          }
+        }
+      }
+    }
+  }
+  acc = osa_block_sum<256>(acc, red);
+  if (threadIdx.x == 0 && ws) ws[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void osa_kl_final_kernel(const double* __restrict__ ws, int nblk,
+                                                           double denom, float* __restrict__ out) {
+  __shared__ double red[17];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += ws[k];
+  s = osa_block_sum<256>(s, red);
+  if (threadIdx.x == 0) *out = (float)(s / denom);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static size_t osa_mb_lds_bytes(const OsaNet& nd) {
+  return (size_t)(4 * nd.H + 2 * nd.OUTP) * OSA_SLD * sizeof(float) + 32 * sizeof(float) +
+         64 * sizeof(long);
+}
+
+static int osa_check_dims(int obs_dim, int act_dim, int hidden) {
+  if (obs_dim < 1 || act_dim < 1) return OSA_EINVAL;
+  if (hidden != 64) return OSA_EUNSUPPORTED;   // hidden_sizes [64, 64] (all BASELINE configs)
+  if (act_dim > 32) return OSA_EUNSUPPORTED;
+  return OSA_OK;
+}
+
+#define OSA_DISPATCH_OT(nd, CALL)            \
+  do {                                       \
+    if ((nd).OUTP == 16) { CALL(4, 1); }     \
+    else { CALL(4, 2); }                     \
+  } while (0)
+
+extern "C" {
+
+int osa_mlp_layout(int obs_dim, int act_dim, int hidden, int* out12) {
+  OSA_REQUIRE(out12 != nullptr);
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  const OsaNet n = osa_make_net(obs_dim, act_dim, hidden);
+  const int v[12] = {n.INP, n.OUTP, n.oW1, n.ob1, n.oW2, n.ob2, n.oW3, n.ob3, n.oLS, n.P, n.H, n.KB};
+  for (int k = 0; k < 12; ++k) out12[k] = v[k];
+  return OSA_OK;
+}
+
+int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
+                    int ld_obs, int N, const float* eps, unsigned long long seed,
+                    unsigned long long offset, int deterministic, int nets_mask, float* act,
+                    int ld_act, float* value_r, float* value_c, float* logp, float* mean_out,
+                    int ld_mean, void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(params && obs && N > 0 && ld_obs >= obs_dim);
+  OSA_REQUIRE(!act || ld_act >= act_dim);
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  const dim3 grid((N + 63) / 64, 3);
+#define OSA_CALL(HT, OT)                                                                          \
+  hipLaunchKernelGGL((osa_policy_step_kernel<HT, OT>), grid, dim3(256), 0, osa_stream(stream), nd, \
+                     params, obs, ld_obs, N, eps, seed, offset, deterministic, nets_mask, act,    \
+                     ld_act, value_r, value_c, logp, mean_out, ld_mean)
+  OSA_DISPATCH_OT(nd, OSA_CALL);
+#undef OSA_CALL
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+size_t osa_minibatch_ws_floats(int obs_dim, int act_dim, int hidden, int max_blocks) {
+  if (osa_check_dims(obs_dim, act_dim, hidden) != OSA_OK || max_blocks < 1) return 0;
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  return (size_t)3 * max_blocks * (nd.P + OSA_NSTAT);
+}
+
+int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
+                      float* adam_v, int* adam_step, float* grads, const float* obs, int ld_obs,
+                      const float* act, int ld_act, const float* logp, const float* target_value_r,
+                      const float* target_value_c, const float* adv_r, const float* adv_c,
+                      const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
+                      int loss_kind, int mode, int nets_mask, int max_blocks, float* ws,
+                      float* step_stats, void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && grads && obs && act && logp && hp);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && step_stats && B > 0);
+  OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && mode >= 0 && mode <= 2);
+  OsaMbArgs a;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step; a.grads = grads;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.idx = idx; a.B = B; a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.mode = mode; a.stats = step_stats; a.loss_kind = loss_kind;
+  a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3);
+  const int nchunk = (B + 63) / 64;
+  int nblk = nchunk;
+  if (max_blocks < 1) max_blocks = 1;
+  if (nblk > max_blocks) nblk = max_blocks;
+  if (nblk > 1) OSA_REQUIRE(ws != nullptr);
+  a.nblk = nblk; a.slabs = ws;
+  const size_t lds = osa_mb_lds_bytes(a.nd);
+#define OSA_CALL(HT, OT)                                                                          \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=    \
+          hipSuccess)                                                                             \
+        return OSA_EHIP;                                                                          \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT>), dim3(nblk, 3), dim3(256), lds,               \
+                       osa_stream(stream), a);                                                    \
+  } while (0)
+  OSA_DISPATCH_OT(a.nd, OSA_CALL);
+#undef OSA_CALL
+  if (nblk > 1) {
+    const int W = a.nd.P + OSA_NSTAT;
+    hipLaunchKernelGGL(osa_slab_reduce_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
+                       osa_stream(stream), a);
+    hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 1);
+  }
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                   int* adam_step, float* grads, const osa_ppo_hparams* hp, int nets_mask,
+                   void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && grads && hp);
+  OsaMbArgs a = {};
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step; a.grads = grads;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps;
+  a.nets_mask = nets_mask;
+  a.mode = 3;
+  hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 0);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params, const float* obs,
+                 int ld_obs, long M, const float* old_mean, int ld_old, const float* old_log_std,
+                 int reduce_mode, float* mean_out, int ld_mean, double* ws, float* kl_out,
+                 void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(actor_params && obs && M > 0 && ld_obs >= obs_dim);
+  OSA_REQUIRE((old_mean == nullptr) || (old_log_std && ws && kl_out));
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  long nb = (M + 63) / 64;
+  if (nb > 1024) nb = 1024;
+#define OSA_CALL(HT, OT)                                                                          \
+  hipLaunchKernelGGL((osa_actor_kl_kernel<HT, OT>), dim3((unsigned)nb), dim3(256), 0,             \
+                     osa_stream(stream), nd, actor_params, obs, ld_obs, M, old_mean, ld_old,      \
+                     old_log_std, mean_out, ld_mean, ws)
+  OSA_DISPATCH_OT(nd, OSA_CALL);
+#undef OSA_CALL
+  if (old_mean) {
+    const double denom = reduce_mode == 0 ? (double)M : (double)M * act_dim;
+    hipLaunchKernelGGL(osa_kl_final_kernel, dim3(1), dim3(256), 0, osa_stream(stream), ws, (int)nb,
+                       denom, kl_out);
+  }
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+}  // extern "C"

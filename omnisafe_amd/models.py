@@ -1,0 +1,275 @@
+"""HBM-resident ConstraintActorCritic.
+
+Mirror of omnisafe/models/actor_critic/constraint_actor_critic.py:57-109 (+ actor_critic.py:60-136,
+models/actor/gaussian_learning_actor.py:29-139, models/critic/v_critic.py:40-92): a Gaussian MLP
+policy with state-independent log_std, a reward critic and a cost critic, each with an Adam optimiser,
+and a LinearLR/ConstantLR schedule on the actor.  Instead of three torch modules the three networks
+are three padded float32 blocks in ONE device tensor ``params[3][P]`` (layout: osa_mlp_layout), with
+Adam moments and gradients in tensors of the same shape; every forward / backward / optimiser step is
+a HIP kernel of libomnisafe_amd.  ``state_dict()`` of each network reproduces the reference's
+parameter names, shapes and order, so checkpoints (``torch_save/epoch-N.pt`` key ``pi``) stay loadable
+by the reference's Evaluator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spaces import is_box
+
+ACTOR, REWARD_CRITIC, COST_CRITIC = 0, 1, 2
+
+
+class HParams(C.Structure):
+    """ctypes mirror of ``osa_ppo_hparams`` (include/omnisafe_amd.h)."""
+
+    _fields_ = [('clip', C.c_float), ('entropy_coef', C.c_float), ('critic_norm_coef', C.c_float),
+                ('max_grad_norm', C.c_float), ('lr_actor', C.c_float), ('lr_critic', C.c_float),
+                ('beta1', C.c_float), ('beta2', C.c_float), ('adam_eps', C.c_float),
+                ('use_critic_norm', C.c_int), ('use_max_grad_norm', C.c_int), ('use_cost', C.c_int)]
+
+
+class Layout:
+    """Padded parameter block of one network + index maps to the reference tensor order."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden: int):
+        lib = _lib.load()
+        out = (C.c_int * 12)()
+        _lib.check(lib.osa_mlp_layout(obs_dim, act_dim, hidden, out), 'osa_mlp_layout')
+        (self.INP, self.OUTP, self.oW1, self.ob1, self.oW2, self.ob2, self.oW3, self.ob3, self.oLS,
+         self.P, self.H, self.KB) = list(out)
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+
+    def tensors(self, net: int) -> list[tuple[str, tuple[int, ...], np.ndarray]]:
+        """(name, shape, padded offsets) in the reference's ``named_parameters`` order: the actor
+        yields log_std first (its own Parameter precedes sub-modules), then mean.{0,2,4}.{weight,bias};
+        critics yield critic_0.{0,2,4}.{weight,bias}."""
+        H, D_o = self.H, self.obs_dim
+        out_dim = self.act_dim if net == ACTOR else 1
+        prefix = 'mean' if net == ACTOR else 'critic_0'
+
+        def mat(off, rows, cols, ld):
+            return (off + np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]).reshape(-1)
+
+        items = []
+        if net == ACTOR:
+            items.append(('log_std', (self.act_dim,), self.oLS + np.arange(self.act_dim)))
+        items += [
+            (f'{prefix}.0.weight', (H, D_o), mat(self.oW1, H, D_o, self.INP)),
+            (f'{prefix}.0.bias', (H,), self.ob1 + np.arange(H)),
+            (f'{prefix}.2.weight', (H, H), mat(self.oW2, H, H, H)),
+            (f'{prefix}.2.bias', (H,), self.ob2 + np.arange(H)),
+            (f'{prefix}.4.weight', (out_dim, H), mat(self.oW3, out_dim, H, H)),
+            (f'{prefix}.4.bias', (out_dim,), self.ob3 + np.arange(out_dim)),
+        ]
+        return items
+
+
+class NetView:
+    """One network of the actor-critic: reference-shaped access to its padded parameter block."""
+
+    def __init__(self, owner: 'ConstraintActorCritic', net: int):
+        self._o, self._net = owner, net
+        items = owner.layout.tensors(net)
+        self._items = items
+        self._flat_index = torch.from_numpy(np.concatenate([ix for _, _, ix in items])).to(owner.device)
+
+    @property
+    def num_params(self) -> int:
+        return int(self._flat_index.numel())
+
+    def _block(self, which: str = 'params') -> torch.Tensor:
+        return getattr(self._o, which)[self._net]
+
+    def flat_params(self) -> torch.Tensor:
+        """get_flat_params_from (omnisafe/utils/tools.py:35-65): reference-ordered flat vector."""
+        return self._block('params')[self._flat_index]
+
+    def flat_grads(self) -> torch.Tensor:
+        """get_flat_gradients_from (tools.py:68-91)."""
+        return self._block('grads')[self._flat_index]
+
+    def set_flat_params(self, vals: torch.Tensor) -> None:
+        """set_param_values_to_model (tools.py:94-129)."""
+        assert vals.numel() == self.num_params
+        self._block('params')[self._flat_index] = vals.to(self._o.device, torch.float32)
+
+    def pad(self, flat_ref: torch.Tensor) -> torch.Tensor:
+        """Reference-ordered flat vector -> padded block vector (zeros in the padding)."""
+        out = torch.zeros(self._o.layout.P, dtype=torch.float32, device=self._o.device)
+        out[self._flat_index] = flat_ref.to(self._o.device, torch.float32)
+        return out
+
+    def unpad(self, padded: torch.Tensor) -> torch.Tensor:
+        return padded[self._flat_index]
+
+    def state_dict(self) -> 'OrderedDict[str, torch.Tensor]':
+        flat = self.flat_params()
+        sd, i = OrderedDict(), 0
+        for name, shape, ix in self._items:
+            sd[name] = flat[i:i + len(ix)].reshape(shape).clone()
+            i += len(ix)
+        return sd
+
+    def load_state_dict(self, sd) -> None:
+        parts = []
+        for name, shape, _ in self._items:
+            t = torch.as_tensor(sd[name], dtype=torch.float32)
+            assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), shape)
+            parts.append(t.reshape(-1))
+        self.set_flat_params(torch.cat(parts))
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    @property
+    def std(self) -> float:
+        """GaussianLearningActor.std (gaussian_learning_actor.py:131-134)."""
+        assert self._net == ACTOR
+        lay = self._o.layout
+        return float(torch.exp(self._block()[lay.oLS:lay.oLS + lay.act_dim]).mean())
+
+    @property
+    def log_std(self) -> torch.Tensor:
+        lay = self._o.layout
+        return self._block()[lay.oLS:lay.oLS + lay.act_dim]
+
+
+class _ActorSchedule:
+    """LinearLR(start_factor=1, end_factor=0, total_iters=epochs) / ConstantLR(factor=1)
+    (actor_critic.py:99-113), closed form."""
+
+    def __init__(self, base_lr: float, epochs: int, linear: bool):
+        self.base_lr, self.epochs, self.linear, self.k = base_lr, max(int(epochs), 1), linear, 0
+
+    def step(self) -> None:
+        self.k += 1
+
+    def get_last_lr(self) -> list[float]:
+        if not self.linear:
+            return [self.base_lr]
+        return [self.base_lr * (1.0 - min(self.k, self.epochs) / self.epochs)]
+
+
+class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
+    """``ConstraintActorCritic(obs_space, act_space, model_cfgs, epochs)`` on the device.
+
+    ``model_cfgs`` needs: actor.hidden_sizes/activation/lr, critic.hidden_sizes/activation/lr,
+    weight_initialization_mode, actor_type, linear_lr_decay (attribute access, like the reference's
+    Config)."""
+
+    def __init__(self, obs_space, act_space, model_cfgs, epochs: int, device='cuda:0') -> None:
+        if not is_box(obs_space) or not is_box(act_space):
+            raise NotImplementedError  # models/base.py:66-74
+        self._lib = _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        self.obs_dim, self.act_dim = int(obs_space.shape[0]), int(act_space.shape[0])
+        a_h, c_h = list(model_cfgs.actor.hidden_sizes), list(model_cfgs.critic.hidden_sizes)
+        if a_h != c_h or len(a_h) != 2 or a_h[0] != a_h[1]:
+            raise NotImplementedError(f'hidden_sizes {a_h}/{c_h}: omnisafe_amd supports [H, H] for both')
+        if model_cfgs.actor.activation != 'tanh' or model_cfgs.critic.activation != 'tanh':
+            raise NotImplementedError('omnisafe_amd kernels implement tanh MLPs (every on-policy YAML default)')
+        if getattr(model_cfgs, 'actor_type', 'gaussian_learning') != 'gaussian_learning':
+            raise NotImplementedError('only actor_type gaussian_learning is on the accelerated path')
+        self.hidden = int(a_h[0])
+        self.layout = Layout(self.obs_dim, self.act_dim, self.hidden)
+        P = self.layout.P
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(3, P, **f32)
+        self.adam_m = torch.zeros(3, P, **f32)
+        self.adam_v = torch.zeros(3, P, **f32)
+        self.grads = torch.zeros(3, P, **f32)
+        self.adam_step = torch.zeros(3, dtype=torch.int32, device=self.device)
+        self.actor = NetView(self, ACTOR)
+        self.reward_critic = NetView(self, REWARD_CRITIC)
+        self.cost_critic = NetView(self, COST_CRITIC)
+        self._init_parameters(getattr(model_cfgs, 'weight_initialization_mode', 'kaiming_uniform'))
+        self.actor_lr = model_cfgs.actor.lr
+        self.critic_lr = model_cfgs.critic.lr
+        if self.actor_lr is not None:
+            self.actor_scheduler = _ActorSchedule(float(self.actor_lr), epochs,
+                                                  bool(getattr(model_cfgs, 'linear_lr_decay', True)))
+        self._rng_offset = 0
+        self.seed = 0
+
+    # ------------------------------------------------------------------ init
+    def _init_parameters(self, mode: str) -> None:
+        """Same construction order and initialisers as the reference so that an identical torch seed
+        yields identical initial weights: actor mean layers, reward critic, cost critic; each
+        nn.Linear default-initialised then kaiming_uniform_(a=sqrt(5)) on the weight
+        (omnisafe/utils/model.py:25-45,103-111).  Runs once on the host (plumbing, not hot path)."""
+        def mlp_state(sizes, prefix):
+            sd = OrderedDict()
+            for j in range(len(sizes) - 1):
+                lin = torch.nn.Linear(sizes[j], sizes[j + 1])
+                if mode == 'kaiming_uniform':
+                    torch.nn.init.kaiming_uniform_(lin.weight, a=math.sqrt(5))
+                elif mode == 'xavier_normal':
+                    torch.nn.init.xavier_normal_(lin.weight)
+                elif mode in ('glorot', 'xavier_uniform'):
+                    torch.nn.init.xavier_uniform_(lin.weight)
+                elif mode == 'orthogonal':
+                    torch.nn.init.orthogonal_(lin.weight, gain=math.sqrt(2))
+                else:
+                    raise TypeError(f'Invalid initialization function: {mode}')
+                sd[f'{prefix}.{2 * j}.weight'] = lin.weight.detach()
+                sd[f'{prefix}.{2 * j}.bias'] = lin.bias.detach()
+            return sd
+
+        H = self.hidden
+        sd = mlp_state([self.obs_dim, H, H, self.act_dim], 'mean')
+        sd['log_std'] = torch.zeros(self.act_dim)
+        self.actor.load_state_dict(sd)
+        self.reward_critic.load_state_dict(mlp_state([self.obs_dim, H, H, 1], 'critic_0'))
+        self.cost_critic.load_state_dict(mlp_state([self.obs_dim, H, H, 1], 'critic_0'))
+
+    # ------------------------------------------------------------------ rollout step
+    def step(self, obs: torch.Tensor, deterministic: bool = False, eps: torch.Tensor | None = None,
+             out: dict | None = None, nets_mask: int = 7):
+        """constraint_actor_critic.py:84-109: ``(act, value_r, value_c, logp)`` for a batch (N, D_o) or a
+        single row (D_o,).  ``eps`` injects the standard-normal noise (tests); ``out`` may provide
+        pre-allocated destination tensors (e.g. rows of the rollout buffer)."""
+        single = obs.dim() == 1
+        x = obs.reshape(-1, self.obs_dim).to(self.device, torch.float32)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        N = x.shape[0]
+        o = out or {}
+        f32 = dict(dtype=torch.float32, device=self.device)
+        act = o.get('act') if 'act' in o else torch.empty(N, self.act_dim, **f32)
+        v_r = o.get('value_r') if 'value_r' in o else torch.empty(N, **f32)
+        v_c = o.get('value_c') if 'value_c' in o else torch.empty(N, **f32)
+        logp = o.get('logp') if 'logp' in o else torch.empty(N, **f32)
+        e = None
+        if eps is not None:
+            e = eps.reshape(N, self.act_dim).to(self.device, torch.float32).contiguous()
+        self._rng_offset += 1
+        _lib.check(self._lib.osa_policy_step(
+            self.obs_dim, self.act_dim, self.hidden, _lib.ptr(self.params), _lib.ptr(x), x.stride(0), N,
+            _lib.ptr(e), self.seed, self._rng_offset, int(deterministic), nets_mask, _lib.ptr(act),
+            self.act_dim, _lib.ptr(v_r), _lib.ptr(v_c), _lib.ptr(logp), None, 0, _lib.stream_ptr()),
+            'osa_policy_step')
+        if single:
+            return act[0], v_r[0], v_c[0], logp[0]
+        return act, v_r, v_c, logp
+
+    def values(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """Critic values only (bootstrap V(s) at truncation / epoch end)."""
+        _, v_r, v_c, _ = self.step(obs, deterministic=True, nets_mask=6)
+        return v_r, v_c
+
+    def set_seed(self, seed: int) -> None:
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------ distributed
+    def sync_params(self) -> None:
+        """distributed.sync_params (omnisafe/utils/distributed.py:201-228): broadcast rank 0's
+        parameters -- one message for all three networks."""
+        from . import distributed as dist
+
+        dist.broadcast_(self.params, src=0)

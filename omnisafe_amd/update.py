@@ -1,0 +1,161 @@
+"""Minibatch update loop of PolicyGradient._update on the device.
+
+Restates the control flow of omnisafe/algorithms/on_policy/base/policy_gradient.py:345-405 --
+``update_iters`` passes over shuffled minibatches, reward-critic / cost-critic / actor step per
+minibatch, full-batch KL(old || new) after each pass with optional early stop -- with every step of
+arithmetic inside libomnisafe_amd kernels:
+
+  * one launch per minibatch updates all three networks (osa_ppo_minibatch), instead of the
+    reference's ~180 torch kernels + 3 ``.item()`` host syncs;
+  * per-step statistics (losses, mean ratio, ...) stay on the device and are reduced once per epoch;
+  * the only host synchronisation is the KL scalar once per pass when ``kl_early_stop`` is on.
+
+Data parallelism (world_size > 1): local gradient-norm clip, then ONE flat all-reduce of the three
+networks' gradients, then Adam (clip-then-average order of policy_gradient.py:437-442).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import distributed as dist
+from .models import ConstraintActorCritic, HParams
+
+NSTAT = 16
+
+
+class PPOUpdater:  # pylint: disable=too-many-instance-attributes
+    def __init__(self, ac: ConstraintActorCritic, *, batch_size: int, update_iters: int,
+                 target_kl: float, kl_early_stop: bool, clip: float = 0.2, entropy_coef: float = 0.0,
+                 use_critic_norm: bool = True, critic_norm_coef: float = 0.001,
+                 use_max_grad_norm: bool = True, max_grad_norm: float = 40.0, use_cost: bool = True,
+                 loss_kind: int = 0, max_blocks: int = 256, update_actor: bool = True) -> None:
+        self.ac = ac
+        self.lib = _lib.load(require_gpu=True)
+        self.batch_size, self.update_iters = int(batch_size), int(update_iters)
+        self.target_kl, self.kl_early_stop = float(target_kl), bool(kl_early_stop)
+        self.loss_kind = loss_kind
+        self.update_actor = update_actor
+        self.hp = HParams(clip=clip, entropy_coef=entropy_coef, critic_norm_coef=critic_norm_coef,
+                          max_grad_norm=max_grad_norm, lr_actor=0.0, lr_critic=0.0, beta1=0.9,
+                          beta2=0.999, adam_eps=1e-8, use_critic_norm=int(use_critic_norm),
+                          use_max_grad_norm=int(use_max_grad_norm), use_cost=int(use_cost))
+        self.max_blocks = int(max_blocks)
+        dev = ac.device
+        nws = self.lib.osa_minibatch_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, self.max_blocks)
+        self._ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dev)
+        self._kl_ws = torch.empty(1024, dtype=torch.float64, device=dev)
+        self._kl = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._old_mean: torch.Tensor | None = None
+        self._old_log_std = torch.zeros(ac.layout.OUTP, dtype=torch.float32, device=dev)
+        self._stats: torch.Tensor | None = None
+
+    # ------------------------------------------------------------------
+    def _nets_mask(self) -> int:
+        m = 0b110 if self.hp.use_cost else 0b010
+        return m | (1 if self.update_actor else 0)
+
+    def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
+                  stats_row: torch.Tensor) -> None:
+        ac, lib, st = self.ac, self.lib, _lib.stream_ptr()
+        ws = dist.world_size()
+        mode = 0 if ws == 1 else 1
+        _lib.check(lib.osa_ppo_minibatch(
+            ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+            _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']),
+            data['obs'].stride(0), _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+            _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+            _lib.ptr(data['adv_c']), _lib.ptr(idx), B, _lib.ptr(lagrange), C.byref(self.hp),
+            self.loss_kind, mode, self._nets_mask(), self.max_blocks, _lib.ptr(self._ws),
+            _lib.ptr(stats_row), st), 'osa_ppo_minibatch')
+        if ws > 1:
+            dist.all_reduce_avg_(ac.grads)  # C1: one flat message for pi, V_r, V_c
+            _lib.check(lib.osa_adam_apply(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params),
+                                          _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+                                          _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), C.byref(self.hp),
+                                          self._nets_mask(), st), 'osa_adam_apply')
+
+    def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
+        """old_distribution = actor(obs) (policy_gradient.py:357)."""
+        ac, M = self.ac, obs.shape[0]
+        if self._old_mean is None or self._old_mean.shape[0] != M:
+            self._old_mean = torch.empty(M, ac.act_dim, dtype=torch.float32, device=ac.device)
+        _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
+                                         _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0,
+                                         _lib.ptr(self._old_mean), ac.act_dim, None, None,
+                                         _lib.stream_ptr()), 'osa_actor_kl(snapshot)')
+        lay = ac.layout
+        self._old_log_std[:lay.act_dim].copy_(ac.params[0, lay.oLS:lay.oLS + lay.act_dim])
+
+    def kl(self, obs: torch.Tensor, reduce_mode: int = 0) -> torch.Tensor:
+        """Device scalar KL(old || new), rank-averaged (dist_avg, policy_gradient.py:390)."""
+        ac, M = self.ac, obs.shape[0]
+        _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
+                                         _lib.ptr(obs), obs.stride(0), M, _lib.ptr(self._old_mean),
+                                         ac.act_dim, _lib.ptr(self._old_log_std), reduce_mode, None, 0,
+                                         _lib.ptr(self._kl_ws), _lib.ptr(self._kl), _lib.stream_ptr()),
+                   'osa_actor_kl')
+        dist.all_reduce_avg_(self._kl)
+        return self._kl
+
+    # ------------------------------------------------------------------
+    def run(self, data: dict, lagrange: torch.Tensor, perms=None, actor_lr: float | None = None,
+            critic_lr: float | None = None) -> dict:
+        """One call of PolicyGradient._update after ``data = buf.get()``.  ``perms`` (optional, list of
+        update_iters index tensors) injects the minibatch order for parity tests; by default a fresh
+        device permutation is drawn per pass (DataLoader(shuffle=True), policy_gradient.py:359-363)."""
+        ac = self.ac
+        self.hp.lr_actor = float(actor_lr if actor_lr is not None else (ac.actor_lr or 0.0))
+        self.hp.lr_critic = float(critic_lr if critic_lr is not None else ac.critic_lr)
+        obs = data['obs']
+        M, B = obs.shape[0], self.batch_size
+        nmb = (M + B - 1) // B
+        total = self.update_iters * nmb
+        if self._stats is None or self._stats.shape[0] < total:
+            self._stats = torch.zeros(total, NSTAT, dtype=torch.float32, device=ac.device)
+        stats = self._stats
+        if self.update_actor:
+            self.snapshot_old_distribution(obs)
+        update_counts, final_kl, step = 0, 0.0, 0
+        kl_dev = None
+        for i in range(self.update_iters):
+            if perms is not None:
+                perm = torch.as_tensor(perms[i]).to(ac.device, torch.int64)
+            else:
+                perm = torch.randperm(M, device=ac.device)
+            for s in range(0, M, B):
+                nb = min(B, M - s)
+                self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
+                step += 1
+            update_counts += 1
+            if self.update_actor:
+                kl_dev = self.kl(obs)
+                if self.kl_early_stop:
+                    final_kl = float(kl_dev)  # the one host sync per pass
+                    if final_kl > self.target_kl:
+                        break
+        used = stats[:step]
+        out = {'stop_iter': update_counts, 'steps': step, 'stats': used}
+        if self.update_actor:
+            out['kl'] = float(kl_dev) if kl_dev is not None else final_kl
+        return out
+
+    @staticmethod
+    def summarize(run_out: dict, critic_norm_coef: float, use_critic_norm: bool) -> dict:
+        """Per-key means over the optimiser steps of the epoch (what Logger.get_stats averages,
+        omnisafe/common/logger.py:359-374), from ONE device->host copy."""
+        s = run_out['stats'].double().cpu()
+        coef = critic_norm_coef if use_critic_norm else 0.0
+        loss_r = s[:, 0] + coef * s[:, 5]
+        loss_c = s[:, 1] + coef * s[:, 6]
+        return {
+            'Loss/Loss_reward_critic': float(loss_r.mean()), 'Loss/Loss_cost_critic': float(loss_c.mean()),
+            'Loss/Loss_pi': float(s[:, 2].mean()), 'Train/PolicyRatio': float(s[:, 3].mean()),
+            'Train/PolicyRatio/Min': float(s[:, 3].min()), 'Train/PolicyRatio/Max': float(s[:, 3].max()),
+            'Train/PolicyRatio/Std': float(s[:, 3].std(unbiased=False)) if len(s) > 1 else 0.0,
+            'Train/Entropy': float(s[:, 4].mean()),
+            'per_step': {'loss_r': loss_r.numpy(), 'loss_c': loss_c.numpy(), 'loss_pi': s[:, 2].numpy(),
+                         'ratio_mean': s[:, 3].numpy(), 'entropy': s[:, 4].numpy()},
+        }

@@ -1,0 +1,238 @@
+"""GPU parity of the matrix-core actor-critic kernels against the reference's golden vectors and the
+oracle.  Floating-point tolerances (float32 MFMA fma-chains vs the reference's CPU sgemm):
+  forward (act / value / logp):           rtol 1e-4, atol 1e-5
+  one optimiser step (loss, params):      rtol 1e-4, atol 1e-6   
+  parameters after 9 chained Adam steps:  atol 5e-6 on values of magnitude <= 1 (Adam's
+  m/sqrt(v) normalisation turns 1e-7 gradient noise into ~1e-3*lr parameter noise per step)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def model_cfgs(lr=3e-4):
+    ns = types.SimpleNamespace
+    return ns(actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr),
+              critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr),
+              weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
+              linear_lr_decay=True)
+
+
+def make_ac(obs_dim, act_dim, g=None, prefix='', epochs=4):
+    from omnisafe_amd.models import ConstraintActorCritic
+    from omnisafe_amd.spaces import Box
+
+    ac = ConstraintActorCritic(Box(-np.inf, np.inf, (obs_dim,)), Box(-1, 1, (act_dim,)), model_cfgs(),
+                               epochs, device=DEV)
+    if g is not None:
+        for net in ('actor', 'reward_critic', 'cost_critic'):
+            sd = {k[len(prefix) + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
+                  if k.startswith(f'{prefix}{net}/')}
+            getattr(ac, net).load_state_dict(sd)
+    return ac
+
+
+def test_state_dict_roundtrip_and_order(golden):
+    g = golden('actor_critic_step.npz')
+    ac = make_ac(60, 2, g)
+    sd = ac.actor.state_dict()
+    assert list(sd) == ['log_std', 'mean.0.weight', 'mean.0.bias', 'mean.2.weight', 'mean.2.bias',
+                        'mean.4.weight', 'mean.4.bias']
+    for k, v in sd.items():
+        assert np.array_equal(v.cpu().numpy(), g[f'actor/{k}'])
+    assert list(ac.reward_critic.state_dict())[0] == 'critic_0.0.weight'
+    assert ac.actor.num_params == 8196 and ac.reward_critic.num_params == 8129
+    flat = ac.actor.flat_params()
+    ref = np.concatenate([g[f'actor/{k}'].reshape(-1) for k in sd])
+    assert np.array_equal(flat.cpu().numpy(), ref)
+    # padding stays zero
+    total = float(ac.params.abs().sum())
+    only = sum(float(getattr(ac, n).flat_params().abs().sum()) for n in ('actor', 'reward_critic', 'cost_critic'))
+    assert abs(total - only) < 1e-3 * total
+
+
+def test_same_seed_same_init_as_oracle_construction():
+    """Identical torch seed -> identical initial weights as the reference's module construction order
+    (actor, reward critic, cost critic)."""
+    torch.manual_seed(123)
+    ac = make_ac(60, 2)
+    torch.manual_seed(123)
+    ref = O.ActorCritic(60, 2)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        a, b = getattr(ac, net).state_dict(), getattr(ref, net).state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert np.array_equal(a[k].cpu().numpy(), b[k].numpy()), (net, k)
+
+
+def test_policy_step_vs_reference(golden):
+    g = golden('actor_critic_step.npz')
+    ac = make_ac(60, 2, g)
+    obs = torch.from_numpy(g['obs']).to(DEV)
+    act, v_r, v_c, logp = ac.step(obs, eps=torch.from_numpy(g['eps']).to(DEV))
+    np.testing.assert_allclose(act.cpu().numpy(), g['act'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(v_r.cpu().numpy(), g['value_r'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(v_c.cpu().numpy(), g['value_c'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), g['logp'], rtol=1e-4, atol=1e-5)
+    a_det, _, _, lp_det = ac.step(obs, deterministic=True)
+    np.testing.assert_allclose(a_det.cpu().numpy(), g['act_det'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lp_det.cpu().numpy(), g['logp_det'], rtol=1e-4, atol=1e-5)
+    # single-row call (bootstrap path of the adapter)
+    a1, vr1, vc1, _ = ac.step(obs[5], deterministic=True)
+    np.testing.assert_allclose(vr1.cpu().numpy(), g['value_r'][5], rtol=1e-4, atol=1e-5)
+    assert a1.shape == (2,)
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,N', [(60, 2, 4096), (27, 8, 100), (376, 17, 130), (72, 2, 1),
+                                               (5, 1, 64)])
+def test_policy_step_vs_oracle_shapes(obs_dim, act_dim, N):
+    """BASELINE config shapes (PointGoal1 60/2, Ant 27/8, Humanoid 376/17, CarGoal1 72/2) incl. obs_dim
+    not a multiple of 4 or 16, act_dim > 16 (two output tiles), ragged N."""
+    torch.manual_seed(obs_dim * 7 + act_dim)
+    ref = O.ActorCritic(obs_dim, act_dim)
+    ac = make_ac(obs_dim, act_dim)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ac, net).load_state_dict(getattr(ref, net).state_dict())
+    with torch.no_grad():
+        ref.actor.log_std.copy_(torch.linspace(-0.5, 0.3, act_dim))
+    ac.actor.load_state_dict(ref.actor.state_dict())
+    obs = torch.randn(N, obs_dim)
+    eps = torch.randn(N, act_dim)
+    act, v_r, v_c, logp = ref.step(obs, eps=eps)
+    a2, r2, c2, l2 = ac.step(obs.to(DEV), eps=eps.to(DEV))
+    np.testing.assert_allclose(a2.cpu().numpy(), act.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(r2.cpu().numpy(), v_r.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(c2.cpu().numpy(), v_c.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l2.cpu().numpy(), logp.numpy(), rtol=1e-4, atol=5e-5)
+
+
+def test_device_noise_is_standard_normal():
+    ac = make_ac(60, 2)
+    ac.set_seed(7)
+    obs = torch.zeros(65536, 60, device=DEV)
+    with torch.no_grad():
+        a1, _, _, lp = ac.step(obs)
+        mean_det, _, _, _ = ac.step(obs, deterministic=True)
+        a2, _, _, _ = ac.step(obs)
+    e = (a1 - mean_det).double()  # log_std = 0 -> act - mean = eps
+    assert abs(float(e.mean())) < 0.02 and abs(float(e.std()) - 1.0) < 0.02
+    assert abs(float((e ** 4).mean()) - 3.0) < 0.2  # kurtosis of a normal
+    assert not torch.equal(a1, a2)  # the counter advances between calls
+    # logp is consistent with the sampled action
+    ref_lp = (-0.5 * e ** 2 - 0.9189385332).sum(-1)
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _update_data(g, dev=DEV):
+    a_r, a_c, _ = O.buffer_get(g['buffer/adv_r'], g['buffer/adv_c'])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    d = {'obs': t(O.env_major(g['buffer/obs'])), 'act': t(O.env_major(g['buffer/act'])),
+         'logp': t(O.env_major(g['buffer/logp'])),
+         'target_value_r': t(O.env_major(g['buffer/target_value_r'])),
+         'target_value_c': t(O.env_major(g['buffer/target_value_c'])), 'adv_r': t(a_r), 'adv_c': t(a_c)}
+    return d, {k: v.to(dev) for k, v in d.items()}
+
+
+def test_single_minibatch_step_vs_oracle(golden):
+    """One optimiser step of all three networks: losses, clipped gradients' effect, post-Adam params."""
+    from omnisafe_amd.update import PPOUpdater
+
+    g = golden('ppolag_epoch.npz')
+    cpu, dev = _update_data(g)
+    ac = make_ac(60, 2, g, 'init/')
+    ref = O.ActorCritic(60, 2)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ref, net).load_state_dict({k: v.cpu() for k, v in getattr(ac, net).state_dict().items()})
+    lam = 0.37
+    idx = torch.from_numpy(g['update/perms'][0][:64].copy())
+    lr_, lc_, lp_ = [], [], []
+    lr_.append(O.critic_step(ref.reward_critic, ref.reward_critic_optimizer, cpu['obs'][idx],
+                             cpu['target_value_r'][idx]))
+    lc_.append(O.critic_step(ref.cost_critic, ref.cost_critic_optimizer, cpu['obs'][idx],
+                             cpu['target_value_c'][idx]))
+    lp, ent, ratio = O.actor_step(ref.actor, ref.actor_optimizer, cpu['obs'][idx], cpu['act'][idx],
+                                  cpu['logp'][idx], cpu['adv_r'][idx], cpu['adv_c'][idx], lam)
+    up = PPOUpdater(ac, batch_size=64, update_iters=1, target_kl=0.02, kl_early_stop=False)
+    up.hp.lr_actor = up.hp.lr_critic = 3e-4
+    stats = torch.zeros(16, device=DEV)
+    up.minibatch(dev, idx.to(DEV), 64, torch.tensor([lam], device=DEV), stats)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[0] + 0.001 * s[5], lr_[0], rtol=1e-4)
+    np.testing.assert_allclose(s[1] + 0.001 * s[6], lc_[0], rtol=1e-4)
+    np.testing.assert_allclose(s[2], lp, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s[3], float(ratio.mean()), rtol=1e-5)
+    np.testing.assert_allclose(s[4], ent, rtol=1e-6)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), getattr(ref, net).state_dict()[k].numpy(),
+                                       rtol=1e-4, atol=1e-6, err_msg=f'{net}/{k}')
+    assert ac.adam_step.cpu().tolist() == [1, 1, 1]
+
+
+def test_ppolag_update_vs_reference(golden):
+    """Whole PolicyGradient._update (3 passes x 3 minibatches incl. a ragged last one of 32 rows) from
+    the reference's initial parameters, buffer contents and recorded permutations."""
+    from omnisafe_amd.update import PPOUpdater
+
+    g = golden('ppolag_epoch.npz')
+    _, dev = _update_data(g)
+    ac = make_ac(60, 2, g, 'init/')
+    up = PPOUpdater(ac, batch_size=64, update_iters=3, target_kl=0.02, kl_early_stop=False)
+    lam = torch.tensor([float(g['update/lambda_after'])], device=DEV)
+    out = up.run(dev, lam, perms=[torch.from_numpy(p.copy()) for p in g['update/perms']],
+                 actor_lr=3e-4, critic_lr=3e-4)
+    assert out['stop_iter'] == int(g['update/stop_iter'][-1]) and out['steps'] == 9
+    summ = PPOUpdater.summarize(out, 0.001, True)
+    ps = summ['per_step']
+    np.testing.assert_allclose(ps['loss_r'], g['update/loss_r'], rtol=2e-4)
+    np.testing.assert_allclose(ps['loss_c'], g['update/loss_c'], rtol=2e-4)
+    np.testing.assert_allclose(ps['loss_pi'], g['update/loss_pi'], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(ps['ratio_mean'], g['update/ratio_mean'], rtol=1e-5)
+    np.testing.assert_allclose(out['kl'], g['update/kl'][-1], rtol=2e-3, atol=1e-7)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{net}/{k}'], rtol=0, atol=5e-6,
+                                       err_msg=f'{net}/{k}')
+
+
+def test_large_batch_multiblock_equals_single_pass():
+    """B = 4096 rows split over 64 workgroups + slab reduction == oracle full-batch step."""
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(3)
+    M, obs_dim, act_dim = 4096, 60, 2
+    ref = O.ActorCritic(obs_dim, act_dim)
+    ac = make_ac(obs_dim, act_dim)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ac, net).load_state_dict(getattr(ref, net).state_dict())
+    cpu = {'obs': torch.randn(M, obs_dim), 'act': torch.randn(M, act_dim), 'logp': -2 + 0.1 * torch.randn(M),
+           'target_value_r': torch.randn(M), 'target_value_c': torch.randn(M), 'adv_r': torch.randn(M),
+           'adv_c': torch.randn(M)}
+    with torch.no_grad():
+        d = ref.actor.dist(cpu['obs'])
+        cpu['logp'] = d.log_prob(cpu['act']).sum(-1) + 0.3 * torch.randn(M)  # ratios spread around 1
+    dev = {k: v.to(DEV) for k, v in cpu.items()}
+    lam = 0.5
+    l_r = O.critic_step(ref.reward_critic, ref.reward_critic_optimizer, cpu['obs'], cpu['target_value_r'])
+    l_c = O.critic_step(ref.cost_critic, ref.cost_critic_optimizer, cpu['obs'], cpu['target_value_c'])
+    l_p, ent, ratio = O.actor_step(ref.actor, ref.actor_optimizer, cpu['obs'], cpu['act'], cpu['logp'],
+                                   cpu['adv_r'], cpu['adv_c'], lam)
+    up = PPOUpdater(ac, batch_size=M, update_iters=1, target_kl=0.02, kl_early_stop=False, max_blocks=64)
+    up.hp.lr_actor = up.hp.lr_critic = 3e-4
+    stats = torch.zeros(16, device=DEV)
+    up.minibatch(dev, None, M, torch.tensor([lam], device=DEV), stats)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[0] + 0.001 * s[5], l_r, rtol=1e-4)
+    np.testing.assert_allclose(s[1] + 0.001 * s[6], l_c, rtol=1e-4)
+    np.testing.assert_allclose(s[2], l_p, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(s[3], float(ratio.mean()), rtol=1e-4)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), getattr(ref, net).state_dict()[k].numpy(),
+                                       rtol=1e-4, atol=2e-6, err_msg=f'{net}/{k}')
