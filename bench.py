@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/sec (rollout + update), PPO-Lag on SafetyPointGoal1 shapes.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE EPOCH of the hot path on one batch of synthetic input: rollout of T = 16 vector steps
+over 4096 device-resident envs per GPU (65 536 env-steps per GPU), dual GAE + standardisation, then the
+PPO-Lag update with the reference's YAML defaults (batch_size 64, update_iters 40 -> 40 960 sequential
+optimiser steps x 3 networks) with kl_early_stop OFF so that every epoch does the maximum work (the
+reference would usually stop earlier).  This is BASELINE.json configs[1] ("PPOLag on
+SafetyPointGoal1-v0, 1xMI355X, 4096 vectorized envs, steps_per_epoch=65536"); weak scaling: each rank
+owns 4096 envs, steps_per_epoch = 65 536 x world_size, gradients are all-reduced over RCCL.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     dominant kernel (osa_mb_grad_kernel: fused fwd+bwd+clip+Adam of one 64-row minibatch of
+               all three networks), algorithmic FLOPs / mean launch time measured with HIP events
+  cpu_baseline the oracle (oracle/np_oracle.py, a CPU restatement pinned bit-exact to the reference)
+               timed on this box's host cores on a bounded sample of the same workload
+and a "throughput_variant" object: the same workload shape with the large-batch setting the reference
+itself uses for GPU-resident envs (PPOLag.yaml ShadowHand* blocks: batch_size 8192 -> here 16 384,
+update_iters 8), which shows what the kernels do when the optimiser chain is not 64 rows wide.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OBS_DIM, ACT_DIM, HIDDEN = 60, 2, 64
+W_PI = OBS_DIM * HIDDEN + HIDDEN * HIDDEN + HIDDEN * ACT_DIM  # 8064 weights (no biases)
+W_V = OBS_DIM * HIDDEN + HIDDEN * HIDDEN + HIDDEN * 1         # 8000
+FLOPS_PER_SAMPLE_STEP = 6 * (W_PI + 2 * W_V)                  # fwd 2W + bwd 4W, three nets
+PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md (f32-input MFMA)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--steps-per-env', type=int, default=16)
+    ap.add_argument('--batch-size', type=int, default=64)
+    ap.add_argument('--update-iters', type=int, default=40)
+    ap.add_argument('--kl-early-stop', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-variant', action='store_true')
+    ap.add_argument('--algo', default='PPOLag')
+    return ap.parse_args()
+
+
+def make_algo(args, world, batch_size, update_iters, epochs, log_dir):
+    import omnisafe_amd
+
+    spe = args.envs * args.steps_per_env * world
+    cfg = {
+        'seed': 0,
+        'train_cfgs': {'device': f'cuda:{int(os.environ.get("LOCAL_RANK", 0))}', 'vector_env_nums': args.envs,
+                       'total_steps': spe * epochs},
+        'algo_cfgs': {'steps_per_epoch': spe, 'batch_size': batch_size, 'update_iters': update_iters,
+                      'kl_early_stop': bool(args.kl_early_stop)},
+        'logger_cfgs': {'log_dir': log_dir, 'save_model_freq': 10 ** 9, 'verbose': False},
+        # horizon <= T so that episodes finish inside an epoch (the reference resets envs every epoch,
+        # onpolicy_adapter.py:80; with longer episodes EpCost is empty and ppo_lag.py:74 asserts)
+        'env_cfgs': {'horizon': args.steps_per_env, 'cost_p': 0.05},
+    }
+    return omnisafe_amd.Agent(args.algo, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+
+
+def run_epochs(algo, n, sync):
+    """The body of PolicyGradient.learn()'s epoch loop (policy_gradient.py:252-292)."""
+    for _ in range(n):
+        algo._env.rollout(steps_per_epoch=algo._steps_per_epoch, agent=algo._actor_critic,
+                          buffer=algo._buf, logger=algo._logger)
+        algo._update()
+        if algo._cfgs.model_cfgs.actor.lr is not None:
+            algo._actor_critic.actor_scheduler.step()
+        algo._logger.dump_tabular()
+    sync()
+
+
+def timed(algo, steps, warmup, world, dev):
+    import torch.distributed as dist
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    run_epochs(algo, warmup, sync)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_epochs(algo, steps, sync)
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt
+
+
+def kernel_roofline(algo, batch_size, dev):
+    """Mean duration of the dominant kernel with HIP events on the launch stream: `reps` back-to-back
+    dependent minibatch launches (the exact launch sequence of one update pass), events before the
+    first and after the last.  Includes the ~1.5 us dependent-launch boundary between kernels."""
+    up = algo._updater
+    data = algo._buf._out
+    M = data['obs'].shape[0]
+    lam = algo._lagrange_tensor()
+    up.hp.lr_actor, up.hp.lr_critic = 3e-4, 3e-4
+    perm = torch.randperm(M, device=dev)
+    stats = torch.zeros(16, device=dev)
+    nmb = (M + batch_size - 1) // batch_size
+    reps = 1024 if batch_size <= 256 else 128
+    for _ in range(16):  # warm
+        up.minibatch(data, perm[:batch_size], batch_size, lam, stats)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(reps):
+        s = (k * batch_size) % (M - batch_size + 1)
+        up.minibatch(data, perm[s:s + batch_size], batch_size, lam, stats)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = FLOPS_PER_SAMPLE_STEP * batch_size
+    achieved = flops / (us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+            'kernel': 'osa_mb_grad_kernel<4,1>', 'us_per_launch': round(us, 3),
+            'flops_per_launch': flops, 'rows_per_launch': batch_size,
+            'note': ('3 workgroups (one per network) x 64 rows per launch: latency-bound by the '
+                     "reference's batch_size=64 optimiser chain, see throughput_variant")
+            if batch_size <= 64 else 'large-batch launch: ceil(B/64) workgroups per network'}
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement of the reference, bit-exact to it) on a bounded sample of the same
+    epoch: the full rollout (65 536 transitions: per-env loop, normaliser, policy step, GAE, get)
+    plus `n_mb` of the 40 960 minibatch optimiser steps and one full-batch KL pass; the update time is
+    scaled to 40 passes."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import np_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N, T = args.envs, args.steps_per_env
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    ac = O.ActorCritic(OBS_DIM, ACT_DIM)
+    norm = O.Normalizer((OBS_DIM,), clip=5)
+    trunc = np.zeros((T, N), bool)
+    trunc[T - 1] = True
+    trace = {'reset_obs': rng.standard_normal((N, OBS_DIM)).astype(np.float32),
+             'obs': rng.standard_normal((T, N, OBS_DIM)).astype(np.float32),
+             'reward': rng.standard_normal((T, N)).astype(np.float32),
+             'cost': (rng.random((T, N)) < 0.05).astype(np.float32),
+             'terminated': np.zeros((T, N), bool), 'truncated': trunc,
+             'final_obs': rng.standard_normal((T, N, OBS_DIM)).astype(np.float32),
+             'eps': rng.standard_normal((T, N, ACT_DIM)).astype(np.float32)}
+    t0 = time.perf_counter()
+    buf, gae, _aux = O.rollout_on_trace(ac, norm, trace)
+    a_r, a_c, _ = O.buffer_get(gae['adv_r'], gae['adv_c'])
+    t_roll = time.perf_counter() - t0
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    data = {'obs': tt(O.env_major(buf['obs'])), 'act': tt(O.env_major(buf['act'])),
+            'logp': tt(O.env_major(buf['logp'])), 'target_value_r': tt(O.env_major(gae['tgt_r'])),
+            'target_value_c': tt(O.env_major(gae['tgt_c'])), 'adv_r': tt(a_r), 'adv_c': tt(a_c)}
+    M = N * T
+    n_mb = 2048
+    perm = torch.randperm(M)
+    t0 = time.perf_counter()
+    O.ppolag_update(ac, data, 0.001, [perm], batch_size=args.batch_size, update_iters=1,
+                    kl_early_stop=False, max_minibatches=n_mb)
+    t_upd_sample = time.perf_counter() - t0
+    with torch.no_grad():
+        old = ac.actor.dist(data['obs'])
+        om, osd = old.mean.clone(), old.stddev.clone()
+    t0 = time.perf_counter()
+    O.kl_old_new(ac.actor, data['obs'], om, osd)
+    t_kl = time.perf_counter() - t0
+    nmb_full = (M + args.batch_size - 1) // args.batch_size
+    per_mb = (t_upd_sample - t_kl) / n_mb
+    t_epoch = t_roll + args.update_iters * (nmb_full * per_mb + t_kl)
+    return {'value': round(M / t_epoch, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': (f'full rollout+GAE+get of {M} transitions ({t_roll:.2f} s) + {n_mb} of '
+                       f'{args.update_iters * nmb_full} minibatch optimiser steps ({per_mb * 1e3:.3f} ms '
+                       f'each) + 1 KL pass ({t_kl * 1e3:.1f} ms); update extrapolated to '
+                       f'{args.update_iters} passes'),
+            'rollout_s': round(t_roll, 3), 'ms_per_minibatch_step': round(per_mb * 1e3, 4)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device(f'cuda:{local}')
+    torch.cuda.set_device(dev)
+    import tempfile
+
+    log_dir = tempfile.mkdtemp(prefix='osa_bench_')
+    algo = make_algo(args, world, args.batch_size, args.update_iters, args.steps + args.warmup + 1, log_dir)
+    dt = timed(algo, args.steps, args.warmup, world, dev)
+    per_gpu_steps = args.envs * args.steps_per_env
+    value = world * per_gpu_steps * args.steps / dt
+    out = {
+        'metric': 'env-steps/sec (rollout+update), PPO-Lag SafetyPointGoal1',
+        'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': (f'PPOLag, SafetyPointGoal1 shapes (obs 60, act 2, 64x64 tanh), '
+                                f'{args.envs} vectorized envs/GPU, steps_per_epoch={per_gpu_steps}/GPU '
+                                f'(T={args.steps_per_env}), batch_size={args.batch_size}, '
+                                f'update_iters={args.update_iters}, kl_early_stop='
+                                f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
+                   'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}'},
+    }
+    out['roofline'] = kernel_roofline(algo, args.batch_size, dev)
+    if world == 1 and not args.no_variant and rank == 0:
+        del algo
+        torch.cuda.empty_cache()
+        v_algo = make_algo(args, world, 16384, 8, 6, log_dir)
+        v_steps = 5
+        v_dt = timed(v_algo, v_steps, 1, world, dev)
+        out['throughput_variant'] = {
+            'workload': 'same shapes, batch_size=16384, update_iters=8 (large-batch setting of PPOLag.yaml '
+                        'GPU-env blocks)',
+            'value': round(per_gpu_steps * v_steps / v_dt, 1), 'unit': 'env-steps/s',
+            'ms_per_step': round(v_dt / v_steps * 1e3, 3),
+            'roofline': kernel_roofline(v_algo, 16384, dev)}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args)
+    else:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -182,6 +182,55 @@ int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params
                  int reduce_mode, float* mean_out, int ld_mean, double* ws, float* kl_out,
                  void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rollout step (replaces the wrapper chain and the per-env loop of OnPolicyAdapter.rollout)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Normalizer._push (omnisafe/common/normalizer.py:109-139) with a batch of the rows of x selected by
+ * mask (NULL = all N rows; zero selected rows = no-op): Chan/Golub/LeVeque merge of the batch mean and
+ * centred sum of squares into the running state, var = sumsq/(count-1), std = max(sqrt(var), 1e-2).
+ * State: mean/sumsq/var/std float32[D], count int64[1] (all device).  ws: osa_normalizer_ws_doubles. */
+size_t osa_normalizer_ws_doubles(int N, int D);
+int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mask, float* mean,
+                        float* sumsq, float* var, float* std_, long* count, double* ws,
+                        void* stream);
+
+/* Normalizer.normalize's output (normalizer.py:102-107): y = clamp((x - mean)/std, -clip, clip) for
+ * rows selected by mask (others copied unchanged); x copied unchanged while count <= 1. */
+int osa_normalizer_apply(const float* x, int ld_x, float* y, int ld_y, int N, int D,
+                         const uint8_t* mask, const float* mean, const float* std_, const long* count,
+                         float clip, void* stream);
+
+/* ActionScale.step (omnisafe/envs/wrapper.py:510-514):
+ * out = old_min + (old_max - old_min) * (act - min_action) / (max_action - min_action). */
+int osa_action_scale(const float* act, int ld_act, float* out, int ld_out, int N, int act_dim,
+                     const float* old_min, const float* old_max, float min_action, float max_action,
+                     void* stream);
+
+/* The per-env loop of OnPolicyAdapter.rollout (omnisafe/adapter/onpolicy_adapter.py:86-136) for all N
+ * envs at one step: episode return/cost/length accumulation (_log_value :155-157), path-end flag and
+ * bootstrap selection -- 0 if terminated, V(final_observation) (vfinal_*) if truncated, V(next_obs)
+ * (vnext_*) at epoch end (:114-126) -- written into row t of the buffer's path_end/boot_r/boot_c, and
+ * the finished episodes' metrics (_log_metrics :159-174) into row t of ep_done/ep_*_out, after which
+ * the per-env accumulators reset (:128-134).  vnext_* / vfinal_* may be NULL when not needed. */
+int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float* cost,
+                          const uint8_t* terminated, const uint8_t* truncated, const float* vnext_r,
+                          const float* vnext_c, const float* vfinal_r, const float* vfinal_c,
+                          float* ep_ret, float* ep_cost, float* ep_len, uint8_t* path_end,
+                          float* boot_r, float* boot_c, uint8_t* ep_done, float* ep_ret_out,
+                          float* ep_cost_out, float* ep_len_out, void* stream);
+
+/* Synthetic fixed-shape vector CMDP for throughput runs (stand-in for Safety-Gymnasium, whose physics
+ * is third-party CPU code outside the reference repo; same role as tests/simple_env.py:30-90 of the
+ * reference): obs ~ N(0,1)^obs_dim, reward ~ N(0,1), cost ~ Bernoulli(cost_p), never terminates,
+ * truncates every `horizon` steps with gymnasium's vector auto-reset convention (the returned obs is
+ * the post-reset obs; the pre-reset obs goes to final_obs).  reset_only != 0 draws initial
+ * observations and zeroes the step counters. */
+int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+                       int horizon, float cost_p, int* steps, float* obs, int ld_obs, float* reward,
+                       float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
+                       int ld_final, int reset_only, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

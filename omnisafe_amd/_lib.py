@@ -38,6 +38,12 @@ SIGNATURES: dict[str, tuple] = {
                                _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     'osa_actor_kl': (_I, [_I, _I, _I, _P, _P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    'osa_normalizer_ws_doubles': (C.c_size_t, [_I, _I]),
+    'osa_normalizer_push': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'osa_normalizer_apply': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _P]),
+    'osa_action_scale': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _P]),
+    'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 19),
+    'osa_synth_env_step': (_I, [_U, _U, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 

@@ -1,0 +1,309 @@
+// Rollout-side kernels: running observation normaliser (K2), action scaling (K3), per-step episode
+// accounting + bootstrap selection (the per-env Python loop of OnPolicyAdapter.rollout), and the
+// synthetic fixed-shape vector environment used by the throughput benchmark.
+#include "mlp_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// K2  Normalizer._push + normalize  (omnisafe/common/normalizer.py:88-139)
+// State (device): mean[D], sumsq[D], var[D], std[D] float32; count int64[1].
+// The batch moments are reduced in float64 as shifted sums S1 = sum(x - c), S2 = sum((x - c)^2) with
+// c = current running mean, then merged with the reference's Chan update in float32.
+// ------------------------------------------------------------------------------------------------
+#define OSA_NORM_ROWS 128  // rows per workgroup in the partial reduction
+
+__global__ __launch_bounds__(256) void osa_norm_partial_kernel(
+    const float* __restrict__ x, int ld, int N, int D, const uint8_t* __restrict__ mask,
+    const float* __restrict__ mean, double* __restrict__ ws) {
+  __shared__ double s1[4][64], s2[4][64];
+  __shared__ int scnt[4];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + cx;
+  const int r0 = blockIdx.x * OSA_NORM_ROWS;
+  const int r1 = min(N, r0 + OSA_NORM_ROWS);
+  const double c = (col < D) ? (double)mean[col] : 0.0;
+  double a1 = 0.0, a2 = 0.0;
+  int cnt = 0;
+  for (int r = r0 + ry; r < r1; r += 4) {
+    const bool on = mask == nullptr || mask[r] != 0;
+    if (on) {
+      ++cnt;
+      if (col < D) {
+        const double d = (double)x[(long)r * ld + col] - c;
+        a1 += d;
+        a2 += d * d;
+      }
+    }
+  }
+  s1[ry][cx] = a1;
+  s2[ry][cx] = a2;
+  if (cx == 0) scnt[ry] = cnt;
+  __syncthreads();
+  if (ry == 0) {
+    const int nrb = gridDim.x;
+    if (col < D) {
+      double* o = ws + ((long)blockIdx.x * D + col) * 2;
+      o[0] = s1[0][cx] + s1[1][cx] + s1[2][cx] + s1[3][cx];
+      o[1] = s2[0][cx] + s2[1][cx] + s2[2][cx] + s2[3][cx];
+    }
+    if (cx == 0 && blockIdx.y == 0)
+      ws[(long)nrb * D * 2 + blockIdx.x] = (double)(scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void osa_norm_merge_kernel(
+    const double* __restrict__ ws, int nrb, int D, float* __restrict__ mean,
+    float* __restrict__ sumsq, float* __restrict__ var, float* __restrict__ std_,
+    long* __restrict__ count) {
+#pragma clang fp contract(off)
+  __shared__ long s_n;
+  if (threadIdx.x == 0) {
+    double n = 0.0;
+    for (int b = 0; b < nrb; ++b) n += ws[(long)nrb * D * 2 + b];
+    s_n = (long)n;
+  }
+  __syncthreads();
+  const long n_raw = s_n;
+  if (n_raw == 0) return;
+  const long cnt_old = *count;
+  const long cnt_new = cnt_old + n_raw;
+  for (int col = threadIdx.x; col < D; col += blockDim.x) {
+    double S1 = 0.0, S2 = 0.0;
+    for (int b = 0; b < nrb; ++b) {
+      S1 += ws[((long)b * D + col) * 2];
+      S2 += ws[((long)b * D + col) * 2 + 1];
+    }
+    const double c = (double)mean[col];
+    const float mean_raw = (float)(c + S1 / (double)n_raw);
+    // sum((x - mean_raw)^2) = S2 - S1^2/n   (exact identity; float64 keeps ~1e-12 relative)
+    double q = S2 - S1 * S1 / (double)n_raw;
+    if (q < 0.0) q = 0.0;
+    const float sumq_raw = (float)q;
+    float m_new, ss_new;
+    if (cnt_old == 0) {  // normalizer.py:118-126 (first push)
+      m_new = mean_raw;
+      ss_new = sumq_raw;
+    } else {  // normalizer.py:127-136
+      const float delta = mean_raw - mean[col];
+      m_new = mean[col] + delta * (float)n_raw / (float)cnt_new;
+      ss_new = sumsq[col] + (sumq_raw + delta * delta * (float)cnt_old * (float)n_raw / (float)cnt_new);
+    }
+    mean[col] = m_new;
+    sumsq[col] = ss_new;
+    const float v = ss_new / (float)(cnt_new - 1);  // count == 1 -> 0/0 = NaN, as the reference
+    var[col] = v;
+    const float s = sqrtf(v);
+    std_[col] = fmaxf(s, 1e-2f);  // torch.max(std, 1e-2): NaN propagates like torch.max
+    if (s != s) std_[col] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *count = cnt_new;
+}
+
+__global__ __launch_bounds__(256) void osa_normalize_kernel(
+    const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int N, int D,
+    const uint8_t* __restrict__ mask, const float* __restrict__ mean, const float* __restrict__ std_,
+    const long* __restrict__ count, float clip) {
+#pragma clang fp contract(off)
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)N * D) return;
+  const int r = (int)(gid / D), col = (int)(gid - (long)r * D);
+  float v = x[(long)r * ld_x + col];
+  const bool on = mask == nullptr || mask[r] != 0;
+  if (on && *count > 1) {  // normalizer.py:104-107
+    v = (v - mean[col]) / std_[col];
+    v = fminf(fmaxf(v, -clip), clip);
+  }
+  y[(long)r * ld_y + col] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  ActionScale.step (omnisafe/envs/wrapper.py:510-514)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_action_scale_kernel(
+    const float* __restrict__ act, int ld_a, float* __restrict__ out, int ld_o, int N, int D,
+    const float* __restrict__ old_min, const float* __restrict__ old_max, float min_a, float max_a) {
+#pragma clang fp contract(off)
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)N * D) return;
+  const int r = (int)(gid / D), d = (int)(gid - (long)r * D);
+  const float a = act[(long)r * ld_a + d];
+  out[(long)r * ld_o + d] = old_min[d] + (old_max[d] - old_min[d]) * (a - min_a) / (max_a - min_a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1  per-step episode accounting + bootstrap selection (onpolicy_adapter.py:86-136, :138-190)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_rollout_post_step_kernel(
+    int N, int epoch_end, const float* __restrict__ reward, const float* __restrict__ cost,
+    const uint8_t* __restrict__ terminated, const uint8_t* __restrict__ truncated,
+    const float* __restrict__ vnext_r, const float* __restrict__ vnext_c,
+    const float* __restrict__ vfinal_r, const float* __restrict__ vfinal_c,
+    float* __restrict__ ep_ret, float* __restrict__ ep_cost, float* __restrict__ ep_len,
+    uint8_t* __restrict__ path_end, float* __restrict__ boot_r, float* __restrict__ boot_c,
+    uint8_t* __restrict__ ep_done, float* __restrict__ ep_ret_out, float* __restrict__ ep_cost_out,
+    float* __restrict__ ep_len_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  // _log_value (:155-157)
+  float er = ep_ret[n] + reward[n];
+  float ec = ep_cost[n] + cost[n];
+  float el = ep_len[n] + 1.f;
+  const bool done = terminated[n] != 0, time_out = truncated[n] != 0;
+  uint8_t pe = 0, ed = 0;
+  float lr = 0.f, lc = 0.f;
+  if (epoch_end || done || time_out) {  // :115-136
+    if (!done) {
+      if (epoch_end && vnext_r) {
+        lr = vnext_r[n];
+        lc = vnext_c[n];
+      }
+      if (time_out && vfinal_r) {
+        lr = vfinal_r[n];
+        lc = vfinal_c[n];
+      }
+    }
+    pe = 1;
+    if (done || time_out) {
+      ed = 1;
+      ep_ret_out[n] = er;
+      ep_cost_out[n] = ec;
+      ep_len_out[n] = el;
+      er = ec = el = 0.f;
+    }
+  }
+  path_end[n] = pe;
+  boot_r[n] = lr;
+  boot_c[n] = lc;
+  ep_done[n] = ed;
+  ep_ret[n] = er;
+  ep_cost[n] = ec;
+  ep_len[n] = el;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic fixed-shape vector environment (benchmark stand-in for Safety-Gymnasium, whose MuJoCo
+// physics is third-party CPU code outside the reference repository): obs ~ N(0,1)^D_o,
+// reward ~ N(0,1), cost ~ Bernoulli(p), never terminates, truncates every `horizon` steps with the
+// gymnasium vector auto-reset convention (returned obs is the post-reset obs, the pre-reset obs is
+// handed back as final_observation).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_synth_env_kernel(
+    unsigned long long seed, unsigned long long step, int N, int D, int horizon, float cost_p,
+    int* __restrict__ steps, float* __restrict__ obs, int ld, float* __restrict__ reward,
+    float* __restrict__ cost, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+    float* __restrict__ final_obs, int ld_f, int reset_only) {
+  const int n = blockIdx.x;  // one workgroup per env row; threads over feature pairs
+  uint8_t trunc = 0;
+  if (!reset_only) trunc = (steps[n] + 1 >= horizon) ? 1 : 0;
+  for (int pair = threadIdx.x; 2 * pair < D; pair += blockDim.x) {
+    uint32_t w[4];
+    osa_philox(seed, step, ((unsigned long long)n << 20) + pair, w);
+    float a, b, c2, d2;
+    osa_box_muller(w[0], w[1], a, b);
+    osa_box_muller(w[2], w[3], c2, d2);  // second pair: the post-reset observation
+    const int i0 = 2 * pair, i1 = 2 * pair + 1;
+    if (trunc) {
+      if (final_obs) {
+        final_obs[(long)n * ld_f + i0] = a;
+        if (i1 < D) final_obs[(long)n * ld_f + i1] = b;
+      }
+      obs[(long)n * ld + i0] = c2;
+      if (i1 < D) obs[(long)n * ld + i1] = d2;
+    } else {
+      obs[(long)n * ld + i0] = a;
+      if (i1 < D) obs[(long)n * ld + i1] = b;
+    }
+  }
+  if (threadIdx.x == 0 && !reset_only) {
+    uint32_t w[4];
+    osa_philox(seed ^ 0x9E3779B97F4A7C15ull, step, (unsigned long long)n, w);
+    float a, b;
+    osa_box_muller(w[0], w[1], a, b);
+    reward[n] = a;
+    cost[n] = (osa_u01(w[2]) <= cost_p) ? 1.f : 0.f;
+    terminated[n] = 0;
+    truncated[n] = trunc;
+    steps[n] = trunc ? 0 : steps[n] + 1;
+  }
+  if (threadIdx.x == 0 && reset_only) steps[n] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+size_t osa_normalizer_ws_doubles(int N, int D) {
+  if (N < 1 || D < 1) return 0;
+  const size_t nrb = (size_t)(N + OSA_NORM_ROWS - 1) / OSA_NORM_ROWS;
+  return nrb * D * 2 + nrb;
+}
+
+int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mask, float* mean,
+                        float* sumsq, float* var, float* std_, long* count, double* ws,
+                        void* stream) {
+  OSA_REQUIRE(x && mean && sumsq && var && std_ && count && ws && N > 0 && D > 0 && ld >= D);
+  const int nrb = (N + OSA_NORM_ROWS - 1) / OSA_NORM_ROWS;
+  hipLaunchKernelGGL(osa_norm_partial_kernel, dim3(nrb, (D + 63) / 64), dim3(256), 0,
+                     osa_stream(stream), x, ld, N, D, mask, mean, ws);
+  hipLaunchKernelGGL(osa_norm_merge_kernel, dim3(1), dim3(256), 0, osa_stream(stream), ws, nrb, D,
+                     mean, sumsq, var, std_, count);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_normalizer_apply(const float* x, int ld_x, float* y, int ld_y, int N, int D,
+                         const uint8_t* mask, const float* mean, const float* std_, const long* count,
+                         float clip, void* stream) {
+  OSA_REQUIRE(x && y && mean && std_ && count && N > 0 && D > 0 && ld_x >= D && ld_y >= D);
+  const long total = (long)N * D;
+  hipLaunchKernelGGL(osa_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     osa_stream(stream), x, ld_x, y, ld_y, N, D, mask, mean, std_, count, clip);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_action_scale(const float* act, int ld_act, float* out, int ld_out, int N, int act_dim,
+                     const float* old_min, const float* old_max, float min_action, float max_action,
+                     void* stream) {
+  OSA_REQUIRE(act && out && old_min && old_max && N > 0 && act_dim > 0);
+  const long total = (long)N * act_dim;
+  hipLaunchKernelGGL(osa_action_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     osa_stream(stream), act, ld_act, out, ld_out, N, act_dim, old_min, old_max,
+                     min_action, max_action);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float* cost,
+                          const uint8_t* terminated, const uint8_t* truncated, const float* vnext_r,
+                          const float* vnext_c, const float* vfinal_r, const float* vfinal_c,
+                          float* ep_ret, float* ep_cost, float* ep_len, uint8_t* path_end,
+                          float* boot_r, float* boot_c, uint8_t* ep_done, float* ep_ret_out,
+                          float* ep_cost_out, float* ep_len_out, void* stream) {
+  OSA_REQUIRE(N > 0 && reward && cost && terminated && truncated && ep_ret && ep_cost && ep_len);
+  OSA_REQUIRE(path_end && boot_r && boot_c && ep_done && ep_ret_out && ep_cost_out && ep_len_out);
+  OSA_REQUIRE((vnext_r == nullptr) == (vnext_c == nullptr));
+  OSA_REQUIRE((vfinal_r == nullptr) == (vfinal_c == nullptr));
+  hipLaunchKernelGGL(osa_rollout_post_step_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                     osa_stream(stream), N, epoch_end, reward, cost, terminated, truncated, vnext_r,
+                     vnext_c, vfinal_r, vfinal_c, ep_ret, ep_cost, ep_len, path_end, boot_r, boot_c,
+                     ep_done, ep_ret_out, ep_cost_out, ep_len_out);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+                       int horizon, float cost_p, int* steps, float* obs, int ld_obs, float* reward,
+                       float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
+                       int ld_final, int reset_only, void* stream) {
+  OSA_REQUIRE(N > 0 && obs_dim > 0 && steps && obs && ld_obs >= obs_dim);
+  if (!reset_only) OSA_REQUIRE(reward && cost && terminated && truncated && horizon > 0);
+  hipLaunchKernelGGL(osa_synth_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, N,
+                     obs_dim, horizon, cost_p, steps, obs, ld_obs, reward, cost, terminated,
+                     truncated, final_obs, ld_final, reset_only);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+}  // extern "C"

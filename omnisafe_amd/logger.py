@@ -1,0 +1,184 @@
+"""Epoch logger -- mirror of the part of omnisafe/common/logger.py:59-389 the on-policy path uses:
+registered keys with window deques, ``/Min /Max /Std /Delta`` variants, cross-rank statistics,
+``progress.csv`` with the reference's column names, ``torch_save/epoch-N.pt`` checkpoints with keys
+``pi`` and ``obs_normalizer``.  Values arrive as Python floats once per epoch (the kernels accumulate
+on the device), so the per-step ``.item()`` host syncs of the reference (logger.py:277-278) are gone.
+"""
+from __future__ import annotations
+
+import csv
+import json
+import os
+import time
+from collections import deque
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import distributed as dist
+
+
+class Logger:  # pylint: disable=too-many-instance-attributes
+    def __init__(self, output_dir: str, exp_name: str, seed: int = 0, use_tensorboard: bool = False,
+                 use_wandb: bool = False, config=None, verbose: bool = True) -> None:
+        hms = time.strftime('%Y-%m-%d-%H-%M-%S')
+        rel = f'seed-{str(seed).zfill(3)}-{hms}'
+        self._log_dir = os.path.join(output_dir, exp_name, rel)
+        self._maste_proc = dist.rank() == 0
+        self._verbose = verbose
+        self._epoch = 0
+        self._first_row = True
+        self._what_to_save: dict[str, Any] | None = None
+        self._data: dict[str, deque | list] = {}
+        self._headers_windows: dict[str, int | None] = {}
+        self._headers_minmax: dict[str, bool] = {}
+        self._headers_delta: dict[str, bool] = {}
+        self._current_row: dict[str, float] = {}
+        self._csv = None
+        if self._maste_proc:
+            os.makedirs(self._log_dir, exist_ok=True)
+            self._output_file = open(os.path.join(self._log_dir, 'progress.csv'), 'w', encoding='utf-8',
+                                     newline='')
+            self._csv_writer = csv.writer(self._output_file)
+            if config is not None:
+                with open(os.path.join(self._log_dir, 'config.json'), 'w', encoding='utf-8') as f:
+                    json.dump(config.todict() if hasattr(config, 'todict') else dict(config), f,
+                              indent=4, default=str)
+
+    # ------------------------------------------------------------------
+    @property
+    def current_epoch(self) -> int:
+        return self._epoch
+
+    @property
+    def log_dir(self) -> str:
+        return self._log_dir
+
+    def log(self, msg: str, color: str = 'green', bold: bool = False) -> None:
+        if self._maste_proc and self._verbose:
+            print(msg, flush=True)
+
+    def register_key(self, key: str, window_length: int | None = None, min_and_max: bool = False,
+                     delta: bool = False) -> None:
+        """logger.py:196-251."""
+        assert key not in self._current_row, f'Key {key} has been registered'
+        self._current_row[key] = 0
+        if min_and_max:
+            for suf in ('/Min', '/Max', '/Std'):
+                self._current_row[key + suf] = 0
+        if delta:
+            self._current_row[key + '/Delta'] = 0
+        self._headers_minmax[key], self._headers_delta[key] = min_and_max, delta
+        self._headers_windows[key] = window_length
+        self._data[key] = deque(maxlen=window_length) if window_length is not None else []
+
+    def store(self, data: dict[str, Any] | None = None, /, **kwargs: Any) -> None:
+        """logger.py:253-282: scalars appended; tensors/arrays contribute their mean."""
+        if data is not None:
+            kwargs.update(data)
+        for key, val in kwargs.items():
+            assert key in self._current_row, f'Key {key} has not been registered'
+            if isinstance(val, (int, float)):
+                self._data[key].append(val)
+            elif isinstance(val, torch.Tensor):
+                self._data[key].append(val.float().mean().item())
+            elif isinstance(val, np.ndarray):
+                self._data[key].append(float(val.mean()))
+            else:
+                raise ValueError(f'Unsupported type {type(val)}')
+
+    def extend(self, key: str, values) -> None:
+        """Append many scalars at once (per-episode metrics extracted from the device once per epoch)."""
+        assert key in self._current_row, f'Key {key} has not been registered'
+        self._data[key].extend(float(v) for v in values)
+
+    def get_stats(self, key: str, min_and_max: bool = False) -> tuple[float, ...]:
+        """logger.py:344-374 via dist_statistics_scalar (distributed.py:361-393): global mean (and
+        population std / min / max) over all ranks' values.  Unlike the reference, min/max use scalar
+        reductions (the reference all-reduces a vector whose length may differ per rank)."""
+        vals = torch.tensor(list(self._data[key]), dtype=torch.float32)
+        if dist.world_size() == 1:
+            if len(vals) == 0:
+                nan = float('nan')
+                return (nan, nan, nan, nan) if min_and_max else (nan,)
+            mean = vals.sum() / len(vals)
+            if not min_and_max:
+                return (mean.item(),)
+            std = torch.sqrt(((vals - mean) ** 2).sum() / len(vals))
+            return mean.item(), vals.min().item(), vals.max().item(), std.item()
+        return _dist_stats(vals, min_and_max)
+
+    def dump_tabular(self) -> None:
+        """logger.py:284-319: compute this epoch's row, write csv, reset non-window keys."""
+        self._update_current_row()
+        if self._maste_proc:
+            if self._first_row:
+                self._csv_writer.writerow(self._current_row.keys())
+                self._first_row = False
+            self._csv_writer.writerow(self._current_row.values())
+            self._output_file.flush()
+            if self._verbose:
+                width = max(len(k) for k in self._current_row)
+                print('\n'.join(f'  {k:<{width}}  {v}' for k, v in self._current_row.items()), flush=True)
+        self._epoch += 1
+
+    def _update_current_row(self) -> None:
+        for key in self._data:
+            old = self._current_row[key]
+            if self._headers_minmax[key]:
+                mean, mn, mx, std = self.get_stats(key, True)
+                self._current_row[key] = mean
+                self._current_row[key + '/Min'], self._current_row[key + '/Max'] = mn, mx
+                self._current_row[key + '/Std'] = std
+            else:
+                mean = self.get_stats(key, False)[0]
+                self._current_row[key] = mean
+            if self._headers_delta[key]:
+                self._current_row[key + '/Delta'] = mean - old
+            if self._headers_windows[key] is None:
+                self._data[key] = []
+
+    def setup_torch_saver(self, what_to_save: dict[str, Any]) -> None:
+        self._what_to_save = what_to_save
+
+    def torch_save(self) -> None:
+        """logger.py:183-194: {'pi': state_dict, 'obs_normalizer': state_dict} (CPU tensors)."""
+        if not self._maste_proc:
+            return
+        assert self._what_to_save is not None, 'Please setup torch saver first'
+        path = os.path.join(self._log_dir, 'torch_save', f'epoch-{self._epoch}.pt')
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        params = {}
+        for k, v in self._what_to_save.items():
+            sd = v.state_dict() if hasattr(v, 'state_dict') else v
+            params[k] = {n: t.detach().cpu() for n, t in sd.items()} if isinstance(sd, dict) else sd
+        torch.save(params, path)
+
+    def close(self) -> None:
+        if self._maste_proc:
+            self._output_file.close()
+
+
+def _dist_stats(vals: torch.Tensor, min_and_max: bool):
+    """Cross-rank statistics through gloo/RCCL: [sum, n] -> mean; [sumsq] -> std; scalar min/max."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if (
+        torch.cuda.is_available() and torch.distributed.get_backend() == 'nccl') else torch.device('cpu')
+    n = len(vals)
+    s = torch.tensor([float(vals.sum()) if n else 0.0, float(n)], dtype=torch.float64, device=dev)
+    dist.all_reduce_sum_(s)
+    if s[1].item() == 0:
+        nan = float('nan')
+        return (nan, nan, nan, nan) if min_and_max else (nan,)
+    mean = (s[0] / s[1]).item()
+    if not min_and_max:
+        return (mean,)
+    sq = torch.tensor([float(((vals.double() - mean) ** 2).sum()) if n else 0.0], dtype=torch.float64,
+                      device=dev)
+    dist.all_reduce_sum_(sq)
+    std = float(torch.sqrt(sq[0] / s[1]))
+    lo = torch.tensor([float(vals.min()) if n else float('inf')], dtype=torch.float64, device=dev)
+    hi = torch.tensor([float(vals.max()) if n else float('-inf')], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    return mean, lo.item(), hi.item(), std

@@ -1,0 +1,38 @@
+"""Drop-in installation behind the reference's own ``omnisafe.Agent``.
+
+``omnisafe_amd.install()`` (call it after ``import omnisafe``) swaps the registry entries of the
+accelerated algorithms for the classes of this package -- ``Registry._register_module`` raises KeyError
+on duplicates (omnisafe/algorithms/registry.py:55-58), so the entries are replaced in ``_module_dict``
+directly -- and registers the synthetic device environments with the reference's env registry.  After
+that ``omnisafe.Agent('PPOLag', env_id, custom_cfgs={'train_cfgs': {'device': 'cuda:0'}}).learn()``
+constructs ``omnisafe_amd.algorithms.PPOLag`` with the reference's own Config (YAML defaults) and
+runs the HIP path; nothing else in the reference changes.  See INTEGRATION.md.
+"""
+from __future__ import annotations
+
+ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO')
+
+
+def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
+    """Replace the reference's registry entries; returns the names that were swapped."""
+    import omnisafe  # the reference; must be importable by the caller's environment
+    from omnisafe.algorithms import registry as ref_registry
+    from omnisafe.envs import core as ref_env_core
+
+    from . import envs as amd_envs
+    from .algorithms import registry as amd_registry
+
+    swapped = []
+    for name in (algorithms or ACCELERATED):
+        if name in amd_registry.REGISTRY._module_dict and name in ref_registry.REGISTRY._module_dict:  # noqa: SLF001
+            ref_registry.REGISTRY._module_dict[name] = amd_registry.get(name)  # noqa: SLF001
+            swapped.append(name)
+    # make the synthetic ids valid env ids for the reference's config checks (envs/core.py:362-386)
+    reg = ref_env_core.ENV_REGISTRY
+    known = set(reg.support_envs())
+    new_ids = [e for e in amd_envs.SYNTH_DIMS if e not in known]
+    if new_ids:
+        reg._class['OmnisafeAmdSynthVectorEnv'] = amd_envs.SynthVectorEnv  # noqa: SLF001
+        reg._support_envs['OmnisafeAmdSynthVectorEnv'] = new_ids  # noqa: SLF001
+    del omnisafe
+    return swapped

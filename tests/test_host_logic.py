@@ -1,0 +1,164 @@
+"""CPU tests of host-side logic that involves no device arithmetic: config merge, registry, Lagrange
+scalar algebra (vs the reference), logger csv columns, plugin installation behind the reference's
+omnisafe.Agent, no-GPU failure mode."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+
+def test_config_defaults_match_reference_yaml_values():
+    from omnisafe_amd.config import get_default_kwargs
+
+    d = get_default_kwargs('PPOLag')
+    a = d['algo_cfgs']
+    assert (a['steps_per_epoch'], a['update_iters'], a['batch_size']) == (20000, 40, 64)
+    assert (a['target_kl'], a['clip'], a['gamma'], a['lam'], a['lam_c']) == (0.02, 0.2, 0.99, 0.95, 0.95)
+    assert d['lagrange_cfgs'] == {'cost_limit': 25.0, 'lagrangian_multiplier_init': 0.001,
+                                  'lambda_lr': 0.035, 'lambda_optimizer': 'Adam'}
+    t = get_default_kwargs('TRPOLag')
+    assert t['model_cfgs']['actor']['lr'] is None and t['model_cfgs']['critic']['lr'] == 0.001
+    assert (t['algo_cfgs']['cg_iters'], t['algo_cfgs']['cg_damping'], t['algo_cfgs']['batch_size']) == (15, 0.1, 128)
+    c = get_default_kwargs('CPO')
+    assert c['algo_cfgs']['cost_limit'] == 25.0 and 'lagrange_cfgs' not in c
+
+
+@pytest.mark.reference
+def test_config_defaults_equal_reference_yaml():
+    """Every default of the three accelerated algorithms equals the reference's YAML ``defaults``."""
+    import yaml
+
+    from omnisafe_amd.config import get_default_kwargs
+
+    for algo in ('PPOLag', 'TRPOLag', 'CPO'):
+        ref = yaml.safe_load(open(f'/root/reference/omnisafe/configs/on-policy/{algo}.yaml'))['defaults']
+        mine = get_default_kwargs(algo)
+
+        def walk(r, m, path):
+            for k, v in r.items():
+                if path + [k] in (['train_cfgs', 'device'], ['logger_cfgs', 'use_tensorboard']):
+                    continue  # deliberate: GPU device, no tensorboard dependency
+                assert k in m, path + [k]
+                if isinstance(v, dict):
+                    walk(v, m[k], path + [k])
+                else:
+                    assert m[k] == v, (algo, path + [k], m[k], v)
+
+        walk(ref, mine, [])
+
+
+def test_custom_cfg_validation():
+    import omnisafe_amd
+    from omnisafe_amd.config import get_default_kwargs, recursive_check_config
+
+    recursive_check_config({'algo_cfgs': {'batch_size': 128}}, get_default_kwargs('PPOLag'))
+    with pytest.raises(KeyError):
+        recursive_check_config({'algo_cfgs': {'bogus': 1}}, get_default_kwargs('PPOLag'))
+    with pytest.raises(AssertionError):
+        omnisafe_amd.Agent('NoSuchAlgo', 'SynthTiny-v0')
+
+
+def test_registry_semantics():
+    from omnisafe_amd.algorithms import registry
+
+    assert registry.get('PPOLag').__name__ == 'PPOLag'
+    with pytest.raises(KeyError):
+        registry.REGISTRY._register_module(registry.get('PPOLag'))  # duplicate name
+    with pytest.raises(KeyError):
+        registry.get('Nope')
+
+
+def test_lagrange_matches_oracle_trajectory():
+    from omnisafe_amd.lagrange import Lagrange
+
+    rng = np.random.default_rng(0)
+    mine = Lagrange(25.0, 0.001, 0.035)
+    ref = O.Lagrange(25.0, 0.001, 0.035)
+    for Jc in rng.uniform(0, 60, size=50):
+        mine.update_lagrange_multiplier(float(Jc))
+        ref.update_lagrange_multiplier(float(Jc))
+        assert np.float32(mine.lagrangian_multiplier) == np.float32(ref.lagrangian_multiplier.item())
+    up = Lagrange(25.0, 0.5, 0.1, lagrangian_upper_bound=0.6)
+    for _ in range(20):
+        up.update_lagrange_multiplier(100.0)
+    assert up.lagrangian_multiplier == pytest.approx(0.6)
+
+
+def test_lagrange_vs_reference_golden(golden):
+    from omnisafe_amd.lagrange import Lagrange
+
+    g = golden('ppolag_epoch.npz')
+    lag = Lagrange(25.0, 0.001, 0.035)
+    assert np.float32(lag.lagrangian_multiplier) == g['update/lambda_before']
+    lag.update_lagrange_multiplier(float(g['update/Jc']))
+    assert np.float32(lag.lagrangian_multiplier) == g['update/lambda_after']
+
+
+def test_logger_columns(tmp_path):
+    from omnisafe_amd.logger import Logger
+
+    lg = Logger(str(tmp_path), 'exp', seed=3, verbose=False)
+    lg.register_key('Metrics/EpRet', window_length=3)
+    lg.register_key('Train/PolicyRatio', min_and_max=True)
+    lg.register_key('Loss/Loss_pi', delta=True)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        lg.store({'Metrics/EpRet': v})
+    lg.store({'Train/PolicyRatio': 0.5})
+    lg.store({'Train/PolicyRatio': 1.5})
+    lg.store({'Loss/Loss_pi': 2.0})
+    assert lg.get_stats('Metrics/EpRet')[0] == pytest.approx(3.0)  # window of 3
+    lg.dump_tabular()
+    lg.store({'Loss/Loss_pi': 0.5})
+    lg.store({'Train/PolicyRatio': 1.0})
+    lg.dump_tabular()
+    lg.close()
+    rows = list(csv.reader(open(os.path.join(lg.log_dir, 'progress.csv'))))
+    assert rows[0] == ['Metrics/EpRet', 'Train/PolicyRatio', 'Train/PolicyRatio/Min',
+                       'Train/PolicyRatio/Max', 'Train/PolicyRatio/Std', 'Loss/Loss_pi',
+                       'Loss/Loss_pi/Delta']
+    assert float(rows[1][1]) == 1.0 and float(rows[1][2]) == 0.5 and float(rows[1][3]) == 1.5
+    assert float(rows[2][6]) == pytest.approx(-1.5)  # delta vs the previous epoch
+    assert float(rows[2][0]) == pytest.approx(3.0)   # window keys persist across epochs
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_agent_fails_loudly_without_gpu():
+    import omnisafe_amd
+
+    with pytest.raises(RuntimeError, match='no CPU fallback|GPU only'):
+        omnisafe_amd.Agent('PPOLag', 'SynthPointGoal1-v0')
+    with pytest.raises(RuntimeError, match='GPU only'):
+        omnisafe_amd.Agent('PPOLag', 'SynthPointGoal1-v0', custom_cfgs={'train_cfgs': {'device': 'cpu'}})
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(torch.cuda.is_available(), reason='build-container wiring test')
+def test_plugin_installs_behind_reference_agent(tmp_path, monkeypatch):
+    """``import omnisafe; omnisafe_amd.install()``: the reference's own Agent/AlgoWrapper + YAML config
+    machinery constructs OUR PPOLag class (and would run the HIP path on a GPU box)."""
+    import ref_harness
+
+    omnisafe = ref_harness.import_reference()
+    import omnisafe_amd
+    from omnisafe.algorithms import registry as ref_registry
+
+    keep = dict(ref_registry.REGISTRY._module_dict)
+    # the reference itself calls torch.cuda.set_device for a cuda device (algo_wrapper.py:164); there is
+    # no GPU in the build container, so neutralise that one call to reach the registry lookup.
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda *_a, **_k: None)
+    try:
+        swapped = omnisafe_amd.install()
+        assert 'PPOLag' in swapped
+        assert ref_registry.REGISTRY.get('PPOLag') is omnisafe_amd.algorithms.registry.get('PPOLag')
+        cfg = {'train_cfgs': {'device': 'cuda:0', 'total_steps': 2000, 'vector_env_nums': 4},
+               'algo_cfgs': {'steps_per_epoch': 1000},
+               'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': str(tmp_path)}}
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            omnisafe.Agent('PPOLag', 'SynthPointGoal1-v0', custom_cfgs=cfg)
+    finally:
+        ref_registry.REGISTRY._module_dict.clear()
+        ref_registry.REGISTRY._module_dict.update(keep)

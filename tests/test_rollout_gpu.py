@@ -1,0 +1,236 @@
+"""GPU parity of the rollout side: running normaliser, the whole OnPolicyAdapter.rollout replayed on
+the reference's recorded environment trace, the synthetic device env, and an end-to-end
+``Agent('PPOLag').learn()``.
+
+Tolerances: normaliser statistics rtol 1e-5 (float64 batch moments vs the reference's float32);
+stored observations / actions / values / logp rtol 1e-4, atol 2e-5 (normalised obs feed float32 MFMA
+chains); GAE outputs rtol 1e-4, atol 1e-4 (they inherit the value differences); episode metrics and
+path boundaries exact."""
+import csv
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_normalizer_vs_reference(golden):
+    from omnisafe_amd.normalizer import Normalizer
+
+    g = golden('normalizer.npz')
+    norm = Normalizer((7,), clip=5, device=DEV)
+    for i in range(int(g['n_batches'])):
+        y = norm.normalize(torch.from_numpy(g[f'in{i}']).to(DEV))
+        np.testing.assert_allclose(y.cpu().numpy(), g[f'out{i}'], rtol=2e-5, atol=1e-6, err_msg=str(i))
+        np.testing.assert_allclose(norm.mean.cpu().numpy(), g[f'mean{i}'], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(norm._sumsq.cpu().numpy(), g[f'sumsq{i}'], rtol=1e-5, atol=1e-7)
+        if i > 0:
+            np.testing.assert_allclose(norm.std.cpu().numpy(), g[f'std{i}'], rtol=1e-5)
+        else:
+            assert np.isnan(norm.std.cpu().numpy()).all()  # count == 1: 0/0, as the reference
+        assert int(norm._count) == int(g[f'count{i}'])
+    sd = norm.state_dict()
+    assert list(sd) == ['_mean', '_sumsq', '_var', '_std', '_count', '_clip']  # Evaluator-loadable
+
+
+def test_normalizer_masked_push_matches_oracle():
+    from omnisafe_amd.normalizer import Normalizer
+
+    rng = np.random.default_rng(5)
+    ref = O.Normalizer((60,), clip=5)
+    norm = Normalizer((60,), clip=5, device=DEV)
+    for _ in range(4):
+        x = (rng.standard_normal((300, 60)) * 3 + 1).astype(np.float32)
+        mask = rng.random(300) < 0.3
+        yr = ref.normalize(torch.from_numpy(x[mask]))
+        y = norm.normalize(torch.from_numpy(x).to(DEV), mask=torch.from_numpy(mask).to(DEV))
+        np.testing.assert_allclose(y.cpu().numpy()[mask], yr.numpy(), rtol=1e-4, atol=2e-5)
+        assert np.array_equal(y.cpu().numpy()[~mask], x[~mask])  # unselected rows pass through
+        x2 = rng.standard_normal((300, 60)).astype(np.float32)
+        np.testing.assert_allclose(norm.normalize(torch.from_numpy(x2).to(DEV)).cpu().numpy(),
+                                   ref.normalize(torch.from_numpy(x2)).numpy(), rtol=1e-4, atol=2e-5)
+    assert int(norm._count) == ref.count
+    # an all-false mask is a no-op (the reference only pushes when some env finished)
+    before = norm.mean.clone()
+    norm.push(torch.zeros(300, 60, device=DEV), mask=torch.zeros(300, dtype=torch.uint8, device=DEV))
+    assert torch.equal(before, norm.mean)
+
+
+class TraceEnv:
+    """Replays the raw env outputs recorded from the reference run (tests/golden/ppolag_epoch.npz)."""
+    need_auto_reset_wrapper = False
+    need_time_limit_wrapper = False
+
+    def __init__(self, g):
+        from omnisafe_amd.spaces import Box
+
+        self.g, self.t = g, 0
+        self.num_envs = int(g['N'])
+        self.observation_space = Box(-np.inf, np.inf, (60,))
+        self.action_space = Box(-1.0, 1.0, (2,))
+        self.actions = []
+
+    def set_seed(self, seed):
+        pass
+
+    def reset(self, seed=None, options=None):
+        self.t = 0
+        return torch.from_numpy(self.g['rollout/reset_obs']).to(DEV), {}
+
+    def step(self, action):
+        g, t = self.g, self.t
+        self.actions.append(action.cpu().numpy().copy())
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+        info = {}
+        fin = g['rollout/truncated'][t] | g['rollout/terminated'][t]
+        if fin.any():
+            info['final_observation'] = dev(g['rollout/final_obs'][t])
+            info['_final_observation'] = dev(fin.astype(np.uint8))
+        self.t += 1
+        return (dev(g['rollout/obs'][t]), dev(g['rollout/reward'][t]), dev(g['rollout/cost'][t]),
+                dev(g['rollout/terminated'][t].astype(np.uint8)),
+                dev(g['rollout/truncated'][t].astype(np.uint8)), info)
+
+    def close(self):
+        pass
+
+
+class _LoggerStub:
+    def __init__(self):
+        self.data = {}
+        self._headers_windows = {'Metrics/EpRet': 100}
+
+    def extend(self, k, v):
+        self.data.setdefault(k, []).extend(v)
+
+    def store(self, d):
+        for k, v in d.items():
+            self.data.setdefault(k, []).append(v)
+
+
+def _cfgs(**algo):
+    ns = types.SimpleNamespace
+    a = dict(obs_normalize=True, reward_normalize=False, cost_normalize=False, use_cost=True)
+    a.update(algo)
+    return ns(train_cfgs=ns(device=DEV), algo_cfgs=ns(**a), env_cfgs=None)
+
+
+def test_rollout_on_reference_trace(golden):
+    from omnisafe_amd.adapter import OnPolicyAdapter
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from test_mlp_gpu import make_ac
+
+    g = golden('ppolag_epoch.npz')
+    N, T = int(g['N']), int(g['T'])
+    env = TraceEnv(g)
+    adapter = OnPolicyAdapter('trace', N, 0, _cfgs(), env=env)
+    ac = make_ac(60, 2, g, 'init/')
+    eps_iter = iter(g['rollout/eps'])
+    plain_step = ac.step
+
+    def step_with_recorded_noise(obs, deterministic=False, eps=None, out=None, nets_mask=7):
+        if out is not None and 'act' in out and not deterministic:  # the vector policy step
+            eps = torch.from_numpy(next(eps_iter)).to(DEV)
+        return plain_step(obs, deterministic=deterministic, eps=eps, out=out, nets_mask=nets_mask)
+
+    ac.step = step_with_recorded_noise
+    buf = VectorOnPolicyBuffer(adapter.observation_space, adapter.action_space, T, 0.99, 0.95, 0.95,
+                               'gae', 0.0, True, True, num_envs=N, device=DEV)
+    logger = _LoggerStub()
+    adapter.rollout(T, ac, buf, logger)
+    assert buf.ptr == T
+    buf.compute_advantages()
+    b = {k: v.cpu().numpy() for k, v in buf.data.items()}
+    for k in ('obs', 'act', 'value_r', 'value_c', 'logp'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
+    assert np.array_equal(b['reward'], g['buffer/reward']) and np.array_equal(b['cost'], g['buffer/cost'])
+    # the env saw the ActionScale'd actions the reference's env saw
+    np.testing.assert_allclose(np.stack(env.actions), g['rollout/action'], rtol=1e-4, atol=2e-5)
+    # path boundaries: truncation every `horizon` steps and at epoch end
+    pe = (g['rollout/truncated'] | g['rollout/terminated']).astype(np.uint8)
+    pe[-1] = 1
+    assert np.array_equal(b['path_end'], pe)
+    for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c', 'discounted_ret'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=1e-4, err_msg=k)
+    norm = adapter.save()['obs_normalizer']
+    np.testing.assert_allclose(norm.mean.cpu().numpy(), g['rollout/norm_mean'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(norm.std.cpu().numpy(), g['rollout/norm_std'], rtol=1e-5)
+    assert int(norm._count) == int(g['rollout/norm_count'])
+    # episode metrics in the reference's (step, env) order
+    np.testing.assert_allclose(logger.data['Metrics/EpRet'], g['rollout/ep_ret_window'], rtol=1e-6)
+    assert np.array_equal(np.float32(logger.data['Metrics/EpCost']), g['rollout/ep_cost_window'])
+    assert np.array_equal(np.float32(logger.data['Metrics/EpLen']), g['rollout/ep_len_window'])
+    np.testing.assert_allclose(logger.data['Value/reward'][0], g['rollout/value_r_log_mean'], rtol=1e-3,
+                               atol=1e-5)
+
+
+def test_synth_env_statistics_and_autoreset():
+    from omnisafe_amd import envs
+
+    env = envs.make('SynthPointGoal1-v0', num_envs=4096, device=DEV, horizon=5, cost_p=0.05)
+    env.set_seed(3)
+    obs0, _ = env.reset()
+    assert obs0.shape == (4096, 60)
+    costs, rewards, all_obs = [], [], [obs0.clone()]
+    for t in range(1, 11):
+        obs, r, c, term, trunc, info = env.step(torch.zeros(4096, 2, device=DEV))
+        all_obs.append(obs.clone())
+        costs.append(c.clone())
+        rewards.append(r.clone())
+        assert int(term.sum()) == 0
+        if t % 5 == 0:
+            assert int(trunc.sum()) == 4096 and 'final_observation' in info
+            assert info['final_observation'].shape == (4096, 60)
+            assert not torch.equal(info['final_observation'], obs)  # post-reset obs differs
+        else:
+            assert int(trunc.sum()) == 0 and 'final_observation' not in info
+    x = torch.stack(all_obs).double()
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.std()) - 1) < 5e-3
+    assert abs(float(torch.stack(rewards).double().std()) - 1) < 2e-2
+    assert abs(float(torch.stack(costs).mean()) - 0.05) < 5e-3
+    assert not torch.equal(all_obs[0], all_obs[1])
+    # determinism: same seed -> same stream
+    env2 = envs.make('SynthPointGoal1-v0', num_envs=4096, device=DEV, horizon=5, cost_p=0.05)
+    env2.set_seed(3)
+    o2, _ = env2.reset()
+    assert torch.equal(o2, all_obs[0])
+
+
+def test_agent_ppolag_end_to_end(tmp_path):
+    """omnisafe_amd.Agent('PPOLag', ...).learn(): two epochs on the synthetic env; csv columns are the
+    reference's; checkpoint carries the reference's keys."""
+    import omnisafe_amd
+
+    cfg = {'seed': 1,
+           'train_cfgs': {'device': DEV, 'total_steps': 2 * 64 * 40, 'vector_env_nums': 64},
+           'algo_cfgs': {'steps_per_epoch': 64 * 40, 'update_iters': 2, 'batch_size': 64},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'save_model_freq': 1},
+           'env_cfgs': {'horizon': 10, 'cost_p': 0.5}}
+    agent = omnisafe_amd.Agent('PPOLag', 'SynthTiny-v0', custom_cfgs=cfg)
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert ep_len == 10.0 and 3.0 < ep_cost < 7.0 and abs(ep_ret) < 5.0
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(str(tmp_path), '*', '*', 'progress.csv'))[0])))
+    assert len(rows) == 2
+    expected = ['Metrics/EpRet', 'Metrics/EpCost', 'Metrics/EpLen', 'Train/Epoch', 'Train/Entropy',
+                'Train/KL', 'Train/StopIter', 'Train/PolicyRatio', 'Train/PolicyRatio/Min',
+                'Train/PolicyRatio/Max', 'Train/PolicyRatio/Std', 'Train/LR', 'Train/PolicyStd',
+                'TotalEnvSteps', 'Loss/Loss_pi', 'Loss/Loss_pi/Delta', 'Value/Adv',
+                'Loss/Loss_reward_critic', 'Loss/Loss_reward_critic/Delta', 'Value/reward',
+                'Loss/Loss_cost_critic', 'Loss/Loss_cost_critic/Delta', 'Value/cost', 'Time/Total',
+                'Time/Rollout', 'Time/Update', 'Time/Epoch', 'Time/FPS', 'Metrics/LagrangeMultiplier',
+                'Metrics/LagrangeMultiplier/Min', 'Metrics/LagrangeMultiplier/Max',
+                'Metrics/LagrangeMultiplier/Std']
+    assert list(rows[0]) == expected  # reference column set and order (policy_gradient.py:133-236)
+    assert float(rows[1]['TotalEnvSteps']) == 2 * 64 * 40 and float(rows[1]['Time/FPS']) > 0
+    assert all(np.isfinite(float(v)) for v in rows[1].values())
+    assert float(rows[1]['Train/LR']) == 0.0  # LinearLR reaches 0 after the last epoch
+    ck = torch.load(glob.glob(os.path.join(str(tmp_path), '*', '*', 'torch_save', 'epoch-2.pt'))[0])
+    assert list(ck['pi'])[0] == 'log_std' and ck['pi']['mean.0.weight'].shape == (64, 6)
+    assert set(ck['obs_normalizer']) == {'_mean', '_sumsq', '_var', '_std', '_count', '_clip'}
