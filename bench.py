@@ -156,7 +156,10 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import np_oracle as O
 
-    cores = os.cpu_count() or 1
+    # threads: the reference's own default torch_threads (PPOLag.yaml: 16), capped by the host; the
+    # 64-wide MLPs do not scale past a few cores and over-subscription on many-core hosts is
+    # pathological, so "all cores" is not used.
+    cores = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(cores)
     N, T = args.envs, args.steps_per_env
     rng = np.random.default_rng(0)
@@ -180,21 +183,27 @@ def cpu_baseline(args):
     data = {'obs': tt(O.env_major(buf['obs'])), 'act': tt(O.env_major(buf['act'])),
             'logp': tt(O.env_major(buf['logp'])), 'target_value_r': tt(O.env_major(gae['tgt_r'])),
             'target_value_c': tt(O.env_major(gae['tgt_c'])), 'adv_r': tt(a_r), 'adv_c': tt(a_c)}
-    M = N * T
-    n_mb = 2048
+    M, B = N * T, args.batch_size
     perm = torch.randperm(M)
+    budget_s, n_mb = 10.0, 0
     t0 = time.perf_counter()
-    O.ppolag_update(ac, data, 0.001, [perm], batch_size=args.batch_size, update_iters=1,
-                    kl_early_stop=False, max_minibatches=n_mb)
-    t_upd_sample = time.perf_counter() - t0
+    for s in range(0, M - B + 1, B):  # time-bounded sample of the minibatch chain
+        idx = perm[s:s + B]
+        O.critic_step(ac.reward_critic, ac.reward_critic_optimizer, data['obs'][idx], data['target_value_r'][idx])
+        O.critic_step(ac.cost_critic, ac.cost_critic_optimizer, data['obs'][idx], data['target_value_c'][idx])
+        O.actor_step(ac.actor, ac.actor_optimizer, data['obs'][idx], data['act'][idx], data['logp'][idx],
+                     data['adv_r'][idx], data['adv_c'][idx], 0.001)
+        n_mb += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    per_mb = (time.perf_counter() - t0) / n_mb
     with torch.no_grad():
         old = ac.actor.dist(data['obs'])
         om, osd = old.mean.clone(), old.stddev.clone()
     t0 = time.perf_counter()
     O.kl_old_new(ac.actor, data['obs'], om, osd)
     t_kl = time.perf_counter() - t0
-    nmb_full = (M + args.batch_size - 1) // args.batch_size
-    per_mb = (t_upd_sample - t_kl) / n_mb
+    nmb_full = (M + B - 1) // B
     t_epoch = t_roll + args.update_iters * (nmb_full * per_mb + t_kl)
     return {'value': round(M / t_epoch, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
             'sample': (f'full rollout+GAE+get of {M} transitions ({t_roll:.2f} s) + {n_mb} of '

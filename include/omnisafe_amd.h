@@ -166,6 +166,25 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
                       int loss_kind, int mode, int nets_mask, int max_blocks, float* ws,
                       float* step_stats, void* stream);
 
+/* Persistent form of the same update: ONE launch runs a whole pass of PolicyGradient._update's inner
+ * loop (policy_gradient.py:366-382) -- ceil(M/B) dependent minibatch steps over the permutation
+ * perm[M] (NULL = identity), B <= 64 -- for all three networks, with the parameters resident in LDS
+ * and the Adam moments in registers for the whole pass (see csrc/ppo_pass_kernel.hip).  Same
+ * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above.  Single
+ * process only (world_size == 1: the data-parallel path needs an all-reduce between gradient and
+ * Adam and uses osa_ppo_minibatch).  osa_ppo_pass_supported: 1 if (obs_dim, act_dim, hidden) fit. */
+int osa_ppo_pass_supported(int obs_dim, int act_dim, int hidden);
+int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                 int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                 const float* logp, const float* target_value_r, const float* target_value_c,
+                 const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                 const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                 float* step_stats, void* stream);
+
+/* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
+ * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */
+int osa_debug_set_clock_buffer(long long* dev_ptr);
+
 /* Adam step on already clipped (and, for world_size > 1, all-reduce-averaged) gradients. */
 int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                    int* adam_step, float* grads, const osa_ppo_hparams* hp, int nets_mask,

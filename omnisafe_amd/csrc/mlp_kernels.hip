@@ -40,7 +40,13 @@ struct OsaMbArgs {
   float* stats;  // [OSA_NSTAT] statistics of this optimiser step
   int loss_kind; // 0 PPO clipped surrogate (base/ppo.py:66-78), 1 plain ratio*adv (policy_gradient.py:574)
   int nets_mask; // bit0 actor, bit1 reward critic, bit2 cost critic
+  long long* dbg;  // optional [3][16] phase timestamps (s_memtime) of the last launch, or nullptr
 };
+
+#define OSA_TICK(k)                                                                  \
+  do {                                                                               \
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[blockIdx.y * 16 + (k)] = clock64(); \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // K1  rollout policy step
@@ -148,6 +154,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
       gsq += gv * gv;
       gbuf[e] = gv;
     }
+    OSA_TICK(9);
     gsq = osa_block_sum_f(gsq, red);
     psq = osa_block_sum_f(psq, red);
     const float total_norm = sqrtf(gsq);
@@ -164,6 +171,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
     if (mode == 1) return;
     __syncthreads();
   }
+  OSA_TICK(10);
   // ---- Adam
   const int step = a.adam_step[net] + 1;
   const double b1 = a.hp.beta1, b2 = a.hp.beta2;
@@ -172,6 +180,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
   const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
+  OSA_TICK(11);
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, eps = a.hp.adam_eps;
   float* __restrict__ m = a.adam_m + (long)net * P;
   float* __restrict__ v = a.adam_v + (long)net * P;
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
 
+  OSA_TICK(0);
   float loss_acc = 0.f, ratio_acc = 0.f;  // per-lane partial sums over this block's chunks
   const int nchunk = (a.B + 63) / 64;
   bool first = true;
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
     f32x4 h1[HT], h2[HT], out[OT];
     osa_mlp_forward<HT, OT>(nd, p, valid ? a.obs + row * a.ld_obs : nullptr, a.ld_obs, vec_ok, h1, h2,
                             out);
+    OSA_TICK(1);
     // ---- loss and dL/d(out), S layout
     f32x4 dO[OT], dLS[OT];
 #pragma unroll
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         dO[0][0] = 2.f * diff * invB;
       }
     }
+    OSA_TICK(2);
     // ---- backward through the hidden layers (S layout, activations stay in registers)
     const float* __restrict__ W2 = p + nd.oW2;
     const float* __restrict__ W3 = p + nd.oW3;
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
       }
       z1[t] = acc * (1.f - h1[t] * h1[t]);
     }
+    OSA_TICK(3);
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f*SLD + c]
     const int c = 16 * wave + j;
 #pragma unroll
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
       }
     }
     __syncthreads();
+    OSA_TICK(4);
     // ---- weight gradients: contraction over the 64 samples of the chunk.
     // D tile: lane (cc = l&15, g) holds dW[row 4g + r][col cc].
     const int cc = j;
@@ -398,6 +412,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
       }
     }
+    OSA_TICK(5);
     // dW3: output tiles o x column tile `wave`
     if (wave < HT) {
 #pragma unroll
@@ -421,6 +436,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
       }
     }
+    OSA_TICK(6);
     // bias / log_std gradients: one thread per feature sums its LDS row over the 64 samples
     {
       const int tid = threadIdx.x;
@@ -449,6 +465,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
   }  // chunks
   // ---- block-level loss statistics (deterministic order)
   __syncthreads();
+  OSA_TICK(7);
   const float loss_sum = osa_block_sum_f(loss_acc, red);
   const float ratio_sum = osa_block_sum_f(ratio_acc, red);
   if (a.nblk > 1) {
@@ -473,7 +490,9 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
   if (net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < nd.act_dim)
     gout[nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)nd.act_dim;
   __syncthreads();
+  OSA_TICK(8);
   osa_finalize_net(a, net, red);
+  OSA_TICK(12);
 }
 
 // Sum the per-block partial slabs into grads[net] (large-batch path), then finalize in a second launch.
@@ -519,7 +538,9 @@ __global__ __launch_bounds__(1024) void osa_finalize_kernel(OsaMbArgs a, int add
   if (add_entropy_grad && net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < a.nd.act_dim)
     a.grads[a.nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)a.nd.act_dim;
   __syncthreads();
+  OSA_TICK(8);
   osa_finalize_net(a, net, red);
+  OSA_TICK(12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,7 +615,14 @@ static int osa_check_dims(int obs_dim, int act_dim, int hidden) {
     else { CALL(4, 2); }                     \
   } while (0)
 
+static long long* g_osa_dbg_clocks = nullptr;
+
 extern "C" {
+
+int osa_debug_set_clock_buffer(long long* dev_ptr) {
+  g_osa_dbg_clocks = dev_ptr;
+  return OSA_OK;
+}
 
 int osa_mlp_layout(int obs_dim, int act_dim, int hidden, int* out12) {
   OSA_REQUIRE(out12 != nullptr);
@@ -658,6 +686,7 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.mode = mode; a.stats = step_stats; a.loss_kind = loss_kind;
   a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3);
+  a.dbg = g_osa_dbg_clocks;
   const int nchunk = (B + 63) / 64;
   int nblk = nchunk;
   if (max_blocks < 1) max_blocks = 1;

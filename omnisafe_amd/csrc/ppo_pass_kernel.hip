@@ -1,0 +1,663 @@
+// Persistent PPO-Lag update pass: ONE launch performs a whole pass of PolicyGradient._update's inner
+// loop (policy_gradient.py:366-382) -- `nmb` dependent minibatch optimiser steps -- for all three
+// networks (blockIdx.x = network; one 256-thread workgroup = 4 waves = 64 samples each).
+//
+// Why: with the reference's batch_size = 64 the update is a chain of 40 960 dependent optimiser steps
+// per epoch.  A launch per step spends its time on global-memory latency (weights, Adam state and
+// gradients make several L2 round trips per step: measured 57 us/step, of which MFMA work is ~5 us).
+// Here the network lives in the CU for the whole pass:
+//   * parameters: LDS-resident master copy (padded rows, conflict-free MFMA fragment reads),
+//     loaded once, written back once;
+//   * Adam moments m, v: REGISTERS (each lane owns the ~37 parameters its weight-gradient MFMA tiles
+//     produce), loaded once, written back once;
+//   * gradients never leave registers: MFMA accumulator -> (+2*coef*w) -> block-reduced norm -> clip
+//     -> Adam -> LDS master;
+//   * the next minibatch's rows (gathered by the permutation) are prefetched into registers while the
+//     current one computes.
+// Arithmetic is identical to osa_mb_grad_kernel + osa_finalize_net (same fragment algebra, same
+// operation order per element); tests compare both against the reference's golden vectors.
+#include "mlp_device.h"
+
+#define PSLD 68  // leading dimension (floats) of [feature][sample] tiles and of W2/W3 rows
+#define PNSTAT 16
+
+struct OsaPassHp {
+  float clip, entropy_coef, critic_norm_coef, max_grad_norm;
+  float lr_actor, lr_critic, beta1, beta2, adam_eps;
+  int use_critic_norm, use_max_grad_norm, use_cost;
+};
+
+struct OsaPassArgs {
+  OsaNet nd;
+  float* params;   // [3][P] padded global layout
+  float* adam_m;   // [3][P]
+  float* adam_v;   // [3][P]
+  int* adam_step;  // [3]
+  const float* obs;
+  int ld_obs;
+  const float* act;
+  int ld_act;
+  const float* logp;
+  const float* tgt_r;
+  const float* tgt_c;
+  const float* adv_r;
+  const float* adv_c;
+  const long* perm;  // [M] sample rows of the whole pass (nullptr = identity)
+  long M;            // rows in the pass
+  int B;             // minibatch size (<= 64); last minibatch may be smaller
+  int nmb;           // minibatches in this launch
+  const float* lagrange;
+  OsaPassHp hp;
+  int loss_kind;
+  int nets_mask;
+  float* stats;  // [nmb][PNSTAT]
+};
+
+template <int KB, int OT>
+__global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const OsaNet& nd = a.nd;
+  const int net = blockIdx.x;
+  if (!((a.nets_mask >> net) & 1)) return;
+  constexpr int H = 64, HT = 4, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + 4;
+  // ---- LDS carve-up (all offsets multiples of 4 floats)
+  float* sW1 = smem;                    // [H][W1LD]
+  float* sW2 = sW1 + H * W1LD;          // [H][PSLD]
+  float* sW3 = sW2 + H * PSLD;          // [OUTP][PSLD]
+  float* sB1 = sW3 + OUTP * PSLD;       // [H]
+  float* sB2 = sB1 + H;                 // [H]
+  float* sB3 = sB2 + H;                 // [OUTP]
+  float* sLS = sB3 + OUTP;              // [OUTP]
+  float* sH1 = sLS + OUTP;              // [H][PSLD]   tiles: element (feature f, sample c)
+  float* sH2 = sH1 + H * PSLD;
+  float* sZ1 = sH2 + H * PSLD;
+  float* sZ2 = sZ1 + H * PSLD;
+  float* sX = sZ2 + H * PSLD;           // [INP][PSLD]
+  float* sDO = sX + INP * PSLD;         // [OUTP][PSLD]
+  float* sDL = sDO + OUTP * PSLD;       // [OUTP][PSLD]
+  float* red = sDL + OUTP * PSLD;       // [4 waves][4] + spare
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int i = j, cc = j;
+  const int P = nd.P;
+  float* __restrict__ gp = a.params + (long)net * P;
+  float* __restrict__ gm = a.adam_m + (long)net * P;
+  float* __restrict__ gv = a.adam_v + (long)net * P;
+  const bool critic = net != 0;
+  const int out_dim = critic ? 1 : nd.act_dim;
+
+  // ---- load parameters into the LDS master copy (coalesced)
+  for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
+  for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
+  for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
+  if (tid < H) {
+    sB1[tid] = gp[nd.ob1 + tid];
+    sB2[tid] = gp[nd.ob2 + tid];
+  }
+  if (tid < OUTP) {
+    sB3[tid] = gp[nd.ob3 + tid];
+    sLS[tid] = gp[nd.oLS + tid];
+  }
+  // ---- ownership: the parameters whose gradients this lane's accumulator tiles produce.
+  //   W2[(16w+4g+r)][16ti+cc]  ti<4 | W1[(16w+4g+r)][16kb+cc] kb<KB | W3[(16o+4g+r)][16w+cc] o<OT
+  //   + one bias-like scalar per thread: tid<64 b1 | <128 b2 | <128+OUTP b3 | <128+2*OUTP log_std
+  f32x4 m2[HT], v2[HT], m1[KB], v1[KB], m3[OT], v3[OT];
+  float mb_ = 0.f, vb_ = 0.f;
+  int boff = -1;  // global offset of the owned bias-like scalar
+  float* sbias = nullptr;
+  if (tid < H) { boff = nd.ob1 + tid; sbias = sB1 + tid; }
+  else if (tid < 2 * H) { boff = nd.ob2 + tid - H; sbias = sB2 + tid - H; }
+  else if (tid < 2 * H + OUTP) { boff = nd.ob3 + tid - 2 * H; sbias = sB3 + tid - 2 * H; }
+  else if (tid < 2 * H + 2 * OUTP) { boff = nd.oLS + tid - 2 * H - OUTP; sbias = sLS + tid - 2 * H - OUTP; }
+  if (critic && boff >= nd.oLS) boff = -1;  // critics have no log_std
+#pragma unroll
+  for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+      m2[ti][r] = gm[off];
+      v2[ti][r] = gv[off];
+    }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
+      m1[kb][r] = gm[off];
+      v1[kb][r] = gv[off];
+    }
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+      m3[o][r] = gm[off];
+      v3[o][r] = gv[off];
+    }
+  if (boff >= 0) {
+    mb_ = gm[boff];
+    vb_ = gv[boff];
+  }
+  const int step0 = a.adam_step[net];
+  double b1pow = pow((double)a.hp.beta1, (double)step0), b2pow = pow((double)a.hp.beta2, (double)step0);
+  const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+  const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
+  const bool l2 = critic && a.hp.use_critic_norm;
+  const float c2 = 2.f * a.hp.critic_norm_coef;
+  float lam = 0.f;
+  if (net == 0 && a.lagrange) lam = *a.lagrange;
+  const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
+  const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
+
+  // ---- prefetch machinery: everything this lane needs for its sample of one minibatch
+  struct Pre {
+    f32x4 x[KB];
+    float act[4 * OT];
+    float logp, adv_r, adv_c, tgt;
+    bool valid;
+  };
+  auto fetch = [&](int mb, Pre& q) {
+    const long pos = (long)mb * a.B + 16 * wave + j;
+    const long end = min((long)(mb + 1) * a.B, a.M);
+    q.valid = (mb < a.nmb) && (16 * wave + j < a.B) && (pos < end);
+    const long row = q.valid ? (a.perm ? a.perm[pos] : pos) : -1;
+    const float* xrow = q.valid ? a.obs + row * a.ld_obs : nullptr;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) q.x[kb] = osa_load_x(xrow, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+    q.logp = q.adv_r = q.adv_c = q.tgt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 * OT; ++k) q.act[k] = 0.f;
+    if (q.valid) {
+      if (net == 0) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * o + 4 * g + r;
+            if (d < nd.act_dim) q.act[4 * o + r] = a.act[row * a.ld_act + d];
+          }
+        q.logp = a.logp[row];
+        q.adv_r = a.adv_r[row];
+        q.adv_c = a.adv_c[row];
+      } else {
+        q.tgt = tgt[row];
+      }
+    }
+  };
+  Pre cur, nxt;
+  fetch(0, cur);
+  __syncthreads();  // LDS master copy complete
+
+  for (int mb = 0; mb < a.nmb; ++mb) {
+    fetch(mb + 1, nxt);  // in flight while this minibatch computes
+    const long mb_lo = (long)mb * a.B;
+    const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
+    const float invB = 1.f / (float)Bcur;
+    const bool valid = cur.valid;
+    // ================= forward (S layout; weights from the LDS master) =================
+    f32x4 h1[HT], h2[HT], out[OT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 x = cur.x[kb];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW1 + (16 * t + i) * W1LD + 16 * kb + 4 * g);
+        h1[t] = OSA_MFMA(w.x, x.x, h1[t]);
+        h1[t] = OSA_MFMA(w.y, x.y, h1[t]);
+        h1[t] = OSA_MFMA(w.z, x.z, h1[t]);
+        h1[t] = OSA_MFMA(w.w, x.w, h1[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h1[t] = osa_tanh4(h1[t]);
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(sB2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * PSLD + 16 * kb + 4 * g);
+        h2[t] = OSA_MFMA(w.x, h1[kb].x, h2[t]);
+        h2[t] = OSA_MFMA(w.y, h1[kb].y, h2[t]);
+        h2[t] = OSA_MFMA(w.z, h1[kb].z, h2[t]);
+        h2[t] = OSA_MFMA(w.w, h1[kb].w, h2[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h2[t] = osa_tanh4(h2[t]);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
+#pragma unroll
+    for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
+        out[o] = OSA_MFMA(w.x, h2[kb].x, out[o]);
+        out[o] = OSA_MFMA(w.y, h2[kb].y, out[o]);
+        out[o] = OSA_MFMA(w.z, h2[kb].z, out[o]);
+        out[o] = OSA_MFMA(w.w, h2[kb].w, out[o]);
+      }
+    }
+    // ================= loss, dL/d(out) =================
+    f32x4 dO[OT], dLS[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
+    if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
+      for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
+      ent_pre /= (float)nd.act_dim;
+    }
+    if (net == 0) {
+      float lp = 0.f;
+      f32x4 zv[OT], ivar[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * o + 4 * g + r;
+          zv[o][r] = 0.f;
+          ivar[o][r] = 0.f;
+          if (d < nd.act_dim && valid) {
+            const float sd = expf(sLS[d]);
+            const float var = sd * sd;
+            const float z = cur.act[4 * o + r] - out[o][r];
+            zv[o][r] = z;
+            ivar[o][r] = 1.f / var;
+            lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+          }
+        }
+      }
+      lp = osa_sum_over_groups(lp);
+      if (valid) {
+        const float ratio = expf(lp - cur.logp);
+        const float adv = (cur.adv_r - lam * cur.adv_c) / (1.f + lam);
+        float dratio, li;
+        if (a.loss_kind == 0) {
+          const float lo = 1.f - a.hp.clip, hi = 1.f + a.hp.clip;
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float s1 = ratio * adv, s2 = rc * adv;
+          const bool inrange = ratio >= lo && ratio <= hi;
+          li = -fminf(s1, s2);
+          dratio = (s1 < s2 || inrange) ? -adv : 0.f;
+        } else {
+          li = -(ratio * adv);
+          dratio = -adv;
+        }
+        const float dlogp = dratio * ratio * invB;
+        if (g == 0) {
+          loss_part = li;
+          ratio_part = ratio;
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = zv[o][r], iv = ivar[o][r];
+            dO[o][r] = dlogp * z * iv;
+            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) : 0.f;
+          }
+        }
+      }
+    } else if (valid) {
+      const float diff = out[0][0] - cur.tgt;
+      if (g == 0) {
+        loss_part = diff * diff;
+        dO[0][0] = 2.f * diff * invB;
+      }
+    }
+    // ================= backward through the hidden layers =================
+    f32x4 z2[HT], z1[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
+          const float w = sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i];
+          acc = OSA_MFMA(w, dO[o][s], acc);
+        }
+      }
+      z2[t] = acc * (1.f - h2[t] * h2[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+          const float w = sW2[(16 * kb + 4 * g + s) * PSLD + 16 * t + i];
+          acc = OSA_MFMA(w, z2[kb][s], acc);
+        }
+      }
+      z1[t] = acc * (1.f - h1[t] * h1[t]);
+    }
+    // ================= S layout -> F layout through LDS =================
+    const int c = 16 * wave + j;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * g + r;
+        sH1[f * PSLD + c] = h1[t][r];
+        sH2[f * PSLD + c] = h2[t][r];
+        sZ1[f * PSLD + c] = z1[t][r];
+        sZ2[f * PSLD + c] = z2[t][r];
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sX[(16 * kb + 4 * g + r) * PSLD + c] = cur.x[kb][r];
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * o + 4 * g + r;
+        sDO[f * PSLD + c] = dO[o][r];
+        sDL[f * PSLD + c] = dLS[o][r];
+      }
+    }
+    __syncthreads();  // (A) tiles complete
+    // ================= weight gradients (registers) =================
+    f32x4 g2[HT], g1[KB], g3[OT];
+    {
+      f32x4 a2[4], a1[4];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
+        a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
+      }
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * PSLD + 16 * sb + 4 * g);
+          acc = OSA_MFMA(a2[sb].x, b.x, acc);
+          acc = OSA_MFMA(a2[sb].y, b.y, acc);
+          acc = OSA_MFMA(a2[sb].z, b.z, acc);
+          acc = OSA_MFMA(a2[sb].w, b.w, acc);
+        }
+        g2[ti] = acc;
+      }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * PSLD + 16 * sb + 4 * g);
+          acc = OSA_MFMA(a1[sb].x, b.x, acc);
+          acc = OSA_MFMA(a1[sb].y, b.y, acc);
+          acc = OSA_MFMA(a1[sb].z, b.z, acc);
+          acc = OSA_MFMA(a1[sb].w, b.w, acc);
+        }
+        g1[kb] = acc;
+      }
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * PSLD + 16 * sb + 4 * g);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
+          acc = OSA_MFMA(av.x, b.x, acc);
+          acc = OSA_MFMA(av.y, b.y, acc);
+          acc = OSA_MFMA(av.z, b.z, acc);
+          acc = OSA_MFMA(av.w, b.w, acc);
+        }
+        g3[o] = acc;
+      }
+    }
+    // bias-like gradient owned by this thread: row sum over the 64 samples
+    float gb = 0.f;
+    if (boff >= 0) {
+      const float* srow = (tid < H) ? sZ1 + tid * PSLD
+                          : (tid < 2 * H) ? sZ2 + (tid - H) * PSLD
+                          : (tid < 2 * H + OUTP) ? sDO + (tid - 2 * H) * PSLD
+                                                 : sDL + (tid - 2 * H - OUTP) * PSLD;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(srow + 4 * k);
+        gb += q.x;
+        gb += q.y;
+        gb += q.z;
+        gb += q.w;
+      }
+      if (net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
+        gb -= a.hp.entropy_coef / (float)nd.act_dim;
+    }
+    // ================= + 2*coef*w (critics), squared norms =================
+    float gsq = 0.f, psq = 0.f;
+    f32x4 w2[HT], w1[KB], w3[OT];
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float w = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+        w2[ti][r] = w;
+        if (l2) g2[ti][r] += c2 * w;
+        psq += w * w;
+        gsq += g2[ti][r] * g2[ti][r];
+      }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float w = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+        w1[kb][r] = w;
+        if (l2) g1[kb][r] += c2 * w;
+        psq += w * w;
+        gsq += g1[kb][r] * g1[kb][r];
+      }
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float w = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+        w3[o][r] = w;
+        if (l2) g3[o][r] += c2 * w;
+        psq += w * w;
+        gsq += g3[o][r] * g3[o][r];
+      }
+    float wb = 0.f;
+    if (boff >= 0) {
+      wb = *sbias;
+      if (l2) gb += c2 * wb;
+      psq += wb * wb;
+      gsq += gb * gb;
+    }
+    // ---- block reduction of (gsq, psq, loss, ratio): wave shuffles, then a fixed-order sum
+    gsq = osa_wave_sum(gsq);
+    psq = osa_wave_sum(psq);
+    loss_part = osa_wave_sum(loss_part);
+    ratio_part = osa_wave_sum(ratio_part);
+    if (lane == 0) {
+      red[4 * wave + 0] = gsq;
+      red[4 * wave + 1] = psq;
+      red[4 * wave + 2] = loss_part;
+      red[4 * wave + 3] = ratio_part;
+    }
+    __syncthreads();  // (B)
+    const float t_gsq = red[0] + red[4] + red[8] + red[12];
+    const float t_psq = red[1] + red[5] + red[9] + red[13];
+    const float t_loss = red[2] + red[6] + red[10] + red[14];
+    const float t_ratio = red[3] + red[7] + red[11] + red[15];
+    const float total_norm = sqrtf(t_gsq);
+    float coef = 1.f;
+    if (a.hp.use_max_grad_norm) {
+      coef = a.hp.max_grad_norm / (total_norm + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+    // ================= Adam on the owned parameters; LDS master updated in place =================
+    b1pow *= (double)beta1;
+    b2pow *= (double)beta2;
+    const float step_size = (float)((double)lr / (1.0 - b1pow));
+    const float bc2_sqrt = (float)sqrt(1.0 - b2pow);
+    const bool do_clip = a.hp.use_max_grad_norm != 0;
+#define OSA_ADAM(G, MV, VV, W, DST)                              \
+  do {                                                           \
+    float gval_ = (G);                                           \
+    if (do_clip) gval_ *= coef;                                  \
+    float mv_ = (MV), vv_ = (VV);                                \
+    mv_ = mv_ + (gval_ - mv_) * (1.f - beta1);                   \
+    vv_ = vv_ * beta2 + (1.f - beta2) * gval_ * gval_;           \
+    const float denom_ = sqrtf(vv_) / bc2_sqrt + aeps;           \
+    (MV) = mv_;                                                  \
+    (VV) = vv_;                                                  \
+    (DST) = (W) - step_size * (mv_ / denom_);                    \
+  } while (0)
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        OSA_ADAM(g2[ti][r], m2[ti][r], v2[ti][r], w2[ti][r],
+                 sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc]);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        OSA_ADAM(g1[kb][r], m1[kb][r], v1[kb][r], w1[kb][r],
+                 sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc]);
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        OSA_ADAM(g3[o][r], m3[o][r], v3[o][r], w3[o][r],
+                 sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc]);
+    if (boff >= 0) OSA_ADAM(gb, mb_, vb_, wb, *sbias);
+#undef OSA_ADAM
+    // ---- statistics of this optimiser step
+    if (tid == 0) {
+      float* st = a.stats + (long)mb * PNSTAT;
+      if (net == 0) {
+        st[2] = t_loss * invB - a.hp.entropy_coef * ent_pre;
+        st[3] = t_ratio * invB;
+        st[4] = ent_pre;
+        st[7] = total_norm;
+      } else {
+        st[net - 1] = t_loss * invB;
+        st[4 + net] = t_psq;
+        st[7 + net] = total_norm;
+      }
+    }
+    cur = nxt;
+    __syncthreads();  // (C) master copy updated, tiles and `red` free for the next minibatch
+  }
+  // ---- write back parameters and Adam state
+  for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
+  for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * PSLD + (e & 63)];
+  for (int e = tid; e < OUTP * H; e += 256) gp[nd.oW3 + e] = sW3[(e >> 6) * PSLD + (e & 63)];
+  if (tid < H) {
+    gp[nd.ob1 + tid] = sB1[tid];
+    gp[nd.ob2 + tid] = sB2[tid];
+  }
+  if (tid < OUTP) {
+    gp[nd.ob3 + tid] = sB3[tid];
+    if (!critic) gp[nd.oLS + tid] = sLS[tid];
+  }
+#pragma unroll
+  for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+      gm[off] = m2[ti][r];
+      gv[off] = v2[ti][r];
+    }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
+      gm[off] = m1[kb][r];
+      gv[off] = v1[kb][r];
+    }
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+      gm[off] = m3[o][r];
+      gv[off] = v3[o][r];
+    }
+  if (boff >= 0) {
+    gm[boff] = mb_;
+    gv[boff] = vb_;
+  }
+  if (tid == 0) a.adam_step[net] = step0 + a.nmb;
+  (void)out_dim;
+}
+
+// ------------------------------------------------------------------------------------------------
+static size_t osa_pass_lds_bytes(int KB, int OT) {
+  const int H = 64, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + 4;
+  const size_t fl = (size_t)H * W1LD + (size_t)H * PSLD + (size_t)OUTP * PSLD + 2 * H + 2 * OUTP +
+                    4 * (size_t)H * PSLD + (size_t)INP * PSLD + 2 * (size_t)OUTP * PSLD + 64;
+  return fl * sizeof(float);
+}
+
+template <int KB, int OT>
+static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds = osa_pass_lds_bytes(KB, OT);
+  if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return OSA_EHIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT>), dim3(3), dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+extern "C" {
+
+int osa_ppo_pass_supported(int obs_dim, int act_dim, int hidden) {
+  if (hidden != 64 || obs_dim < 1 || act_dim < 1 || act_dim > 32) return 0;
+  const int KB = (obs_dim + 15) / 16, OT = (act_dim + 15) / 16;
+  return (KB <= 6 && OT <= 2 && osa_pass_lds_bytes(KB, OT) <= 160 * 1024) ? 1 : 0;
+}
+
+int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                 int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                 const float* logp, const float* target_value_r, const float* target_value_c,
+                 const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                 const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                 float* step_stats, void* stream) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && B <= 64);
+  OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
+  OsaPassArgs a;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = perm; a.M = M; a.B = B; a.nmb = (int)((M + B - 1) / B); a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
+  const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
+  hipStream_t st = osa_stream(stream);
+#define OSA_PASS_CASE(K, O) \
+  if (KB == K && OT == O) return osa_launch_pass<K, O>(a, st)
+  OSA_PASS_CASE(1, 1); OSA_PASS_CASE(2, 1); OSA_PASS_CASE(3, 1); OSA_PASS_CASE(4, 1);
+  OSA_PASS_CASE(5, 1); OSA_PASS_CASE(6, 1);
+  OSA_PASS_CASE(1, 2); OSA_PASS_CASE(2, 2); OSA_PASS_CASE(3, 2); OSA_PASS_CASE(4, 2);
+  OSA_PASS_CASE(5, 2); OSA_PASS_CASE(6, 2);
+#undef OSA_PASS_CASE
+  return OSA_EUNSUPPORTED;
+}
+
+}  // extern "C"

@@ -31,13 +31,15 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                  target_kl: float, kl_early_stop: bool, clip: float = 0.2, entropy_coef: float = 0.0,
                  use_critic_norm: bool = True, critic_norm_coef: float = 0.001,
                  use_max_grad_norm: bool = True, max_grad_norm: float = 40.0, use_cost: bool = True,
-                 loss_kind: int = 0, max_blocks: int = 256, update_actor: bool = True) -> None:
+                 loss_kind: int = 0, max_blocks: int = 256, update_actor: bool = True,
+                 persistent: bool = True) -> None:
         self.ac = ac
         self.lib = _lib.load(require_gpu=True)
         self.batch_size, self.update_iters = int(batch_size), int(update_iters)
         self.target_kl, self.kl_early_stop = float(target_kl), bool(kl_early_stop)
         self.loss_kind = loss_kind
         self.update_actor = update_actor
+        self.persistent = persistent
         self.hp = HParams(clip=clip, entropy_coef=entropy_coef, critic_norm_coef=critic_norm_coef,
                           max_grad_norm=max_grad_norm, lr_actor=0.0, lr_critic=0.0, beta1=0.9,
                           beta2=0.999, adam_eps=1e-8, use_critic_norm=int(use_critic_norm),
@@ -76,6 +78,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                                           _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
                                           _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), C.byref(self.hp),
                                           self._nets_mask(), st), 'osa_adam_apply')
+
+    def run_pass(self, data: dict, perm: torch.Tensor, lagrange: torch.Tensor,
+                 stats_rows: torch.Tensor) -> None:
+        """osa_ppo_pass: all ceil(M/B) minibatch steps of one pass in a single persistent launch."""
+        ac = self.ac
+        M = data['obs'].shape[0]
+        _lib.check(self.lib.osa_ppo_pass(
+            ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+            _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
+            _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+            _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+            _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
+            C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
+            _lib.stream_ptr()), 'osa_ppo_pass')
 
     def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
         """old_distribution = actor(obs) (policy_gradient.py:357)."""
@@ -120,15 +136,21 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.snapshot_old_distribution(obs)
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
+        use_pass = (self.persistent and dist.world_size() == 1 and B <= 64 and bool(
+            self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         for i in range(self.update_iters):
             if perms is not None:
                 perm = torch.as_tensor(perms[i]).to(ac.device, torch.int64)
             else:
                 perm = torch.randperm(M, device=ac.device)
-            for s in range(0, M, B):
-                nb = min(B, M - s)
-                self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
-                step += 1
+            if use_pass:  # one persistent launch for the whole pass
+                self.run_pass(data, perm, lagrange, stats[step:step + nmb])
+                step += nmb
+            else:
+                for s in range(0, M, B):
+                    nb = min(B, M - s)
+                    self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
+                    step += 1
             update_counts += 1
             if self.update_actor:
                 kl_dev = self.kl(obs)

@@ -400,7 +400,7 @@ def ppo_loss_pi(actor, obs, act, logp, adv, clip=0.2, entropy_coef=0.0):
     ratio_cliped = torch.clamp(ratio, 1 - clip, 1 + clip)
     loss = -torch.min(ratio * adv, ratio_cliped * adv).mean()
     loss = loss - entropy_coef * d.entropy().mean()
-    return loss, float(d.entropy().mean()), ratio.detach()
+    return loss, float(d.entropy().mean().detach()), ratio.detach()
 
 
 def pg_loss_pi(actor, obs, act, logp, adv):
@@ -408,7 +408,7 @@ def pg_loss_pi(actor, obs, act, logp, adv):
     d = actor.dist(obs)
     logp_ = d.log_prob(act).sum(axis=-1)
     ratio = torch.exp(logp_ - logp)
-    return -(ratio * adv).mean(), float(d.entropy().mean()), ratio.detach()
+    return -(ratio * adv).mean(), float(d.entropy().mean().detach()), ratio.detach()
 
 
 def lag_adv_surrogate(adv_r, adv_c, lam):

@@ -236,3 +236,38 @@ def test_large_batch_multiblock_equals_single_pass():
         for k, v in getattr(ac, net).state_dict().items():
             np.testing.assert_allclose(v.cpu().numpy(), getattr(ref, net).state_dict()[k].numpy(),
                                        rtol=1e-4, atol=2e-6, err_msg=f'{net}/{k}')
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
+                                                (90, 17, 512, 64), (5, 1, 130, 64)])
+def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
+    """osa_ppo_pass (one persistent launch per pass, weights in LDS, Adam moments in registers) vs
+    osa_ppo_minibatch (one launch per optimiser step): same parameters, moments and statistics after
+    two passes, including ragged last minibatches and every (KB, OT) template instance family."""
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(obs_dim + act_dim)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    acs, outs = [], []
+    perms = [torch.randperm(M), torch.randperm(M)]
+    for persistent in (True, False):
+        torch.manual_seed(99)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))  # logp of mean action
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False,
+                        entropy_coef=0.01, persistent=persistent)
+        lam = torch.tensor([0.3], device=DEV)
+        outs.append(up.run(data, lam, perms=perms, actor_lr=3e-4, critic_lr=1e-3))
+        acs.append(ac)
+    assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
+    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
+    for name in ('params', 'adam_m', 'adam_v'):
+        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=name)
+    s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
+    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
