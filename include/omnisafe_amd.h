@@ -184,6 +184,8 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */
 int osa_debug_set_clock_buffer(long long* dev_ptr);
+/* same for osa_ppo_pass: accumulated cycles per phase over the pass, [3 networks][16]. */
+int osa_debug_set_pass_clock_buffer(long long* dev_ptr);
 
 /* Adam step on already clipped (and, for world_size > 1, all-reduce-averaged) gradients. */
 int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,

@@ -52,13 +52,41 @@ __host__ __device__ inline OsaNet osa_make_net(int obs_dim, int act_dim, int H) 
   return n;
 }
 
+// tanh, branch-free, ~12 VALU ops (ocml's tanhf costs several times that and dominated the forward
+// pass): odd Taylor polynomial to x^9 for |x| < 0.3 (truncation < 2e-8 absolute), otherwise
+// 1 - 2 / (1 + e^{2|x|}) on the hardware exp2 / rcp units (|relative error| < ~5e-7).
+__device__ __forceinline__ float osa_tanhf(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  float p = fmaf(x2, 62.f / 2835.f, -17.f / 315.f);
+  p = fmaf(x2, p, 2.f / 15.f);
+  p = fmaf(x2, p, -1.f / 3.f);
+  p = fmaf(x2 * x, p, x);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f);  // e^{2|x|} = 2^{2|x| log2 e}
+  const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+  return ax < 0.3f ? p : copysignf(r, x);
+}
 __device__ __forceinline__ f32x4 osa_tanh4(f32x4 v) {
   f32x4 r;
-  r.x = tanhf(v.x);
-  r.y = tanhf(v.y);
-  r.z = tanhf(v.z);
-  r.w = tanhf(v.w);
+  r.x = osa_tanhf(v.x);
+  r.y = osa_tanhf(v.y);
+  r.z = osa_tanhf(v.z);
+  r.w = osa_tanhf(v.w);
   return r;
+}
+
+// One Adam step of one parameter (torch.optim.Adam single-tensor form):
+//   m <- lerp(m, g, 1-b1); v <- b2 v + (1-b2) g^2; w <- w - step_size * m / (sqrt(v)/bc2_sqrt + eps)
+// inv_bc2_sqrt = 1/sqrt(1 - b2^t), step_size = lr/(1 - b1^t) are formed once per step in float64.
+// sqrt and the reciprocal use the hardware units (1 ulp): the relative error of the *update* is
+// ~1e-7 of a step of size ~lr, i.e. far below float32 resolution of the parameter.
+__device__ __forceinline__ float osa_adam_update(float g, float& m, float& v, float w, float beta1,
+                                                 float beta2, float step_size, float inv_bc2_sqrt,
+                                                 float eps) {
+  m = fmaf(g - m, 1.f - beta1, m);
+  v = fmaf(v, beta2, (1.f - beta2) * g * g);
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
+  return fmaf(-step_size * m, __builtin_amdgcn_rcpf(denom), w);
 }
 
 // X fragment (S layout): 4 consecutive input features [col0, col0+4) of this lane's sample row.

@@ -142,17 +142,32 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
     const bool l2 = critic && a.hp.use_critic_norm;
     const float c2 = 2.f * a.hp.critic_norm_coef;
     float gsq = 0.f, psq = 0.f;
-    for (int e = threadIdx.x; e < P; e += blockDim.x) {
-      float gv = gbuf[e];
-      const float pv = p[e];
-      if (critic && e >= nd.oLS) {  // critics have no log_std; keep the slot inert
-        gv = 0.f;
-      } else {
-        if (l2) gv += c2 * pv;
-        if (critic) psq += pv * pv;
+    for (int e0 = 0; e0 < P; e0 += 8 * blockDim.x) {
+      float g8[8], p8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = e0 + k * blockDim.x + threadIdx.x;
+        if (e < P) {
+          g8[k] = gbuf[e];
+          p8[k] = p[e];
+        }
       }
-      gsq += gv * gv;
-      gbuf[e] = gv;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = e0 + k * blockDim.x + threadIdx.x;
+        if (e < P) {
+          float gv = g8[k];
+          const float pv = p8[k];
+          if (critic && e >= nd.oLS) {  // critics have no log_std; keep the slot inert
+            gv = 0.f;
+          } else {
+            if (l2) gv += c2 * pv;
+            if (critic) psq += pv * pv;
+          }
+          gsq += gv * gv;
+          gbuf[e] = gv;
+        }
+      }
     }
     OSA_TICK(9);
     gsq = osa_block_sum_f(gsq, red);
@@ -179,20 +194,32 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
   const double bc2 = 1.0 - pow(b2, (double)step);
   const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
   const float step_size = (float)((double)lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   OSA_TICK(11);
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, eps = a.hp.adam_eps;
   float* __restrict__ m = a.adam_m + (long)net * P;
   float* __restrict__ v = a.adam_v + (long)net * P;
-  for (int e = threadIdx.x; e < P; e += blockDim.x) {
-    const float gv = gbuf[e];
-    float mv = m[e], vv = v[e];
-    mv = mv + (gv - mv) * (1.f - beta1);              // exp_avg.lerp_(grad, 1 - beta1)
-    vv = vv * beta2 + (1.f - beta2) * gv * gv;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
-    p[e] = p[e] - step_size * (mv / denom);           // param.addcdiv_(exp_avg, denom, -step_size)
-    m[e] = mv;
-    v[e] = vv;
+  for (int e0 = 0; e0 < P; e0 += 8 * blockDim.x) {  // batches of 8 independent loads per thread
+    float gv8[8], mv8[8], vv8[8], pv8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = e0 + k * blockDim.x + threadIdx.x;
+      if (e < P) {
+        gv8[k] = gbuf[e];
+        mv8[k] = m[e];
+        vv8[k] = v[e];
+        pv8[k] = p[e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = e0 + k * blockDim.x + threadIdx.x;
+      if (e < P) {
+        p[e] = osa_adam_update(gv8[k], mv8[k], vv8[k], pv8[k], beta1, beta2, step_size, inv_bc2_sqrt, eps);
+        m[e] = mv8[k];
+        v[e] = vv8[k];
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) a.adam_step[net] = step;

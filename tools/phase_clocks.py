@@ -45,3 +45,17 @@ for k in range(1000):
     up.minibatch(data, perm[k * 64:(k + 1) * 64], 64, lam, stats)
 e1.record(); torch.cuda.synchronize()
 print('us per launch', e0.elapsed_time(e1))
+
+# ---- persistent pass kernel
+dbg2 = torch.zeros(48, dtype=torch.int64, device=dev)
+lib.osa_debug_set_pass_clock_buffer(dbg2.data_ptr())
+st = torch.zeros(1024, 16, device=dev)
+up.run_pass(data, perm, lam, st); torch.cuda.synchronize()
+e0.record(); up.run_pass(data, perm, lam, st); e1.record(); torch.cuda.synchronize()
+lib.osa_debug_set_pass_clock_buffer(None)
+d = dbg2.cpu().numpy().reshape(3, 16)[:, :10] / 1024.0
+names2 = ['prefetch-issue', 'fwd', 'loss', 'bwd', 'transpose+barA', 'dW', 'bias+norms', 'barB', 'adam', 'stats+barC']
+print('PASS kernel: cycles per minibatch   actor  V_r  V_c')
+for i, n in enumerate(names2):
+    print(f'{n:24s}', *[f'{v:9.0f}' for v in d[:, i]])
+print('total', d.sum(1), 'us per minibatch (event)', e0.elapsed_time(e1) * 1e3 / 1024)
