@@ -111,39 +111,30 @@ def timed(algo, steps, warmup, world, dev):
     return dt
 
 
-def kernel_roofline(algo, batch_size, dev):
-    """Mean duration of the dominant kernel with HIP events on the launch stream: `reps` back-to-back
-    dependent minibatch launches (the exact launch sequence of one update pass), events before the
-    first and after the last.  Includes the ~1.5 us dependent-launch boundary between kernels."""
-    up = algo._updater
-    data = algo._buf._out
-    M = data['obs'].shape[0]
-    lam = algo._lagrange_tensor()
-    up.hp.lr_actor, up.hp.lr_critic = 3e-4, 3e-4
-    perm = torch.randperm(M, device=dev)
-    stats = torch.zeros(16, device=dev)
-    nmb = (M + batch_size - 1) // batch_size
-    reps = 1024 if batch_size <= 256 else 128
-    for _ in range(16):  # warm
-        up.minibatch(data, perm[:batch_size], batch_size, lam, stats)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for k in range(reps):
-        s = (k * batch_size) % (M - batch_size + 1)
-        up.minibatch(data, perm[s:s + batch_size], batch_size, lam, stats)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    flops = FLOPS_PER_SAMPLE_STEP * batch_size
-    achieved = flops / (us * 1e-6) / 1e12
-    return {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
-            'kernel': 'osa_mb_grad_kernel<4,1>', 'us_per_launch': round(us, 3),
-            'flops_per_launch': flops, 'rows_per_launch': batch_size,
-            'note': ('3 workgroups (one per network) x 64 rows per launch: latency-bound by the '
-                     "reference's batch_size=64 optimiser chain, see throughput_variant")
-            if batch_size <= 64 else 'large-batch launch: ceil(B/64) workgroups per network'}
+def roofline_from_events(events, batch_size):
+    """Dominant-kernel roofline from HIP events recorded around every update launch inside the timed
+    region (torch.cuda.Event on the launch stream).  B <= 64: osa_ppo_pass_kernel, one launch = one
+    whole pass of ceil(M/B) dependent optimiser steps of the three networks (3 workgroups).
+    Larger B: osa_mb_grad_kernel (+ the two small reduce/finalize launches it is bracketed with)."""
+    name = events[0][0]
+    rows = sum(e[1] for e in events)
+    ms = sum(e[2][0].elapsed_time(e[2][1]) for e in events)
+    flops = FLOPS_PER_SAMPLE_STEP * rows
+    achieved = flops / (ms * 1e-3) / 1e12
+    us = ms * 1e3 / len(events)
+    out = {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
+           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+           'kernel': name, 'launches_timed': len(events), 'us_per_launch': round(us, 2),
+           'flops_per_launch': flops // len(events), 'rows_per_launch': rows // len(events)}
+    if name == 'osa_ppo_pass_kernel':
+        steps = rows // len(events) // batch_size
+        out['us_per_optimiser_step'] = round(us / steps, 3)
+        out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
+                       'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
+                       'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
+    else:
+        out['note'] = 'large-batch step: ceil(B/64) workgroups per network + slab reduce + clip/Adam launches'
+    return out
 
 
 def cpu_baseline(args):
@@ -225,7 +216,11 @@ def main():
 
     log_dir = tempfile.mkdtemp(prefix='osa_bench_')
     algo = make_algo(args, world, args.batch_size, args.update_iters, args.steps + args.warmup + 1, log_dir)
-    dt = timed(algo, args.steps, args.warmup, world, dev)
+    events = []
+    run_epochs(algo, args.warmup, lambda: torch.cuda.synchronize(dev))
+    algo._updater.profile_events = events
+    dt = timed(algo, args.steps, 0, world, dev)
+    algo._updater.profile_events = None
     per_gpu_steps = args.envs * args.steps_per_env
     value = world * per_gpu_steps * args.steps / dt
     out = {
@@ -240,19 +235,23 @@ def main():
                                 f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
                    'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}'},
     }
-    out['roofline'] = kernel_roofline(algo, args.batch_size, dev)
+    out['roofline'] = roofline_from_events(events, args.batch_size)
     if world == 1 and not args.no_variant and rank == 0:
         del algo
         torch.cuda.empty_cache()
         v_algo = make_algo(args, world, 16384, 8, 6, log_dir)
         v_steps = 5
-        v_dt = timed(v_algo, v_steps, 1, world, dev)
+        v_events = []
+        run_epochs(v_algo, 1, lambda: torch.cuda.synchronize(dev))
+        v_algo._updater.profile_events = v_events
+        v_dt = timed(v_algo, v_steps, 0, world, dev)
+        v_algo._updater.profile_events = None
         out['throughput_variant'] = {
             'workload': 'same shapes, batch_size=16384, update_iters=8 (large-batch setting of PPOLag.yaml '
                         'GPU-env blocks)',
             'value': round(per_gpu_steps * v_steps / v_dt, 1), 'unit': 'env-steps/s',
             'ms_per_step': round(v_dt / v_steps * 1e3, 3),
-            'roofline': kernel_roofline(v_algo, 16384, dev)}
+            'roofline': roofline_from_events(v_events, 16384)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     else:

@@ -53,6 +53,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._old_mean: torch.Tensor | None = None
         self._old_log_std = torch.zeros(ac.layout.OUTP, dtype=torch.float32, device=dev)
         self._stats: torch.Tensor | None = None
+        # optional profiling: list collecting (start, end) HIP events around every update launch on
+        # torch's current stream (bench.py turns this on for the timed region)
+        self.profile_events: list | None = None
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
@@ -64,6 +67,10 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         ac, lib, st = self.ac, self.lib, _lib.stream_ptr()
         ws = dist.world_size()
         mode = 0 if ws == 1 else 1
+        ev = None
+        if self.profile_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _lib.check(lib.osa_ppo_minibatch(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']),
@@ -72,6 +79,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(data['adv_c']), _lib.ptr(idx), B, _lib.ptr(lagrange), C.byref(self.hp),
             self.loss_kind, mode, self._nets_mask(), self.max_blocks, _lib.ptr(self._ws),
             _lib.ptr(stats_row), st), 'osa_ppo_minibatch')
+        if ev is not None:
+            ev[1].record()
+            self.profile_events.append(('osa_mb_grad_kernel', B, ev))
         if ws > 1:
             dist.all_reduce_avg_(ac.grads)  # C1: one flat message for pi, V_r, V_c
             _lib.check(lib.osa_adam_apply(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params),
@@ -84,6 +94,10 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         """osa_ppo_pass: all ceil(M/B) minibatch steps of one pass in a single persistent launch."""
         ac = self.ac
         M = data['obs'].shape[0]
+        ev = None
+        if self.profile_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _lib.check(self.lib.osa_ppo_pass(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
@@ -92,6 +106,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
             C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
             _lib.stream_ptr()), 'osa_ppo_pass')
+        if ev is not None:
+            ev[1].record()
+            self.profile_events.append(('osa_ppo_pass_kernel', M, ev))
 
     def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
         """old_distribution = actor(obs) (policy_gradient.py:357)."""
