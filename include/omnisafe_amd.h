@@ -252,6 +252,55 @@ int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, 
                        float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                        int ld_final, int reset_only, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Trust-region machinery (NaturalPG / TRPO / TRPOLag / CPO actor update)
+ *
+ * Flat vectors here are PADDED actor parameter vectors of P floats (osa_mlp_layout; padding entries
+ * are zero in every vector, so dot products equal those of the reference's compact flat vectors of
+ * omnisafe/utils/tools.py:35-129).  The full-batch policy gradient is osa_ppo_minibatch with idx = NULL,
+ * B = M, loss_kind = 1, mode = 2, nets_mask = 1 (raw gradient of -mean(ratio * adv) in grads[0]).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* NaturalPG._fvp without damping (omnisafe/algorithms/on_policy/base/natural_pg.py:91-111): the
+ * Hessian-vector product of mean KL(pi_old || pi_theta) -- `.mean()` over all M x act_dim elements --
+ * at theta = theta_old, restricted to the mean-network parameters: J^T diag(1/sigma^2) J vec / (M D_a),
+ * computed as forward-mode JVP followed by the ordinary backward pass (no double backward; exact for
+ * a Gaussian policy with state-independent log_std because dKL/dmu = 0 at theta_old).  Result (raw,
+ * local to this rank) in grads[0 .. P).  ws: osa_minibatch_ws_floats(.., max_blocks) floats. */
+int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float* grads,
+                      const float* obs, int ld_obs, long M, const float* vec, int max_blocks,
+                      float* ws, float* step_stats, void* stream);
+
+/* out = raw + damping * v  (natural_pg.py:119) plus the analytic log_std block of the Fisher matrix:
+ * out[ls_off + d] += ls_coef * v[ls_off + d], ls_coef = 2 / act_dim.  (With world_size > 1 the caller
+ * averages `raw` across ranks first: distributed.avg_tensor, natural_pg.py:112.) */
+int osa_fvp_finish(int n, const float* raw, const float* v, float damping, int ls_off, int ls_n,
+                   float ls_coef, float* out, void* stream);
+
+/* conjugate_gradients (omnisafe/utils/math.py:116-132) split at the Fisher-vector product:
+ *   osa_cg_init: x = 0, r = b (F(0) = 0), p = r, scal[0] = r.r, scal[1] = 0 (not converged)
+ *   osa_cg_step(z = F p): alpha = r.r/(p.z + eps); x += alpha p; r -= alpha z; if sqrt(r.r) <
+ *     residual_tol set scal[1] = 1 (the reference's `break`; later calls are no-ops) else
+ *     p = r + (r.r_new/(r.r + eps)) p.   scal: 4 floats on the device. */
+int osa_cg_init(int n, const float* b, float* x, float* r, float* p, float* scal, void* stream);
+int osa_cg_step(int n, const float* z, float* x, float* r, float* p, float* scal, float residual_tol,
+                float eps, void* stream);
+
+/* out = a*x + b*y (y may be NULL) and *out = x.y: step-direction algebra of trpo.py:202-222 and
+ * cpo.py:284-337, parameter candidates theta_old + frac * step of the line searches. */
+int osa_vec_lincomb(int n, float a, const float* x, float b, const float* y, float* out, void* stream);
+int osa_vec_dot(int n, const float* x, const float* y, float* out, void* stream);
+
+/* Full-batch evaluation of a candidate actor for the line searches (TRPO._search_step_size
+ * trpo.py:102-138, CPO._cpo_search_step cpo.py:114-171): out4 = { loss_pi = -mean(ratio * adv) with
+ * adv = (adv_r - lambda adv_c)/(1 + lambda), loss_cost = mean(ratio * adv_c), KL(old || new).mean(),
+ * mean ratio }.  ws: at least 4096 doubles. */
+int osa_actor_eval(int obs_dim, int act_dim, int hidden, const float* actor_params, const float* obs,
+                   int ld_obs, long M, const float* act, int ld_act, const float* logp,
+                   const float* adv_r, const float* adv_c, const float* lagrange,
+                   const float* old_mean, int ld_old, const float* old_log_std, double* ws,
+                   float* out4, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

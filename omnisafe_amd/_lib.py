@@ -42,6 +42,13 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                           _P, _P, _I, _I, _P, _P]),
     'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'osa_actor_fvp_raw': (_I, [_I, _I, _I, _P, _P, _P, _I, _L, _P, _I, _P, _P, _P]),
+    'osa_fvp_finish': (_I, [_I, _P, _P, _F, _I, _I, _F, _P, _P]),
+    'osa_cg_init': (_I, [_I, _P, _P, _P, _P, _P, _P]),
+    'osa_cg_step': (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _P]),
+    'osa_vec_lincomb': (_I, [_I, _F, _P, _F, _P, _P, _P]),
+    'osa_vec_dot': (_I, [_I, _P, _P, _P, _P]),
+    'osa_actor_eval': (_I, [_I, _I, _I, _P, _P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     'osa_actor_kl': (_I, [_I, _I, _I, _P, _P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
     'osa_normalizer_ws_doubles': (C.c_size_t, [_I, _I]),
     'osa_normalizer_push': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1,6 +1,7 @@
 """Accelerated on-policy algorithms; same names as the reference's registry entries."""
 from . import registry
 from .policy_gradient import PPO, PolicyGradient, PPOLag
+from .trust_region_algos import CPO, TRPO, NaturalPG, TRPOLag
 
 ALGORITHMS = {'on-policy': tuple(sorted(registry.REGISTRY._module_dict))}  # noqa: SLF001
-__all__ = ['PolicyGradient', 'PPO', 'PPOLag', 'registry', 'ALGORITHMS']
+__all__ = ['PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO', 'registry', 'ALGORITHMS']

@@ -103,7 +103,11 @@ _PPO.pop('lagrange_cfgs')
 _TRPO = copy.deepcopy(_TRPOLAG)
 _TRPO.pop('lagrange_cfgs')
 
-DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO}
+_PG = copy.deepcopy(_PPO)
+_NPG = copy.deepcopy(_TRPO)
+
+DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO,
+            'PolicyGradient': _PG, 'NaturalPG': _NPG}
 
 
 def get_default_kwargs(algo: str) -> dict:

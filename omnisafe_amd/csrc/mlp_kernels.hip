@@ -41,6 +41,8 @@ struct OsaMbArgs {
   int loss_kind; // 0 PPO clipped surrogate (base/ppo.py:66-78), 1 plain ratio*adv (policy_gradient.py:574)
   int nets_mask; // bit0 actor, bit1 reward critic, bit2 cost critic
   long long* dbg;  // optional [3][16] phase timestamps (s_memtime) of the last launch, or nullptr
+  const float* vec;  // loss_kind 2 (Fisher-vector product): tangent vector, padded actor layout [P]
+  float fvp_scale;   // 1 / (M * act_dim): natural_pg.py:95 takes .mean() over all M x D_a elements
 };
 
 #define OSA_TICK(k)                                                                  \
@@ -273,7 +275,80 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
       dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (net == 0) {
+    if (net == 0 && a.loss_kind == 2) {
+      // Fisher-vector product (NaturalPG._fvp, natural_pg.py:91-119).  For a Gaussian policy with
+      // state-independent log_std the Hessian of mean KL(pi_old || pi_theta) at theta = theta_old is
+      // exactly J^T diag(1/sigma^2) J / (M D_a) on the mean-network parameters (plus 2/D_a on
+      // log_std, added by osa_fvp_finish): JVP through the network here, the VJP is the ordinary
+      // backward pass below with dL/d(out) = (J v) / sigma^2 / (M D_a).  No double backward.
+      const float* __restrict__ v = a.vec;
+      const float* xrow = valid ? a.obs + row * a.ld_obs : nullptr;
+      f32x4 t1[HT], t2[HT], tm[OT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) t1[t] = *reinterpret_cast<const f32x4*>(v + nd.ob1 + 16 * t + 4 * g);
+      for (int kb = 0; kb < nd.KB; ++kb) {
+        const f32x4 x = osa_load_x(xrow, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(v + nd.oW1 + (long)(16 * t + i) * INP + 16 * kb + 4 * g);
+          t1[t] = OSA_MFMA(w.x, x.x, t1[t]);
+          t1[t] = OSA_MFMA(w.y, x.y, t1[t]);
+          t1[t] = OSA_MFMA(w.z, x.z, t1[t]);
+          t1[t] = OSA_MFMA(w.w, x.w, t1[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < HT; ++t) t1[t] = t1[t] * (1.f - h1[t] * h1[t]);
+#pragma unroll
+      for (int t = 0; t < HT; ++t) t2[t] = *reinterpret_cast<const f32x4*>(v + nd.ob2 + 16 * t + 4 * g);
+#pragma unroll
+      for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(v + nd.oW2 + (16 * t + i) * H + 16 * kb + 4 * g);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(p + nd.oW2 + (16 * t + i) * H + 16 * kb + 4 * g);
+          t2[t] = OSA_MFMA(wv.x, h1[kb].x, t2[t]);
+          t2[t] = OSA_MFMA(wv.y, h1[kb].y, t2[t]);
+          t2[t] = OSA_MFMA(wv.z, h1[kb].z, t2[t]);
+          t2[t] = OSA_MFMA(wv.w, h1[kb].w, t2[t]);
+          t2[t] = OSA_MFMA(w.x, t1[kb].x, t2[t]);
+          t2[t] = OSA_MFMA(w.y, t1[kb].y, t2[t]);
+          t2[t] = OSA_MFMA(w.z, t1[kb].z, t2[t]);
+          t2[t] = OSA_MFMA(w.w, t1[kb].w, t2[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < HT; ++t) t2[t] = t2[t] * (1.f - h2[t] * h2[t]);
+#pragma unroll
+      for (int o = 0; o < OT; ++o) tm[o] = *reinterpret_cast<const f32x4*>(v + nd.ob3 + 16 * o + 4 * g);
+#pragma unroll
+      for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(v + nd.oW3 + (16 * o + i) * H + 16 * kb + 4 * g);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(p + nd.oW3 + (16 * o + i) * H + 16 * kb + 4 * g);
+          tm[o] = OSA_MFMA(wv.x, h2[kb].x, tm[o]);
+          tm[o] = OSA_MFMA(wv.y, h2[kb].y, tm[o]);
+          tm[o] = OSA_MFMA(wv.z, h2[kb].z, tm[o]);
+          tm[o] = OSA_MFMA(wv.w, h2[kb].w, tm[o]);
+          tm[o] = OSA_MFMA(w.x, t2[kb].x, tm[o]);
+          tm[o] = OSA_MFMA(w.y, t2[kb].y, tm[o]);
+          tm[o] = OSA_MFMA(w.z, t2[kb].z, tm[o]);
+          tm[o] = OSA_MFMA(w.w, t2[kb].w, tm[o]);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * o + 4 * g + r;
+          if (d < nd.act_dim && valid) {
+            const float sd = expf(p[nd.oLS + d]);
+            dO[o][r] = tm[o][r] / (sd * sd) * a.fvp_scale;
+          }
+        }
+      }
+    } else if (net == 0) {
       float lp = 0.f;
       f32x4 zv[OT], ivar[OT];
 #pragma unroll
@@ -622,6 +697,175 @@ __global__ __launch_bounds__(256) void osa_kl_final_kernel(const double* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// K14  full-batch evaluation of a candidate actor (line searches of TRPO._search_step_size
+//      trpo.py:93-148 and CPO._cpo_search_step cpo.py:106-180): sums of ratio*adv (surrogate),
+//      ratio*adv_c, KL(old || new) and ratio over all rows.
+// ------------------------------------------------------------------------------------------------
+template <int HT, int OT>
+__global__ __launch_bounds__(256) void osa_actor_eval_kernel(
+    OsaNet nd, const float* __restrict__ params, const float* __restrict__ obs, int ld, long M,
+    const float* __restrict__ act, int ld_act, const float* __restrict__ logp,
+    const float* __restrict__ adv_r, const float* __restrict__ adv_c,
+    const float* __restrict__ lagrange, const float* __restrict__ old_mean, int ld_old,
+    const float* __restrict__ old_log_std, double* __restrict__ ws) {
+  __shared__ double red[17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+  const float lam = lagrange ? *lagrange : 0.f;
+  double s_sur = 0.0, s_cost = 0.0, s_kl = 0.0, s_ratio = 0.0;
+  for (long base = (long)blockIdx.x * 64; base < M; base += (long)gridDim.x * 64) {
+    const long row = base + 16 * wave + j;
+    const bool valid = row < M;
+    f32x4 h1[HT], h2[HT], out[OT];
+    osa_mlp_forward<HT, OT>(nd, params, valid ? obs + row * ld : nullptr, ld, vec_ok, h1, h2, out);
+    float lp = 0.f, klp = 0.f;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 16 * o + 4 * g + r;
+        if (d < nd.act_dim && valid) {
+          const float mu = out[o][r];
+          const float qs = expf(params[nd.oLS + d]);
+          const float z = act[row * ld_act + d] - mu;
+          lp += -(z * z) / (2.f * (qs * qs)) - logf(qs) - 0.91893853320467274178f;
+          const float ps = expf(old_log_std[d]);
+          const float vr = (ps / qs) * (ps / qs);
+          const float t1 = (old_mean[row * ld_old + d] - mu) / qs;
+          klp += 0.5f * (vr + t1 * t1 - 1.f - logf(vr));
+        }
+      }
+    }
+    lp = osa_sum_over_groups(lp);
+    klp = osa_sum_over_groups(klp);
+    if (valid && g == 0) {
+      const float ratio = expf(lp - logp[row]);
+      const float adv = (adv_r[row] - lam * adv_c[row]) / (1.f + lam);
+      s_sur += (double)(ratio * adv);
+      s_cost += (double)(ratio * adv_c[row]);
+      s_kl += (double)klp;
+      s_ratio += (double)ratio;
+    }
+  }
+  s_sur = osa_block_sum<256>(s_sur, red);
+  s_cost = osa_block_sum<256>(s_cost, red);
+  s_kl = osa_block_sum<256>(s_kl, red);
+  s_ratio = osa_block_sum<256>(s_ratio, red);
+  if (threadIdx.x == 0) {
+    ws[4 * blockIdx.x + 0] = s_sur;
+    ws[4 * blockIdx.x + 1] = s_cost;
+    ws[4 * blockIdx.x + 2] = s_kl;
+    ws[4 * blockIdx.x + 3] = s_ratio;
+  }
+}
+
+__global__ __launch_bounds__(256) void osa_eval_final_kernel(const double* __restrict__ ws, int nblk,
+                                                             double M, double act_dim,
+                                                             float* __restrict__ out4) {
+  __shared__ double red[17];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = threadIdx.x; k < nblk; k += 256)
+    for (int q = 0; q < 4; ++q) s[q] += ws[4 * k + q];
+  for (int q = 0; q < 4; ++q) s[q] = osa_block_sum<256>(s[q], red);
+  if (threadIdx.x == 0) {
+    out4[0] = (float)(-s[0] / M);            // loss_pi = -mean(ratio * adv)   (policy_gradient.py:574-578)
+    out4[1] = (float)(s[1] / M);             // loss_cost = mean(ratio * adv_c) (cpo.py:209-212)
+    out4[2] = (float)(s[2] / (M * act_dim)); // kl_divergence(p, q).mean()      (trpo.py:113, cpo.py:133)
+    out4[3] = (float)(s[3] / M);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K13/K16  flat-vector algebra of conjugate gradients (omnisafe/utils/math.py:116-132) on padded
+// parameter vectors (padding entries are zero in every vector, so dot products are unaffected).
+// One workgroup; scalars stay on the device: scal[0] = r.r, scal[1] = done flag, scal[2] = p.z.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double osa_dot_block(const float* __restrict__ x, const float* __restrict__ y,
+                                                int n, double* red) {
+  double s = 0.0;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) s += (double)x[e] * (double)y[e];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  s = osa_wave_sum(s);
+  __syncthreads();
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    red[16] = t;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+__global__ __launch_bounds__(1024) void osa_cg_init_kernel(int n, const float* __restrict__ b,
+                                                           float* __restrict__ x, float* __restrict__ r,
+                                                           float* __restrict__ p, float* __restrict__ scal) {
+  __shared__ double red[17];
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {  // x = 0; r = b - F(0) = b; p = r
+    x[e] = 0.f;
+    r[e] = b[e];
+    p[e] = b[e];
+  }
+  const double rr = osa_dot_block(b, b, n, red);
+  if (threadIdx.x == 0) {
+    scal[0] = (float)rr;
+    scal[1] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void osa_cg_step_kernel(int n, const float* __restrict__ z,
+                                                           float* __restrict__ x, float* __restrict__ r,
+                                                           float* __restrict__ p, float* __restrict__ scal,
+                                                           float residual_tol, float eps) {
+  __shared__ double red[17];
+  if (scal[1] != 0.f) return;  // the reference broke out of the loop: x is final
+  const float rdotr = scal[0];
+  const float pz = (float)osa_dot_block(p, z, n, red);
+  const float alpha = rdotr / (pz + eps);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    x[e] += alpha * p[e];
+    r[e] -= alpha * z[e];
+  }
+  __syncthreads();
+  const float new_rdotr = (float)osa_dot_block(r, r, n, red);
+  if (sqrtf(new_rdotr) < residual_tol) {
+    if (threadIdx.x == 0) scal[1] = 1.f;
+    return;
+  }
+  const float mu = new_rdotr / (rdotr + eps);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) p[e] = r[e] + mu * p[e];
+  if (threadIdx.x == 0) scal[0] = new_rdotr;
+}
+
+// out = raw + damping * v, plus the analytic log_std block of the Fisher matrix (2 / D_a) * v[ls]
+__global__ __launch_bounds__(1024) void osa_fvp_finish_kernel(int n, const float* __restrict__ raw,
+                                                              const float* __restrict__ v, float damping,
+                                                              int ls_off, int ls_n, float ls_coef,
+                                                              float* __restrict__ out) {
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    float o = raw[e] + damping * v[e];
+    if (e >= ls_off && e < ls_off + ls_n) o += ls_coef * v[e];
+    out[e] = o;
+  }
+}
+
+__global__ __launch_bounds__(1024) void osa_vec_lincomb_kernel(int n, float a, const float* __restrict__ x,
+                                                               float b, const float* __restrict__ y,
+                                                               float* __restrict__ out) {
+  for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < n; e += blockDim.x * gridDim.x)
+    out[e] = a * x[e] + (y ? b * y[e] : 0.f);
+}
+
+__global__ __launch_bounds__(1024) void osa_vec_dot_kernel(int n, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           float* __restrict__ out) {
+  __shared__ double red[17];
+  const double s = osa_dot_block(x, y, n, red);
+  if (threadIdx.x == 0) *out = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 static size_t osa_mb_lds_bytes(const OsaNet& nd) {
@@ -714,6 +958,7 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
   a.mode = mode; a.stats = step_stats; a.loss_kind = loss_kind;
   a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3);
   a.dbg = g_osa_dbg_clocks;
+  a.vec = nullptr; a.fvp_scale = 0.f;
   const int nchunk = (B + 63) / 64;
   int nblk = nchunk;
   if (max_blocks < 1) max_blocks = 1;
@@ -760,6 +1005,108 @@ int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* a
   a.nets_mask = nets_mask;
   a.mode = 3;
   hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 0);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float* grads,
+                      const float* obs, int ld_obs, long M, const float* vec, int max_blocks,
+                      float* ws, float* step_stats, void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(params && grads && obs && vec && ws && step_stats && M > 0 && ld_obs >= obs_dim);
+  OsaMbArgs a = {};
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.grads = grads; a.obs = obs; a.ld_obs = ld_obs;
+  a.B = (int)M; a.idx = nullptr; a.mode = 2; a.stats = step_stats; a.loss_kind = 2; a.nets_mask = 1;
+  a.vec = vec; a.fvp_scale = (float)(1.0 / ((double)M * act_dim));
+  a.hp.use_cost = 1;
+  const int nchunk = (int)((M + 63) / 64);
+  int nblk = nchunk;
+  if (max_blocks < 1) max_blocks = 1;
+  if (nblk > max_blocks) nblk = max_blocks;
+  a.nblk = nblk; a.slabs = ws;
+  const size_t lds = osa_mb_lds_bytes(a.nd);
+#define OSA_CALL(HT, OT)                                                                          \
+  do {                                                                                            \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT>),           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=      \
+        hipSuccess)                                                                               \
+      return OSA_EHIP;                                                                            \
+    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT>), dim3(nblk, 1), dim3(256), lds,               \
+                       osa_stream(stream), a);                                                    \
+  } while (0)
+  OSA_DISPATCH_OT(a.nd, OSA_CALL);
+#undef OSA_CALL
+  if (nblk > 1) {
+    const int W = a.nd.P + OSA_NSTAT;
+    hipLaunchKernelGGL(osa_slab_reduce_kernel, dim3((W + 255) / 256, 1), dim3(256), 0,
+                       osa_stream(stream), a);
+  }
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_fvp_finish(int n, const float* raw, const float* v, float damping, int ls_off, int ls_n,
+                   float ls_coef, float* out, void* stream) {
+  OSA_REQUIRE(n > 0 && raw && v && out);
+  hipLaunchKernelGGL(osa_fvp_finish_kernel, dim3(1), dim3(1024), 0, osa_stream(stream), n, raw, v,
+                     damping, ls_off, ls_n, ls_coef, out);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_cg_init(int n, const float* b, float* x, float* r, float* p, float* scal, void* stream) {
+  OSA_REQUIRE(n > 0 && b && x && r && p && scal);
+  hipLaunchKernelGGL(osa_cg_init_kernel, dim3(1), dim3(1024), 0, osa_stream(stream), n, b, x, r, p, scal);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_cg_step(int n, const float* z, float* x, float* r, float* p, float* scal, float residual_tol,
+                float eps, void* stream) {
+  OSA_REQUIRE(n > 0 && z && x && r && p && scal);
+  hipLaunchKernelGGL(osa_cg_step_kernel, dim3(1), dim3(1024), 0, osa_stream(stream), n, z, x, r, p,
+                     scal, residual_tol, eps);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_vec_lincomb(int n, float a, const float* x, float b, const float* y, float* out, void* stream) {
+  OSA_REQUIRE(n > 0 && x && out);
+  hipLaunchKernelGGL(osa_vec_lincomb_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, osa_stream(stream),
+                     n, a, x, b, y, out);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_vec_dot(int n, const float* x, const float* y, float* out, void* stream) {
+  OSA_REQUIRE(n > 0 && x && y && out);
+  hipLaunchKernelGGL(osa_vec_dot_kernel, dim3(1), dim3(1024), 0, osa_stream(stream), n, x, y, out);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_actor_eval(int obs_dim, int act_dim, int hidden, const float* actor_params, const float* obs,
+                   int ld_obs, long M, const float* act, int ld_act, const float* logp,
+                   const float* adv_r, const float* adv_c, const float* lagrange,
+                   const float* old_mean, int ld_old, const float* old_log_std, double* ws,
+                   float* out4, void* stream) {
+  const int rc = osa_check_dims(obs_dim, act_dim, hidden);
+  if (rc != OSA_OK) return rc;
+  OSA_REQUIRE(actor_params && obs && act && logp && adv_r && adv_c && old_mean && old_log_std && ws && out4);
+  OSA_REQUIRE(M > 0 && ld_obs >= obs_dim && ld_act >= act_dim && ld_old >= act_dim);
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  long nb = (M + 63) / 64;
+  if (nb > 1024) nb = 1024;
+#define OSA_CALL(HT, OT)                                                                          \
+  hipLaunchKernelGGL((osa_actor_eval_kernel<HT, OT>), dim3((unsigned)nb), dim3(256), 0,           \
+                     osa_stream(stream), nd, actor_params, obs, ld_obs, M, act, ld_act, logp,     \
+                     adv_r, adv_c, lagrange, old_mean, ld_old, old_log_std, ws)
+  OSA_DISPATCH_OT(nd, OSA_CALL);
+#undef OSA_CALL
+  hipLaunchKernelGGL(osa_eval_final_kernel, dim3(1), dim3(256), 0, osa_stream(stream), ws, (int)nb,
+                     (double)M, (double)act_dim, out4);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

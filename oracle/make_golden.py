@@ -171,8 +171,11 @@ def _make_algo(algo, env_id, n_envs, steps_per_epoch, horizon, extra_algo=None, 
                        'torch_threads': 8, 'device': 'cpu'},
         'algo_cfgs': dict({'steps_per_epoch': steps_per_epoch}, **(extra_algo or {})),
         'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d},
-        'env_cfgs': {'horizon': horizon},
     }
+    if algo in ('PPOLag',):
+        cfg['env_cfgs'] = {'horizon': horizon}
+    else:  # TRPOLag.yaml / CPO.yaml have no env_cfgs key: custom env_cfgs would be rejected
+        ref_harness.DEFAULT_HORIZON = horizon
     agent = omnisafe.Agent(algo, env_id, custom_cfgs=cfg)
     return agent.agent
 
@@ -283,6 +286,97 @@ def gen_rollout_and_ppolag_update():
     np.savez(os.path.join(OUT, 'ppolag_epoch.npz'), **out)
 
 
+def gen_trust_region_updates():
+    """TRPOLag._update_actor and CPO._update_actor on a reference-collected buffer: policy gradient g,
+    CG solution x, xHx, (CPO: cost gradient b, CG solution p, q/r/s, optimisation case, lambda*, nu*),
+    accepted line-search index and the parameters after the step.  Intermediate tensors are captured
+    by wrapping omnisafe.utils.math.conjugate_gradients as imported by the algorithm modules."""
+    import omnisafe.algorithms.on_policy.base.natural_pg as npg_mod
+    import omnisafe.algorithms.on_policy.base.trpo as trpo_mod
+    import omnisafe.algorithms.on_policy.second_order.cpo as cpo_mod
+
+    N, T, horizon = 4, 64, 16
+    for algo_name in ('TRPOLag', 'CPO'):
+        algo = _make_algo(algo_name, 'SynthPointGoal1-v0', N, N * T, horizon,
+                          extra_algo={'update_iters': 2, 'batch_size': 128})
+        ac = algo._actor_critic
+        out = {'N': N, 'T': T}
+        torch.manual_seed(21)
+        algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+        # make the cost signal matter: overwrite costs / adv so that the constraint is active
+        if algo_name == 'TRPOLag':
+            with torch.no_grad():
+                algo._lagrange.lagrangian_multiplier.data.fill_(0.7)
+        for net in ('actor', 'reward_critic', 'cost_critic'):
+            for k, v in _state(getattr(ac, net)).items():
+                out[f'init/{net}/{k}'] = v
+        data = algo._buf.get()
+        for k, v in data.items():
+            out[f'data/{k}'] = _np(v)
+        calls = []
+        orig_cg = trpo_mod.conjugate_gradients
+
+        def spy_cg(fvp, b, num_steps):
+            x = orig_cg(fvp, b, num_steps)
+            calls.append((b.clone(), x.clone(), fvp(x).clone()))
+            return x
+
+        for m in (npg_mod, trpo_mod, cpo_mod):
+            m.conjugate_gradients = spy_cg
+        ls_calls = []
+        if algo_name == 'CPO':
+            orig_ls = algo._cpo_search_step
+
+            def spy_ls(**kw):
+                r = orig_ls(**kw)
+                ls_calls.append((kw['step_direction'].clone(), r[0].clone(), r[1], kw['optim_case'],
+                                 float(kw['loss_reward_before']), float(kw['loss_cost_before'])))
+                return r
+
+            algo._cpo_search_step = spy_ls
+            # CPO reads Jc from the logger window: pin it
+            out['ep_cost_mean'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])
+        else:
+            orig_ls = algo._search_step_size
+
+            def spy_ls(**kw):
+                r = orig_ls(**kw)
+                ls_calls.append((kw['step_direction'].clone(), r[0].clone(), r[1], float(kw['loss_before'])))
+                return r
+
+            algo._search_step_size = spy_ls
+            out['lambda'] = _np(algo._lagrange.lagrangian_multiplier)
+        algo._update_actor(data['obs'], data['act'], data['logp'], data['adv_r'], data['adv_c'])
+        for m in (npg_mod, trpo_mod, cpo_mod):
+            m.conjugate_gradients = orig_cg
+        out['g'] = _np(calls[0][0])
+        out['x'] = _np(calls[0][1])
+        out['Fx'] = _np(calls[0][2])  # includes damping
+        if algo_name == 'CPO':
+            out['b'] = _np(calls[1][0])
+            out['p'] = _np(calls[1][1])
+            out['optim_case'] = np.int32(ls_calls[0][3])
+            out['loss_reward_before'] = np.float32(ls_calls[0][4])
+            out['loss_cost_before'] = np.float32(ls_calls[0][5])
+        else:
+            out['loss_before'] = np.float32(ls_calls[0][3])
+        out['step_direction'] = _np(ls_calls[0][0])
+        out['final_step'] = _np(ls_calls[0][1])
+        out['accept_step'] = np.int32(ls_calls[0][2])
+        for k, v in _state(ac.actor).items():
+            out[f'post/actor/{k}'] = v
+        lg = algo._logger._data
+        for key in ('Misc/Alpha', 'Misc/xHx', 'Misc/H_inv_g', 'Misc/gradient_norm', 'Misc/FinalStepNorm',
+                    'Train/KL'):
+            if key in lg and len(lg[key]):
+                out['log/' + key] = np.asarray(list(lg[key]), np.float32)
+        if algo_name == 'CPO':
+            for key in ('Misc/Lambda_star', 'Misc/Nu_star', 'Misc/A', 'Misc/B', 'Misc/q', 'Misc/r', 'Misc/s',
+                        'Misc/cost_gradient_norm'):
+                out['log/' + key] = np.asarray(list(lg[key]), np.float32)
+        np.savez(os.path.join(OUT, f'{algo_name.lower()}_actor_update.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_harness.import_reference()
@@ -292,6 +386,7 @@ def main():
     gen_normalizer()
     gen_actor_critic_step()
     gen_rollout_and_ppolag_update()
+    gen_trust_region_updates()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -149,6 +149,7 @@ def import_reference():
 
 
 _SYNTH_REGISTERED = False
+DEFAULT_HORIZON = 1000  # used when env_cfgs carries no 'horizon' (TRPOLag/CPO YAMLs have no env_cfgs key)
 
 
 def register_synth_env():
@@ -186,7 +187,7 @@ def register_synth_env():
             self._device = torch.device(device)
             d_o, d_a = dims[env_id]
             self._d_o, self._d_a = d_o, d_a
-            self._horizon = int(kwargs.get('horizon', 1000))
+            self._horizon = int(kwargs.get('horizon', DEFAULT_HORIZON))
             self._cost_p = float(kwargs.get('cost_p', 0.05))
             self._observation_space = Box(-float('inf'), float('inf'), (d_o,))
             self._action_space = Box(-1.0, 1.0, (d_a,))

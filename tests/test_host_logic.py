@@ -162,3 +162,25 @@ def test_plugin_installs_behind_reference_agent(tmp_path, monkeypatch):
     finally:
         ref_registry.REGISTRY._module_dict.clear()
         ref_registry.REGISTRY._module_dict.update(keep)
+
+
+@pytest.mark.parametrize('c,q,r,s', [(-1.0, 1.0, 1.0, 1.0), (-0.01, 1.0, 1.0, 1.0), (0.01, 1.0, 1.0, 1.0),
+                                     (1.0, 1.0, 1.0, 1.0), (-0.05, 0.5, -0.2, 0.3), (0.05, 0.4, 0.1, 0.2),
+                                     (0.3, 0.4, -0.1, 0.2), (-2.0, 0.4475, -0.0214, 0.2417)])
+def test_cpo_case_algebra_matches_oracle(c, q, r, s):
+    """CPO._determine_case / _step_direction host algebra (cpo.py:237-337): every optimisation case."""
+    from omnisafe_amd.algorithms.trust_region_algos import cpo_determine_case, cpo_step_coefficients
+
+    t = torch.tensor
+    P = 12
+    torch.manual_seed(0)
+    x, p, b = torch.randn(P), torch.randn(P), torch.randn(P)
+    for bvec in (b, b * 1e-4):
+        case_o, A_o, B_o = O.cpo_determine_case(bvec, t(c), t(q), t(r), t(s), target_kl=0.01)
+        case, A, B = cpo_determine_case(float(bvec.dot(bvec)), c, q, r, s, 0.01)
+        assert case == case_o
+        d_o, lam_o, nu_o = O.cpo_step_direction(case_o, t(q), x, A_o, B_o, t(q), p, t(r), t(s), t(c), 0.01)
+        cx, cp, lam, nu = cpo_step_coefficients(case, q, A, B, q, r, s, c, 0.01)
+        np.testing.assert_allclose((float(cx) * x + float(cp) * p).numpy(), d_o.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(float(lam), float(lam_o), rtol=2e-5)
+        np.testing.assert_allclose(float(nu), float(nu_o), rtol=2e-5, atol=1e-7)
