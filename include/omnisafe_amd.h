@@ -168,9 +168,10 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
 
 /* Persistent form of the same update: ONE launch runs a whole pass of PolicyGradient._update's inner
  * loop (policy_gradient.py:366-382) -- ceil(M/B) dependent minibatch steps over the permutation
- * perm[M] (NULL = identity), B <= 64 -- for all three networks, with the parameters resident in LDS
+ * perm[M] (NULL = identity) -- for all three networks, with the parameters resident in LDS
  * and the Adam moments in registers for the whole pass (see csrc/ppo_pass_kernel.hip).  Same
- * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above.  Single
+ * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above.  A step with
+ * B > 64 rows accumulates ceil(B/64) chunks in the accumulator registers before its clip + Adam.  Single
  * process only (world_size == 1: the data-parallel path needs an all-reduce between gradient and
  * Adam and uses osa_ppo_minibatch).  osa_ppo_pass_supported: 1 if (obs_dim, act_dim, hidden) fit. */
 int osa_ppo_pass_supported(int obs_dim, int act_dim, int hidden);

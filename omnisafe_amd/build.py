@@ -52,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))):
             cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
-                   '-Wall', '-Wno-unused-function']
+                   '-Wall', '-Wno-unused-function'] + os.environ.get('OSA_EXTRA_CFLAGS', '').split()
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

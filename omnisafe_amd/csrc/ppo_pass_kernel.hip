@@ -44,7 +44,7 @@ struct OsaPassArgs {
   const float* adv_c;
   const long* perm;  // [M] sample rows of the whole pass (nullptr = identity)
   long M;            // rows in the pass
-  int B;             // minibatch size (<= 64); last minibatch may be smaller
+  int B;             // minibatch size; > 64 is processed as ceil(B/64) chunks; last minibatch may be smaller
   int nmb;           // minibatches in this launch
   const float* lagrange;
   OsaPassHp hp;
@@ -63,7 +63,7 @@ struct OsaPassArgs {
     }                                                 \
   } while (0)
 
-template <int KB, int OT>
+template <int KB, int OT, bool MULTI>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -170,12 +170,16 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     float logp, adv_r, adv_c, tgt;
     bool valid;
   };
-  auto pos_ok = [&](int mb) -> bool {
-    const long pos = (long)mb * a.B + 16 * wave + j;
-    return (mb < a.nmb) && (16 * wave + j < a.B) && (pos < min((long)(mb + 1) * a.B, a.M));
+  // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
+  const int nchunk = MULTI ? (a.B + 63) / 64 : 1;
+  auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
+    const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
+    const long inb = ch * 64 + 16 * wave + j;
+    return (mb < a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
   };
-  auto row_of = [&](int mb) -> long {  // raw (unconsumed) load of the permutation entry
-    const long pc = pos_ok(mb) ? (long)mb * a.B + 16 * wave + j : 0;
+  auto row_of = [&](long cidx) -> long {  // raw (unconsumed) load of the permutation entry
+    const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
+    const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
     return a.perm ? a.perm[pc] : pc;
   };
   auto fetch = [&](long rr, bool ok, Pre& q) {
@@ -225,13 +229,28 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   long long dbg_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long dbg_last = clock64();
 
+  long cidx = 0;
   for (int mb = 0; mb < a.nmb; ++mb) {
-    fetch(row_nxt, pos_ok(mb + 1), nxt);  // in flight while this minibatch computes
-    row_nxt = row_of(mb + 2);
-    PTICK(0);
     const long mb_lo = (long)mb * a.B;
     const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
     const float invB = 1.f / (float)Bcur;
+    // weight-gradient accumulators of this optimiser step (summed over its 64-row chunks)
+    f32x4 g2[HT], g1[KB], g3[OT];
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti) g2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) g1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < OT; ++o) g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
+    if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
+      for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
+      ent_pre /= (float)nd.act_dim;
+    }
+    for (int ch = 0; ch < nchunk; ++ch, ++cidx) {
+    fetch(row_nxt, pos_ok(cidx + 1), nxt);  // in flight while this chunk computes
+    row_nxt = row_of(cidx + 2);
+    PTICK(0);
     const bool valid = cur.valid;
     // deferred masking of the prefetched observation chunks (padding columns, invalid rows)
 #pragma unroll
@@ -239,52 +258,71 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) cur.x[kb][r] = (valid && cm[kb][r]) ? cur.x[kb][r] : 0.f;
     // ================= forward (S layout; weights from the LDS master) =================
+    // Software-pipelined in two halves of the output tiles (A = tiles 0,1; B = tiles 2,3): the tanh of a
+    // finished half is VALU work placed in the shadow of the other half's / the next layer's MFMAs
+    // (a v_mfma_f32_16x16x4 occupies the matrix pipe for 32 cycles, the wave can issue ~6 VALU ops
+    // meanwhile).  Two accumulators alternate, so no MFMA waits on its own predecessor.
     f32x4 h1[HT], h2[HT], out[OT];
+#define L1_TILES(T0)                                                                              \
+  _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) {                                             \
+    const f32x4 x = cur.x[kb];                                                                    \
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(sW1 + (16 * (T0) + i) * W1LD + 16 * kb + 4 * g);       \
+    const f32x4 wb = *reinterpret_cast<const f32x4*>(sW1 + (16 * ((T0) + 1) + i) * W1LD + 16 * kb + 4 * g); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
+      h1[(T0)] = OSA_MFMA(wa[s], x[s], h1[(T0)]);                                                 \
+      h1[(T0) + 1] = OSA_MFMA(wb[s], x[s], h1[(T0) + 1]);                                         \
+    }                                                                                             \
+  }
+#define L2_STEP(T0, KB0)                                                                          \
+  _Pragma("unroll") for (int kb = (KB0); kb < (KB0) + 2; ++kb) {                                  \
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(sW2 + (16 * (T0) + i) * PSLD + 16 * kb + 4 * g);       \
+    const f32x4 wb = *reinterpret_cast<const f32x4*>(sW2 + (16 * ((T0) + 1) + i) * PSLD + 16 * kb + 4 * g); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
+      h2[(T0)] = OSA_MFMA(wa[s], h1[kb][s], h2[(T0)]);                                            \
+      h2[(T0) + 1] = OSA_MFMA(wb[s], h1[kb][s], h2[(T0) + 1]);                                    \
+    }                                                                                             \
+  }
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 x = cur.x[kb];
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW1 + (16 * t + i) * W1LD + 16 * kb + 4 * g);
-        h1[t] = OSA_MFMA(w.x, x.x, h1[t]);
-        h1[t] = OSA_MFMA(w.y, x.y, h1[t]);
-        h1[t] = OSA_MFMA(w.z, x.z, h1[t]);
-        h1[t] = OSA_MFMA(w.w, x.w, h1[t]);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < HT; ++t) h1[t] = osa_tanh4(h1[t]);
-#pragma unroll
     for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(sB2 + 16 * t + 4 * g);
 #pragma unroll
-    for (int kb = 0; kb < HT; ++kb) {
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * PSLD + 16 * kb + 4 * g);
-        h2[t] = OSA_MFMA(w.x, h1[kb].x, h2[t]);
-        h2[t] = OSA_MFMA(w.y, h1[kb].y, h2[t]);
-        h2[t] = OSA_MFMA(w.z, h1[kb].z, h2[t]);
-        h2[t] = OSA_MFMA(w.w, h1[kb].w, h2[t]);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < HT; ++t) h2[t] = osa_tanh4(h2[t]);
-#pragma unroll
     for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
+    L1_TILES(0)
+    L1_TILES(2)                       // MFMAs of tiles 2,3 ...
+    h1[0] = osa_tanh4(h1[0]);         // ... cover tanh of tiles 0,1
+    h1[1] = osa_tanh4(h1[1]);
+    L2_STEP(0, 0)                     // layer 2, K blocks 0,1 (need h1[0], h1[1] only)
+    L2_STEP(2, 0)
+    h1[2] = osa_tanh4(h1[2]);         // covered by the layer-2 MFMAs above
+    h1[3] = osa_tanh4(h1[3]);
+    L2_STEP(0, 2)                     // K blocks 2,3: tiles 0,1 complete first
+    L2_STEP(2, 2)
+    h2[0] = osa_tanh4(h2[0]);
+    h2[1] = osa_tanh4(h2[1]);
 #pragma unroll
-    for (int kb = 0; kb < HT; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {  // output layer, K blocks 0,1
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
-        out[o] = OSA_MFMA(w.x, h2[kb].x, out[o]);
-        out[o] = OSA_MFMA(w.y, h2[kb].y, out[o]);
-        out[o] = OSA_MFMA(w.z, h2[kb].z, out[o]);
-        out[o] = OSA_MFMA(w.w, h2[kb].w, out[o]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    h2[2] = osa_tanh4(h2[2]);
+    h2[3] = osa_tanh4(h2[3]);
+#pragma unroll
+    for (int kb = 2; kb < 4; ++kb) {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
+      }
+    }
+#undef L1_TILES
+#undef L2_STEP
+
     PTICK(1);
     // ================= loss, dL/d(out) =================
     f32x4 dO[OT], dLS[OT];
@@ -292,11 +330,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int o = 0; o < OT; ++o) {
       dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    float loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
-    if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
-      for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
-      ent_pre /= (float)nd.act_dim;
     }
     if (net == 0) {
       float lp = 0.f;
@@ -336,8 +369,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         }
         const float dlogp = dratio * ratio * invB;
         if (g == 0) {
-          loss_part = li;
-          ratio_part = ratio;
+          loss_part += li;
+          ratio_part += ratio;
         }
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
@@ -352,41 +385,44 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     } else if (valid) {
       const float diff = out[0][0] - cur.tgt;
       if (g == 0) {
-        loss_part = diff * diff;
+        loss_part += diff * diff;
         dO[0][0] = 2.f * diff * invB;
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+
     PTICK(2);
     // ================= backward through the hidden layers =================
     f32x4 z2[HT], z1[HT];
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < HT; ++t) z2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
+    for (int o = 0; o < OT; ++o) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
-          const float w = sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i];
-          acc = OSA_MFMA(w, dO[o][s], acc);
-        }
+      for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]; the 4 tiles t are independent
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+          z2[t] = OSA_MFMA(sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i], dO[o][s], z2[t]);
       }
-      z2[t] = acc * (1.f - h2[t] * h2[t]);
     }
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < HT; ++t) z2[t] = z2[t] * (1.f - h2[t] * h2[t]);
 #pragma unroll
-      for (int kb = 0; kb < HT; ++kb) {
+    for (int t = 0; t < HT; ++t) z1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
-          const float w = sW2[(16 * kb + 4 * g + s) * PSLD + 16 * t + i];
-          acc = OSA_MFMA(w, z2[kb][s], acc);
-        }
-      }
-      z1[t] = acc * (1.f - h1[t] * h1[t]);
+    for (int kb = 0; kb < HT; ++kb) {
+      float wt[4][HT];  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) wt[s][t] = sW2[(16 * kb + 4 * g + s) * PSLD + 16 * t + i];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) z1[t] = OSA_MFMA(wt[s][t], z2[kb][s], z1[t]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < HT; ++t) z1[t] = z1[t] * (1.f - h1[t] * h1[t]);
+
     PTICK(3);
     // ================= S layout -> F layout through LDS =================
     const int c = 16 * wave + j;
@@ -418,7 +454,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     __syncthreads();  // (A) tiles complete
     PTICK(4);
     // ================= weight gradients (registers) =================
-    f32x4 g2[HT], g1[KB], g3[OT];
     {
       f32x4 a2[4], a1[4];
 #pragma unroll
@@ -427,50 +462,42 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
       }
 #pragma unroll
-      for (int ti = 0; ti < HT; ++ti) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int sb = 0; sb < 4; ++sb) {
+        f32x4 b[HT];
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * PSLD + 16 * sb + 4 * g);
-          acc = OSA_MFMA(a2[sb].x, b.x, acc);
-          acc = OSA_MFMA(a2[sb].y, b.y, acc);
-          acc = OSA_MFMA(a2[sb].z, b.z, acc);
-          acc = OSA_MFMA(a2[sb].w, b.w, acc);
-        }
-        g2[ti] = acc;
+        for (int ti = 0; ti < HT; ++ti)
+          b[ti] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * PSLD + 16 * sb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ti = 0; ti < HT; ++ti) g2[ti] = OSA_MFMA(a2[sb][s], b[ti][s], g2[ti]);
       }
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int sb = 0; sb < 4; ++sb) {
+        f32x4 b[KB];
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * PSLD + 16 * sb + 4 * g);
-          acc = OSA_MFMA(a1[sb].x, b.x, acc);
-          acc = OSA_MFMA(a1[sb].y, b.y, acc);
-          acc = OSA_MFMA(a1[sb].z, b.z, acc);
-          acc = OSA_MFMA(a1[sb].w, b.w, acc);
-        }
-        g1[kb] = acc;
+        for (int kb = 0; kb < KB; ++kb)
+          b[kb] = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * PSLD + 16 * sb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) g1[kb] = OSA_MFMA(a1[sb][s], b[kb][s], g1[kb]);
       }
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
           const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * PSLD + 16 * sb + 4 * g);
           const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
-          acc = OSA_MFMA(av.x, b.x, acc);
-          acc = OSA_MFMA(av.y, b.y, acc);
-          acc = OSA_MFMA(av.z, b.z, acc);
-          acc = OSA_MFMA(av.w, b.w, acc);
+          g3[o] = OSA_MFMA(av.x, b.x, g3[o]);
+          g3[o] = OSA_MFMA(av.y, b.y, g3[o]);
+          g3[o] = OSA_MFMA(av.z, b.z, g3[o]);
+          g3[o] = OSA_MFMA(av.w, b.w, g3[o]);
         }
-        g3[o] = acc;
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
     PTICK(5);
-    // bias-like gradient owned by this thread: row sum over the 64 samples
-    float gb = 0.f;
+    // bias-like gradient owned by this thread: row sum over the 64 samples of the chunk
     if (boff >= 0) {
       const float* srow = (tid < H) ? sZ1 + tid * PSLD
                           : (tid < 2 * H) ? sZ2 + (tid - H) * PSLD
@@ -484,9 +511,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         gb += q.z;
         gb += q.w;
       }
-      if (net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
-        gb -= a.hp.entropy_coef / (float)nd.act_dim;
     }
+    cur = nxt;
+    if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
+    }  // chunks
+    if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
+      gb -= a.hp.entropy_coef / (float)nd.act_dim;
     // ================= + 2*coef*w (critics), squared norms =================
     float gsq = 0.f, psq = 0.f;
 #pragma unroll
@@ -597,7 +627,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         st[7 + net] = total_norm;
       }
     }
-    cur = nxt;
     __syncthreads();  // (C) master copy updated, tiles and `red` free for the next minibatch
     PTICK(9);
   }
@@ -657,18 +686,18 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT>
+template <int KB, int OT, bool MULTI>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT>), dim3(3), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI>), dim3(3), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -693,7 +722,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
                  float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
-  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && B <= 64);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
   OsaPassArgs a;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
@@ -711,7 +740,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PASS_CASE(K, O) \
-  if (KB == K && OT == O) return osa_launch_pass<K, O>(a, st)
+  if (KB == K && OT == O) return (B > 64) ? osa_launch_pass<K, O, true>(a, st) : osa_launch_pass<K, O, false>(a, st)
   OSA_PASS_CASE(1, 1); OSA_PASS_CASE(2, 1); OSA_PASS_CASE(3, 1); OSA_PASS_CASE(4, 1);
   OSA_PASS_CASE(5, 1); OSA_PASS_CASE(6, 1);
   OSA_PASS_CASE(1, 2); OSA_PASS_CASE(2, 2); OSA_PASS_CASE(3, 2); OSA_PASS_CASE(4, 2);

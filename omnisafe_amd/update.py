@@ -39,7 +39,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.target_kl, self.kl_early_stop = float(target_kl), bool(kl_early_stop)
         self.loss_kind = loss_kind
         self.update_actor = update_actor
-        self.persistent = persistent
+        self.persistent = persistent  # persistent pass kernel (world_size 1) vs one launch per step
+        self.persistent_max_batch = 512  # beyond this a step has enough rows to fill the chip per launch
         self.hp = HParams(clip=clip, entropy_coef=entropy_coef, critic_norm_coef=critic_norm_coef,
                           max_grad_norm=max_grad_norm, lr_actor=0.0, lr_critic=0.0, beta1=0.9,
                           beta2=0.999, adam_eps=1e-8, use_critic_norm=int(use_critic_norm),
@@ -98,7 +99,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if self.profile_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(self.lib.osa_ppo_pass(
+        name, fn = self._pass_fn if getattr(self, '_pass_fn', None) else ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
+        _lib.check(fn(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
             _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
@@ -108,7 +110,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.stream_ptr()), 'osa_ppo_pass')
         if ev is not None:
             ev[1].record()
-            self.profile_events.append(('osa_ppo_pass_kernel', M, ev))
+            self.profile_events.append((name, M, ev))
 
     def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
         """old_distribution = actor(obs) (policy_gradient.py:357)."""
@@ -153,8 +155,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.snapshot_old_distribution(obs)
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
-        use_pass = (self.persistent and dist.world_size() == 1 and B <= 64 and bool(
-            self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
+        self._pass_fn = None
+        if (self.persistent and dist.world_size() == 1 and B <= self.persistent_max_batch and bool(
+                self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
+            self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
+        use_pass = self._pass_fn is not None
         for i in range(self.update_iters):
             if perms is not None:
                 perm = torch.as_tensor(perms[i]).to(ac.device, torch.int64)

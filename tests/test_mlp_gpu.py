@@ -239,7 +239,8 @@ def test_large_batch_multiblock_equals_single_pass():
 
 
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
-                                                (90, 17, 512, 64), (5, 1, 130, 64)])
+                                                (90, 17, 512, 64), (5, 1, 130, 64), (60, 2, 1000, 128),
+                                                (72, 2, 700, 200)])
 def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     """osa_ppo_pass (one persistent launch per pass, weights in LDS, Adam moments in registers) vs
     osa_ppo_minibatch (one launch per optimiser step): same parameters, moments and statistics after
@@ -265,9 +266,13 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
         acs.append(ac)
     assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
     assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
+    # B <= 64: identical operation order (bit-equal in practice).  B > 64: the pass kernel accumulates
+    # the 64-row chunks in registers, the per-step path reduces per-workgroup slabs -- a different
+    # float32 summation order that Adam's m/sqrt(v) amplifies to ~1e-6 in the parameters.
+    atol = 1e-7 if B <= 64 else 5e-6
     for name in ('params', 'adam_m', 'adam_v'):
         a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=name)
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=name)
     s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
     np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)

@@ -59,3 +59,4 @@ print('PASS kernel: cycles per minibatch   actor  V_r  V_c')
 for i, n in enumerate(names2):
     print(f'{n:24s}', *[f'{v:9.0f}' for v in d[:, i]])
 print('total', d.sum(1), 'us per minibatch (event)', e0.elapsed_time(e1) * 1e3 / 1024)
+
