@@ -111,6 +111,20 @@ def timed(algo, steps, warmup, world, dev):
     return dt
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction);
+    PMC counters cannot be read from inside the process, so this is the offline measurement of the
+    same command.  None if no matching entry."""
+    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    for k, v in json.load(open(path)).items():
+        if k.startswith(kernel_name):
+            return v['traffic_bytes_per_launch']
+    return None
+
+
 def roofline_from_events(events, batch_size):
     """Dominant-kernel roofline from HIP events recorded around every update launch inside the timed
     region (torch.cuda.Event on the launch stream).  B <= 64: osa_ppo_pass_kernel, one launch = one
@@ -123,7 +137,7 @@ def roofline_from_events(events, batch_size):
     achieved = flops / (ms * 1e-3) / 1e12
     us = ms * 1e3 / len(events)
     out = {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
-           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': pmc_traffic(name),
            'kernel': name, 'launches_timed': len(events), 'us_per_launch': round(us, 2),
            'flops_per_launch': flops // len(events), 'rows_per_launch': rows // len(events)}
     if name == 'osa_ppo_pass_kernel':
