@@ -47,6 +47,25 @@ __device__ __forceinline__ float osa_wave_min(float v) {
   return v;
 }
 
+// Wave-wide float sum on the DPP network (VALU only, no LDS round trips): inclusive scan with
+// row_shr:1,2,4,8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 across rows (the
+// sequence LLVM's AMDGPU atomic optimizer emits for wave64 on gfx9); lane 63 holds the total, which is
+// returned wave-uniformly.
+__device__ __forceinline__ float osa_wave_sum_dpp(float v) {
+  int x = __float_as_int(v);
+#define OSA_DPP_ADD(CTRL, ROWMASK)                                                            \
+  x = __float_as_int(__int_as_float(x) +                                                      \
+                     __int_as_float(__builtin_amdgcn_update_dpp(0, x, (CTRL), (ROWMASK), 0xf, false)))
+  OSA_DPP_ADD(0x111, 0xf);  // row_shr:1
+  OSA_DPP_ADD(0x112, 0xf);  // row_shr:2
+  OSA_DPP_ADD(0x114, 0xf);  // row_shr:4
+  OSA_DPP_ADD(0x118, 0xf);  // row_shr:8
+  OSA_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+  OSA_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#undef OSA_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 // Block-wide sum of a double; result returned to every thread.  `red` = LDS scratch of >= 17 doubles.
 template <int THREADS>
 __device__ __forceinline__ double osa_block_sum(double v, double* red) {

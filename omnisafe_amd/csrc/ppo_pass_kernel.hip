@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
+  const float inv_1p_lam = 1.f / (1.f + lam);
   const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
   const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   };
   auto fetch = [&](long rr, bool ok, Pre& q) {
     q.valid = ok;
-    const float* xrow = a.obs + rr * a.ld_obs;
+    const float* xrow = a.obs + (int)rr * a.ld_obs;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int col0 = 16 * kb + 4 * g;
@@ -199,21 +200,24 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         q.x[kb].w = xrow[min(col0 + 3, last)];
       }
     }
-    if (net == 0) {  // block-uniform
+    // 32-bit index arithmetic (host guarantees M * ld < 2^31): 64-bit multiplies per load made the
+    // prefetch issue itself cost ~1k cycles.  The actor-only loads sit behind a block-uniform branch.
+    const int ri = (int)rr;
+    if (net == 0) {
+      const float* arow = a.act + ri * a.ld_act;
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          q.act[4 * o + r] = a.act[rr * a.ld_act + min(16 * o + 4 * g + r, nd.act_dim - 1)];
-      q.logp = a.logp[rr];
-      q.adv_r = a.adv_r[rr];
-      q.adv_c = a.adv_c[rr];
+        for (int r = 0; r < 4; ++r) q.act[4 * o + r] = arow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
+      q.logp = a.logp[ri];
+      q.adv_r = a.adv_r[ri];
+      q.adv_c = a.adv_c[ri];
       q.tgt = 0.f;
     } else {
 #pragma unroll
       for (int k = 0; k < 4 * OT; ++k) q.act[k] = 0.f;
       q.logp = q.adv_r = q.adv_c = 0.f;
-      q.tgt = tgt[rr];
+      q.tgt = tgt[ri];
     }
   };
   // column validity of this lane's 4-float chunks (static per lane)
@@ -342,19 +346,21 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           zv[o][r] = 0.f;
           ivar[o][r] = 0.f;
           if (d < nd.act_dim && valid) {
-            const float sd = expf(sLS[d]);
-            const float var = sd * sd;
+            // Normal.log_prob with sigma = exp(log_std): 1/var = exp(-2 log_std) (one hardware exp2),
+            // log(sigma) = log_std (the reference takes log(exp(log_std)): equal to float32 rounding)
+            const float ls = sLS[d];
+            const float iv = __builtin_amdgcn_exp2f(ls * -2.88539008177792681472f);
             const float z = cur.act[4 * o + r] - out[o][r];
             zv[o][r] = z;
-            ivar[o][r] = 1.f / var;
-            lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+            ivar[o][r] = iv;
+            lp += -0.5f * (z * z) * iv - ls - 0.91893853320467274178f;
           }
         }
       }
       lp = osa_sum_over_groups(lp);
       if (valid) {
-        const float ratio = expf(lp - cur.logp);
-        const float adv = (cur.adv_r - lam * cur.adv_c) / (1.f + lam);
+        const float ratio = __builtin_amdgcn_exp2f((lp - cur.logp) * 1.44269504088896340736f);
+        const float adv = (cur.adv_r - lam * cur.adv_c) * inv_1p_lam;
         float dratio, li;
         if (a.loss_kind == 0) {
           const float lo = 1.f - a.hp.clip, hi = 1.f + a.hp.clip;
@@ -517,35 +523,37 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }  // chunks
     if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
-    // ================= + 2*coef*w (critics), squared norms =================
-    float gsq = 0.f, psq = 0.f;
+    // ================= + 2*coef*w (critics), squared norms (packed f32 math) =================
+    f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ti = 0; ti < HT; ++ti)
+    for (int ti = 0; ti < HT; ++ti) {
+      f32x4 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float w = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
-        if (l2) g2[ti][r] += c2 * w;
-        psq += w * w;
-        gsq += g2[ti][r] * g2[ti][r];
-      }
+      for (int r = 0; r < 4; ++r) w[r] = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+      if (l2) g2[ti] = g2[ti] + w * c2;
+      acc_p = acc_p + w * w;
+      acc_g = acc_g + g2[ti] * g2[ti];
+    }
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int kb = 0; kb < KB; ++kb) {
+      f32x4 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float w = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
-        if (l2) g1[kb][r] += c2 * w;
-        psq += w * w;
-        gsq += g1[kb][r] * g1[kb][r];
-      }
+      for (int r = 0; r < 4; ++r) w[r] = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+      if (l2) g1[kb] = g1[kb] + w * c2;
+      acc_p = acc_p + w * w;
+      acc_g = acc_g + g1[kb] * g1[kb];
+    }
 #pragma unroll
-    for (int o = 0; o < OT; ++o)
+    for (int o = 0; o < OT; ++o) {
+      f32x4 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float w = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
-        if (l2) g3[o][r] += c2 * w;
-        psq += w * w;
-        gsq += g3[o][r] * g3[o][r];
-      }
+      for (int r = 0; r < 4; ++r) w[r] = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+      if (l2) g3[o] = g3[o] + w * c2;
+      acc_p = acc_p + w * w;
+      acc_g = acc_g + g3[o] * g3[o];
+    }
+    float gsq = (acc_g.x + acc_g.y) + (acc_g.z + acc_g.w);
+    float psq = (acc_p.x + acc_p.y) + (acc_p.z + acc_p.w);
     float wb = 0.f;
     if (boff >= 0) {
       wb = *sbias;
@@ -554,10 +562,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       gsq += gb * gb;
     }
     // ---- block reduction of (gsq, psq, loss, ratio): wave shuffles, then a fixed-order sum
-    gsq = osa_wave_sum(gsq);
-    psq = osa_wave_sum(psq);
-    loss_part = osa_wave_sum(loss_part);
-    ratio_part = osa_wave_sum(ratio_part);
+    gsq = osa_wave_sum_dpp(gsq);
+    psq = osa_wave_sum_dpp(psq);
+    loss_part = osa_wave_sum_dpp(loss_part);
+    ratio_part = osa_wave_sum_dpp(ratio_part);
     if (lane == 0) {
       red[4 * wave + 0] = gsq;
       red[4 * wave + 1] = psq;
@@ -583,35 +591,40 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const float step_size = (float)((double)lr / (1.0 - b1pow));
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
     const bool do_clip = a.hp.use_max_grad_norm != 0;
-#define OSA_ADAM(G, MV, VV, W, DST)                                                              \
-  do {                                                                                           \
-    float gval_ = (G);                                                                           \
-    if (do_clip) gval_ *= coef;                                                                  \
-    float mv_ = (MV), vv_ = (VV);                                                                \
-    (DST) = osa_adam_update(gval_, mv_, vv_, (W), beta1, beta2, step_size, inv_bc2_sqrt, aeps);  \
-    (MV) = mv_;                                                                                  \
-    (VV) = vv_;                                                                                  \
-  } while (0)
+    const float gscale = do_clip ? coef : 1.f;
 #pragma unroll
-    for (int ti = 0; ti < HT; ++ti)
+    for (int ti = 0; ti < HT; ++ti) {
+      f32x4 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        OSA_ADAM(g2[ti][r], m2[ti][r], v2[ti][r], sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc],
-                 sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc]);
+      for (int r = 0; r < 4; ++r) w[r] = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+      w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+      for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc] = w[r];
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        OSA_ADAM(g1[kb][r], m1[kb][r], v1[kb][r], sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc],
-                 sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc]);
+    for (int kb = 0; kb < KB; ++kb) {
+      f32x4 w;
 #pragma unroll
-    for (int o = 0; o < OT; ++o)
+      for (int r = 0; r < 4; ++r) w[r] = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+      w = osa_adam_update4(g1[kb] * gscale, m1[kb], v1[kb], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        OSA_ADAM(g3[o][r], m3[o][r], v3[o][r], sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc],
-                 sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc]);
-    if (boff >= 0) OSA_ADAM(gb, mb_, vb_, wb, *sbias);
-#undef OSA_ADAM
+      for (int r = 0; r < 4; ++r) sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc] = w[r];
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      f32x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+      w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc] = w[r];
+    }
+    if (boff >= 0) {
+      float mv_ = mb_, vv_ = vb_;
+      *sbias = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+      mb_ = mv_;
+      vb_ = vv_;
+    }
     PTICK(8);
     // ---- statistics of this optimiser step
     if (tid == 0) {
@@ -724,6 +737,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
+  if ((double)M * ld_obs >= 2147483647.0 || (double)M * ld_act >= 2147483647.0) return OSA_EUNSUPPORTED;
   OsaPassArgs a;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
