@@ -40,7 +40,8 @@ extern "C" {
 #define OSA_EST_GAE 0
 #define OSA_EST_GAE_RTG 1
 #define OSA_EST_PLAIN 2
-/* 'vtrace' (onpolicy_buffer.py:312-326,338-405) is not implemented: OSA_EUNSUPPORTED */
+#define OSA_EST_VTRACE 3 /* onpolicy_buffer.py:312-326 -> _calculate_v_trace :338-405; the reference passes
+                            the same probabilities as policy and behaviour, i.e. rho = c = 1 */
 
 const char* osa_strerror(int code);
 int osa_version(void);            /* ABI version, currently 1 */

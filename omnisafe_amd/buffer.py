@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from .spaces import is_box
 
-_EST = {'gae': 0, 'gae-rtg': 1, 'plain': 2}
+_EST = {'gae': 0, 'gae-rtg': 1, 'plain': 2, 'vtrace': 3}
 
 
 class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
@@ -40,8 +40,6 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
             raise ValueError('num_envs must be greater than 0.')  # vector_onpolicy_buffer.py:74-75
         if not is_box(obs_space) or not is_box(act_space):
             raise NotImplementedError  # buffer/base.py:73-80 (Box only)
-        if advantage_estimator == 'vtrace':
-            raise NotImplementedError('vtrace is not implemented in omnisafe_amd (SURVEY 8f-4)')
         if advantage_estimator not in _EST:
             raise NotImplementedError  # onpolicy_buffer.py:333-334
         self._lib = _lib.load(require_gpu=True)

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void osa_gae_scan_kernel(
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float nv_r = 0.f, nv_c = 0.f;
+  float vs_r = 0.f, vs_c = 0.f;  // v-trace: v_s of the following step (float32 recursion)
   double a_r = 0.0, a_c = 0.0, ret = 0.0, rtg_r = 0.0, rtg_c = 0.0;
   for (int t0 = T - 1; t0 >= 0; t0 -= U) {
     float r[U], c[U], vr[U], vc[U], br[U], bc[U];
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(256) void osa_gae_scan_kernel(
         const float pb = pc * bc[u];
         rtg_r = (double)(br[u] - pb);
         rtg_c = (double)bc[u];
+        vs_r = br[u];  // v-trace: last_v_s = values[-1] (un-penalised bootstrap, onpolicy_buffer.py:397)
+        vs_c = bc[u];
       }
       const float pcost = pc * c[u];
       const float r_pen = r[u] - pcost;
@@ -94,6 +97,29 @@ __global__ __launch_bounds__(256) void osa_gae_scan_kernel(
       const double m0 = d_g * ret;
       ret = (double)r[u] + m0;
       double out_ar, out_ac, out_tr, out_tc;
+      if (EST == OSA_EST_VTRACE) {
+        // OnPolicyBuffer._calculate_v_trace (onpolicy_buffer.py:380-405) with the reference's call
+        // arguments: policy == behaviour probabilities, so rho = c = 1 (a float32 recursion):
+        //   delta = r + g*v' - v;  v_s = v + (delta + g*(v_s' - v'));  adv = (r + g*v_s') - v
+        // (v' and v_s' are both seeded with values[-1] = the bootstrap at a path end, see above;
+        // rewards[-1], the penalised bootstrap, is never read by the recursion)
+        const float adv_vr = (r_pen + g32 * vs_r) - vr[u];
+        const float adv_vc = (c[u] + g32 * vs_c) - vc[u];
+        const float t3r = vs_r - nv_r, t3c = vs_c - nv_c;
+        const float t4r = g32 * t3r, t4c = g32 * t3c;
+        const float t5r = delta_r + t4r, t5c = delta_c + t4c;
+        vs_r = vr[u] + t5r;
+        vs_c = vc[u] + t5c;
+        const long iv = (long)t * N + n;
+        adv_r[iv] = adv_vr;
+        adv_c[iv] = adv_vc;
+        tgt_r[iv] = vs_r;
+        tgt_c[iv] = vs_c;
+        disc_ret[iv] = (float)ret;
+        nv_r = vr[u];
+        nv_c = vc[u];
+        continue;
+      }
       if (EST != OSA_EST_GAE) {
         const double m1 = d_g * rtg_r;
         rtg_r = (double)r_pen + m1;
@@ -303,7 +329,7 @@ int osa_gae_scan(const float* reward, const float* cost, const float* value_r, c
   OSA_REQUIRE(T > 0 && N > 0);
   OSA_REQUIRE(reward && cost && value_r && value_c && path_end && boot_r && boot_c);
   OSA_REQUIRE(adv_r && adv_c && target_value_r && target_value_c && discounted_ret);
-  if (estimator < OSA_EST_GAE || estimator > OSA_EST_PLAIN) return OSA_EUNSUPPORTED;
+  if (estimator < OSA_EST_GAE || estimator > OSA_EST_VTRACE) return OSA_EUNSUPPORTED;
   const float g32 = (float)gamma;  // gamma * float32 tensor: the scalar is rounded to float32
   const double d_g = gamma, d_r = gamma * lam, d_c = gamma * lam_c;  // python-float products
   const int threads = N >= 256 ? 256 : 64;
@@ -316,7 +342,8 @@ int osa_gae_scan(const float* reward, const float* cost, const float* value_r, c
                      target_value_c, discounted_ret)
   if (estimator == OSA_EST_GAE) OSA_GAE_LAUNCH(OSA_EST_GAE);
   else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_LAUNCH(OSA_EST_GAE_RTG);
-  else OSA_GAE_LAUNCH(OSA_EST_PLAIN);
+  else if (estimator == OSA_EST_PLAIN) OSA_GAE_LAUNCH(OSA_EST_PLAIN);
+  else OSA_GAE_LAUNCH(OSA_EST_VTRACE);
 #undef OSA_GAE_LAUNCH
   OSA_CHECK_LAUNCH();
   return OSA_OK;

@@ -79,7 +79,7 @@ def gen_buffer():
     boot_c = np.where(kind == 2, rng.standard_normal((T, N)), 0.0).astype(np.float32)
     out = dict(inp, path_end=(kind != 0).astype(np.uint8), boot_r=boot_r, boot_c=boot_c,
                gamma=0.99, lam=0.95, lam_c=0.9)
-    for est in ('gae', 'gae-rtg', 'plain'):
+    for est in ('gae', 'gae-rtg', 'plain', 'vtrace'):
         for pc in (0.0, 0.3):
             buf = VectorOnPolicyBuffer(
                 obs_space=Box(-np.inf, np.inf, (D_o,)), act_space=Box(-1, 1, (D_a,)), size=T,

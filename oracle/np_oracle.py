@@ -74,6 +74,19 @@ def finish_path(reward, cost, value_r, value_c, last_value_r, last_value_c, gamm
         elif estimator == 'plain':
             adv = ((rews[:-1] + (g32 * values[1:]).astype(f32)).astype(f32) - values[:-1]).astype(f32)
             target = discount_cumsum(rews, gamma)[:-1]
+        elif estimator == 'vtrace':
+            # onpolicy_buffer.py:312-326 -> _calculate_v_trace :380-405 with policy == behaviour
+            # probabilities (rho = c = 1): an all-float32 backward recursion
+            L = len(values) - 1
+            v_s = values[:-1].copy()
+            last = values[-1]
+            for idx in range(L - 1, -1, -1):
+                delta = f32(f32(rews[idx] + f32(g32 * values[idx + 1])) - values[idx])
+                v_s[idx] = f32(v_s[idx] + f32(delta + f32(g32 * f32(last - values[idx + 1]))))
+                last = v_s[idx]
+            v_s_plus_1 = np.concatenate([v_s[1:], values[-1:]])
+            adv = ((rews[:-1] + (g32 * v_s_plus_1).astype(f32)).astype(f32) - values[:-1]).astype(f32)
+            target = v_s
         else:
             raise NotImplementedError(estimator)
         return adv.astype(f32), target.astype(f32)
@@ -108,6 +121,8 @@ def gae_time_major(reward, cost, value_r, value_c, path_end, boot_r, boot_c, gam
     ret_r = np.zeros(N, f64)  # discounted return of raw reward
     rtg_r = np.zeros(N, f64)  # rewards-to-go of penalised reward (gae-rtg / plain targets)
     rtg_c = np.zeros(N, f64)
+    vs_r = np.zeros(N, f32)  # v-trace carries (float32 recursion)
+    vs_c = np.zeros(N, f32)
     d_r, d_c, d_g = f64(gamma * lam), f64(gamma * lam_c), f64(gamma)
     for t in range(T - 1, -1, -1):
         end = np.asarray(path_end[t]) != 0
@@ -120,12 +135,24 @@ def gae_time_major(reward, cost, value_r, value_c, path_end, boot_r, boot_c, gam
         ret_r = np.where(end, br.astype(f64), ret_r)
         rtg_r = np.where(end, (br - pc * bc).astype(f32).astype(f64), rtg_r)
         rtg_c = np.where(end, bc.astype(f64), rtg_c)
+        vs_r = np.where(end, br, vs_r)
+        vs_c = np.where(end, bc, vs_c)
         r_pen = (reward[t] - pc * cost[t]).astype(f32)
         delta_r = ((r_pen + (g32 * nv_r).astype(f32)).astype(f32) - value_r[t]).astype(f32)
         delta_c = ((cost[t] + (g32 * nv_c).astype(f32)).astype(f32) - value_c[t]).astype(f32)
         ret_r = reward[t].astype(f64) + d_g * ret_r
         rtg_r = r_pen.astype(f64) + d_g * rtg_r
         rtg_c = cost[t].astype(f64) + d_g * rtg_c
+        if estimator == 'vtrace':
+            adv_vr = ((r_pen + (g32 * vs_r).astype(f32)).astype(f32) - value_r[t]).astype(f32)
+            adv_vc = ((cost[t] + (g32 * vs_c).astype(f32)).astype(f32) - value_c[t]).astype(f32)
+            vs_r = (value_r[t] + (delta_r + (g32 * (vs_r - nv_r).astype(f32)).astype(f32)).astype(f32)).astype(f32)
+            vs_c = (value_c[t] + (delta_c + (g32 * (vs_c - nv_c).astype(f32)).astype(f32)).astype(f32)).astype(f32)
+            out['adv_r'][t], out['adv_c'][t] = adv_vr, adv_vc
+            out['tgt_r'][t], out['tgt_c'][t] = vs_r, vs_c
+            out['disc_ret'][t] = ret_r.astype(f32)
+            nv_r, nv_c = value_r[t], value_c[t]
+            continue
         if estimator == 'plain':
             adv_r64, adv_c64 = delta_r.astype(f64), delta_c.astype(f64)
         else:

@@ -39,7 +39,7 @@ def _fill(buf, g_in, path_end, boot_r, boot_c, vector_finish=True):
 IN_KEYS = ('obs', 'act', 'reward', 'cost', 'value_r', 'value_c', 'logp')
 
 
-@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain'])
+@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain', 'vtrace'])
 @pytest.mark.parametrize('pc', [0.0, 0.3])
 @pytest.mark.parametrize('vector_finish', [True, False])
 def test_golden_buffer(golden, est, pc, vector_finish):

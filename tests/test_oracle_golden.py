@@ -45,7 +45,7 @@ def test_cpo_case_ids(b, c, q, r, s, case):
 
 
 # ---- buffer / GAE ----------------------------------------------------------------------------
-@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain'])
+@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain', 'vtrace'])
 @pytest.mark.parametrize('pc', [0.0, 0.3])
 def test_gae_bit_exact_vs_reference(golden, est, pc):
     g = golden('buffer.npz')
