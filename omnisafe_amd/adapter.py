@@ -44,8 +44,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             raise NotImplementedError('TimeLimit/AutoReset wrappers are not on the accelerated path: '
                                       'the env must auto-reset (gymnasium vector convention)')
         a = cfgs.algo_cfgs
-        if getattr(a, 'reward_normalize', False) or getattr(a, 'cost_normalize', False):
-            raise NotImplementedError('reward/cost normalisation wrappers: SURVEY 8f-4 (next)')
         self._num_envs = int(self._env.num_envs)
         self._obs_dim = int(self._env.observation_space.shape[0])
         self._act_dim = int(self._env.action_space.shape[0])
@@ -53,6 +51,13 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         f32 = dict(dtype=torch.float32, device=dev)
         self._obs_normalizer = (Normalizer((self._obs_dim,), clip=5, device=dev)
                                 if a.obs_normalize else None)
+        # RewardNormalize / CostNormalize wrappers (envs/wrapper.py:280-423): scalar running statistics
+        # over the batch of N rewards (costs) of each step, clip 5; episode metrics keep the ORIGINAL
+        # reward / cost (info['original_reward'], onpolicy_adapter.py:155-156)
+        self._reward_normalizer = (Normalizer((1,), clip=5, device=dev)
+                                   if getattr(a, 'reward_normalize', False) else None)
+        self._cost_normalizer = (Normalizer((1,), clip=5, device=dev)
+                                 if getattr(a, 'cost_normalize', False) else None)
         # ActionScale(low=-1, high=1): agent acts in [-1, 1], env receives [space.low, space.high]
         self._old_min = torch.as_tensor(self._env.action_space.low, **f32).reshape(-1).contiguous()
         self._old_max = torch.as_tensor(self._env.action_space.high, **f32).reshape(-1).contiguous()
@@ -90,6 +95,10 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         saved = {}
         if self._obs_normalizer is not None:
             saved['obs_normalizer'] = self._obs_normalizer
+        if self._reward_normalizer is not None:
+            saved['reward_normalizer'] = self._reward_normalizer
+        if self._cost_normalizer is not None:
+            saved['cost_normalizer'] = self._cost_normalizer
         return saved
 
     def close(self) -> None:
@@ -143,8 +152,17 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                                             self._act_dim, N, self._act_dim, _lib.ptr(self._old_min),
                                             _lib.ptr(self._old_max), -1.0, 1.0, st), 'osa_action_scale')
             next_raw, reward, cost, terminated, truncated, info = self._env.step(self._act_env)
-            b['reward'][t].copy_(reward.reshape(N))
-            b['cost'][t].copy_(cost.reshape(N))
+            reward, cost = reward.reshape(N), cost.reshape(N)
+            if self._reward_normalizer is not None:
+                self._reward_normalizer.normalize(reward.reshape(N, 1), out=b['reward'][t].view(N, 1))
+            else:
+                b['reward'][t].copy_(reward)
+            if self._cost_normalizer is not None:
+                self._cost_normalizer.normalize(cost.reshape(N, 1), out=b['cost'][t].view(N, 1))
+            else:
+                b['cost'][t].copy_(cost)
+            reward = reward.to(torch.float32).contiguous()  # original values for the episode metrics
+            cost = cost.to(torch.float32).contiguous()
             term = terminated.reshape(N).to(torch.uint8)
             trunc = truncated.reshape(N).to(torch.uint8)
             vfinal = (None, None)
@@ -158,7 +176,7 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             self._normalize(next_raw, out=nxt)
             vnext = agent.values(nxt) if epoch_end else (None, None)
             _lib.check(lib.osa_rollout_post_step(
-                N, int(epoch_end), _lib.ptr(b['reward'][t]), _lib.ptr(b['cost'][t]), _lib.ptr(term),
+                N, int(epoch_end), _lib.ptr(reward), _lib.ptr(cost), _lib.ptr(term),
                 _lib.ptr(trunc), _lib.ptr(vnext[0]), _lib.ptr(vnext[1]), _lib.ptr(vfinal[0]),
                 _lib.ptr(vfinal[1]), _lib.ptr(self._ep_ret), _lib.ptr(self._ep_cost),
                 _lib.ptr(self._ep_len), _lib.ptr(b['path_end'][t]), _lib.ptr(b['boot_r'][t]),

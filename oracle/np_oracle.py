@@ -243,12 +243,12 @@ class Normalizer:
 
     def __init__(self, shape, clip=5.0):
         self.shape = tuple(shape)
-        self.mean = torch.zeros(*shape)
-        self.sumsq = torch.zeros(*shape)
-        self.var = torch.zeros(*shape)
-        self.std = torch.zeros(*shape)
+        self.mean = torch.zeros(self.shape)
+        self.sumsq = torch.zeros(self.shape)
+        self.var = torch.zeros(self.shape)
+        self.std = torch.zeros(self.shape)
         self.count = 0
-        self.clip = clip * torch.ones(*shape)
+        self.clip = clip * torch.ones(self.shape)
         self.first = True
 
     def push(self, raw: torch.Tensor) -> None:

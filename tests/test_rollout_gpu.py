@@ -234,3 +234,42 @@ def test_agent_ppolag_end_to_end(tmp_path):
     ck = torch.load(glob.glob(os.path.join(str(tmp_path), '*', '*', 'torch_save', 'epoch-2.pt'))[0])
     assert list(ck['pi'])[0] == 'log_std' and ck['pi']['mean.0.weight'].shape == (64, 6)
     assert set(ck['obs_normalizer']) == {'_mean', '_sumsq', '_var', '_std', '_count', '_clip'}
+
+
+def test_reward_and_cost_normalize_wrappers():
+    """RewardNormalize / CostNormalize (envs/wrapper.py:280-423): the buffer receives the normalised
+    streams (scalar running statistics over each step's batch, clip 5), episode metrics the originals."""
+    from omnisafe_amd.adapter import OnPolicyAdapter
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from test_mlp_gpu import make_ac
+
+    N, T = 256, 12
+    cfgs = _cfgs(reward_normalize=True, cost_normalize=True)
+    cfgs.env_cfgs = types.SimpleNamespace(todict=lambda: {'horizon': 6, 'cost_p': 0.3})
+    adapter = OnPolicyAdapter('SynthTiny-v0', N, 3, cfgs)
+    ac = make_ac(6, 2)
+    buf = VectorOnPolicyBuffer(adapter.observation_space, adapter.action_space, T, 0.99, 0.95, 0.95, 'gae',
+                               0.0, True, True, num_envs=N, device=DEV)
+    raw_r, raw_c = [], []
+    env_step = adapter._env.step
+
+    def spy(a):
+        out = env_step(a)
+        raw_r.append(out[1].clone())
+        raw_c.append(out[2].clone())
+        return out
+
+    adapter._env.step = spy
+    logger = _LoggerStub()
+    adapter.rollout(T, ac, buf, logger)
+    rn, cn = O.Normalizer((), clip=5), O.Normalizer((), clip=5)
+    for t in range(T):
+        np.testing.assert_allclose(buf.data['reward'][t].cpu().numpy(), rn.normalize(raw_r[t].cpu()).numpy(),
+                                   rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(buf.data['cost'][t].cpu().numpy(), cn.normalize(raw_c[t].cpu()).numpy(),
+                                   rtol=1e-4, atol=1e-5)
+    # episode metrics use the original rewards / costs
+    ep_cost = torch.stack(raw_c).cpu().reshape(2, 6, N).sum(1).reshape(-1)
+    assert np.allclose(sorted(logger.data['Metrics/EpCost']), sorted(ep_cost.numpy()[-100:]), atol=1e-5) or \
+        np.allclose(np.float32(logger.data['Metrics/EpCost']), ep_cost.numpy()[-100:], atol=1e-5)
+    assert set(adapter.save()) == {'obs_normalizer', 'reward_normalizer', 'cost_normalizer'}
