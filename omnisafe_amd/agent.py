@@ -50,6 +50,8 @@ class Agent:  # the reference exposes AlgoWrapper under this name (omnisafe/__in
         dev = str(self.cfgs.train_cfgs.device)
         if dist.world_size() > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1:
             local = int(os.environ.get('LOCAL_RANK', '0'))
+            if os.environ.get('OSA_SINGLE_DEVICE_RANKS'):  # test hook: all ranks share cuda:0
+                local = 0
             dev = f'cuda:{local}'
             self.cfgs.train_cfgs.recurisve_update({'device': dev})
         os.environ['OMNISAFE_DEVICE'] = dev

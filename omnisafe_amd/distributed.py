@@ -46,10 +46,13 @@ def init_from_env(device: torch.device | str | None = None) -> bool:
     use_gpu = device is not None and torch.device(device).type == 'cuda'
     if use_gpu:
         torch.cuda.set_device(torch.device(device))
+    # OSA_DIST_BACKEND=gloo forces gloo on device tensors (staged through the host): used by the tests
+    # that run several ranks on ONE GPU, where RCCL refuses duplicate devices.  Production: nccl = RCCL.
+    backend = os.environ.get('OSA_DIST_BACKEND', 'nccl' if use_gpu else 'gloo')
     kwargs = {}
-    if use_gpu:
+    if use_gpu and backend == 'nccl':
         kwargs['device_id'] = torch.device(device)
-    dist.init_process_group(backend='nccl' if use_gpu else 'gloo', **kwargs)
+    dist.init_process_group(backend=backend, **kwargs)
     return True
 
 
