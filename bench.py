@@ -140,7 +140,11 @@ def roofline_from_events(events, batch_size):
            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': pmc_traffic(name),
            'kernel': name, 'launches_timed': len(events), 'us_per_launch': round(us, 2),
            'flops_per_launch': flops // len(events), 'rows_per_launch': rows // len(events)}
-    if name == 'osa_ppo_pass_kernel':
+    if name == 'osa_ppo_dp_step':
+        out['kernel'] = 'osa_ppo_pass_kernel (data-parallel gradient mode) + osa_dp_apply_kernel'
+        out['note'] = ('replicated-data DP: each rank computes all ranks\' minibatches of every optimiser step '
+                       '(W x 3 workgroups) on the all-gathered rollout, hipGraph of one pass replayed; rows = W x M')
+    elif name == 'osa_ppo_pass_kernel':
         steps = rows // len(events) // batch_size
         out['us_per_optimiser_step'] = round(us / steps, 3)
         out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
@@ -247,7 +251,8 @@ def main():
                                 f'(T={args.steps_per_env}), batch_size={args.batch_size}, '
                                 f'update_iters={args.update_iters}, kl_early_stop='
                                 f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
-                   'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}'},
+                   'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}',
+                   'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None)},
     }
     out['roofline'] = roofline_from_events(events, args.batch_size)
     if world == 1 and not args.no_variant and rank == 0:

@@ -183,6 +183,28 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
                  const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                  float* step_stats, void* stream);
 
+/* Data-parallel optimiser step WITHOUT a per-step cross-GPU collective ("replicated data").  The data
+ * arrays hold the all-gathered env-major rollouts of all `world` ranks ([world * M] rows, rank r at
+ * rows r*M ..), perm[world][M] each rank's own permutation (local row indices).  One call performs
+ * optimiser step `step_index` of the pass for every virtual rank -- `world` workgroups per network
+ * compute the locally clipped gradients of rank r's minibatch perm[r][step*B ..] -- then averages them
+ * (distributed.avg_grads, omnisafe/utils/distributed.py:193-198, clip-then-average order of
+ * policy_gradient.py:437-442) and applies Adam.  Every rank executes the same arithmetic on the same
+ * data, so replicas stay bit-identical without exchanging gradients or parameters.  lr_dev: optional
+ * device float[2] {lr_actor, lr_critic} overriding hp (keeps a captured hipGraph valid across epochs).
+ * slabs: osa_ppo_dp_ws_floats(...) floats.  step_stats[16]: rank-averaged statistics.  The Adam step
+ * count used is adam_step[net] + step_index + 1; call osa_ppo_dp_end_pass once after the last step of
+ * a pass to advance adam_step by the number of steps. */
+size_t osa_ppo_dp_ws_floats(int obs_dim, int act_dim, int hidden, int world);
+int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                    int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                    const float* logp, const float* target_value_r, const float* target_value_c,
+                    const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                    int step_index, const float* lagrange, const osa_ppo_hparams* hp,
+                    const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
+                    float* step_stats, void* stream);
+int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream);
+
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */
 int osa_debug_set_clock_buffer(long long* dev_ptr);

@@ -7,6 +7,7 @@ libomnisafe_amd kernels (see omnisafe_amd/update.py, adapter.py, buffer.py).
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -67,7 +68,8 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
             target_kl=a.target_kl, kl_early_stop=a.kl_early_stop, clip=getattr(a, 'clip', 0.2),
             entropy_coef=a.entropy_coef, use_critic_norm=a.use_critic_norm,
             critic_norm_coef=a.critic_norm_coef, use_max_grad_norm=a.use_max_grad_norm,
-            max_grad_norm=a.max_grad_norm, use_cost=a.use_cost, loss_kind=self._loss_kind)
+            max_grad_norm=a.max_grad_norm, use_cost=a.use_cost, loss_kind=self._loss_kind,
+            seed=int(self._cfgs.seed), dp_mode=os.environ.get('OSA_DP_MODE', 'replicated'))
 
     def _init_log(self) -> None:
         """policy_gradient.py:133-236: same keys, same order."""

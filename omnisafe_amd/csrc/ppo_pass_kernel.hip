@@ -51,6 +51,12 @@ struct OsaPassArgs {
   int loss_kind;
   int nets_mask;
   float* stats;  // [nmb][PNSTAT]
+  // data-parallel gradient mode (osa_ppo_dp_step): grid (3, dp_world); workgroup (net, rk) processes
+  // minibatch mb0 of virtual rank rk (rows rk*M .. rk*M+M-1 of the all-gathered arrays, permutation
+  // perm[rk*M ..]) and writes its locally clipped gradient to dp_slabs instead of applying Adam.
+  float* dp_slabs;  // [3][dp_world][P + PNSTAT] or nullptr
+  int dp_world;
+  int mb0;          // first minibatch index processed by this launch
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -69,6 +75,15 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const OsaNet& nd = a.nd;
   const int net = blockIdx.x;
   if (!((a.nets_mask >> net) & 1)) return;
+  const int rk = blockIdx.y;  // virtual rank (0 outside the data-parallel mode)
+  const bool dp = a.dp_slabs != nullptr;
+  const long roff = (long)rk * a.M;
+  const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
+  const float* __restrict__ act_p = a.act + roff * a.ld_act;
+  const float* __restrict__ logp_p = a.logp + roff;
+  const float* __restrict__ advr_p = a.adv_r + roff;
+  const float* __restrict__ advc_p = a.adv_c + roff;
+  const long* __restrict__ perm_p = a.perm ? a.perm + roff : nullptr;
   constexpr int H = 64, HT = 4, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + 4;
   // ---- LDS carve-up (all offsets multiples of 4 floats)
   float* sW1 = smem;                    // [H][W1LD]
@@ -98,8 +113,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 
   // ---- load parameters into the LDS master copy (coalesced)
   for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
-  for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
-  for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   if (tid < H) {
     sB1[tid] = gp[nd.ob1 + tid];
     sB2[tid] = gp[nd.ob2 + tid];
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     sB3[tid] = gp[nd.ob3 + tid];
     sLS[tid] = gp[nd.oLS + tid];
   }
+  // (W2 / W3 are loaded after the first minibatch's gather has been issued, see below)
   // ---- ownership: the parameters whose gradients this lane's accumulator tiles produce.
   //   W2[(16w+4g+r)][16ti+cc]  ti<4 | W1[(16w+4g+r)][16kb+cc] kb<KB | W3[(16o+4g+r)][16w+cc] o<OT
   //   + one bias-like scalar per thread: tid<64 b1 | <128 b2 | <128+OUTP b3 | <128+2*OUTP log_std
@@ -125,31 +139,35 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
-      m2[ti][r] = gm[off];
-      v2[ti][r] = gv[off];
+      m2[ti][r] = dp ? 0.f : gm[off];
+      v2[ti][r] = dp ? 0.f : gv[off];
     }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
-      m1[kb][r] = gm[off];
-      v1[kb][r] = gv[off];
+      m1[kb][r] = dp ? 0.f : gm[off];
+      v1[kb][r] = dp ? 0.f : gv[off];
     }
 #pragma unroll
   for (int o = 0; o < OT; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
-      m3[o][r] = gm[off];
-      v3[o][r] = gv[off];
+      m3[o][r] = dp ? 0.f : gm[off];
+      v3[o][r] = dp ? 0.f : gv[off];
     }
-  if (boff >= 0) {
+  if (boff >= 0 && !dp) {
     mb_ = gm[boff];
     vb_ = gv[boff];
   }
-  const int step0 = a.adam_step[net];
-  double b1pow = pow((double)a.hp.beta1, (double)step0), b2pow = pow((double)a.hp.beta2, (double)step0);
+  const int step0 = dp ? 0 : a.adam_step[net];
+  double b1pow = 1.0, b2pow = 1.0;
+  if (!dp) {
+    b1pow = pow((double)a.hp.beta1, (double)step0);
+    b2pow = pow((double)a.hp.beta2, (double)step0);
+  }
   const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
   const bool l2 = critic && a.hp.use_critic_norm;
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   if (net == 0 && a.lagrange) lam = *a.lagrange;
   const float inv_1p_lam = 1.f / (1.f + lam);
   const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
-  const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
+  const float* __restrict__ tgt = ((net == 1) ? a.tgt_r : a.tgt_c) + roff;
 
   // ---- prefetch machinery: everything this lane needs for its sample of one minibatch.
   // The loads are CONSUMER-FREE: addresses are clamped into the allocation instead of predicating the
@@ -176,16 +194,16 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
     const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
     const long inb = ch * 64 + 16 * wave + j;
-    return (mb < a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
+    return (mb < a.mb0 + a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
   };
   auto row_of = [&](long cidx) -> long {  // raw (unconsumed) load of the permutation entry
     const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
     const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
-    return a.perm ? a.perm[pc] : pc;
+    return perm_p ? perm_p[pc] : pc;
   };
   auto fetch = [&](long rr, bool ok, Pre& q) {
     q.valid = ok;
-    const float* xrow = a.obs + (int)rr * a.ld_obs;
+    const float* xrow = obs_p + (int)rr * a.ld_obs;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int col0 = 16 * kb + 4 * g;
@@ -204,14 +222,14 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     // prefetch issue itself cost ~1k cycles.  The actor-only loads sit behind a block-uniform branch.
     const int ri = (int)rr;
     if (net == 0) {
-      const float* arow = a.act + ri * a.ld_act;
+      const float* arow = act_p + ri * a.ld_act;
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int r = 0; r < 4; ++r) q.act[4 * o + r] = arow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
-      q.logp = a.logp[ri];
-      q.adv_r = a.adv_r[ri];
-      q.adv_c = a.adv_c[ri];
+      q.logp = logp_p[ri];
+      q.adv_r = advr_p[ri];
+      q.adv_c = advc_p[ri];
       q.tgt = 0.f;
     } else {
 #pragma unroll
@@ -227,14 +245,17 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) cm[kb][r] = (16 * kb + 4 * g + r) < nd.obs_dim;
   Pre cur, nxt;
-  fetch(row_of(0), pos_ok(0), cur);
-  long row_nxt = row_of(1);
+  long cidx = (long)a.mb0 * nchunk;
+  fetch(row_of(cidx), pos_ok(cidx), cur);  // first gather in flight ...
+  long row_nxt = row_of(cidx + 1);
+  // ... while the remaining weights stream into LDS (matters for the one-step-per-launch dp mode)
+  for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
+  for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   __syncthreads();  // LDS master copy complete
   long long dbg_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long dbg_last = clock64();
 
-  long cidx = 0;
-  for (int mb = 0; mb < a.nmb; ++mb) {
+  for (int mb = a.mb0; mb < a.mb0 + a.nmb; ++mb) {
     const long mb_lo = (long)mb * a.B;
     const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
     const float invB = 1.f / (float)Bcur;
@@ -585,6 +606,34 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       coef = a.hp.max_grad_norm / (total_norm + 1e-6f);
       coef = coef > 1.f ? 1.f : coef;
     }
+    if (dp) {
+      // publish the locally clipped gradient of (net, rk) and its statistics; reduce + Adam follow in
+      // osa_dp_apply_kernel (clip-then-average order of policy_gradient.py:437-442)
+      float* __restrict__ slab = a.dp_slabs + ((long)net * a.dp_world + rk) * (P + PNSTAT);
+      const float gs = a.hp.use_max_grad_norm ? coef : 1.f;
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc] = g2[ti][r] * gs;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc] = g1[kb][r] * gs;
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc] = g3[o][r] * gs;
+      if (boff >= 0) slab[boff] = gb * gs;
+      if (critic && tid < OUTP) slab[nd.oLS + tid] = 0.f;
+      if (tid == 0) {
+        slab[P + 0] = t_loss * invB - (net == 0 ? a.hp.entropy_coef * ent_pre : 0.f);
+        slab[P + 1] = t_ratio * invB;
+        slab[P + 2] = t_psq;
+        slab[P + 3] = total_norm;
+        slab[P + 4] = ent_pre;
+      }
+      return;  // nmb == 1 in this mode: nothing else to do (weights, moments untouched)
+    }
     // ================= Adam on the owned parameters; LDS master updated in place =================
     b1pow *= (double)beta1;
     b2pow *= (double)beta2;
@@ -628,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     PTICK(8);
     // ---- statistics of this optimiser step
     if (tid == 0) {
-      float* st = a.stats + (long)mb * PNSTAT;
+      float* st = a.stats + (long)(mb - a.mb0) * PNSTAT;
       if (net == 0) {
         st[2] = t_loss * invB - a.hp.entropy_coef * ent_pre;
         st[3] = t_ratio * invB;
@@ -700,7 +749,7 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 }
 
 template <int KB, int OT, bool MULTI>
-static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream) {
+static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
@@ -710,7 +759,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream) {
       return OSA_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI>), dim3(3), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI>), dim3(3, grid_y), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -751,6 +800,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   a.dbg = g_osa_pass_dbg;
+  a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PASS_CASE(K, O) \
@@ -761,6 +811,129 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   OSA_PASS_CASE(5, 2); OSA_PASS_CASE(6, 2);
 #undef OSA_PASS_CASE
   return OSA_EUNSUPPORTED;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Data-parallel step without a per-step cross-GPU collective ("replicated data"): every rank holds the
+// all-gathered rollout of all W ranks and redundantly computes the whole global optimiser step --
+// W workgroups per network produce the W locally clipped gradients (osa_ppo_pass_kernel in dp mode),
+// osa_dp_apply_kernel averages them and applies Adam.  Identical arithmetic on every rank => the
+// replicas stay bit-identical with no parameter traffic at all; the only collectives left are the
+// per-epoch all-gather of the rollout and the scalar statistics.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_dp_apply_kernel(OsaNet nd, float* params, float* adam_m,
+                                                           float* adam_v, const int* adam_step,
+                                                           const float* slabs, int W, OsaPassHp hp,
+                                                           const float* lr_dev, int nets_mask,
+                                                           float* stats, int step_index) {
+  // grid (ceil(P/256), 3): one parameter per thread, W independent slab loads in flight per thread
+  const int net = blockIdx.y;
+  if (!((nets_mask >> net) & 1)) return;
+  const int P = nd.P, SW = P + PNSTAT;
+  const bool critic = net != 0;
+  const float* __restrict__ sl = slabs + (long)net * W * SW;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int step = adam_step[net] + step_index + 1;  // adam_step advances once per pass (osa_ppo_dp_end_pass)
+  const float lr = lr_dev ? lr_dev[critic ? 1 : 0] : (critic ? hp.lr_critic : hp.lr_actor);
+  // 1 - beta^t via exp(t log beta) in float64 (a double pow() per thread costs more than the update)
+  const double bc1 = -expm1((double)step * log((double)hp.beta1));
+  const double bc2 = -expm1((double)step * log((double)hp.beta2));
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float invW = 1.f / (float)W;
+  if (e < P) {
+    float g = 0.f;
+    for (int r = 0; r < W; ++r) g += sl[(long)r * SW + e];  // fixed order: deterministic on every rank
+    g *= invW;                                              // avg_grads (distributed.py:193-198)
+    if (critic && e >= nd.oLS) g = 0.f;
+    const long o = (long)net * P + e;
+    float mv = adam_m[o], vv = adam_v[o];
+    params[o] = osa_adam_update(g, mv, vv, params[o], hp.beta1, hp.beta2, step_size, inv_bc2_sqrt, hp.adam_eps);
+    adam_m[o] = mv;
+    adam_v[o] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    float t = 0.f;
+    for (int r = 0; r < W; ++r) t += sl[(long)r * SW + P + k];
+    t *= invW;  // what Logger.get_stats averages across ranks
+    // k: 0 loss, 1 ratio, 2 sum p^2, 3 |g|, 4 entropy
+    if (net == 0) {
+      if (k == 0) stats[2] = t;
+      if (k == 1) stats[3] = t;
+      if (k == 4) stats[4] = t;
+      if (k == 3) stats[7] = t;
+    } else {
+      if (k == 0) stats[net - 1] = t;
+      if (k == 2) stats[4 + net] = t;
+      if (k == 3) stats[7 + net] = t;
+    }
+  }
+}
+
+__global__ void osa_dp_step_count_kernel(int* adam_step, int nets_mask, int nsteps) {
+  const int net = threadIdx.x;
+  if (net < 3 && ((nets_mask >> net) & 1)) adam_step[net] += nsteps;
+}
+
+extern "C" {
+
+size_t osa_ppo_dp_ws_floats(int obs_dim, int act_dim, int hidden, int world) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  return (size_t)3 * world * (nd.P + PNSTAT);
+}
+
+int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                    int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                    const float* logp, const float* target_value_r, const float* target_value_c,
+                    const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                    int step_index, const float* lagrange, const osa_ppo_hparams* hp,
+                    const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
+                    float* step_stats, void* stream) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && slabs);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
+  OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && step_index >= 0 && (long)step_index * B < M);
+  if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  OsaPassArgs a;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = perm; a.M = M; a.B = B; a.nmb = 1; a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
+  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = world; a.mb0 = step_index;
+  const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
+  hipStream_t st = osa_stream(stream);
+  int rc = OSA_EUNSUPPORTED;
+#define OSA_DP_CASE(K, O)                                                                        \
+  if (KB == K && OT == O)                                                                        \
+    rc = (B > 64) ? osa_launch_pass<K, O, true>(a, st, world) : osa_launch_pass<K, O, false>(a, st, world)
+  OSA_DP_CASE(1, 1); OSA_DP_CASE(2, 1); OSA_DP_CASE(3, 1); OSA_DP_CASE(4, 1); OSA_DP_CASE(5, 1);
+  OSA_DP_CASE(6, 1); OSA_DP_CASE(1, 2); OSA_DP_CASE(2, 2); OSA_DP_CASE(3, 2); OSA_DP_CASE(4, 2);
+  OSA_DP_CASE(5, 2); OSA_DP_CASE(6, 2);
+#undef OSA_DP_CASE
+  if (rc != OSA_OK) return rc;
+  hipLaunchKernelGGL(osa_dp_apply_kernel, dim3((a.nd.P + 255) / 256, 3), dim3(256), 0, st, a.nd, params,
+                     adam_m, adam_v, adam_step, slabs, world, a.hp, lr_dev, a.nets_mask, step_stats,
+                     step_index);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream) {
+  OSA_REQUIRE(adam_step && nsteps > 0);
+  hipLaunchKernelGGL(osa_dp_step_count_kernel, dim3(1), dim3(64), 0, osa_stream(stream), adam_step,
+                     nets_mask, nsteps);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
 }
 
 }  // extern "C"

@@ -85,3 +85,23 @@ def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
 def barrier() -> None:
     if world_size() > 1:
         dist.barrier()
+
+
+def all_gather_rows(t: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Concatenate every rank's tensor along dim 0 (rank r occupies rows r*n .. r*n+n-1).  Used once per
+    epoch by the replicated-data update path to hand every rank the whole rollout."""
+    ws = world_size()
+    if ws == 1:
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+    t = t.contiguous()
+    if out is None:
+        out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(out, t)
+    else:
+        parts = list(out.chunk(ws, dim=0))
+        dist.all_gather(parts, t)
+    return out

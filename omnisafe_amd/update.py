@@ -32,7 +32,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                  use_critic_norm: bool = True, critic_norm_coef: float = 0.001,
                  use_max_grad_norm: bool = True, max_grad_norm: float = 40.0, use_cost: bool = True,
                  loss_kind: int = 0, max_blocks: int = 256, update_actor: bool = True,
-                 persistent: bool = True) -> None:
+                 persistent: bool = True, dp_mode: str = 'replicated', seed: int = 0) -> None:
         self.ac = ac
         self.lib = _lib.load(require_gpu=True)
         self.batch_size, self.update_iters = int(batch_size), int(update_iters)
@@ -41,6 +41,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.update_actor = update_actor
         self.persistent = persistent  # persistent pass kernel (world_size 1) vs one launch per step
         self.persistent_max_batch = 512  # beyond this a step has enough rows to fill the chip per launch
+        # world_size > 1: 'replicated' = all-gather the rollout once per epoch and compute the whole
+        # global step on every rank (no per-step collective); 'allreduce' = per-step flat RCCL all-reduce
+        self.dp_mode = dp_mode
+        self.seed = int(seed)
+        self._dp: dict = {}
         self.hp = HParams(clip=clip, entropy_coef=entropy_coef, critic_norm_coef=critic_norm_coef,
                           max_grad_norm=max_grad_norm, lr_actor=0.0, lr_critic=0.0, beta1=0.9,
                           beta2=0.999, adam_eps=1e-8, use_critic_norm=int(use_critic_norm),
@@ -112,6 +117,102 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev[1].record()
             self.profile_events.append((name, M, ev))
 
+    # ------------------------------------------------------------------ replicated-data DP path
+    _DP_KEYS = ('obs', 'act', 'logp', 'target_value_r', 'target_value_c', 'adv_r', 'adv_c')
+
+    def gather_for_replicated(self, data: dict, W: int) -> dict:
+        """All-gather this epoch's env-major batch of every rank into persistent [W*M, ...] buffers
+        (one collective per tensor per epoch instead of one all-reduce per optimiser step)."""
+        M = data['obs'].shape[0]
+        st = self._dp
+        if st.get('M') != M or st.get('W') != W:
+            st.clear()
+            st.update(M=M, W=W, graph=None)
+            st['data'] = {k: torch.empty((W * M,) + tuple(data[k].shape[1:]), dtype=torch.float32,
+                                         device=self.ac.device) for k in self._DP_KEYS}
+        for k in self._DP_KEYS:
+            dist.all_gather_rows(data[k], out=st['data'][k])
+        return st['data']
+
+    def _dp_state(self, M: int, W: int, nmb: int) -> dict:
+        ac, st = self.ac, self._dp
+        if st.get('M') != M or st.get('W') != W:
+            st.clear()
+            st.update(M=M, W=W, graph=None)
+        if 'perm' not in st:
+            dev = ac.device
+            st['perm'] = torch.zeros(W, M, dtype=torch.int64, device=dev)
+            st['pass_stats'] = torch.zeros(nmb, NSTAT, dtype=torch.float32, device=dev)
+            st['slabs'] = torch.empty(self.lib.osa_ppo_dp_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W),
+                                      dtype=torch.float32, device=dev)
+            st['lr'] = torch.zeros(2, dtype=torch.float32, device=dev)
+            # one generator per virtual rank, seeded like the ranks' own (seed + 1000 * rank): every rank
+            # draws the SAME W permutations without communicating
+            st['gens'] = []
+            for r in range(W):
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(self.seed + 1000 * r + 7919)
+                st['gens'].append(gen)
+            st['graph'] = None
+        return st
+
+    def _dp_enqueue_pass(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor, st: dict, nmb: int) -> None:
+        ac, lib = self.ac, self.lib
+        for k in range(nmb):
+            _lib.check(lib.osa_ppo_dp_step(
+                ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),
+                data_all['obs'].stride(0), _lib.ptr(data_all['act']), data_all['act'].stride(0),
+                _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
+                _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
+                _lib.ptr(st['perm']), M, self.batch_size, W, k, _lib.ptr(lagrange), C.byref(self.hp),
+                _lib.ptr(st['lr']), self.loss_kind, self._nets_mask(), _lib.ptr(st['slabs']),
+                _lib.ptr(st['pass_stats'][k]), _lib.stream_ptr()), 'osa_ppo_dp_step')
+        _lib.check(lib.osa_ppo_dp_end_pass(_lib.ptr(ac.adam_step), self._nets_mask() & (7 if self.hp.use_cost else 3),
+                                           nmb, _lib.stream_ptr()), 'osa_ppo_dp_end_pass')
+
+    def run_pass_replicated(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor,
+                            stats_rows: torch.Tensor, perms_all: torch.Tensor | None = None,
+                            use_graph: bool = True) -> None:
+        """One pass of the global update on the all-gathered data: ceil(M/B) steps x (W x 3 gradient
+        workgroups + reduce/Adam), captured once as a hipGraph and replayed per pass (2 launches per
+        step would otherwise be host-launch-bound)."""
+        ac = self.ac
+        nmb = (M + self.batch_size - 1) // self.batch_size
+        st = self._dp_state(M, W, nmb)
+        if perms_all is not None:
+            st['perm'].copy_(perms_all.reshape(W, M))
+        else:
+            for r in range(W):
+                st['perm'][r].copy_(torch.randperm(M, generator=st['gens'][r], device=ac.device))
+        st['lr'][0] = float(self.hp.lr_actor)
+        st['lr'][1] = float(self.hp.lr_critic)
+        key = (M, W, nmb, self._nets_mask(), int(lagrange.data_ptr()), data_all['obs'].data_ptr())
+        ev = None
+        if self.profile_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        graph_ok = use_graph and not st.get('graph_failed', False) and st.get('warm', False)
+        if graph_ok and (st.get('graph') is None or st.get('graph_key') != key):
+            try:  # capture records the launches without executing them
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._dp_enqueue_pass(data_all, M, W, lagrange, st, nmb)
+                st['graph'], st['graph_key'] = g, key
+            except Exception:  # pragma: no cover - capture unsupported: stay on eager launches
+                st['graph_failed'], st['graph'] = True, None
+                graph_ok = False
+        if graph_ok and st.get('graph') is not None:
+            st['graph'].replay()
+        else:
+            # first pass (also sets the kernels' LDS attributes, which must not happen under capture)
+            self._dp_enqueue_pass(data_all, M, W, lagrange, st, nmb)
+            st['warm'] = True
+        if ev is not None:
+            ev[1].record()
+            self.profile_events.append(('osa_ppo_dp_step', W * M, ev))
+        stats_rows.copy_(st['pass_stats'][:stats_rows.shape[0]])
+
     def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
         """old_distribution = actor(obs) (policy_gradient.py:357)."""
         ac, M = self.ac, obs.shape[0]
@@ -160,12 +261,23 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
         use_pass = self._pass_fn is not None
+        W = dist.world_size()
+        use_repl = (W > 1 and self.dp_mode == 'replicated' and B <= self.persistent_max_batch and bool(
+            self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
+        if use_repl:
+            gathered = self.gather_for_replicated(data, W)
         for i in range(self.update_iters):
-            if perms is not None:
+            if use_repl:
+                perm = None
+            elif perms is not None:
                 perm = torch.as_tensor(perms[i]).to(ac.device, torch.int64)
             else:
                 perm = torch.randperm(M, device=ac.device)
-            if use_pass:  # one persistent launch for the whole pass
+            if use_repl:
+                pa = None if perms is None else torch.as_tensor(perms[i]).to(ac.device, torch.int64)
+                self.run_pass_replicated(gathered, M, W, lagrange, stats[step:step + nmb], perms_all=pa)
+                step += nmb
+            elif use_pass:  # one persistent launch for the whole pass
                 self.run_pass(data, perm, lagrange, stats[step:step + nmb])
                 step += nmb
             else:

@@ -276,3 +276,68 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
     np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize('W,M,B,use_graph', [(2, 512, 64, False), (4, 300, 64, True), (3, 256, 128, True)])
+def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph):
+    """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
+    workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
+    data-parallel semantics emulated rank by rank with the per-step kernels (gradient + local clip per
+    rank, average, Adam): policy_gradient.py:437-442, distributed.py:193-198."""
+    import ctypes as C
+
+    from omnisafe_amd import _lib
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(W * 100 + M)
+    obs_dim, act_dim = 60, 2
+    data_all = {'obs': torch.randn(W * M, obs_dim, device=DEV), 'act': torch.randn(W * M, act_dim, device=DEV),
+                'target_value_r': torch.randn(W * M, device=DEV), 'target_value_c': torch.randn(W * M, device=DEV),
+                'adv_r': torch.randn(W * M, device=DEV), 'adv_c': torch.randn(W * M, device=DEV)}
+    perms = [torch.stack([torch.randperm(M) for _ in range(W)]).to(DEV) for _ in range(3)]
+    lam = torch.tensor([0.4], device=DEV)
+    nmb = (M + B - 1) // B
+    results = []
+    for mode in ('replicated', 'emulated'):
+        torch.manual_seed(5)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data_all:
+            _, _, _, lp = ac.step(data_all['obs'], eps=data_all['act'] * 0)
+            data_all['logp'] = lp + 0.2 * torch.randn(W * M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=3, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        stats = torch.zeros(3 * nmb, 16, device=DEV)
+        if mode == 'replicated':
+            for i in range(3):
+                up.run_pass_replicated(data_all, M, W, lam, stats[i * nmb:(i + 1) * nmb], perms_all=perms[i],
+                                       use_graph=use_graph)
+            if use_graph:
+                assert up._dp.get('graph') is not None and not up._dp.get('graph_failed', False)
+        else:
+            lib = _lib.load()
+            row = torch.zeros(16, device=DEV)
+            for i in range(3):
+                for k in range(nmb):
+                    acc = torch.zeros_like(ac.grads)
+                    for r in range(W):
+                        idx = (perms[i][r, k * B:(k + 1) * B] + r * M).contiguous()
+                        _lib.check(lib.osa_ppo_minibatch(
+                            obs_dim, act_dim, 64, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+                            _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data_all['obs']), obs_dim,
+                            _lib.ptr(data_all['act']), act_dim, _lib.ptr(data_all['logp']),
+                            _lib.ptr(data_all['target_value_r']), _lib.ptr(data_all['target_value_c']),
+                            _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']), _lib.ptr(idx), idx.numel(),
+                            _lib.ptr(lam), C.byref(up.hp), 0, 1, 7, 4, _lib.ptr(up._ws), _lib.ptr(row),
+                            _lib.stream_ptr()))
+                        acc += ac.grads
+                    ac.grads.copy_(acc / W)
+                    _lib.check(lib.osa_adam_apply(obs_dim, act_dim, 64, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                                                  _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads),
+                                                  C.byref(up.hp), 7, _lib.stream_ptr()))
+        results.append((ac, stats.cpu().numpy()))
+    a0, a1 = results[0][0], results[1][0]
+    assert a0.adam_step.cpu().tolist() == a1.adam_step.cpu().tolist() == [3 * nmb] * 3
+    for name in ('params', 'adam_m', 'adam_v'):
+        np.testing.assert_allclose(getattr(a0, name).cpu().numpy(), getattr(a1, name).cpu().numpy(), rtol=1e-5,
+                                   atol=5e-6, err_msg=name)
+    assert np.isfinite(results[0][1][:, :10]).all() and (results[0][1][:, 3] > 0).all()

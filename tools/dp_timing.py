@@ -1,0 +1,28 @@
+"""GPU tool: time one pass of the replicated-data DP update for W virtual ranks on ONE GPU.  Each real rank of
+a W-GPU run executes exactly this work, so this predicts the per-rank update time of the multi-GPU bench."""
+import os, sys, types
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omnisafe_amd.models import ConstraintActorCritic
+from omnisafe_amd.spaces import Box
+from omnisafe_amd.update import PPOUpdater
+ns = types.SimpleNamespace
+mc = ns(actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4), critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4),
+        weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning', linear_lr_decay=True)
+dev = 'cuda:0'
+M, B = 65536, 64
+for W in (1, 2, 4, 8):
+    ac = ConstraintActorCritic(Box(-np.inf, np.inf, (60,)), Box(-1, 1, (2,)), mc, 4, device=dev)
+    data = {'obs': torch.randn(W * M, 60, device=dev), 'act': torch.randn(W * M, 2, device=dev), 'logp': torch.randn(W * M, device=dev) - 2,
+            'target_value_r': torch.randn(W * M, device=dev), 'target_value_c': torch.randn(W * M, device=dev),
+            'adv_r': torch.randn(W * M, device=dev), 'adv_c': torch.randn(W * M, device=dev)}
+    up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+    up.hp.lr_actor = up.hp.lr_critic = 3e-4
+    lam = torch.zeros(1, device=dev); st = torch.zeros(1024, 16, device=dev)
+    for use_graph in (False, True):
+        for _ in range(2):
+            up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph); e1.record(); torch.cuda.synchronize()
+        print(f'W={W} graph={use_graph}: {e0.elapsed_time(e1):8.2f} ms per pass = {e0.elapsed_time(e1)*1e3/1024:6.2f} us per optimiser step', flush=True)
