@@ -64,7 +64,8 @@ def make_algo(args, world, batch_size, update_iters, epochs, log_dir):
     spe = args.envs * args.steps_per_env * world
     cfg = {
         'seed': 0,
-        'train_cfgs': {'device': f'cuda:{int(os.environ.get("LOCAL_RANK", 0))}', 'vector_env_nums': args.envs,
+        'train_cfgs': {'device': 'cuda:0' if os.environ.get('OSA_SINGLE_DEVICE_RANKS') else
+                       f'cuda:{int(os.environ.get("LOCAL_RANK", 0))}', 'vector_env_nums': args.envs,
                        'total_steps': spe * epochs},
         'algo_cfgs': {'steps_per_epoch': spe, 'batch_size': batch_size, 'update_iters': update_iters,
                       'kl_early_stop': bool(args.kl_early_stop)},
@@ -227,6 +228,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('OSA_SINGLE_DEVICE_RANKS'):  # test hook: several ranks on one GPU (gloo)
+        local = 0
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device(f'cuda:{local}')
     torch.cuda.set_device(dev)
