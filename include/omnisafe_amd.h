@@ -205,6 +205,25 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
                     float* step_stats, void* stream);
 int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream);
 
+/* The same replicated-data optimiser chain as ONE cooperative persistent launch per pass: 3 x world
+ * workgroups stay resident for all ceil(M/B) steps; workgroup (net, r) keeps its own LDS/register copy
+ * of the network and of the Adam moments, computes rank r's locally clipped gradient, publishes it in
+ * `exchange` (osa_ppo_dp_pass_ws_floats floats), meets its `world` peers at an agent-scope arrival
+ * counter (sync: int[4], counters + sticky time-out flag sync[3] that the caller should check; a peer
+ * that never arrives is flagged after a bounded spin instead of hanging the device), then sums the
+ * gradients in rank order and applies Adam locally -- every peer does identical arithmetic, rank 0's
+ * copy is written back at the end and adam_step advances by the number of steps.  Requires
+ * 3 * world <= compute units (OSA_EUNSUPPORTED otherwise: use osa_ppo_dp_step).
+ * Replaces: the minibatch loop of PolicyGradient._update under torch.distributed
+ * (policy_gradient.py:366-382, 437-442; distributed.py:193-198). */
+size_t osa_ppo_dp_pass_ws_floats(int obs_dim, int act_dim, int hidden, int world);
+int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                    int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                    const float* logp, const float* target_value_r, const float* target_value_c,
+                    const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                    const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                    float* exchange, int* sync, float* step_stats, void* stream);
+
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */
 int osa_debug_set_clock_buffer(long long* dev_ptr);

@@ -12,6 +12,7 @@ import torch
 from . import build as _build
 
 _LIB = None
+OSA_OK, OSA_EUNSUPPORTED = 0, -3  # include/omnisafe_amd.h
 
 c_f32p = C.c_void_p  # device pointers travel as integers
 c_ptr = C.c_void_p
@@ -41,6 +42,9 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_pass_supported': (_I, [_I, _I, _I]),
     'osa_ppo_dp_end_pass': (_I, [_P, _I, _I, _P]),
     'osa_ppo_dp_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_ppo_dp_pass_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_ppo_dp_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
+                        _P, _P, _I, _I, _P, _P, _P, _P]),
     'osa_ppo_dp_step': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,

@@ -57,6 +57,13 @@ struct OsaPassArgs {
   float* dp_slabs;  // [3][dp_world][P + PNSTAT] or nullptr
   int dp_world;
   int mb0;          // first minibatch index processed by this launch
+  // cooperative data-parallel pass (osa_ppo_dp_pass): grid (3, dp_world), ALL workgroups persistent over
+  // the nmb steps.  Workgroup (net, rk) computes rank rk's locally clipped gradient, publishes it in
+  // dp_slabs (exchange layout, double-buffered by step parity), waits on dp_sync[net] for its dp_world
+  // peers, then sums the dp_world gradients in rank order and applies Adam to ITS OWN copy of the
+  // network: all peers perform identical arithmetic, so their copies stay bit-identical and nothing
+  // but gradients ever crosses between compute units.
+  int* dp_sync;     // [4]: arrival counters of the three networks + sticky time-out flag; or nullptr
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -69,14 +76,15 @@ struct OsaPassArgs {
     }                                                 \
   } while (0)
 
-template <int KB, int OT, bool MULTI>
+template <int KB, int OT, bool MULTI, bool COOP>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
   const int net = blockIdx.x;
   if (!((a.nets_mask >> net) & 1)) return;
   const int rk = blockIdx.y;  // virtual rank (0 outside the data-parallel mode)
-  const bool dp = a.dp_slabs != nullptr;
+  constexpr bool coop = COOP;
+  const bool dp = a.dp_slabs != nullptr && !coop;
   const long roff = (long)rk * a.M;
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
@@ -252,8 +260,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
   for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   __syncthreads();  // LDS master copy complete
-  long long dbg_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long dbg_last = clock64();
+  bool coop_dead = false;
 
   for (int mb = a.mb0; mb < a.mb0 + a.nmb; ++mb) {
     const long mb_lo = (long)mb * a.B;
@@ -634,13 +643,119 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       }
       return;  // nmb == 1 in this mode: nothing else to do (weights, moments untouched)
     }
+    float st_loss = t_loss * invB, st_ratio = t_ratio * invB, st_psq = t_psq, st_norm = total_norm,
+          st_ent = ent_pre;
+    if (net == 0) st_loss -= a.hp.entropy_coef * ent_pre;
+    bool apply_clip = a.hp.use_max_grad_norm != 0;
+    if constexpr (coop) {
+      // ---- publish this rank's clipped gradient (exchange layout: one f32x4 per thread per tile, so
+      // every store/load instruction of a wave moves 1 KB contiguous)
+      constexpr int NT = HT + KB + OT, XS = NT * 1024 + 256 + PNSTAT;
+      const int W = a.dp_world, par = (mb - a.mb0) & 1;
+      float* __restrict__ xbase = a.dp_slabs + ((long)par * 3 + net) * W * XS;
+      {
+        float* __restrict__ xs = xbase + (long)rk * XS;
+        f32x4* __restrict__ x4 = reinterpret_cast<f32x4*>(xs);
+        const float gs = apply_clip ? coef : 1.f;
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) x4[ti * 256 + tid] = g2[ti] * gs;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) x4[(HT + kb) * 256 + tid] = g1[kb] * gs;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) x4[(HT + KB + o) * 256 + tid] = g3[o] * gs;
+        xs[NT * 1024 + tid] = (boff >= 0) ? gb * gs : 0.f;
+        if (tid == 0) {
+          float* t = xs + NT * 1024 + 256;
+          t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      PTICK(12);
+      if (tid == 0) {
+        int* cnt = a.dp_sync + net;
+        const int target = W * (mb - a.mb0 + 1);
+        // relaxed atomics: ordering comes from the agent-scope fences on either side of the barriers
+        // (a release/acquire atomic would write back / invalidate the L2 a second time)
+        int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (!coop_dead) {
+          int spins = 0;
+          while (seen < target) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1 << 21)) {  // peers not co-resident / lost: flag it, never hang the GPU
+              __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              coop_dead = true;
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      PTICK(10);
+      // ---- sum the W gradients in rank order (same order on every peer), average
+      f32x4 s2[HT], s1[KB], s3[OT];
+      float sb_ = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) s2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // RU ranks per trip: their loads are all in flight together (one memory round trip per trip,
+      // not per rank); the clamped duplicate loads of a ragged last trip are simply not added
+      constexpr int RU = 4;
+      for (int r0 = 0; r0 < W; r0 += RU) {
+        f32x4 t[RU][NT];
+        float tb[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const float* __restrict__ xr = xbase + (long)min(r0 + u, W - 1) * XS;
+          const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+          for (int q = 0; q < NT; ++q) t[u][q] = x4[q * 256 + tid];
+          tb[u] = xr[NT * 1024 + tid];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          if (r0 + u < W) {  // workgroup-uniform
+#pragma unroll
+            for (int ti = 0; ti < HT; ++ti) s2[ti] = s2[ti] + t[u][ti];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) s1[kb] = s1[kb] + t[u][HT + kb];
+#pragma unroll
+            for (int o = 0; o < OT; ++o) s3[o] = s3[o] + t[u][HT + KB + o];
+            sb_ += tb[u];
+          }
+        }
+      }
+      const float invW = 1.f / (float)W;
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) g2[ti] = s2[ti] * invW;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) g1[kb] = s1[kb] * invW;
+#pragma unroll
+      for (int o = 0; o < OT; ++o) g3[o] = s3[o] * invW;
+      gb = sb_ * invW;
+      PTICK(11);
+      apply_clip = false;  // already clipped per rank (clip-then-average, policy_gradient.py:437-442)
+      if (tid == 0 && rk == 0) {  // what Logger.get_stats averages across ranks
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < W; ++r) {
+          const float* t = xbase + (long)r * XS + NT * 1024 + 256;
+          for (int k = 0; k < 5; ++k) acc[k] += t[k];
+        }
+        st_loss = acc[0] * invW; st_ratio = acc[1] * invW; st_psq = acc[2] * invW;
+        st_norm = acc[3] * invW; st_ent = acc[4] * invW;
+      }
+    }
     // ================= Adam on the owned parameters; LDS master updated in place =================
     b1pow *= (double)beta1;
     b2pow *= (double)beta2;
     const float step_size = (float)((double)lr / (1.0 - b1pow));
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
-    const bool do_clip = a.hp.use_max_grad_norm != 0;
-    const float gscale = do_clip ? coef : 1.f;
+    const float gscale = apply_clip ? coef : 1.f;
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
       f32x4 w;
@@ -676,24 +791,25 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     PTICK(8);
     // ---- statistics of this optimiser step
-    if (tid == 0) {
+    if (tid == 0 && rk == 0) {
       float* st = a.stats + (long)(mb - a.mb0) * PNSTAT;
       if (net == 0) {
-        st[2] = t_loss * invB - a.hp.entropy_coef * ent_pre;
-        st[3] = t_ratio * invB;
-        st[4] = ent_pre;
-        st[7] = total_norm;
+        st[2] = st_loss;
+        st[3] = st_ratio;
+        st[4] = st_ent;
+        st[7] = st_norm;
       } else {
-        st[net - 1] = t_loss * invB;
-        st[4 + net] = t_psq;
-        st[7 + net] = total_norm;
+        st[net - 1] = st_loss;
+        st[4 + net] = st_psq;
+        st[7 + net] = st_norm;
       }
     }
     __syncthreads();  // (C) master copy updated, tiles and `red` free for the next minibatch
     PTICK(9);
   }
-  if (a.dbg && tid == 0)
-    for (int k = 0; k < 10; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
+  if (a.dbg && tid == 0 && rk == 0)
+    for (int k = 0; k < 13; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
+  if (rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
   // ---- write back parameters and Adam state
   for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
   for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * PSLD + (e & 63)];
@@ -748,18 +864,18 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI>
+template <int KB, int OT, bool MULTI, bool COOP = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI>), dim3(3, grid_y), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP>), dim3(3, grid_y), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -800,7 +916,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   a.dbg = g_osa_pass_dbg;
-  a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0;
+  a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0; a.dp_sync = nullptr;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PASS_CASE(K, O) \
@@ -910,7 +1026,7 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
-  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = world; a.mb0 = step_index;
+  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = world; a.mb0 = step_index; a.dp_sync = nullptr;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
   int rc = OSA_EUNSUPPORTED;
@@ -926,6 +1042,59 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
                      adam_m, adam_v, adam_step, slabs, world, a.hp, lr_dev, a.nets_mask, step_stats,
                      step_index);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+static size_t osa_dp_pass_xs(const OsaNet& nd) {
+  return (size_t)(4 + nd.KB + nd.OUTP / 16) * 1024 + 256 + PNSTAT;
+}
+
+size_t osa_ppo_dp_pass_ws_floats(int obs_dim, int act_dim, int hidden, int world) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  return (size_t)2 * 3 * world * osa_dp_pass_xs(nd);
+}
+
+int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                    int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                    const float* logp, const float* target_value_r, const float* target_value_c,
+                    const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                    const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                    float* exchange, int* sync, float* step_stats, void* stream) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
+  OSA_REQUIRE(exchange && sync && ld_obs >= obs_dim && ld_act >= act_dim);
+  if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  // all 3 * world workgroups must be co-resident (one per compute unit: ~150 KB of LDS each)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return OSA_EHIP;
+  if (3 * world > cus) return OSA_EUNSUPPORTED;
+  OsaPassArgs a;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = perm; a.M = M; a.B = B; a.nmb = (int)((M + B - 1) / B); a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
+  a.dbg = g_osa_pass_dbg; a.dp_slabs = exchange; a.dp_world = world; a.mb0 = 0; a.dp_sync = sync;
+  hipStream_t st = osa_stream(stream);
+  if (hipMemsetAsync(sync, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
+#define OSA_DPP_CASE(K, O)                                                                       \
+  if (KB == K && OT == O)                                                                        \
+    return (B > 64) ? osa_launch_pass<K, O, true, true>(a, st, world) : osa_launch_pass<K, O, false, true>(a, st, world)
+  OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);
+  OSA_DPP_CASE(6, 1); OSA_DPP_CASE(1, 2); OSA_DPP_CASE(2, 2); OSA_DPP_CASE(3, 2); OSA_DPP_CASE(4, 2);
+  OSA_DPP_CASE(5, 2); OSA_DPP_CASE(6, 2);
+#undef OSA_DPP_CASE
+  return OSA_EUNSUPPORTED;
 }
 
 int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream) {

@@ -42,7 +42,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.persistent = persistent  # persistent pass kernel (world_size 1) vs one launch per step
         self.persistent_max_batch = 512  # beyond this a step has enough rows to fill the chip per launch
         # world_size > 1: 'replicated' = all-gather the rollout once per epoch and compute the whole
-        # global step on every rank (no per-step collective); 'allreduce' = per-step flat RCCL all-reduce
+        # global step on every rank (no per-step collective) -- as one cooperative persistent launch per
+        # pass (osa_ppo_dp_pass) or, with 'replicated-steps', as two launches per step replayed from a
+        # hipGraph (osa_ppo_dp_step); 'allreduce' = per-step flat RCCL all-reduce
         self.dp_mode = dp_mode
         self.seed = int(seed)
         self._dp: dict = {}
@@ -171,12 +173,43 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         _lib.check(lib.osa_ppo_dp_end_pass(_lib.ptr(ac.adam_step), self._nets_mask() & (7 if self.hp.use_cost else 3),
                                            nmb, _lib.stream_ptr()), 'osa_ppo_dp_end_pass')
 
+    def _dp_coop_pass(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor, st: dict) -> bool:
+        """osa_ppo_dp_pass: the whole pass as ONE cooperative launch of 3 x W persistent workgroups.
+        Returns False when the device cannot hold them (caller falls back to the stepwise path)."""
+        ac, lib = self.ac, self.lib
+        if 'xch' not in st:
+            n = lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
+            st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
+            st['sync'] = torch.zeros(4, dtype=torch.int32, device=ac.device)
+        rc = lib.osa_ppo_dp_pass(
+            ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+            _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),
+            data_all['obs'].stride(0), _lib.ptr(data_all['act']), data_all['act'].stride(0),
+            _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
+            _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
+            _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp),
+            self.loss_kind, self._nets_mask(), _lib.ptr(st['xch']), _lib.ptr(st['sync']),
+            _lib.ptr(st['pass_stats']), _lib.stream_ptr())
+        if rc == _lib.OSA_EUNSUPPORTED:
+            return False
+        _lib.check(rc, 'osa_ppo_dp_pass')
+        st['coop_passes'] = st.get('coop_passes', 0) + 1
+        return True
+
+    def check_dp_sync(self) -> None:
+        """Raise if a cooperative pass flagged a peer workgroup that never arrived (host sync)."""
+        st = self._dp
+        if 'sync' in st and int(st['sync'][3]) != 0:
+            raise RuntimeError('osa_ppo_dp_pass: a peer workgroup timed out (workgroups not co-resident?); '
+                               'set OSA_DP_MODE=replicated-steps')
+
     def run_pass_replicated(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor,
                             stats_rows: torch.Tensor, perms_all: torch.Tensor | None = None,
-                            use_graph: bool = True) -> None:
-        """One pass of the global update on the all-gathered data: ceil(M/B) steps x (W x 3 gradient
-        workgroups + reduce/Adam), captured once as a hipGraph and replayed per pass (2 launches per
-        step would otherwise be host-launch-bound)."""
+                            use_graph: bool = True, coop: bool | None = None) -> None:
+        """One pass of the global update on the all-gathered data.  Default: one cooperative persistent
+        launch (osa_ppo_dp_pass).  Fallback (`coop=False`, dp_mode 'replicated-steps', or more than
+        CUs/3 ranks): ceil(M/B) steps x (W x 3 gradient workgroups + reduce/Adam), captured once as a
+        hipGraph and replayed per pass (2 launches per step would otherwise be host-launch-bound)."""
         ac = self.ac
         nmb = (M + self.batch_size - 1) // self.batch_size
         st = self._dp_state(M, W, nmb)
@@ -185,6 +218,19 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         else:
             for r in range(W):
                 st['perm'][r].copy_(torch.randperm(M, generator=st['gens'][r], device=ac.device))
+        if coop is None:
+            coop = self.dp_mode != 'replicated-steps'
+        if coop:
+            ev = None
+            if self.profile_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            if self._dp_coop_pass(data_all, M, W, lagrange, st):
+                if ev is not None:
+                    ev[1].record()
+                    self.profile_events.append(('osa_ppo_dp_pass', W * M, ev))
+                stats_rows.copy_(st['pass_stats'][:stats_rows.shape[0]])
+                return
         st['lr'][0] = float(self.hp.lr_actor)
         st['lr'][1] = float(self.hp.lr_critic)
         key = (M, W, nmb, self._nets_mask(), int(lagrange.data_ptr()), data_all['obs'].data_ptr())
@@ -262,7 +308,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
         use_pass = self._pass_fn is not None
         W = dist.world_size()
-        use_repl = (W > 1 and self.dp_mode == 'replicated' and B <= self.persistent_max_batch and bool(
+        use_repl = (W > 1 and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         if use_repl:
             gathered = self.gather_for_replicated(data, W)
@@ -292,6 +338,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     final_kl = float(kl_dev)  # the one host sync per pass
                     if final_kl > self.target_kl:
                         break
+        if use_repl:
+            self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
         used = stats[:step]
         out = {'stop_iter': update_counts, 'steps': step, 'stats': used}
         if self.update_actor:

@@ -278,8 +278,11 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize('W,M,B,use_graph', [(2, 512, 64, False), (4, 300, 64, True), (3, 256, 128, True)])
-def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph):
+@pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),
+                                                  (3, 256, 128, True, False), (2, 512, 64, False, True),
+                                                  (4, 300, 64, False, True), (3, 256, 128, False, True),
+                                                  (8, 1024, 64, False, True), (1, 200, 64, False, True)])
+def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop):
     """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
     workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
     data-parallel semantics emulated rank by rank with the per-step kernels (gradient + local clip per
@@ -310,7 +313,10 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
         if mode == 'replicated':
             for i in range(3):
                 up.run_pass_replicated(data_all, M, W, lam, stats[i * nmb:(i + 1) * nmb], perms_all=perms[i],
-                                       use_graph=use_graph)
+                                       use_graph=use_graph, coop=coop)
+            if coop:  # the cooperative persistent launch ran (no silent fallback) and every peer arrived
+                assert up._dp.get('coop_passes') == 3
+                up.check_dp_sync()
             if use_graph:
                 assert up._dp.get('graph') is not None and not up._dp.get('graph_failed', False)
         else:

@@ -3,6 +3,7 @@ a W-GPU run executes exactly this work, so this predicts the per-rank update tim
 import os, sys, types
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omnisafe_amd import _lib
 from omnisafe_amd.models import ConstraintActorCritic
 from omnisafe_amd.spaces import Box
 from omnisafe_amd.update import PPOUpdater
@@ -19,10 +20,19 @@ for W in (1, 2, 4, 8):
     up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
     up.hp.lr_actor = up.hp.lr_critic = 3e-4
     lam = torch.zeros(1, device=dev); st = torch.zeros(1024, 16, device=dev)
-    for use_graph in (False, True):
+    for coop, use_graph in ((True, False), (False, True)):
         for _ in range(2):
-            up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph)
+            up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph, coop=coop)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph); e1.record(); torch.cuda.synchronize()
-        print(f'W={W} graph={use_graph}: {e0.elapsed_time(e1):8.2f} ms per pass = {e0.elapsed_time(e1)*1e3/1024:6.2f} us per optimiser step', flush=True)
+        e0.record(); up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph, coop=coop); e1.record(); torch.cuda.synchronize()
+        up.check_dp_sync()
+        if coop:
+            lib = _lib.load(); dbg = torch.zeros(48, dtype=torch.int64, device=dev)
+            lib.osa_debug_set_pass_clock_buffer(dbg.data_ptr())
+            up.run_pass_replicated(data, M, W, lam, st, coop=True); torch.cuda.synchronize()
+            lib.osa_debug_set_pass_clock_buffer(None)
+            d = dbg.cpu().numpy().reshape(3, 16)[:, :13] / 1024.0
+            names = ['prefetch', 'fwd', 'loss', 'bwd', 'transpose+barA', 'dW', 'bias+norms', 'barB', 'adam', 'stats+barC', 'wait+acquire', 'reduce', 'publish+release']
+            print('   cycles/step (actor, V_r, V_c): ' + '  '.join(f'{n}={d[0, i]:.0f}/{d[1, i]:.0f}/{d[2, i]:.0f}' for i, n in enumerate(names)))
+        print(f'W={W} coop={coop} graph={use_graph}: {e0.elapsed_time(e1):8.2f} ms per pass = {e0.elapsed_time(e1)*1e3/1024:6.2f} us per optimiser step', flush=True)
