@@ -133,6 +133,9 @@ def roofline_from_events(events, batch_size):
     Larger B: osa_mb_grad_kernel (+ the two small reduce/finalize launches it is bracketed with)."""
     name = events[0][0]
     rows = sum(e[1] for e in events)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if name in ('osa_ppo_dp_step', 'osa_ppo_dp_pass'):
+        rows //= world  # algorithmic work of a rank = its own M rows (it executes world x that, redundantly)
     ms = sum(e[2][0].elapsed_time(e[2][1]) for e in events)
     flops = FLOPS_PER_SAMPLE_STEP * rows
     achieved = flops / (ms * 1e-3) / 1e12
@@ -145,6 +148,14 @@ def roofline_from_events(events, batch_size):
         out['kernel'] = 'osa_ppo_pass_kernel (data-parallel gradient mode) + osa_dp_apply_kernel'
         out['note'] = ('replicated-data DP: each rank computes all ranks\' minibatches of every optimiser step '
                        '(W x 3 workgroups) on the all-gathered rollout, hipGraph of one pass replayed; rows = W x M')
+    elif name == 'osa_ppo_dp_pass':
+        steps = rows // len(events) // batch_size
+        out['kernel'] = 'osa_ppo_pass_kernel<..., COOP> (cooperative data-parallel pass)'
+        out['us_per_optimiser_step'] = round(us / steps, 3)
+        out['note'] = (f'replicated-data DP, one persistent launch per pass: 3 x {world} resident workgroups, each '
+                       f'computing one rank\'s {batch_size}-row minibatch of every one of the {steps} global optimiser '
+                       'steps on the all-gathered rollout, exchanging clipped gradients through an agent-scope '
+                       'arrival counter; flops counted for this rank\'s own rows only')
     elif name == 'osa_ppo_pass_kernel':
         steps = rows // len(events) // batch_size
         out['us_per_optimiser_step'] = round(us / steps, 3)
