@@ -2,6 +2,8 @@
 from . import registry
 from .policy_gradient import PPO, PolicyGradient, PPOLag
 from .trust_region_algos import CPO, TRPO, NaturalPG, TRPOLag
+from .siblings import CPPOPID, IPO, PCPO, PDO, RCPO, TRPOPID, OnCRPO
 
 ALGORITHMS = {'on-policy': tuple(sorted(registry.REGISTRY._module_dict))}  # noqa: SLF001
-__all__ = ['PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO', 'registry', 'ALGORITHMS']
+__all__ = ['PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO', 'PDO', 'RCPO', 'IPO',
+           'OnCRPO', 'CPPOPID', 'TRPOPID', 'PCPO', 'registry', 'ALGORITHMS']

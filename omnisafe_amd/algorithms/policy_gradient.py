@@ -165,7 +165,8 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         """policy_gradient.py:308-405."""
         data = self._buf.get()
         out = self._updater.run(data, self._lagrange_tensor(), actor_lr=self._current_actor_lr(),
-                                critic_lr=float(self._cfgs.model_cfgs.critic.lr))
+                                critic_lr=float(self._cfgs.model_cfgs.critic.lr),
+                                perms=getattr(self, '_perms_override', None))  # parity tests inject the order
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
         lg = self._logger

@@ -1,0 +1,193 @@
+"""Sibling on-policy algorithms that only override the surrogate / multiplier logic.
+
+Each class mirrors its reference counterpart's hooks and logged keys; the per-sample arithmetic is the
+same set of libomnisafe_amd kernels as PPOLag / TRPOLag / CPO -- the combined advantage
+(A_r - p A_c) / (1 + p) is formed inside the actor kernels from a device scalar p:
+
+  PDO       naive_lagrange/pdo.py:25-100        PolicyGradient + Lagrange
+  RCPO      naive_lagrange/rcpo.py:25-103       NaturalPG + Lagrange
+  IPO       penalty_function/ipo.py:24-74       PPO + interior-point penalty kappa / (limit - Jc)
+  OnCRPO    primal/crpo.py:25-80                TRPO on A_r, or on -A_c while the cost exceeds the limit
+  CPPOPID   pid_lagrange/cppo_pid.py:25-103     PPO + PID-controlled multiplier
+  TRPOPID   pid_lagrange/trpo_pid.py:25-98      TRPO + PID-controlled multiplier
+  PCPO      second_order/pcpo.py:31-152         CPO's machinery with the projection step
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..lagrange import Lagrange
+from ..pid_lagrange import PIDLagrangian
+from .policy_gradient import PPO, PolicyGradient
+from .registry import register
+from .trust_region_algos import CPO, TRPO, NaturalPG
+
+
+def _cfg_dict(c) -> dict:
+    return c.todict() if hasattr(c, 'todict') else dict(c)
+
+
+class _LagrangeMixin:
+    """_init / _init_log / _update of the naive-Lagrange family (pdo.py:36-80, rcpo.py:36-80)."""
+    _lagrange_min_max = True
+
+    def _init(self) -> None:
+        super()._init()
+        self._lagrange = Lagrange(**_cfg_dict(self._cfgs.lagrange_cfgs), device=self._device)
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Metrics/LagrangeMultiplier', min_and_max=self._lagrange_min_max)
+
+    def _lagrange_tensor(self) -> torch.Tensor:
+        return self._lagrange.device_multiplier
+
+    def _update(self) -> None:
+        Jc = self._logger.get_stats('Metrics/EpCost')[0]
+        self._lagrange.update_lagrange_multiplier(Jc)
+        super()._update()
+        self._logger.store({'Metrics/LagrangeMultiplier': self._lagrange.lagrangian_multiplier})
+
+
+class _PIDMixin:
+    """cppo_pid.py:36-82 / trpo_pid.py:36-78."""
+
+    def _init(self) -> None:
+        super()._init()
+        self._lagrange = PIDLagrangian(**_cfg_dict(self._cfgs.lagrange_cfgs), device=self._device)
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Metrics/LagrangeMultiplier')
+
+    def _lagrange_tensor(self) -> torch.Tensor:
+        return self._lagrange.device_multiplier
+
+    def _update(self) -> None:
+        Jc = self._logger.get_stats('Metrics/EpCost')[0]
+        self._lagrange.pid_update(Jc)
+        super()._update()
+        self._logger.store({'Metrics/LagrangeMultiplier': self._lagrange.lagrangian_multiplier})
+
+
+@register
+class PDO(_LagrangeMixin, PolicyGradient):
+    pass
+
+
+@register
+class RCPO(_LagrangeMixin, NaturalPG):
+    pass
+
+
+@register
+class CPPOPID(_PIDMixin, PPO):
+    pass
+
+
+@register
+class TRPOPID(_PIDMixin, TRPO):
+    pass
+
+
+@register
+class IPO(PPO):
+    def _init(self) -> None:
+        super()._init()
+        self._penalty = torch.zeros(1, dtype=torch.float32, device=self._device)
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Misc/Penalty')
+
+    def _lagrange_tensor(self) -> torch.Tensor:
+        return self._penalty
+
+    def _update(self) -> None:
+        """ipo.py:44-74: the penalty is a function of the epoch's mean episode cost only (the reference
+        recomputes the same value in every minibatch)."""
+        a = self._cfgs.algo_cfgs
+        Jc = self._logger.get_stats('Metrics/EpCost')[0]
+        penalty = a.kappa / (a.cost_limit - Jc + 1e-8)
+        if penalty < 0 or penalty > a.penalty_max:
+            penalty = a.penalty_max
+        self._penalty.fill_(float(penalty))
+        super()._update()
+        self._logger.store({'Misc/Penalty': float(penalty)})
+
+
+@register
+class OnCRPO(TRPO):
+    def __init__(self, env_id: str, cfgs) -> None:
+        super().__init__(env_id, cfgs)
+        self._rew_update = 0
+        self._cost_update = 0
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Misc/RewUpdate')
+        self._logger.register_key('Misc/CostUpdate')
+
+    def _update_actor(self, data: dict) -> None:
+        """crpo.py:58-80: optimise the reward advantage while the cost is within limit + distance,
+        otherwise minimise the cost advantage (surrogate advantage -A_c)."""
+        a = self._cfgs.algo_cfgs
+        Jc = self._logger.get_stats('Metrics/EpCost')[0]
+        if Jc <= a.cost_limit + a.distance:
+            self._rew_update += 1
+            self._adv_key_r = 'adv_r'
+        else:
+            self._cost_update += 1
+            self._logger.store({'Misc/RewUpdate': self._rew_update, 'Misc/CostUpdate': self._cost_update})
+            data = dict(data)
+            data['neg_adv_c'] = -data['adv_c']
+            self._adv_key_r = 'neg_adv_c'
+        super()._update_actor(data)
+
+
+@register
+class PCPO(CPO):
+    def _update_actor(self, data: dict) -> None:
+        """pcpo.py:41-152: reward step sqrt(2 delta / q) F x followed by the projection onto the cost
+        constraint along p = F^-1 b."""
+        ac, s, a = self._actor_critic, self._solver, self._cfgs.algo_cfgs
+        theta_old = ac.params[0].clone()
+        s.begin(data['obs'])
+        loss_r, grad_r = s.actor_loss_grad(data, 'adv_r', 'adv_c', self._lambda_zero)
+        loss_reward_before = float(loss_r)
+        g = s.lincomb(-1.0, grad_r)
+        x = s.conjugate_gradients(g)
+        assert torch.isfinite(x).all(), 'x is not finite'
+        H_inv_g = s.fvp(x)  # (sic) pcpo.py:78: named H_inv_g, computed as F x
+        xHx = float(s.dot(x, H_inv_g))
+        assert xHx >= 0, 'xHx is negative'
+        f = np.float32
+        alpha = float(np.sqrt(f(2 * a.target_kl) / (f(xHx) + f(1e-8))))
+        loss_c, grad_c = s.actor_loss_grad(data, 'adv_c', 'adv_c', self._lambda_zero)
+        loss_cost_before = -float(loss_c)
+        b = s.lincomb(-1.0, grad_c)
+        ep_costs = float(self._logger.get_stats('Metrics/EpCost')[0] - a.cost_limit)
+        p = s.conjugate_gradients(b)
+        q = xHx
+        r = float(s.dot(g, p))
+        sc = float(s.dot(b, p))
+        c1 = np.sqrt(f(2 * a.target_kl) / (f(q) + f(1e-8)))
+        c2 = max((np.sqrt(f(2 * a.target_kl) / f(q)) * f(r) + f(ep_costs)) / f(sc), f(0.0))
+        step_direction = s.lincomb(float(c1), H_inv_g, -float(c2), p)
+        step, accept_step = self._cpo_search_step(data, theta_old, step_direction, g, loss_reward_before,
+                                                  loss_cost_before, total_steps=200, violation_c=ep_costs,
+                                                  optim_case=0)
+        s.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
+        final = s.evaluate_candidates(data, theta_old, step, [1.0], 'adv_r', self._lambda_zero).numpy()
+        self._last_actor_update = dict(g=g, x=x, b=b, p=p, xHx=xHx, alpha=alpha, q=q, r=r, s=sc,
+                                       step_direction=step_direction, final_step=step, accept_step=accept_step,
+                                       loss_reward_before=loss_reward_before, loss_cost_before=loss_cost_before)
+        self._logger.store({
+            'Loss/Loss_pi': float(final[0, 0] + final[0, 1]), 'Misc/AcceptanceStep': accept_step,
+            'Misc/Alpha': alpha, 'Misc/FinalStepNorm': float(step.norm()), 'Misc/xHx': xHx,
+            'Misc/H_inv_g': float(x.norm()), 'Misc/gradient_norm': float(g.norm()),
+            'Misc/cost_gradient_norm': float(b.norm()), 'Misc/Lambda_star': 1.0, 'Misc/Nu_star': 1.0,
+            'Misc/OptimCase': 1, 'Misc/A': 1.0, 'Misc/B': 1.0, 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc,
+            'Train/PolicyRatio': float(final[0, 3]),
+            'Train/Entropy': float(1.4189385332 + ac.actor.log_std.mean())})

@@ -72,7 +72,8 @@ class NaturalPG(PolicyGradient):
         data = self._buf.get()
         self._update_actor(data)
         out = self._updater.run(data, self._lambda_zero, actor_lr=0.0,
-                                critic_lr=float(self._cfgs.model_cfgs.critic.lr))
+                                critic_lr=float(self._cfgs.model_cfgs.critic.lr),
+                                perms=getattr(self, '_perms_override', None))
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
         lg = self._logger
@@ -239,12 +240,23 @@ class CPO(TRPO):
         fracs = [1.0]
         for _ in range(total_steps - 1):
             fracs.append(fracs[-1] * decay)
-        res = self._solver.evaluate_candidates(data, theta_old, step_direction, fracs, 'adv_r',
-                                               self._lambda_zero).numpy()
+        chunk, cache = 20, {}
+
+        def evaluated(k: int):
+            """Candidate k of the geometric sequence; evaluated lazily, 20 candidates per batch (PCPO
+            asks for up to 200 steps and accepts within the first few)."""
+            c0 = (k // chunk) * chunk
+            if c0 not in cache:
+                cache[c0] = self._solver.evaluate_candidates(data, theta_old, step_direction,
+                                                             fracs[c0:c0 + chunk], 'adv_r',
+                                                             self._lambda_zero).numpy()
+            return cache[c0][k - c0]
+
         step_frac, k, kl, acceptance_step, accepted = 1.0, 0, 0.0, 0, False
         for step in range(total_steps):
             acceptance_step = step + 1
-            loss_reward, loss_cost, kl = float(res[k, 0]), float(res[k, 1]), float(res[k, 2])
+            row = evaluated(k)
+            loss_reward, loss_cost, kl = float(row[0]), float(row[1]), float(row[2])
             loss_reward_improve = loss_reward_before - loss_reward
             loss_cost_diff = loss_cost - loss_cost_before
             if not np.isfinite(kl):

@@ -100,14 +100,52 @@ _CPO.pop('lagrange_cfgs')
 # PPO / TRPO bases (same blocks without the Lagrange section) -- used by the class hierarchy
 _PPO = copy.deepcopy(_PPOLAG)
 _PPO.pop('lagrange_cfgs')
+_PPO['algo_cfgs']['use_cost'] = False          # PPO.yaml:80
 _TRPO = copy.deepcopy(_TRPOLAG)
 _TRPO.pop('lagrange_cfgs')
+_TRPO['algo_cfgs']['use_cost'] = False         # TRPO.yaml
 
-_PG = copy.deepcopy(_PPO)
-_NPG = copy.deepcopy(_TRPO)
+_PG = copy.deepcopy(_PPO)                      # PolicyGradient.yaml: 10 passes, no clip, window 50
+_PG['algo_cfgs']['update_iters'] = 10
+_PG['algo_cfgs'].pop('clip')
+_PG['logger_cfgs'] = dict(_COMMON_LOGGER, window_lens=50)
+_NPG = copy.deepcopy(_TRPO)                    # NaturalPG.yaml keeps an (unused) clip entry
+_NPG['algo_cfgs']['clip'] = 0.2
+
+# ---- sibling algorithms (configs/on-policy/{PDO,RCPO,IPO,OnCRPO,CPPOPID,TRPOPID,PCPO}.yaml): differences
+# from the blocks above only
+_PID_LAGRANGE = {'cost_limit': 25.0, 'lagrangian_multiplier_init': 0.001, 'pid_kp': 0.1, 'pid_ki': 0.01,
+                 'pid_kd': 0.01, 'pid_d_delay': 10, 'pid_delta_p_ema_alpha': 0.95,
+                 'pid_delta_d_ema_alpha': 0.95, 'sum_norm': True, 'diff_norm': False, 'penalty_max': 100.0}
+
+
+def _derive(base: dict, algo: dict | None = None, drop_algo=(), model: dict | None = None,
+            lagrange: dict | None | bool = False) -> dict:
+    d = copy.deepcopy(base)
+    d['algo_cfgs'].update(algo or {})
+    for k in drop_algo:
+        d['algo_cfgs'].pop(k, None)
+    for k, v in (model or {}).items():
+        d['model_cfgs'][k] = v
+    if lagrange is None:
+        d.pop('lagrange_cfgs', None)
+    elif lagrange is not False:
+        d['lagrange_cfgs'] = copy.deepcopy(lagrange)
+    return d
+
+
+_PDO = _derive(_PPOLAG, {'reward_normalize': True, 'cost_normalize': True})
+_RCPO = _derive(_TRPOLAG)                                   # linear_lr_decay False, as TRPOLag.yaml
+_IPO = _derive(_PPOLAG, {'update_iters': 10, 'reward_normalize': True, 'cost_normalize': True, 'kappa': 0.01,
+                         'penalty_max': 1.0, 'cost_limit': 25.0})   # IPO.yaml keeps an (unused) lagrange_cfgs
+_ONCRPO = _derive(_TRPO, {'cost_limit': 25.0, 'distance': 2.0, 'use_cost': True})
+_CPPOPID = _derive(_PPOLAG, lagrange=_PID_LAGRANGE)
+_TRPOPID = _derive(_TRPOLAG, {'clip': 0.2}, lagrange=_PID_LAGRANGE)
+_PCPO = _derive(_CPO)
 
 DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO,
-            'PolicyGradient': _PG, 'NaturalPG': _NPG}
+            'PolicyGradient': _PG, 'NaturalPG': _NPG, 'PDO': _PDO, 'RCPO': _RCPO, 'IPO': _IPO,
+            'OnCRPO': _ONCRPO, 'CPPOPID': _CPPOPID, 'TRPOPID': _TRPOPID, 'PCPO': _PCPO}
 
 
 def get_default_kwargs(algo: str) -> dict:

@@ -377,6 +377,110 @@ def gen_trust_region_updates():
         np.savez(os.path.join(OUT, f'{algo_name.lower()}_actor_update.npz'), **out)
 
 
+# (algorithm, tag, extra algo_cfgs, extra lagrange_cfgs): the sibling on-policy algorithms that only
+# override the surrogate / multiplier logic
+SIBLINGS = [
+    ('PolicyGradient', 'policygradient', {}, None),
+    ('PPO', 'ppo', {}, None),
+    ('NaturalPG', 'naturalpg', {}, None),
+    ('TRPO', 'trpo', {}, None),
+    ('PDO', 'pdo', {}, {'cost_limit': 1.0}),
+    ('RCPO', 'rcpo', {}, {'cost_limit': 1.0}),
+    ('IPO', 'ipo', {'cost_limit': 8.0, 'kappa': 0.5}, None),
+    ('OnCRPO', 'oncrpo_reward', {'cost_limit': 1000.0}, None),
+    ('OnCRPO', 'oncrpo_cost', {'cost_limit': 0.0, 'distance': 0.1}, None),
+    ('CPPOPID', 'cppopid', {}, {'cost_limit': 1.0}),
+    ('TRPOPID', 'trpopid', {}, {'cost_limit': 1.0}),
+    ('PCPO', 'pcpo', {'cost_limit': 1.0}, None),
+    ('FOCOPS', 'focops', {'focops_eta': 0.02}, {'cost_limit': 1.0}),
+    ('CUP', 'cup', {}, {'cost_limit': 1.0}),
+    ('P3O', 'p3o', {'cost_limit': 1.0, 'kappa': 2.0}, None),
+]
+
+
+def gen_sibling_updates(only=None):
+    """One reference `_update()` per sibling algorithm on a reference-collected buffer: inputs (initial
+    parameters, `buf.get()` output, EpCost window, recorded permutations) and outputs (parameters,
+    multiplier, logged statistics) -> tests/golden/sibling_<tag>.npz."""
+    N, T, horizon = 4, 40, 16
+    for algo_name, tag, extra, lag in SIBLINGS:
+        if only and tag not in only:
+            continue
+        import omnisafe
+        from omnisafe.utils.config import get_default_kwargs_yaml
+
+        base = get_default_kwargs_yaml(algo_name, 'SynthPointGoal1-v0', 'on-policy').todict()
+        trust_region = 'cg_iters' in base['algo_cfgs']
+        ea = dict({'update_iters': 2, 'batch_size': 128 if trust_region else 64, 'kl_early_stop': False},
+                  **extra)
+        ref_harness.register_synth_env()
+        ref_harness.DEFAULT_HORIZON = horizon
+        d = tempfile.mkdtemp()
+        cfg = {'seed': 0,
+               'train_cfgs': {'total_steps': N * T * 4, 'vector_env_nums': N, 'torch_threads': 8, 'device': 'cpu'},
+               'algo_cfgs': dict({'steps_per_epoch': N * T}, **ea),
+               'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
+        if lag:
+            cfg['lagrange_cfgs'] = lag
+        algo = omnisafe.Agent(algo_name, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+        ac = algo._actor_critic
+        out = {'N': N, 'T': T, 'algo': algo_name}
+        torch.manual_seed(31)
+        algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+        out['ep_cost_window'] = np.asarray(list(algo._logger._data['Metrics/EpCost']), np.float32)
+        out['Jc'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])
+        for net in ('actor', 'reward_critic', 'cost_critic'):
+            for k, v in _state(getattr(ac, net)).items():
+                out[f'init/{net}/{k}'] = v
+        captured = {}
+        orig_get = algo._buf.get
+
+        def spy_get():
+            r = orig_get()
+            if not captured:  # CUP calls get() twice (the buffer is empty the second time around)
+                captured.update({k: v.clone() for k, v in r.items()})
+            return {k: v.clone() for k, v in captured.items()}
+
+        algo._buf.get = spy_get
+        if hasattr(algo, '_lagrange'):
+            lm = algo._lagrange.lagrangian_multiplier
+            out['lambda_before'] = np.float32(float(lm))
+        with _Recorder() as rec:
+            torch.manual_seed(33)
+            algo._update()
+        for k, v in captured.items():
+            out[f'data/{k}'] = _np(v)
+        if hasattr(algo, '_lagrange'):
+            out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+        # RandomSampler draws two permutations per pass (see gen_rollout_and_ppolag_update)
+        out['perms'] = np.stack([_np(p) for p in rec.perms[::2]]) if rec.perms else np.zeros((0, N * T), np.int64)
+        for net in ('actor', 'reward_critic', 'cost_critic'):
+            for k, v in _state(getattr(ac, net)).items():
+                out[f'post/{net}/{k}'] = v
+        for key, val in algo._logger._data.items():
+            if key.startswith(('Loss/', 'Train/', 'Misc/', 'Metrics/LagrangeMultiplier', 'Value/Adv')):
+                vals = list(val) if not isinstance(val, (int, float)) else [val]
+                if len(vals) and all(isinstance(x, (int, float, np.floating)) for x in vals):
+                    out['log/' + key] = np.asarray(vals, np.float32)
+        np.savez(os.path.join(OUT, f'sibling_{tag}.npz'), **out)
+        print('sibling', tag, {k: out[k] for k in ('Jc', 'lambda_before', 'lambda_after') if k in out},
+              'perms', out['perms'].shape)
+
+
+def gen_config_defaults():
+    """Snapshot of the `defaults` blocks of the reference's on-policy YAML files."""
+    import json
+
+    import yaml
+
+    cfg_dir = os.path.join(ref_harness.REFERENCE_ROOT, 'omnisafe', 'configs', 'on-policy')
+    out = {}
+    for name in sorted(os.listdir(cfg_dir)):
+        if name.endswith('.yaml'):
+            out[name[:-5]] = yaml.safe_load(open(os.path.join(cfg_dir, name)))['defaults']
+    json.dump(out, open(os.path.join(OUT, 'config_defaults.json'), 'w'), indent=1, sort_keys=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_harness.import_reference()
@@ -387,6 +491,8 @@ def main():
     gen_actor_critic_step()
     gen_rollout_and_ppolag_update()
     gen_trust_region_updates()
+    gen_sibling_updates()
+    gen_config_defaults()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

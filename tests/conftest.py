@@ -36,3 +36,8 @@ def golden():
         return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
     return load
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return GOLDEN

@@ -184,3 +184,31 @@ def test_cpo_case_algebra_matches_oracle(c, q, r, s):
         np.testing.assert_allclose((float(cx) * x + float(cp) * p).numpy(), d_o.numpy(), rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(float(lam), float(lam_o), rtol=2e-5)
         np.testing.assert_allclose(float(nu), float(nu_o), rtol=2e-5, atol=1e-7)
+
+
+def test_default_configs_match_reference_yaml(golden_dir):
+    """omnisafe_amd.config.DEFAULTS vs the snapshot of the reference's YAML `defaults` blocks
+    (tests/golden/config_defaults.json, written by oracle/make_golden.py).  Deliberate deviations:
+    device (cuda:0), use_tensorboard (off: tensorboard is optional here) and the `verbose` extension."""
+    import json
+    import os
+
+    from omnisafe_amd import config
+
+    ref_all = json.load(open(os.path.join(golden_dir, 'config_defaults.json')))
+
+    def cmp(a, r, m, path=''):
+        for k in r:
+            if k == 'env_cfgs':
+                continue
+            assert k in m, f'{a}: missing {path}{k}'
+            if isinstance(r[k], dict):
+                cmp(a, r[k], m[k], path + k + '.')
+            elif k not in ('device', 'use_tensorboard'):
+                assert r[k] == m[k], f'{a}: {path}{k}: reference {r[k]!r}, ours {m[k]!r}'
+        for k in m:
+            assert k in r or k in ('env_cfgs', 'verbose'), f'{a}: extra {path}{k}'
+
+    assert len(config.DEFAULTS) >= 14
+    for algo in config.DEFAULTS:
+        cmp(algo, ref_all[algo], config.get_default_kwargs(algo))

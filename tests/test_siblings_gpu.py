@@ -1,0 +1,103 @@
+"""GPU parity of the sibling on-policy algorithms against one `_update()` of the
+unmodified reference per algorithm (tests/golden/sibling_<tag>.npz, oracle/make_golden.py::
+gen_sibling_updates): same initial parameters, same `buf.get()` output, same EpCost window, same
+minibatch permutations -> parameters of all three networks, multiplier / penalty and logged statistics.
+
+Tolerances: first-order family (Adam steps) atol 5e-6 on parameters as for PPOLag; trust-region family
+atol 3e-4 on the actor (theta_old + a step of norm ~0.3 whose direction comes out of 15 float32 CG
+iterations), identical accepted line-search index."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+FIRST_ORDER = [('PolicyGradient', 'policygradient'), ('PPO', 'ppo'), ('PDO', 'pdo'), ('IPO', 'ipo'),
+               ('CPPOPID', 'cppopid')]
+TRUST_REGION = [('NaturalPG', 'naturalpg'), ('TRPO', 'trpo'), ('RCPO', 'rcpo'), ('OnCRPO', 'oncrpo_reward'),
+                ('OnCRPO', 'oncrpo_cost'), ('TRPOPID', 'trpopid'), ('PCPO', 'pcpo')]
+# what the golden generator changed relative to the YAML defaults (oracle/make_golden.py::SIBLINGS)
+EXTRA = {'pdo': ({}, {'cost_limit': 1.0}), 'rcpo': ({}, {'cost_limit': 1.0}),
+         'ipo': ({'cost_limit': 8.0, 'kappa': 0.5}, None), 'oncrpo_reward': ({'cost_limit': 1000.0}, None),
+         'oncrpo_cost': ({'cost_limit': 0.0, 'distance': 0.1}, None), 'cppopid': ({}, {'cost_limit': 1.0}),
+         'trpopid': ({}, {'cost_limit': 1.0}), 'pcpo': ({'cost_limit': 1.0}, None),
+         'focops': ({'focops_eta': 0.02}, {'cost_limit': 1.0}), 'cup': ({}, {'cost_limit': 1.0}),
+         'p3o': ({'cost_limit': 1.0, 'kappa': 2.0}, None)}
+
+
+def _run_update(name, tag, g, tmp_path, trust_region):
+    import omnisafe_amd
+
+    N, T = int(g['N']), int(g['T'])
+    extra_algo, lag = EXTRA.get(tag, ({}, None))
+    cfg = {'seed': 0, 'train_cfgs': {'device': DEV, 'total_steps': 4 * N * T, 'vector_env_nums': N},
+           'algo_cfgs': dict({'steps_per_epoch': N * T, 'update_iters': 2, 'kl_early_stop': False,
+                              'batch_size': 128 if trust_region else 64}, **extra_algo),
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}}
+    if lag:
+        cfg['lagrange_cfgs'] = lag
+    algo = omnisafe_amd.Agent(name, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+    ac = algo._actor_critic
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        sd = {k[len('init/') + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
+              if k.startswith(f'init/{net}/')}
+        getattr(ac, net).load_state_dict(sd)
+    data = {k[5:]: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in g.items()
+            if k.startswith('data/')}
+    algo._buf.get = lambda: dict(data)
+    algo._logger.extend('Metrics/EpCost', [float(v) for v in g['ep_cost_window']])
+    algo._perms_override = [torch.from_numpy(p.copy()) for p in g['perms']]
+    algo._update()
+    return algo, ac
+
+
+def _check_params(ac, g, nets, atol):
+    for net in nets:
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{net}/{k}'], rtol=0, atol=atol,
+                                       err_msg=f'{net}/{k}')
+
+
+def _log(algo, key):
+    return np.asarray(list(algo._logger._data[key]), np.float64)
+
+
+@pytest.mark.parametrize('name,tag', FIRST_ORDER)
+def test_first_order_sibling_update_vs_reference(golden, tmp_path, name, tag):
+    g = golden(f'sibling_{tag}.npz')
+    algo, ac = _run_update(name, tag, g, tmp_path, trust_region=False)
+    _check_params(ac, g, ('actor', 'reward_critic', 'cost_critic'), 5e-6)
+    if 'lambda_after' in g:
+        np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    np.testing.assert_allclose(_log(algo, 'Train/KL')[-1], g['log/Train/KL'][-1], rtol=5e-3, atol=1e-7)
+    np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi').mean(), g['log/Loss/Loss_pi'].mean(), rtol=2e-3,
+                               atol=2e-6)
+    np.testing.assert_allclose(_log(algo, 'Loss/Loss_reward_critic').mean(),
+                               g['log/Loss/Loss_reward_critic'].mean(), rtol=2e-4)
+    if tag == 'ipo':
+        np.testing.assert_allclose(_log(algo, 'Misc/Penalty')[-1], g['log/Misc/Penalty'][-1], rtol=1e-6)
+    if not algo._cfgs.algo_cfgs.use_cost:  # PolicyGradient / PPO leave the cost critic untouched
+        for k, v in ac.cost_critic.state_dict().items():
+            assert np.array_equal(v.cpu().numpy(), g[f'init/cost_critic/{k}'])
+
+
+@pytest.mark.parametrize('name,tag', TRUST_REGION)
+def test_trust_region_sibling_update_vs_reference(golden, tmp_path, name, tag):
+    g = golden(f'sibling_{tag}.npz')
+    algo, ac = _run_update(name, tag, g, tmp_path, trust_region=True)
+    _check_params(ac, g, ('actor',), 3e-4)
+    _check_params(ac, g, ('reward_critic', 'cost_critic'), 5e-6)
+    if 'lambda_after' in g:
+        np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    for key, rtol in (('Misc/Alpha', 1e-2), ('Misc/xHx', 1e-2), ('Misc/gradient_norm', 1e-3),
+                      ('Misc/FinalStepNorm', 2e-2)):
+        np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
+    if 'log/Misc/AcceptanceStep' in g:
+        assert int(_log(algo, 'Misc/AcceptanceStep')[-1]) == int(g['log/Misc/AcceptanceStep'][-1])
+    if tag == 'pcpo':
+        for key, rtol in (('Misc/q', 1e-2), ('Misc/r', 5e-2), ('Misc/s', 1e-2), ('Misc/cost_gradient_norm', 1e-3)):
+            np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, atol=1e-4, err_msg=key)
+    if tag.startswith('oncrpo'):
+        assert algo._cost_update == (1 if tag == 'oncrpo_cost' else 0)
+        assert algo._rew_update == (0 if tag == 'oncrpo_cost' else 1)
