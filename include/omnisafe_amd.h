@@ -167,6 +167,40 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
                       int loss_kind, int mode, int nets_mask, int max_blocks, float* ws,
                       float* step_stats, void* stream);
 
+/* Extended actor surrogates for the sibling first-order algorithms; everything else is
+ * osa_ppo_minibatch.  Per-sample actor loss
+ *     l_i = mbar * ratio_scale * s_i + mask_i * kl_coef * KL(pi_theta(.|s_i) || pi_old(.|s_i)),
+ * s_i the loss_kind surrogate, mask_i = 1[KL_i <= kl_mask_eta], mbar = mean_i(mask_i) (kl_mask_eta < 0:
+ * mask_i = mbar = 1) -- exactly what focops.py:84-88 differentiates (its (B,1) x (B,) broadcast makes the
+ * surrogate term see the minibatch MEAN of the mask) -- plus
+ * cost_kappa * relu(mean_i(ratio_i * adv_c_i) + cost_excess) when cost_kappa > 0 (value in step_stats[10]).
+ * mbar and the penalty are minibatch-level quantities: with a mask or a penalty B <= 64 is required
+ * (one block; OSA_EUNSUPPORTED otherwise).
+ *   FOCOPS (first_order/focops.py:83-92): loss_kind 1, kl_coef 1, kl_mask_eta = focops_eta,
+ *                                         ratio_scale = 1/focops_lam
+ *   CUP second stage (first_order/cup.py:96-103): loss_kind 1 on adv = -lambda*coef*adv_c, kl_coef 1
+ *   P3O (penalty_function/p3o.py:62-68,112-114): loss_kind 0 + cost_kappa = kappa, cost_excess = Jc - limit
+ * old_mean[rows][ld_old_mean] / old_log_std[act_dim]: the behaviour policy's Gaussian per sample (same row
+ * indexing as obs).  ext == NULL: identical to osa_ppo_minibatch. */
+typedef struct osa_surrogate_ext {
+  const float* old_mean;
+  int ld_old_mean;
+  const float* old_log_std;
+  float kl_coef;
+  float kl_mask_eta;
+  float ratio_scale;
+  float cost_kappa;
+  float cost_excess;
+} osa_surrogate_ext;
+int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
+                          float* adam_v, int* adam_step, float* grads, const float* obs, int ld_obs,
+                          const float* act, int ld_act, const float* logp,
+                          const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* idx, int B,
+                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int mode,
+                          int nets_mask, int max_blocks, float* ws, float* step_stats,
+                          const osa_surrogate_ext* ext, void* stream);
+
 /* Persistent form of the same update: ONE launch runs a whole pass of PolicyGradient._update's inner
  * loop (policy_gradient.py:366-382) -- ceil(M/B) dependent minibatch steps over the permutation
  * perm[M] (NULL = identity) -- for all three networks, with the parameters resident in LDS

@@ -37,6 +37,8 @@ SIGNATURES: dict[str, tuple] = {
     'osa_minibatch_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
     'osa_ppo_minibatch': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
                                _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'osa_ppo_minibatch_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
+                                   _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     'osa_debug_set_clock_buffer': (_I, [_P]),
     'osa_debug_set_pass_clock_buffer': (_I, [_P]),
     'osa_ppo_pass_supported': (_I, [_I, _I, _I]),

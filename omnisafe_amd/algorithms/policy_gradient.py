@@ -167,6 +167,7 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         out = self._updater.run(data, self._lagrange_tensor(), actor_lr=self._current_actor_lr(),
                                 critic_lr=float(self._cfgs.model_cfgs.critic.lr),
                                 perms=getattr(self, '_perms_override', None))  # parity tests inject the order
+        self._last_update_data, self._last_update_steps = data, out['steps']
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
         lg = self._logger

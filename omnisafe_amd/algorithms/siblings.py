@@ -11,6 +11,10 @@ same set of libomnisafe_amd kernels as PPOLag / TRPOLag / CPO -- the combined ad
   CPPOPID   pid_lagrange/cppo_pid.py:25-103     PPO + PID-controlled multiplier
   TRPOPID   pid_lagrange/trpo_pid.py:25-98      TRPO + PID-controlled multiplier
   PCPO      second_order/pcpo.py:31-152         CPO's machinery with the projection step
+  FOCOPS    first_order/focops.py:31-230        PolicyGradient + Lagrange, KL-regularised masked surrogate
+  CUP       first_order/cup.py:30-200           PPO step, then a KL-regularised cost-projection stage
+  P3O       penalty_function/p3o.py:27-132      PPO + exact penalty kappa * relu(cost surrogate + Jc - limit)
+(the last three use osa_ppo_minibatch_ext: the per-step kernels with the extended actor loss)
 """
 from __future__ import annotations
 
@@ -18,7 +22,9 @@ import numpy as np
 import torch
 
 from ..lagrange import Lagrange
+from ..models import SurrogateExt
 from ..pid_lagrange import PIDLagrangian
+from ..update import PPOUpdater
 from .policy_gradient import PPO, PolicyGradient
 from .registry import register
 from .trust_region_algos import CPO, TRPO, NaturalPG
@@ -191,3 +197,84 @@ class PCPO(CPO):
             'Misc/OptimCase': 1, 'Misc/A': 1.0, 'Misc/B': 1.0, 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc,
             'Train/PolicyRatio': float(final[0, 3]),
             'Train/Entropy': float(1.4189385332 + ac.actor.log_std.mean())})
+
+
+@register
+class FOCOPS(_LagrangeMixin, PolicyGradient):
+    """focops.py: per-sample loss (KL(pi_theta || pi_old) - ratio * adv / focops_lam) * 1[KL <= eta] with the
+    Lagrangian advantage; critics and KL early stop as in PolicyGradient._update."""
+    _lagrange_min_max = False
+
+    def _make_updater(self) -> PPOUpdater:
+        up = super()._make_updater()
+        a = self._cfgs.algo_cfgs
+        up.ext = SurrogateExt(kl_coef=1.0, kl_mask_eta=float(a.focops_eta), ratio_scale=1.0 / float(a.focops_lam))
+        return up
+
+
+@register
+class P3O(PPO):
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Loss/Loss_pi_cost', delta=True)
+
+    def _make_updater(self) -> PPOUpdater:
+        up = super()._make_updater()
+        up.ext = SurrogateExt(cost_kappa=float(self._cfgs.algo_cfgs.kappa))
+        return up
+
+    def _update(self) -> None:
+        """p3o.py:62-68: the penalty offset Jc - cost_limit is a constant of the epoch."""
+        a = self._cfgs.algo_cfgs
+        self._updater.ext.cost_excess = float(self._logger.get_stats('Metrics/EpCost')[0] - a.cost_limit)
+        super()._update()
+        st = self._updater._stats[:self._last_update_steps, 10].double().cpu()  # noqa: SLF001
+        self._logger.store({'Loss/Loss_pi_cost': float(st.mean())})
+
+
+@register
+class CUP(_LagrangeMixin, PPO):
+    """cup.py: stage 1 = PPO on the reward advantage; stage 2 = actor-only minibatch passes on
+    lambda * coef * ratio * A_c + KL(pi_theta || pi_stage1) with their own KL early stop."""
+    _lagrange_min_max = False
+
+    def _lagrange_tensor(self) -> torch.Tensor:
+        return self._lambda_zero  # CUP does not override _compute_adv_surrogate: stage 1 sees A_r only
+
+    def _init(self) -> None:
+        super()._init()
+        a = self._cfgs.algo_cfgs
+        self._updater2 = PPOUpdater(
+            self._actor_critic, batch_size=a.batch_size, update_iters=a.update_iters, target_kl=a.target_kl,
+            kl_early_stop=a.kl_early_stop, entropy_coef=0.0, use_critic_norm=a.use_critic_norm,
+            critic_norm_coef=a.critic_norm_coef, use_max_grad_norm=True,  # cup.py:160 clips whenever set
+            max_grad_norm=a.max_grad_norm, use_cost=a.use_cost, loss_kind=1, seed=int(self._cfgs.seed) + 1,
+            update_critics=False, ext=SurrogateExt(kl_coef=1.0))
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Loss/Loss_pi_c', delta=True)
+        self._logger.register_key('Train/SecondStepStopIter')
+        self._logger.register_key('Train/SecondStepEntropy')
+        self._logger.register_key('Train/SecondStepPolicyRatio', min_and_max=True)
+
+    def _update(self) -> None:
+        a = self._cfgs.algo_cfgs
+        super()._update()  # lambda step, then the PPO stage (which consumes buf.get())
+        data = self._last_update_data
+        lam = self._lagrange.lagrangian_multiplier
+        coef = (1 - a.gamma * a.lam) / (1 - a.gamma)
+        stage2 = dict(data)
+        # -(ratio * adv') with adv' = -(lambda * coef) * A_c is the reference's lambda * coef * ratio * A_c
+        stage2['adv_r'] = data['adv_c'] * (-(lam * coef))
+        perms = getattr(self, '_perms_override', None)
+        if perms is not None:
+            perms = perms[self._updater.update_iters:]
+        out = self._updater2.run(stage2, self._lambda_zero, perms=perms, actor_lr=self._current_actor_lr(),
+                                 critic_lr=0.0)
+        st = out['stats'].double().cpu()
+        lg = self._logger
+        for v in st[:, 3]:
+            lg.store({'Train/SecondStepPolicyRatio': float(v)})
+        lg.store({'Loss/Loss_pi_c': float(st[:, 2].mean()), 'Train/SecondStepEntropy': float(st[:, 4].mean()),
+                  'Train/SecondStepStopIter': out['stop_iter']})

@@ -142,10 +142,15 @@ _ONCRPO = _derive(_TRPO, {'cost_limit': 25.0, 'distance': 2.0, 'use_cost': True}
 _CPPOPID = _derive(_PPOLAG, lagrange=_PID_LAGRANGE)
 _TRPOPID = _derive(_TRPOLAG, {'clip': 0.2}, lagrange=_PID_LAGRANGE)
 _PCPO = _derive(_CPO)
+_LAG_BOUNDED = dict(_PPOLAG['lagrange_cfgs'], lagrangian_upper_bound=2.0)
+_FOCOPS = _derive(_PPOLAG, {'focops_eta': 0.02, 'focops_lam': 1.5}, lagrange=_LAG_BOUNDED)
+_CUP = _derive(_PPOLAG, {'target_kl': 0.01}, lagrange=_LAG_BOUNDED)
+_P3O = _derive(_PPOLAG, {'update_iters': 10, 'kappa': 20.0, 'cost_limit': 25.0}, lagrange=None)
 
 DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO,
             'PolicyGradient': _PG, 'NaturalPG': _NPG, 'PDO': _PDO, 'RCPO': _RCPO, 'IPO': _IPO,
-            'OnCRPO': _ONCRPO, 'CPPOPID': _CPPOPID, 'TRPOPID': _TRPOPID, 'PCPO': _PCPO}
+            'OnCRPO': _ONCRPO, 'CPPOPID': _CPPOPID, 'TRPOPID': _TRPOPID, 'PCPO': _PCPO,
+            'FOCOPS': _FOCOPS, 'CUP': _CUP, 'P3O': _P3O}
 
 
 def get_default_kwargs(algo: str) -> dict:

@@ -43,6 +43,16 @@ struct OsaMbArgs {
   long long* dbg;  // optional [3][16] phase timestamps (s_memtime) of the last launch, or nullptr
   const float* vec;  // loss_kind 2 (Fisher-vector product): tangent vector, padded actor layout [P]
   float fvp_scale;   // 1 / (M * act_dim): natural_pg.py:95 takes .mean() over all M x D_a elements
+  // extended surrogates (osa_ppo_minibatch_ext): per-sample KL(pi_theta || pi_old) term with optional
+  // trust mask (FOCOPS focops.py:83-92, CUP cup.py:96-103) and P3O's exact-penalty term (p3o.py:62-68)
+  const float* old_mean;     // [rows][ld_old_mean] or nullptr
+  int ld_old_mean;
+  const float* old_log_std;  // [act_dim]
+  float ext_kl_coef;         // weight of the KL term (0 = off)
+  float ext_mask_eta;        // >= 0: per-sample loss * 1[KL <= eta]; < 0: off
+  float ext_ratio_scale;     // multiplies the ratio * adv surrogate term
+  float ext_cost_kappa;      // > 0: + kappa * relu(mean(ratio * adv_c) + ext_cost_excess); single chunk only
+  float ext_cost_excess;
 };
 
 #define OSA_TICK(k)                                                                  \
@@ -369,8 +379,58 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
       }
       lp = osa_sum_over_groups(lp);
+      // ---- optional per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal)
+      const bool ext_kl = a.old_mean != nullptr && (a.ext_kl_coef != 0.f || a.ext_mask_eta >= 0.f);
+      float kl = 0.f;
+      f32x4 dkl_mu[OT], dkl_ls[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        dkl_mu[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dkl_ls[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if (ext_kl) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * o + 4 * g + r;
+            if (d < nd.act_dim && valid) {
+              const float sd = expf(p[nd.oLS + d]), sd0 = expf(a.old_log_std[d]);
+              const float q = sd / sd0, var_ratio = q * q;
+              const float dm = out[o][r] - a.old_mean[row * a.ld_old_mean + d];
+              const float u = dm / sd0, t1 = u * u;
+              kl += 0.5f * (var_ratio + t1 - 1.f - logf(var_ratio));
+              dkl_mu[o][r] = dm / (sd0 * sd0);
+              dkl_ls[o][r] = var_ratio - 1.f;
+            }
+          }
+        }
+        kl = osa_sum_over_groups(kl);
+      }
+      const float ratio = valid ? expf(lp - a.logp[row]) : 0.f;
+      // ---- P3O: kappa * relu(mean_i(ratio_i * adv_c_i) + (Jc - limit)); the mean needs the whole minibatch
+      float cost_w = 0.f;
+      if (a.ext_cost_kappa > 0.f) {  // block-uniform; the host guarantees a single chunk
+        const float part = (valid && g == 0) ? ratio * a.adv_c[row] : 0.f;
+        __syncthreads();
+        const float surr_c = osa_block_sum_f(part, red) * invB;
+        const float pen = surr_c + a.ext_cost_excess;
+        if (pen > 0.f) cost_w = a.ext_cost_kappa;
+        if (threadIdx.x == 0) a.stats[10] = a.ext_cost_kappa * fmaxf(pen, 0.f);
+        __syncthreads();
+      }
+      // ---- FOCOPS trust mask.  focops.py:84-88 multiplies a (B,1) KL column, a (B,) ratio*adv row and
+      // the (B,1) mask, i.e. the loss it differentiates is the mean of a (B,B) broadcast:
+      //     mean_i(mask_i KL_i) - mean_i(mask_i) * mean_j(ratio_j adv_j) / focops_lam
+      // -> the KL term is masked per sample, the surrogate term is scaled by the mask's minibatch mean.
+      float mask = 1.f, mask_mean = 1.f;
+      if (a.ext_mask_eta >= 0.f) {  // block-uniform; single chunk (host-checked)
+        mask = (valid && kl <= a.ext_mask_eta) ? 1.f : 0.f;
+        __syncthreads();
+        mask_mean = osa_block_sum_f((valid && g == 0) ? mask : 0.f, red) * invB;
+        __syncthreads();
+      }
       if (valid) {
-        const float ratio = expf(lp - a.logp[row]);
         // PPOLag surrogate advantage (ppo_lag.py:101-102)
         const float adv = (a.adv_r[row] - lam * a.adv_c[row]) / (1.f + lam);
         float dratio, li;
@@ -385,7 +445,11 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
           li = -(ratio * adv);
           dratio = -adv;
         }
+        const float rs = a.ext_ratio_scale * mask_mean;
+        li = li * rs + a.ext_kl_coef * kl * mask;
+        dratio = dratio * rs + cost_w * a.adv_c[row];
         const float dlogp = dratio * ratio * invB;
+        const float dklw = a.ext_kl_coef * mask * invB;
         if (g == 0) {
           loss_acc += li;
           ratio_acc += ratio;
@@ -396,8 +460,8 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
           for (int r = 0; r < 4; ++r) {
             const float z = zv[o][r], iv = ivar[o][r];
             // d logp / d mu = z / var ; d logp / d log_std = z^2 / var - 1
-            dO[o][r] = dlogp * z * iv;
-            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) : 0.f;
+            dO[o][r] = dlogp * z * iv + dklw * dkl_mu[o][r];
+            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) + dklw * dkl_ls[o][r] : 0.f;
           }
         }
       }
@@ -939,12 +1003,37 @@ int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float
                       const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
                       int loss_kind, int mode, int nets_mask, int max_blocks, float* ws,
                       float* step_stats, void* stream) {
+  return osa_ppo_minibatch_ext(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, grads, obs,
+                               ld_obs, act, ld_act, logp, target_value_r, target_value_c, adv_r, adv_c,
+                               idx, B, lagrange, hp, loss_kind, mode, nets_mask, max_blocks, ws,
+                               step_stats, nullptr, stream);
+}
+
+int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
+                          float* adam_v, int* adam_step, float* grads, const float* obs, int ld_obs,
+                          const float* act, int ld_act, const float* logp,
+                          const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* idx, int B,
+                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int mode,
+                          int nets_mask, int max_blocks, float* ws, float* step_stats,
+                          const osa_surrogate_ext* ext, void* stream) {
   const int rc = osa_check_dims(obs_dim, act_dim, hidden);
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && grads && obs && act && logp && hp);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && step_stats && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && mode >= 0 && mode <= 2);
-  OsaMbArgs a;
+  OsaMbArgs a = {};
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
+  if (ext) {
+    const bool need_old = ext->kl_coef != 0.f || ext->kl_mask_eta >= 0.f;
+    OSA_REQUIRE(!need_old || (ext->old_mean && ext->old_log_std && ext->ld_old_mean >= act_dim));
+    // P3O's penalty and FOCOPS' mask mean are minibatch-level quantities: one 64-row block only
+    if ((ext->cost_kappa > 0.f || ext->kl_mask_eta >= 0.f) && B > 64) return OSA_EUNSUPPORTED;
+    a.old_mean = need_old ? ext->old_mean : nullptr; a.ld_old_mean = ext->ld_old_mean;
+    a.old_log_std = ext->old_log_std; a.ext_kl_coef = ext->kl_coef; a.ext_mask_eta = ext->kl_mask_eta;
+    a.ext_ratio_scale = ext->ratio_scale; a.ext_cost_kappa = ext->cost_kappa;
+    a.ext_cost_excess = ext->cost_excess;
+  }
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step; a.grads = grads;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -1020,6 +1109,7 @@ int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float
   a.params = params; a.grads = grads; a.obs = obs; a.ld_obs = ld_obs;
   a.B = (int)M; a.idx = nullptr; a.mode = 2; a.stats = step_stats; a.loss_kind = 2; a.nets_mask = 1;
   a.vec = vec; a.fvp_scale = (float)(1.0 / ((double)M * act_dim));
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.hp.use_cost = 1;
   const int nchunk = (int)((M + 63) / 64);
   int nblk = nchunk;

@@ -34,6 +34,18 @@ class HParams(C.Structure):
                 ('use_critic_norm', C.c_int), ('use_max_grad_norm', C.c_int), ('use_cost', C.c_int)]
 
 
+class SurrogateExt(C.Structure):
+    """ctypes mirror of ``osa_surrogate_ext`` (include/omnisafe_amd.h): FOCOPS / CUP / P3O actor losses."""
+
+    _fields_ = [('old_mean', C.c_void_p), ('ld_old_mean', C.c_int), ('old_log_std', C.c_void_p),
+                ('kl_coef', C.c_float), ('kl_mask_eta', C.c_float), ('ratio_scale', C.c_float),
+                ('cost_kappa', C.c_float), ('cost_excess', C.c_float)]
+
+    def __init__(self, kl_coef: float = 0.0, kl_mask_eta: float = -1.0, ratio_scale: float = 1.0,
+                 cost_kappa: float = 0.0, cost_excess: float = 0.0) -> None:
+        super().__init__(None, 0, None, kl_coef, kl_mask_eta, ratio_scale, cost_kappa, cost_excess)
+
+
 class Layout:
     """Padded parameter block of one network + index maps to the reference tensor order."""
 

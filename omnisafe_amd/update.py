@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from . import distributed as dist
-from .models import ConstraintActorCritic, HParams
+from .models import ConstraintActorCritic, HParams, SurrogateExt
 
 NSTAT = 16
 
@@ -32,8 +32,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                  use_critic_norm: bool = True, critic_norm_coef: float = 0.001,
                  use_max_grad_norm: bool = True, max_grad_norm: float = 40.0, use_cost: bool = True,
                  loss_kind: int = 0, max_blocks: int = 256, update_actor: bool = True,
-                 persistent: bool = True, dp_mode: str = 'replicated', seed: int = 0) -> None:
+                 persistent: bool = True, dp_mode: str = 'replicated', seed: int = 0,
+                 update_critics: bool = True, ext: SurrogateExt | None = None) -> None:
         self.ac = ac
+        # extended actor surrogate (FOCOPS / CUP / P3O): runs on the per-step kernels
+        self.ext = ext
+        self.update_critics = update_critics
         self.lib = _lib.load(require_gpu=True)
         self.batch_size, self.update_iters = int(batch_size), int(update_iters)
         self.target_kl, self.kl_early_stop = float(target_kl), bool(kl_early_stop)
@@ -67,7 +71,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
-        m = 0b110 if self.hp.use_cost else 0b010
+        m = (0b110 if self.hp.use_cost else 0b010) if self.update_critics else 0
         return m | (1 if self.update_actor else 0)
 
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
@@ -79,14 +83,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if self.profile_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(lib.osa_ppo_minibatch(
+        ext = None
+        if self.ext is not None:
+            self.ext.old_mean = self._old_mean.data_ptr()
+            self.ext.ld_old_mean = self._old_mean.stride(0)
+            self.ext.old_log_std = self._old_log_std.data_ptr()
+            ext = C.byref(self.ext)
+        _lib.check(lib.osa_ppo_minibatch_ext(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']),
             data['obs'].stride(0), _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
             _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
             _lib.ptr(data['adv_c']), _lib.ptr(idx), B, _lib.ptr(lagrange), C.byref(self.hp),
             self.loss_kind, mode, self._nets_mask(), self.max_blocks, _lib.ptr(self._ws),
-            _lib.ptr(stats_row), st), 'osa_ppo_minibatch')
+            _lib.ptr(stats_row), ext, st), 'osa_ppo_minibatch_ext')
         if ev is not None:
             ev[1].record()
             self.profile_events.append(('osa_mb_grad_kernel', B, ev))
@@ -303,12 +313,14 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
         self._pass_fn = None
-        if (self.persistent and dist.world_size() == 1 and B <= self.persistent_max_batch and bool(
+        if (self.persistent and self.ext is None and self.update_critics and dist.world_size() == 1
+                and B <= self.persistent_max_batch and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
         use_pass = self._pass_fn is not None
         W = dist.world_size()
-        use_repl = (W > 1 and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
+        use_repl = (W > 1 and self.ext is None and self.update_critics
+                    and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         if use_repl:
             gathered = self.gather_for_replicated(data, W)

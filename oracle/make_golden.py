@@ -393,6 +393,7 @@ SIBLINGS = [
     ('TRPOPID', 'trpopid', {}, {'cost_limit': 1.0}),
     ('PCPO', 'pcpo', {'cost_limit': 1.0}, None),
     ('FOCOPS', 'focops', {'focops_eta': 0.02}, {'cost_limit': 1.0}),
+    ('FOCOPS', 'focops_masked', {'focops_eta': 1e-4}, {'cost_limit': 1.0}),  # trust mask partially active
     ('CUP', 'cup', {}, {'cost_limit': 1.0}),
     ('P3O', 'p3o', {'cost_limit': 1.0, 'kappa': 2.0}, None),
 ]

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 FIRST_ORDER = [('PolicyGradient', 'policygradient'), ('PPO', 'ppo'), ('PDO', 'pdo'), ('IPO', 'ipo'),
-               ('CPPOPID', 'cppopid')]
+               ('CPPOPID', 'cppopid'), ('FOCOPS', 'focops'), ('FOCOPS', 'focops_masked'), ('CUP', 'cup'),
+               ('P3O', 'p3o')]
 TRUST_REGION = [('NaturalPG', 'naturalpg'), ('TRPO', 'trpo'), ('RCPO', 'rcpo'), ('OnCRPO', 'oncrpo_reward'),
                 ('OnCRPO', 'oncrpo_cost'), ('TRPOPID', 'trpopid'), ('PCPO', 'pcpo')]
 # what the golden generator changed relative to the YAML defaults (oracle/make_golden.py::SIBLINGS)
@@ -22,7 +23,8 @@ EXTRA = {'pdo': ({}, {'cost_limit': 1.0}), 'rcpo': ({}, {'cost_limit': 1.0}),
          'ipo': ({'cost_limit': 8.0, 'kappa': 0.5}, None), 'oncrpo_reward': ({'cost_limit': 1000.0}, None),
          'oncrpo_cost': ({'cost_limit': 0.0, 'distance': 0.1}, None), 'cppopid': ({}, {'cost_limit': 1.0}),
          'trpopid': ({}, {'cost_limit': 1.0}), 'pcpo': ({'cost_limit': 1.0}, None),
-         'focops': ({'focops_eta': 0.02}, {'cost_limit': 1.0}), 'cup': ({}, {'cost_limit': 1.0}),
+         'focops': ({'focops_eta': 0.02}, {'cost_limit': 1.0}),
+         'focops_masked': ({'focops_eta': 1e-4}, {'cost_limit': 1.0}), 'cup': ({}, {'cost_limit': 1.0}),
          'p3o': ({'cost_limit': 1.0, 'kappa': 2.0}, None)}
 
 
@@ -75,6 +77,13 @@ def test_first_order_sibling_update_vs_reference(golden, tmp_path, name, tag):
                                atol=2e-6)
     np.testing.assert_allclose(_log(algo, 'Loss/Loss_reward_critic').mean(),
                                g['log/Loss/Loss_reward_critic'].mean(), rtol=2e-4)
+    if tag == 'p3o':
+        np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi_cost')[-1], g['log/Loss/Loss_pi_cost'].mean(),
+                                   rtol=1e-3)
+    if tag == 'cup':
+        np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi_c')[-1], g['log/Loss/Loss_pi_c'].mean(), rtol=2e-3,
+                                   atol=2e-6)
+        assert int(_log(algo, 'Train/SecondStepStopIter')[-1]) == int(g['log/Train/SecondStepStopIter'][-1])
     if tag == 'ipo':
         np.testing.assert_allclose(_log(algo, 'Misc/Penalty')[-1], g['log/Misc/Penalty'][-1], rtol=1e-6)
     if not algo._cfgs.algo_cfgs.use_cost:  # PolicyGradient / PPO leave the cost critic untouched
@@ -101,3 +110,20 @@ def test_trust_region_sibling_update_vs_reference(golden, tmp_path, name, tag):
     if tag.startswith('oncrpo'):
         assert algo._cost_update == (1 if tag == 'oncrpo_cost' else 0)
         assert algo._rew_update == (0 if tag == 'oncrpo_cost' else 1)
+
+
+@pytest.mark.parametrize('algo_name', ['PDO', 'RCPO', 'IPO', 'OnCRPO', 'CPPOPID', 'TRPOPID', 'PCPO', 'FOCOPS',
+                                       'CUP', 'P3O'])
+def test_sibling_agents_end_to_end(tmp_path, algo_name):
+    """Two epochs of `Agent(...).learn()` through the registry with the YAML defaults of each sibling
+    (reward / cost normalisers, PID controller, two-stage CUP update, 200-step PCPO line search, ...)."""
+    import omnisafe_amd
+
+    cfg = {'seed': 2, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 128 * 32, 'vector_env_nums': 128},
+           'algo_cfgs': {'steps_per_epoch': 128 * 32, 'update_iters': 2},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo_name, 'SynthCarGoal1-v0', custom_cfgs=cfg)
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
+    p = agent.agent._actor_critic.params
+    assert bool(torch.isfinite(p).all())
