@@ -318,6 +318,18 @@ int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float
                           float* boot_r, float* boot_c, uint8_t* ep_done, float* ep_ret_out,
                           float* ep_cost_out, float* ep_len_out, void* stream);
 
+/* SauteAdapter.step for all N envs (omnisafe/adapter/saute_adapter.py:124-196; SimmerAdapter shares it with
+ * reset_value = relative budget): safety_obs <- (safety_obs - cost/budget)/saute_gamma; reward_out =
+ * reward if safety_obs > 0 else unsafe_reward; finished envs (terminated | truncated) restart from
+ * reset_value; the new safety_obs becomes column `col` of the (already normalised) next-observation rows
+ * and, when given, of the final-observation rows; ep_budget accumulates it and a finished episode writes
+ * its sum to ep_budget_out (Metrics/EpBudget) and restarts from 0. */
+int osa_saute_step(int N, const float* cost, const float* reward, const uint8_t* terminated,
+                   const uint8_t* truncated, float* safety_obs, const float* budget, float saute_gamma,
+                   float unsafe_reward, const float* reset_value, float* reward_out, float* next_rows,
+                   int ld_next, float* final_rows, int ld_final, int col, float* ep_budget,
+                   float* ep_budget_out, void* stream);
+
 /* Synthetic fixed-shape vector CMDP for throughput runs (stand-in for Safety-Gymnasium, whose physics
  * is third-party CPU code outside the reference repo; same role as tests/simple_env.py:30-90 of the
  * reference): obs ~ N(0,1)^obs_dim, reward ~ N(0,1), cost ~ Bernoulli(cost_p), never terminates,

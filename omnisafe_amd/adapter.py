@@ -45,11 +45,12 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                                       'the env must auto-reset (gymnasium vector convention)')
         a = cfgs.algo_cfgs
         self._num_envs = int(self._env.num_envs)
-        self._obs_dim = int(self._env.observation_space.shape[0])
+        self._raw_obs_dim = int(self._env.observation_space.shape[0])
+        self._obs_dim = self._raw_obs_dim + self._extra_obs_dims()  # what the agent / buffer see
         self._act_dim = int(self._env.action_space.shape[0])
         N, dev = self._num_envs, self._device
         f32 = dict(dtype=torch.float32, device=dev)
-        self._obs_normalizer = (Normalizer((self._obs_dim,), clip=5, device=dev)
+        self._obs_normalizer = (Normalizer((self._raw_obs_dim,), clip=5, device=dev)
                                 if a.obs_normalize else None)
         # RewardNormalize / CostNormalize wrappers (envs/wrapper.py:280-423): scalar running statistics
         # over the batch of N rewards (costs) of each step, clip 5; episode metrics keep the ORIGINAL
@@ -72,9 +73,29 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         self._seed = seed
 
     # ------------------------------------------------------------------ reference surface
+    def _extra_obs_dims(self) -> int:
+        """Columns appended to the (normalised) env observation by the adapter (Saute/Simmer: 1)."""
+        return 0
+
+    def _after_reset(self, obs_rows: torch.Tensor) -> None:
+        """Hook: the first observation rows of the epoch have been written (columns :raw_obs_dim)."""
+
+    def _after_env_step(self, t: int, reward: torch.Tensor, cost: torch.Tensor, term: torch.Tensor,
+                        trunc: torch.Tensor, next_rows: torch.Tensor, final_rows: torch.Tensor | None,
+                        reward_row: torch.Tensor) -> None:
+        """Hook between the wrapper chain and the bootstrap-value evaluation: may rewrite the reward row of
+        the buffer and fill the adapter's extra observation columns of the next / final rows."""
+
+    def _flush_extra(self, logger, idx: torch.Tensor) -> None:
+        """Hook: extra per-episode metrics for the finished episodes `idx` (flat (t, n) indices)."""
+
     @property
     def observation_space(self):
-        return self._env.observation_space
+        if self._obs_dim == self._raw_obs_dim:
+            return self._env.observation_space
+        from .spaces import Box
+
+        return Box(-float('inf'), float('inf'), (self._obs_dim,))
 
     @property
     def action_space(self):
@@ -110,7 +131,9 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
 
     def _normalize(self, raw: torch.Tensor, mask: torch.Tensor | None = None,
                    out: torch.Tensor | None = None) -> torch.Tensor:
-        raw = raw.reshape(self._num_envs, self._obs_dim)
+        raw = raw.reshape(self._num_envs, self._raw_obs_dim)
+        if out is not None and out.shape[-1] != self._raw_obs_dim:
+            out = out[:, :self._raw_obs_dim]  # the adapter's extra columns are filled by its hooks
         if self._obs_normalizer is None:
             if out is None:
                 return raw
@@ -143,6 +166,7 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         b = buffer.data
         obs_raw, _ = self._env.reset()  # the reference resets every epoch (:80)
         self._normalize(obs_raw, out=b['obs'][0])
+        self._after_reset(b['obs'][0])
         for t in range(T):
             st = _lib.stream_ptr()
             obs = b['obs'][t]
@@ -165,15 +189,17 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             cost = cost.to(torch.float32).contiguous()
             term = terminated.reshape(N).to(torch.uint8)
             trunc = truncated.reshape(N).to(torch.uint8)
-            vfinal = (None, None)
-            if 'final_observation' in info:
+            have_final = 'final_observation' in info
+            if have_final:
                 fmask = info.get('_final_observation', None)
                 fmask = (term | trunc) if fmask is None else fmask.reshape(N).to(torch.uint8)
                 self._normalize(info['final_observation'], mask=fmask, out=self._final_norm)
-                vfinal = agent.values(self._final_norm)
             epoch_end = t >= T - 1
             nxt = self._last_obs if epoch_end else b['obs'][t + 1]
             self._normalize(next_raw, out=nxt)
+            self._after_env_step(t, reward, cost, term, trunc, nxt, self._final_norm if have_final else None,
+                                 b['reward'][t])
+            vfinal = agent.values(self._final_norm) if have_final else (None, None)
             vnext = agent.values(nxt) if epoch_end else (None, None)
             _lib.check(lib.osa_rollout_post_step(
                 N, int(epoch_end), _lib.ptr(reward), _lib.ptr(cost), _lib.ptr(term),
@@ -199,6 +225,119 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             logger.extend('Metrics/EpRet', vals[0].tolist())
             logger.extend('Metrics/EpCost', vals[1].tolist())
             logger.extend('Metrics/EpLen', vals[2].tolist())
+            self._flush_extra(logger, idx)
         logger.store({'Value/reward': float(buffer.data['value_r'].mean())})
         if self._cfgs.algo_cfgs.use_cost:
             logger.store({'Value/cost': float(buffer.data['value_c'].mean())})
+
+
+class SauteAdapter(OnPolicyAdapter):
+    """omnisafe/adapter/saute_adapter.py:31-259: the observation is augmented with the remaining safety
+    budget z (1 at episode start, decremented by cost / budget and divided by saute_gamma every step), the
+    reward is replaced by `unsafe_reward` once z <= 0.  One extra kernel per step (osa_saute_step)."""
+
+    def __init__(self, env_id: str, num_envs: int, seed: int, cfgs, env=None) -> None:
+        super().__init__(env_id, num_envs, seed, cfgs, env=env)
+        a = cfgs.algo_cfgs
+        assert not getattr(a, 'reward_normalize', False), 'Reward normalization is not supported'
+        assert not getattr(a, 'cost_normalize', False), 'Cost normalization is not supported'
+        N, dev = self._num_envs, self._device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._saute_gamma = float(a.saute_gamma)
+        self._unsafe_reward = float(a.unsafe_reward)
+        self._budget_scale = (1 - a.saute_gamma ** a.max_ep_len) / (1 - a.saute_gamma) / a.max_ep_len
+        self._safety_budget = torch.full((N,), float(a.safety_budget * self._budget_scale), **f32)
+        self._reset_value = torch.ones(N, **f32)
+        self._safety_obs = torch.ones(N, **f32)
+        self._ep_budget = torch.zeros(N, **f32)
+
+    def _extra_obs_dims(self) -> int:
+        return 1
+
+    def _reset_log(self) -> None:
+        super()._reset_log()
+        self._ep_budget.zero_()
+
+    def _ensure_episode_rows(self, T: int) -> None:
+        super()._ensure_episode_rows(T)
+        if 'budget' not in self._ep_rows or self._ep_rows['budget'].shape[0] != T:
+            self._ep_rows['budget'] = torch.zeros(T, self._num_envs, dtype=torch.float32, device=self._device)
+
+    def _epoch_start_value(self) -> torch.Tensor:
+        return self._reset_value  # saute_adapter.py:118-121: ones
+
+    def _after_reset(self, obs_rows: torch.Tensor) -> None:
+        self._safety_obs.copy_(self._epoch_start_value())
+        obs_rows[:, self._raw_obs_dim].copy_(self._safety_obs)
+
+    def _after_env_step(self, t, reward, cost, term, trunc, next_rows, final_rows, reward_row) -> None:
+        _lib.check(self._lib.osa_saute_step(
+            self._num_envs, _lib.ptr(cost), _lib.ptr(reward), _lib.ptr(term), _lib.ptr(trunc),
+            _lib.ptr(self._safety_obs), _lib.ptr(self._safety_budget), self._saute_gamma, self._unsafe_reward,
+            _lib.ptr(self._reset_value), _lib.ptr(reward_row), _lib.ptr(next_rows), next_rows.stride(0),
+            _lib.ptr(final_rows), 0 if final_rows is None else final_rows.stride(0), self._raw_obs_dim,
+            _lib.ptr(self._ep_budget), _lib.ptr(self._ep_rows['budget'][t]), _lib.stream_ptr()), 'osa_saute_step')
+
+    def _flush_extra(self, logger, idx: torch.Tensor) -> None:
+        logger.extend('Metrics/EpBudget', self._ep_rows['budget'].reshape(-1)[idx].cpu().tolist())
+
+
+class SimmerPIDController:
+    """omnisafe/common/simmer_agent.py:93-189 (SimmerPIDAgent): PID on the blurred budget error, run once
+    per epoch on host tensors with the reference's own sequence of torch CPU operations."""
+
+    def __init__(self, cfgs, budget_bound: torch.Tensor, action_space=(-1, 1)) -> None:
+        from collections import deque
+
+        self._cfgs, self._budget_bound, self._action_space = cfgs, budget_bound, action_space
+        self._sum_history = torch.zeros(1)
+        self._prev_action = torch.zeros(1)
+        self._prev_error = torch.zeros(1)
+        self._prev_raw_action = torch.zeros(1)
+        self._integral_history = deque([], maxlen=10)
+
+    def act(self, safety_budget: torch.Tensor, observation: torch.Tensor) -> torch.Tensor:
+        c = self._cfgs
+        current_error = safety_budget - observation
+        blured_error = c.polyak * self._prev_error + (1 - c.polyak) * current_error
+        self._integral_history.append(blured_error)
+        self._sum_history = torch.as_tensor(sum(self._integral_history))
+        p_part = c.kp * blured_error
+        i_part = c.ki * self._sum_history
+        d_part = c.kd * (self._prev_action - self._prev_raw_action)
+        raw_action = p_part + i_part + d_part
+        action = torch.clamp(raw_action, min=self._action_space[0], max=self._action_space[1])
+        next_safety_budget = torch.clamp(safety_budget + action, 1e-6 * torch.ones_like(safety_budget),
+                                         self._budget_bound)
+        action = next_safety_budget - safety_budget
+        self._prev_action, self._prev_raw_action, self._prev_error = action, raw_action, blured_error
+        return next_safety_budget
+
+
+class SimmerAdapter(SauteAdapter):
+    """omnisafe/adapter/simmer_adapter.py:31-131: Saute whose budget is steered by a PID controller; an
+    epoch starts from the relative budget, episodes ending inside the epoch restart from 1 (the inherited
+    SauteAdapter.step, saute_adapter.py:150-151)."""
+
+    def __init__(self, env_id: str, num_envs: int, seed: int, cfgs, env=None) -> None:
+        super().__init__(env_id, num_envs, seed, cfgs, env=env)
+        a, N = cfgs.algo_cfgs, self._num_envs
+        self._safety_budget_host = a.safety_budget * self._budget_scale * torch.ones(N, 1)
+        self._upper_budget_host = a.upper_budget * self._budget_scale * torch.ones(N, 1)
+        self._rel_budget = torch.ones(N, dtype=torch.float32, device=self._device)
+        self._controller = SimmerPIDController(cfgs.control_cfgs, budget_bound=self._upper_budget_host)
+        self._sync_budget()
+
+    def _sync_budget(self) -> None:
+        self._safety_budget.copy_(self._safety_budget_host.reshape(-1))
+        self._rel_budget.copy_((self._safety_budget_host / self._upper_budget_host).reshape(-1))
+
+    def _epoch_start_value(self) -> torch.Tensor:
+        return self._rel_budget  # simmer_adapter.py:92-95
+
+    def control_budget(self, ep_costs) -> None:
+        """simmer_adapter.py:97-131."""
+        ep_costs = torch.as_tensor(ep_costs, dtype=torch.float32).cpu() * self._budget_scale
+        self._safety_budget_host = self._controller.act(safety_budget=self._safety_budget_host,
+                                                        observation=ep_costs)
+        self._sync_budget()

@@ -15,12 +15,17 @@ same set of libomnisafe_amd kernels as PPOLag / TRPOLag / CPO -- the combined ad
   CUP       first_order/cup.py:30-200           PPO step, then a KL-regularised cost-projection stage
   P3O       penalty_function/p3o.py:27-132      PPO + exact penalty kappa * relu(cost surrogate + Jc - limit)
 (the last three use osa_ppo_minibatch_ext: the per-step kernels with the extended actor loss)
+
+  PPOSaute / TRPOSaute          saute/{ppo,trpo}_saute.py        PPO / TRPO behind the SauteAdapter
+  PPOSimmerPID / TRPOSimmerPID  simmer/{ppo,trpo}_simmer_pid.py  ... behind the SimmerAdapter (PID budget)
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
+from .. import distributed as dist
+from ..adapter import SauteAdapter, SimmerAdapter
 from ..lagrange import Lagrange
 from ..models import SurrogateExt
 from ..pid_lagrange import PIDLagrangian
@@ -278,3 +283,50 @@ class CUP(_LagrangeMixin, PPO):
             lg.store({'Train/SecondStepPolicyRatio': float(v)})
         lg.store({'Loss/Loss_pi_c': float(st[:, 2].mean()), 'Train/SecondStepEntropy': float(st[:, 4].mean()),
                   'Train/SecondStepStopIter': out['stop_iter']})
+
+
+class _AugmentedEnvMixin:
+    """_init_env / _init_log of the Saute and Simmer algorithm classes (ppo_saute.py:37-73)."""
+    _adapter_cls = SauteAdapter
+
+    def _init_env(self) -> None:
+        c = self._cfgs
+        self._env = self._adapter_cls(self._env_id, c.train_cfgs.vector_env_nums, self._seed, c)
+        assert c.algo_cfgs.steps_per_epoch % (dist.world_size() * c.train_cfgs.vector_env_nums) == 0, (
+            'The number of steps per epoch is not divisible by the number of environments.')
+        self._steps_per_epoch = (c.algo_cfgs.steps_per_epoch // dist.world_size()
+                                 // c.train_cfgs.vector_env_nums)
+
+    def _init_log(self) -> None:
+        super()._init_log()
+        self._logger.register_key('Metrics/EpBudget')
+
+
+class _SimmerMixin(_AugmentedEnvMixin):
+    _adapter_cls = SimmerAdapter
+
+    def _update(self) -> None:
+        """ppo_simmer_pid.py:75-79: steer the safety budget with the epoch's mean episode cost first."""
+        Jc = self._logger.get_stats('Metrics/EpCost')[0]
+        self._env.control_budget(Jc)
+        super()._update()
+
+
+@register
+class PPOSaute(_AugmentedEnvMixin, PPO):
+    pass
+
+
+@register
+class TRPOSaute(_AugmentedEnvMixin, TRPO):
+    pass
+
+
+@register
+class PPOSimmerPID(_SimmerMixin, PPO):
+    pass
+
+
+@register
+class TRPOSimmerPID(_SimmerMixin, TRPO):
+    pass

@@ -146,11 +146,19 @@ _LAG_BOUNDED = dict(_PPOLAG['lagrange_cfgs'], lagrangian_upper_bound=2.0)
 _FOCOPS = _derive(_PPOLAG, {'focops_eta': 0.02, 'focops_lam': 1.5}, lagrange=_LAG_BOUNDED)
 _CUP = _derive(_PPOLAG, {'target_kl': 0.01}, lagrange=_LAG_BOUNDED)
 _P3O = _derive(_PPOLAG, {'update_iters': 10, 'kappa': 20.0, 'cost_limit': 25.0}, lagrange=None)
+_SAUTE = {'safety_budget': 25.0, 'saute_gamma': 0.999, 'max_ep_len': 1000, 'unsafe_reward': -1.0}
+_PPOSAUTE = _derive(_PPO, _SAUTE)
+_TRPOSAUTE = _derive(_TRPO, _SAUTE)
+_PPOSIMMER = _derive(_PPO, dict(_SAUTE, upper_budget=25.0))
+_TRPOSIMMER = _derive(_TRPO, dict(_SAUTE, upper_budget=25.0))
+for _d in (_PPOSIMMER, _TRPOSIMMER):
+    _d['control_cfgs'] = {'kp': 0.0005, 'ki': 1e-05, 'kd': 0.0, 'polyak': 0.995}
 
 DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO,
             'PolicyGradient': _PG, 'NaturalPG': _NPG, 'PDO': _PDO, 'RCPO': _RCPO, 'IPO': _IPO,
             'OnCRPO': _ONCRPO, 'CPPOPID': _CPPOPID, 'TRPOPID': _TRPOPID, 'PCPO': _PCPO,
-            'FOCOPS': _FOCOPS, 'CUP': _CUP, 'P3O': _P3O}
+            'FOCOPS': _FOCOPS, 'CUP': _CUP, 'P3O': _P3O, 'PPOSaute': _PPOSAUTE, 'TRPOSaute': _TRPOSAUTE,
+            'PPOSimmerPID': _PPOSIMMER, 'TRPOSimmerPID': _TRPOSIMMER}
 
 
 def get_default_kwargs(algo: str) -> dict:

@@ -180,6 +180,45 @@ __global__ __launch_bounds__(256) void osa_rollout_post_step_kernel(
   ep_len[n] = el;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Saute / Simmer state augmentation (omnisafe/adapter/saute_adapter.py:124-196): one thread per env.
+//   _safety_step      z <- (z - cost / budget) / saute_gamma
+//   _safety_reward    r <- r if z > 0 else unsafe_reward
+//   episode end       z <- z * (1 - done) + done * z_reset
+//   _augment_obs      column `col` of the next / final observation rows <- z   (final rows get the value
+//                     AFTER the reset, as the reference augments them after updating _safety_obs)
+//   _log_value / _log_metrics: ep_budget += z; a finished episode writes its sum to ep_budget_out
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osa_saute_step_kernel(
+    int N, const float* __restrict__ cost, const float* __restrict__ reward,
+    const uint8_t* __restrict__ terminated, const uint8_t* __restrict__ truncated,
+    float* __restrict__ safety_obs, const float* __restrict__ budget, float saute_gamma,
+    float unsafe_reward, const float* __restrict__ reset_value, float* __restrict__ reward_out,
+    float* __restrict__ next_rows, int ld_next, float* __restrict__ final_rows, int ld_final, int col,
+    float* __restrict__ ep_budget, float* __restrict__ ep_budget_out) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float z = safety_obs[n];
+  z = z - cost[n] / budget[n];
+  z = z / saute_gamma;
+  const float safe = z > 0.f ? 1.f : 0.f;
+  reward_out[n] = safe * reward[n] + (1.f - safe) * unsafe_reward;
+  const float done = (terminated[n] != 0 || truncated[n] != 0) ? 1.f : 0.f;
+  z = z * (1.f - done) + done * reset_value[n];
+  safety_obs[n] = z;
+  next_rows[(long)n * ld_next + col] = z;
+  if (final_rows) final_rows[(long)n * ld_final + col] = z;
+  const float eb = ep_budget[n] + z;
+  if (done != 0.f) {
+    ep_budget_out[n] = eb;
+    ep_budget[n] = 0.f;
+  } else {
+    ep_budget[n] = eb;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Synthetic fixed-shape vector environment (benchmark stand-in for Safety-Gymnasium, whose MuJoCo
 // physics is third-party CPU code outside the reference repository): obs ~ N(0,1)^D_o,
@@ -289,6 +328,22 @@ int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float
                      osa_stream(stream), N, epoch_end, reward, cost, terminated, truncated, vnext_r,
                      vnext_c, vfinal_r, vfinal_c, ep_ret, ep_cost, ep_len, path_end, boot_r, boot_c,
                      ep_done, ep_ret_out, ep_cost_out, ep_len_out);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_saute_step(int N, const float* cost, const float* reward, const uint8_t* terminated,
+                   const uint8_t* truncated, float* safety_obs, const float* budget, float saute_gamma,
+                   float unsafe_reward, const float* reset_value, float* reward_out, float* next_rows,
+                   int ld_next, float* final_rows, int ld_final, int col, float* ep_budget,
+                   float* ep_budget_out, void* stream) {
+  OSA_REQUIRE(N > 0 && cost && reward && terminated && truncated && safety_obs && budget && reset_value);
+  OSA_REQUIRE(reward_out && next_rows && ld_next > col && col >= 0 && ep_budget && ep_budget_out);
+  OSA_REQUIRE(!final_rows || ld_final > col);
+  hipLaunchKernelGGL(osa_saute_step_kernel, dim3((N + 255) / 256), dim3(256), 0, osa_stream(stream), N,
+                     cost, reward, terminated, truncated, safety_obs, budget, saute_gamma, unsafe_reward,
+                     reset_value, reward_out, next_rows, ld_next, final_rows, ld_final, col, ep_budget,
+                     ep_budget_out);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

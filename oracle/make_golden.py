@@ -468,6 +468,93 @@ def gen_sibling_updates(only=None):
               'perms', out['perms'].shape)
 
 
+def _record_rollout(algo, T, seed):
+    """Run the reference adapter's rollout with spies on the raw env and on the policy noise; returns the
+    recorded trace + resulting buffer / normaliser / episode-metric contents (keys as in ppolag_epoch)."""
+    ac = algo._actor_critic
+    out = {}
+    env_core = algo._env._env
+    while hasattr(env_core, '_env'):
+        env_core = env_core._env
+    steps, resets = [], []
+    orig_step, orig_reset = env_core.step, env_core.reset
+
+    def spy_step(action):
+        r = orig_step(action)
+        obs, reward, cost, term, trunc, info = r
+        steps.append({'action': _np(action).copy(), 'obs': _np(obs).copy(), 'reward': _np(reward).copy(),
+                      'cost': _np(cost).copy(), 'terminated': _np(term).copy(),
+                      'truncated': _np(trunc).copy(),
+                      'final_obs': (_np(info['final_observation']).copy()
+                                    if 'final_observation' in info else np.zeros_like(_np(obs)))})
+        return r
+
+    def spy_reset(*a, **k):
+        r = orig_reset(*a, **k)
+        resets.append(_np(r[0]).copy())
+        return r
+
+    env_core.step, env_core.reset = spy_step, spy_reset
+    with _Recorder() as rec:
+        torch.manual_seed(seed)
+        algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+    env_core.step, env_core.reset = orig_step, orig_reset
+    out['rollout/reset_obs'] = resets[-1]
+    for k in steps[0]:
+        out[f'rollout/{k}'] = np.stack([s[k] for s in steps])
+    vec_eps = [e for e in rec.normals if e.dim() == 2]
+    assert len(vec_eps) == T
+    out['rollout/eps'] = np.stack([_np(e) for e in vec_eps])
+    for k, v in _snapshot_buffer_raw(algo._buf).items():
+        out[f'buffer/{k}'] = v
+    norm = algo._env.save()['obs_normalizer']
+    for k in ('_mean', '_sumsq', '_var', '_std', '_count'):
+        out[f'rollout/norm{k}'] = _np(getattr(norm, k))
+    for key, name in (('Metrics/EpCost', 'ep_cost_window'), ('Metrics/EpRet', 'ep_ret_window'),
+                      ('Metrics/EpLen', 'ep_len_window'), ('Metrics/EpBudget', 'ep_budget_window')):
+        if key in algo._logger._data:
+            out[f'rollout/{name}'] = np.asarray([float(x) for x in algo._logger._data[key]], np.float32)
+    return out
+
+
+def gen_saute_simmer():
+    """SauteAdapter / SimmerAdapter rollouts of the reference on the synthetic env (budget small enough
+    that the unsafe branch is reached) and the Simmer PID budget controller's trajectory."""
+    import omnisafe
+
+    N, T, horizon = 4, 40, 16
+    for algo_name, tag, extra in (
+            ('PPOSaute', 'saute', {'safety_budget': 1.0, 'max_ep_len': 16, 'unsafe_reward': -0.5}),
+            ('PPOSimmerPID', 'simmer', {'safety_budget': 1.0, 'upper_budget': 2.0, 'max_ep_len': 16,
+                                        'unsafe_reward': -0.5})):
+        ref_harness.register_synth_env()
+        ref_harness.DEFAULT_HORIZON = horizon
+        d = tempfile.mkdtemp()
+        cfg = {'seed': 0,
+               'train_cfgs': {'total_steps': N * T * 4, 'vector_env_nums': N, 'torch_threads': 8, 'device': 'cpu'},
+               'algo_cfgs': dict({'steps_per_epoch': N * T, 'update_iters': 2}, **extra),
+               'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
+        if tag == 'simmer':
+            cfg['control_cfgs'] = {'kp': 0.05, 'ki': 0.01, 'kd': 0.02, 'polyak': 0.9}
+        algo = omnisafe.Agent(algo_name, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+        out = {'N': N, 'T': T, 'horizon': horizon}
+        for net in ('actor', 'reward_critic', 'cost_critic'):
+            for k, v in _state(getattr(algo._actor_critic, net)).items():
+                out[f'init/{net}/{k}'] = v
+        out.update(_record_rollout(algo, T, seed=5))
+        if tag == 'simmer':
+            traj = []
+            for jc in (1.5, 0.2, 3.0, 0.9):
+                algo._env.control_budget(torch.as_tensor(jc, dtype=torch.float32))
+                traj.append(np.concatenate([_np(algo._env._safety_budget).reshape(-1)[:1],
+                                            _np(algo._env._rel_safety_budget).reshape(-1)[:1]]))
+            out['control/jc'] = np.asarray((1.5, 0.2, 3.0, 0.9), np.float32)
+            out['control/budget_rel'] = np.stack(traj)
+        np.savez(os.path.join(OUT, f'{tag}_rollout.npz'), **out)
+        print(tag, 'unsafe steps:', int((out['buffer/reward'] == np.float32(-0.5)).sum()),
+              'EpBudget', out.get('rollout/ep_budget_window'))
+
+
 def gen_config_defaults():
     """Snapshot of the `defaults` blocks of the reference's on-policy YAML files."""
     import json
@@ -493,6 +580,7 @@ def main():
     gen_rollout_and_ppolag_update()
     gen_trust_region_updates()
     gen_sibling_updates()
+    gen_saute_simmer()
     gen_config_defaults()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
