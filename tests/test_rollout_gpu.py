@@ -273,3 +273,71 @@ def test_reward_and_cost_normalize_wrappers():
     assert np.allclose(sorted(logger.data['Metrics/EpCost']), sorted(ep_cost.numpy()[-100:]), atol=1e-5) or \
         np.allclose(np.float32(logger.data['Metrics/EpCost']), ep_cost.numpy()[-100:], atol=1e-5)
     assert set(adapter.save()) == {'obs_normalizer', 'reward_normalizer', 'cost_normalizer'}
+
+
+@pytest.mark.parametrize('tag', ['saute', 'simmer'])
+def test_saute_simmer_rollout_on_reference_trace(golden, tag):
+    """SauteAdapter / SimmerAdapter: replay the raw env outputs + policy noise recorded from the reference's
+    PPOSaute / PPOSimmerPID rollout (tests/golden/{saute,simmer}_rollout.npz); the augmented observations
+    (safety-state column), shaped rewards, bootstrap targets and Metrics/EpBudget must match."""
+    from omnisafe_amd.adapter import SauteAdapter, SimmerAdapter
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from test_mlp_gpu import make_ac
+
+    g = golden(f'{tag}_rollout.npz')
+    N, T = int(g['N']), int(g['T'])
+    ns = types.SimpleNamespace
+    extra = dict(safety_budget=1.0, saute_gamma=0.999, max_ep_len=16, unsafe_reward=-0.5)
+    if tag == 'simmer':
+        extra['upper_budget'] = 2.0
+    cfgs = _cfgs(**extra)
+    cfgs.control_cfgs = ns(kp=0.05, ki=0.01, kd=0.02, polyak=0.9)
+    env = TraceEnv(g)
+    adapter = (SimmerAdapter if tag == 'simmer' else SauteAdapter)('trace', N, 0, cfgs, env=env)
+    assert adapter.observation_space.shape == (61,)
+    ac = make_ac(61, 2, g, 'init/')
+    eps_iter = iter(g['rollout/eps'])
+    plain_step = ac.step
+
+    def step_with_recorded_noise(obs, deterministic=False, eps=None, out=None, nets_mask=7):
+        if out is not None and 'act' in out and not deterministic:
+            eps = torch.from_numpy(next(eps_iter)).to(DEV)
+        return plain_step(obs, deterministic=deterministic, eps=eps, out=out, nets_mask=nets_mask)
+
+    ac.step = step_with_recorded_noise
+    buf = VectorOnPolicyBuffer(adapter.observation_space, adapter.action_space, T, 0.99, 0.95, 0.95,
+                               'gae', 0.0, True, True, num_envs=N, device=DEV)
+    logger = _LoggerStub()
+    adapter.rollout(T, ac, buf, logger)
+    buf.compute_advantages()
+    b = {k: v.cpu().numpy() for k, v in buf.data.items()}
+    # the safety-state column is float32 arithmetic restated op for op: bit-exact
+    assert np.array_equal(b['obs'][:, :, 60], g['buffer/obs'][:, :, 60])
+    assert np.array_equal(b['reward'], g['buffer/reward']) and np.array_equal(b['cost'], g['buffer/cost'])
+    assert (b['reward'] == np.float32(-0.5)).sum() > 20  # the unsafe branch is exercised
+    for k in ('obs', 'act', 'value_r', 'value_c', 'logp'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=1e-4, err_msg=k)
+    np.testing.assert_allclose(logger.data['Metrics/EpBudget'], g['rollout/ep_budget_window'], rtol=1e-6)
+    np.testing.assert_allclose(logger.data['Metrics/EpRet'], g['rollout/ep_ret_window'], rtol=1e-6)
+    assert np.array_equal(np.float32(logger.data['Metrics/EpCost']), g['rollout/ep_cost_window'])
+    if tag == 'simmer':  # PID budget controller trajectory (simmer_agent.py:131-176)
+        for jc, want in zip(g['control/jc'], g['control/budget_rel']):
+            adapter.control_budget(float(jc))
+            got = np.array([float(adapter._safety_budget[0]), float(adapter._rel_budget[0])], np.float32)
+            np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+@pytest.mark.parametrize('algo_name', ['PPOSaute', 'TRPOSaute', 'PPOSimmerPID', 'TRPOSimmerPID'])
+def test_saute_simmer_agents_end_to_end(tmp_path, algo_name):
+    import omnisafe_amd
+
+    cfg = {'seed': 2, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 128 * 32, 'vector_env_nums': 128},
+           'algo_cfgs': {'steps_per_epoch': 128 * 32, 'update_iters': 2, 'safety_budget': 2.0, 'max_ep_len': 16},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo_name, 'SynthCarGoal1-v0', custom_cfgs=cfg)
+    assert agent.agent._actor_critic.obs_dim == 73  # CarGoal1's 72 + the safety state
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
+    assert len(agent.agent._logger._data) > 0
