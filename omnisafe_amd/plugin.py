@@ -10,7 +10,9 @@ runs the HIP path; nothing else in the reference changes.  See INTEGRATION.md.
 """
 from __future__ import annotations
 
-ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO')
+ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO', 'PDO', 'RCPO', 'IPO',
+               'OnCRPO', 'CPPOPID', 'TRPOPID', 'PCPO', 'FOCOPS', 'CUP', 'P3O', 'PPOSaute', 'TRPOSaute',
+               'PPOSimmerPID', 'TRPOSimmerPID')
 
 
 def install(algorithms: tuple[str, ...] | None = None) -> list[str]:

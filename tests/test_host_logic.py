@@ -157,8 +157,11 @@ def test_plugin_installs_behind_reference_agent(tmp_path, monkeypatch):
         cfg = {'train_cfgs': {'device': 'cuda:0', 'total_steps': 2000, 'vector_env_nums': 4},
                'algo_cfgs': {'steps_per_epoch': 1000},
                'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': str(tmp_path)}}
-        with pytest.raises(RuntimeError, match='no CPU fallback'):
-            omnisafe.Agent('PPOLag', 'SynthPointGoal1-v0', custom_cfgs=cfg)
+        assert len(swapped) == 21
+        for name in swapped:  # every accelerated algorithm is reachable through the reference's own Agent
+            assert ref_registry.REGISTRY.get(name) is omnisafe_amd.algorithms.registry.get(name)
+            with pytest.raises(RuntimeError, match='no CPU fallback'):
+                omnisafe.Agent(name, 'SynthPointGoal1-v0', custom_cfgs=cfg)
     finally:
         ref_registry.REGISTRY._module_dict.clear()
         ref_registry.REGISTRY._module_dict.update(keep)
