@@ -324,13 +324,19 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         if use_repl:
             gathered = self.gather_for_replicated(data, W)
+        # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
+        # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
+        all_perms = None
+        if perms is None and not use_repl:
+            keys = torch.randint(0, 1 << 62, (self.update_iters, M), device=ac.device, dtype=torch.int64)
+            all_perms = keys.argsort(dim=1)
         for i in range(self.update_iters):
             if use_repl:
                 perm = None
             elif perms is not None:
                 perm = torch.as_tensor(perms[i]).to(ac.device, torch.int64)
             else:
-                perm = torch.randperm(M, device=ac.device)
+                perm = all_perms[i]
             if use_repl:
                 pa = None if perms is None else torch.as_tensor(perms[i]).to(ac.device, torch.int64)
                 self.run_pass_replicated(gathered, M, W, lagrange, stats[step:step + nmb], perms_all=pa)
@@ -344,7 +350,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
                     step += 1
             update_counts += 1
-            if self.update_actor:
+            # the KL pass feeds the early-stop test; without early stop only the last pass's value is
+            # logged (policy_gradient.py:383-404), so the earlier full-batch passes are not computed
+            if self.update_actor and (self.kl_early_stop or i == self.update_iters - 1):
                 kl_dev = self.kl(obs)
                 if self.kl_early_stop:
                     final_kl = float(kl_dev)  # the one host sync per pass
