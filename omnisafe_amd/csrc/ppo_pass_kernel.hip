@@ -67,6 +67,10 @@ struct OsaPassArgs {
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
+// Phase clocks (s_memtime deltas per phase, tools/phase_clocks.py, tools/dp_timing.py) are a COMPILE-TIME
+// option: the runtime-checked version put a branch -- a scheduling barrier -- between all phases of the
+// step.  Build with OSA_EXTRA_CFLAGS=-DOSA_PASS_CLOCKS to get them.
+#ifdef OSA_PASS_CLOCKS
 #define PTICK(k)                                      \
   do {                                                \
     if (a.dbg && tid == 0) {                          \
@@ -75,6 +79,9 @@ struct OsaPassArgs {
       dbg_last = now_;                                \
     }                                                 \
   } while (0)
+#else
+#define PTICK(k) do { } while (0)
+#endif
 
 template <int KB, int OT, bool MULTI, bool COOP>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
@@ -260,8 +267,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
   for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   __syncthreads();  // LDS master copy complete
+#ifdef OSA_PASS_CLOCKS
   long long dbg_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long dbg_last = clock64();
+#endif
   bool coop_dead = false;
 
   for (int mb = a.mb0; mb < a.mb0 + a.nmb; ++mb) {
@@ -807,8 +816,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     __syncthreads();  // (C) master copy updated, tiles and `red` free for the next minibatch
     PTICK(9);
   }
+#ifdef OSA_PASS_CLOCKS
   if (a.dbg && tid == 0 && rk == 0)
     for (int k = 0; k < 13; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
+#endif
   if (rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
   // ---- write back parameters and Adam state
   for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
