@@ -75,7 +75,8 @@ class OsaError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # OSA_LIB_PATH: an alternative build of the same library (tools/build_clocks_lib.sh: phase clocks)
+    return os.environ.get('OSA_LIB_PATH') or _build.LIB_PATH
 
 
 def load(require_gpu: bool = False):

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   f32x4 m2[HT], v2[HT], m1[KB], v1[KB], m3[OT], v3[OT];
   float mb_ = 0.f, vb_ = 0.f;
   int boff = -1;  // global offset of the owned bias-like scalar
-  float* sbias = nullptr;
+  float* sbias = sB1;  // always a readable address (threads without a bias read it and discard)
   if (tid < H) { boff = nd.ob1 + tid; sbias = sB1 + tid; }
   else if (tid < 2 * H) { boff = nd.ob2 + tid - H; sbias = sB2 + tid - H; }
   else if (tid < 2 * H + OUTP) { boff = nd.ob3 + tid - 2 * H; sbias = sB3 + tid - 2 * H; }
@@ -291,15 +291,20 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       ent_pre /= (float)nd.act_dim;
     }
     for (int ch = 0; ch < nchunk; ++ch, ++cidx) {
-    fetch(row_nxt, pos_ok(cidx + 1), nxt);  // in flight while this chunk computes
-    row_nxt = row_of(cidx + 2);
     PTICK(0);
     const bool valid = cur.valid;
+    const int c = 16 * wave + j;  // this lane's sample column in the [feature][sample] LDS tiles
+    // Tile stores (S layout -> F layout for the weight-gradient contraction) are issued as soon as a
+    // value is final, in the shadow of the MFMAs that follow, instead of in one block before barrier (A)
+#define PUT_TILE(S, V, T)                                                           \
+  _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (S)[(16 * (T) + 4 * g + r_) * PSLD + c] = (V)[r_]
     // deferred masking of the prefetched observation chunks (padding columns, invalid rows)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cur.x[kb][r] = (valid && cm[kb][r]) ? cur.x[kb][r] : 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) PUT_TILE(sX, cur.x[kb], kb);
     // ================= forward (S layout; weights from the LDS master) =================
     // Software-pipelined in two halves of the output tiles (A = tiles 0,1; B = tiles 2,3): the tanh of a
     // finished half is VALU work placed in the shadow of the other half's / the next layer's MFMAs
@@ -333,14 +338,21 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
     L1_TILES(0)
     L1_TILES(2)                       // MFMAs of tiles 2,3 ...
-    h1[0] = osa_tanh4(h1[0]);         // ... cover tanh of tiles 0,1
+    // ... cover the next chunk's gather (address arithmetic + load issue; in flight until the chunk ends)
+    fetch(row_nxt, pos_ok(cidx + 1), nxt);
+    row_nxt = row_of(cidx + 2);
+    h1[0] = osa_tanh4(h1[0]);         // ... and tanh of tiles 0,1
     h1[1] = osa_tanh4(h1[1]);
     L2_STEP(0, 0)                     // layer 2, K blocks 0,1 (need h1[0], h1[1] only)
     L2_STEP(2, 0)
+    PUT_TILE(sH1, h1[0], 0);
+    PUT_TILE(sH1, h1[1], 1);
     h1[2] = osa_tanh4(h1[2]);         // covered by the layer-2 MFMAs above
     h1[3] = osa_tanh4(h1[3]);
     L2_STEP(0, 2)                     // K blocks 2,3: tiles 0,1 complete first
     L2_STEP(2, 2)
+    PUT_TILE(sH1, h1[2], 2);
+    PUT_TILE(sH1, h1[3], 3);
     h2[0] = osa_tanh4(h2[0]);
     h2[1] = osa_tanh4(h2[1]);
 #pragma unroll
@@ -352,6 +364,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
       }
     }
+    PUT_TILE(sH2, h2[0], 0);
+    PUT_TILE(sH2, h2[1], 1);
     h2[2] = osa_tanh4(h2[2]);
     h2[3] = osa_tanh4(h2[3]);
 #pragma unroll
@@ -363,6 +377,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
       }
     }
+    PUT_TILE(sH2, h2[2], 2);
+    PUT_TILE(sH2, h2[3], 3);
 #undef L1_TILES
 #undef L2_STEP
 
@@ -436,66 +452,70 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
 
     PTICK(2);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      PUT_TILE(sDO, dO[o], o);
+      PUT_TILE(sDL, dLS[o], o);
+    }
     // ================= backward through the hidden layers =================
+    // The transposed weight fragments are scalar LDS reads (A[i][k] = W^T[16t+i][k]); with one wave per SIMD
+    // nothing hides their latency, so every block of reads is issued BEFORE the MFMAs of the previous block
+    // (double buffer + sched_barrier: the compiler otherwise sinks each read next to its consumer and
+    // waits ~100 cycles in front of every MFMA pair).
     f32x4 z2[HT], z1[HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) z2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wt[2][4][HT];
+    {
+      float w3t[OT][4][HT];
 #pragma unroll
-    for (int o = 0; o < OT; ++o) {
+      for (int o = 0; o < OT; ++o)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]; the 4 tiles t are independent
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
-          z2[t] = OSA_MFMA(sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i], dO[o][s], z2[t]);
-      }
+          for (int t = 0; t < HT; ++t) w3t[o][s][t] = sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)  // first W2^T block, in flight under the W3^T MFMAs
+#pragma unroll
+        for (int t = 0; t < HT; ++t) wt[0][s][t] = sW2[(4 * g + s) * PSLD + 16 * t + i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)  // the 4 tiles t are independent accumulators
+#pragma unroll
+          for (int t = 0; t < HT; ++t) z2[t] = OSA_MFMA(w3t[o][s][t], dO[o][s], z2[t]);
     }
 #pragma unroll
-    for (int t = 0; t < HT; ++t) z2[t] = z2[t] * (1.f - h2[t] * h2[t]);
+    for (int t = 0; t < HT; ++t) {
+      z2[t] = z2[t] * (1.f - h2[t] * h2[t]);
+      PUT_TILE(sZ2, z2[t], t);
+    }
 #pragma unroll
     for (int t = 0; t < HT; ++t) z1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < HT; ++kb) {
-      float wt[4][HT];  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+      if (kb + 1 < HT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t)
+            wt[(kb + 1) & 1][s][t] = sW2[(16 * (kb + 1) + 4 * g + s) * PSLD + 16 * t + i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < HT; ++t) wt[s][t] = sW2[(16 * kb + 4 * g + s) * PSLD + 16 * t + i];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int t = 0; t < HT; ++t) z1[t] = OSA_MFMA(wt[s][t], z2[kb][s], z1[t]);
+        for (int t = 0; t < HT; ++t) z1[t] = OSA_MFMA(wt[kb & 1][s][t], z2[kb][s], z1[t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int t = 0; t < HT; ++t) z1[t] = z1[t] * (1.f - h1[t] * h1[t]);
-
-    PTICK(3);
-    // ================= S layout -> F layout through LDS =================
-    const int c = 16 * wave + j;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 16 * t + 4 * g + r;
-        sH1[f * PSLD + c] = h1[t][r];
-        sH2[f * PSLD + c] = h2[t][r];
-        sZ1[f * PSLD + c] = z1[t][r];
-        sZ2[f * PSLD + c] = z2[t][r];
-      }
+      z1[t] = z1[t] * (1.f - h1[t] * h1[t]);
+      PUT_TILE(sZ1, z1[t], t);
     }
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sX[(16 * kb + 4 * g + r) * PSLD + c] = cur.x[kb][r];
-    }
-#pragma unroll
-    for (int o = 0; o < OT; ++o) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 16 * o + 4 * g + r;
-        sDO[f * PSLD + c] = dO[o][r];
-        sDL[f * PSLD + c] = dLS[o][r];
-      }
-    }
+#undef PUT_TILE
+    PTICK(3);
     __syncthreads();  // (A) tiles complete
     PTICK(4);
     // ================= weight gradients (registers) =================
@@ -542,20 +562,27 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       }
     }
     PTICK(5);
-    // bias-like gradient owned by this thread: row sum over the 64 samples of the chunk
-    if (boff >= 0) {
+    // bias-like gradient owned by this thread: row sum over the 64 samples of the chunk.  Branch-free
+    // (threads without a bias read row 0 and discard) with all 16 reads in flight before the adds.
+    {
       const float* srow = (tid < H) ? sZ1 + tid * PSLD
                           : (tid < 2 * H) ? sZ2 + (tid - H) * PSLD
                           : (tid < 2 * H + OUTP) ? sDO + (tid - 2 * H) * PSLD
-                                                 : sDL + (tid - 2 * H - OUTP) * PSLD;
+                          : (tid < 2 * H + 2 * OUTP) ? sDL + (tid - 2 * H - OUTP) * PSLD
+                                                     : sZ1;
+      f32x4 q[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) q[k] = *reinterpret_cast<const f32x4*>(srow + 4 * k);
+      __builtin_amdgcn_sched_barrier(0);
+      float rs = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(srow + 4 * k);
-        gb += q.x;
-        gb += q.y;
-        gb += q.z;
-        gb += q.w;
+        rs += q[k].x;
+        rs += q[k].y;
+        rs += q[k].z;
+        rs += q[k].w;
       }
+      gb = (boff >= 0) ? ((MULTI && ch > 0) ? gb + rs : rs) : 0.f;
     }
     cur = nxt;
     if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
@@ -563,39 +590,49 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
     // ================= + 2*coef*w (critics), squared norms (packed f32 math) =================
+    // this lane's parameters: all LDS reads issued up front (one latency for the lot), kept in registers
+    // until the Adam update below
+    f32x4 w2r[HT], w1r[KB], w3r[OT];
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w2r[ti][r] = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1r[kb][r] = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w3r[o][r] = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+    float wb = *sbias;
+    wb = (boff >= 0) ? wb : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+      const f32x4 w = w2r[ti];
       if (l2) g2[ti] = g2[ti] + w * c2;
       acc_p = acc_p + w * w;
       acc_g = acc_g + g2[ti] * g2[ti];
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+      const f32x4 w = w1r[kb];
       if (l2) g1[kb] = g1[kb] + w * c2;
       acc_p = acc_p + w * w;
       acc_g = acc_g + g1[kb] * g1[kb];
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+      const f32x4 w = w3r[o];
       if (l2) g3[o] = g3[o] + w * c2;
       acc_p = acc_p + w * w;
       acc_g = acc_g + g3[o] * g3[o];
     }
     float gsq = (acc_g.x + acc_g.y) + (acc_g.z + acc_g.w);
     float psq = (acc_p.x + acc_p.y) + (acc_p.z + acc_p.w);
-    float wb = 0.f;
     if (boff >= 0) {
-      wb = *sbias;
       if (l2) gb += c2 * wb;
       psq += wb * wb;
       gsq += gb * gb;
@@ -767,27 +804,21 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const float gscale = apply_clip ? coef : 1.f;
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc];
+      f32x4 w = w2r[ti];
       w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc] = w[r];
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc];
+      f32x4 w = w1r[kb];
       w = osa_adam_update4(g1[kb] * gscale, m1[kb], v1[kb], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc] = w[r];
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-      f32x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc];
+      f32x4 w = w3r[o];
       w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc] = w[r];
