@@ -311,76 +311,96 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     // (a v_mfma_f32_16x16x4 occupies the matrix pipe for 32 cycles, the wave can issue ~6 VALU ops
     // meanwhile).  Two accumulators alternate, so no MFMA waits on its own predecessor.
     f32x4 h1[HT], h2[HT], out[OT];
-#define L1_TILES(T0)                                                                              \
-  _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) {                                             \
-    const f32x4 x = cur.x[kb];                                                                    \
-    const f32x4 wa = *reinterpret_cast<const f32x4*>(sW1 + (16 * (T0) + i) * W1LD + 16 * kb + 4 * g);       \
-    const f32x4 wb = *reinterpret_cast<const f32x4*>(sW1 + (16 * ((T0) + 1) + i) * W1LD + 16 * kb + 4 * g); \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
-      h1[(T0)] = OSA_MFMA(wa[s], x[s], h1[(T0)]);                                                 \
-      h1[(T0) + 1] = OSA_MFMA(wb[s], x[s], h1[(T0) + 1]);                                         \
-    }                                                                                             \
-  }
-#define L2_STEP(T0, KB0)                                                                          \
-  _Pragma("unroll") for (int kb = (KB0); kb < (KB0) + 2; ++kb) {                                  \
-    const f32x4 wa = *reinterpret_cast<const f32x4*>(sW2 + (16 * (T0) + i) * PSLD + 16 * kb + 4 * g);       \
-    const f32x4 wb = *reinterpret_cast<const f32x4*>(sW2 + (16 * ((T0) + 1) + i) * PSLD + 16 * kb + 4 * g); \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
-      h2[(T0)] = OSA_MFMA(wa[s], h1[kb][s], h2[(T0)]);                                            \
-      h2[(T0) + 1] = OSA_MFMA(wb[s], h1[kb][s], h2[(T0) + 1]);                                    \
-    }                                                                                             \
-  }
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
 #pragma unroll
     for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(sB2 + 16 * t + 4 * g);
 #pragma unroll
     for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
-    L1_TILES(0)
-    L1_TILES(2)                       // MFMAs of tiles 2,3 ...
-    // ... cover the next chunk's gather (address arithmetic + load issue; in flight until the chunk ends)
-    fetch(row_nxt, pos_ok(cidx + 1), nxt);
-    row_nxt = row_of(cidx + 2);
-    h1[0] = osa_tanh4(h1[0]);         // ... and tanh of tiles 0,1
-    h1[1] = osa_tanh4(h1[1]);
-    L2_STEP(0, 0)                     // layer 2, K blocks 0,1 (need h1[0], h1[1] only)
-    L2_STEP(2, 0)
-    PUT_TILE(sH1, h1[0], 0);
-    PUT_TILE(sH1, h1[1], 1);
-    h1[2] = osa_tanh4(h1[2]);         // covered by the layer-2 MFMAs above
-    h1[3] = osa_tanh4(h1[3]);
-    L2_STEP(0, 2)                     // K blocks 2,3: tiles 0,1 complete first
-    L2_STEP(2, 2)
-    PUT_TILE(sH1, h1[2], 2);
-    PUT_TILE(sH1, h1[3], 3);
-    h2[0] = osa_tanh4(h2[0]);
-    h2[1] = osa_tanh4(h2[1]);
+    // The three layers are one sequence of MFMA groups (8 MFMAs on two alternating accumulator tiles, or
+    // 4*OT for the output layer); the A fragments of group k+1 are read from the LDS master BEFORE the
+    // MFMAs of group k issue (double buffer; OSA_SB pins LDS reads and MFMAs, everything else may float),
+    // so no MFMA waits for an LDS round trip -- with one wave per SIMD nothing else would hide it.
+    //   groups 0 .. 2KB-1        layer 1: tiles (T0, T0+1), T0 = 0 then 2, K block kb over the input
+    //   groups 2KB .. 2KB+7      layer 2: (0,kb0) (0,kb1) (2,kb0) (2,kb1) (0,kb2) (0,kb3) (2,kb2) (2,kb3)
+    //   groups 2KB+8 .. 2KB+11   output layer, K blocks 0..3
+#define OSA_SB() __builtin_amdgcn_sched_barrier(0x676)
+    constexpr int NG1 = 2 * KB, NG = NG1 + 8 + 4;
+    auto load_group = [&](int gi, f32x4 (&dst)[2]) {
+      if (gi < NG1) {
+        const int T0 = 2 * (gi / KB), kb = gi % KB;
+        dst[0] = *reinterpret_cast<const f32x4*>(sW1 + (16 * T0 + i) * W1LD + 16 * kb + 4 * g);
+        dst[1] = *reinterpret_cast<const f32x4*>(sW1 + (16 * (T0 + 1) + i) * W1LD + 16 * kb + 4 * g);
+      } else if (gi < NG1 + 8) {
+        const int q = gi - NG1, T0 = 2 * ((q >> 1) & 1), kb = 2 * (q >> 2) + (q & 1);
+        dst[0] = *reinterpret_cast<const f32x4*>(sW2 + (16 * T0 + i) * PSLD + 16 * kb + 4 * g);
+        dst[1] = *reinterpret_cast<const f32x4*>(sW2 + (16 * (T0 + 1) + i) * PSLD + 16 * kb + 4 * g);
+      } else {
+        const int kb = gi - NG1 - 8;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {  // output layer, K blocks 0,1
-#pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
+        for (int o = 0; o < OT; ++o)
+          dst[o] = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
       }
-    }
-    PUT_TILE(sH2, h2[0], 0);
-    PUT_TILE(sH2, h2[1], 1);
-    h2[2] = osa_tanh4(h2[2]);
-    h2[3] = osa_tanh4(h2[3]);
+    };
+    auto mm_group = [&](int gi, const f32x4 (&w)[2]) {
+      if (gi < NG1) {
+        const int T0 = 2 * (gi / KB), kb = gi % KB;
 #pragma unroll
-    for (int kb = 2; kb < 4; ++kb) {
+        for (int s = 0; s < 4; ++s) {
+          h1[T0] = OSA_MFMA(w[0][s], cur.x[kb][s], h1[T0]);
+          h1[T0 + 1] = OSA_MFMA(w[1][s], cur.x[kb][s], h1[T0 + 1]);
+        }
+      } else if (gi < NG1 + 8) {
+        const int q = gi - NG1, T0 = 2 * ((q >> 1) & 1), kb = 2 * (q >> 2) + (q & 1);
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * PSLD + 16 * kb + 4 * g);
+        for (int s = 0; s < 4; ++s) {
+          h2[T0] = OSA_MFMA(w[0][s], h1[kb][s], h2[T0]);
+          h2[T0 + 1] = OSA_MFMA(w[1][s], h1[kb][s], h2[T0 + 1]);
+        }
+      } else {
+        const int kb = gi - NG1 - 8;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[o][s], h2[kb][s], out[o]);
+      }
+    };
+    f32x4 wq[2][2];
+    load_group(0, wq[0]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) load_group(gi + 1, wq[(gi + 1) & 1]);
+      OSA_SB();
+      mm_group(gi, wq[gi & 1]);
+      OSA_SB();
+      // ---- VALU / memory work placed in the shadow of the MFMA groups that follow
+      if (gi == KB) {  // first group of tiles 2,3 issued; tiles 0,1 of layer 1 are complete
+        fetch(row_nxt, pos_ok(cidx + 1), nxt);  // next chunk's gather: in flight until the chunk ends
+        row_nxt = row_of(cidx + 2);
+        h1[0] = osa_tanh4(h1[0]);
+        h1[1] = osa_tanh4(h1[1]);
+      }
+      if (gi == NG1 + 1) {  // layer 2 on K blocks 0,1 under way
+        PUT_TILE(sH1, h1[0], 0);
+        PUT_TILE(sH1, h1[1], 1);
+        h1[2] = osa_tanh4(h1[2]);
+        h1[3] = osa_tanh4(h1[3]);
+      }
+      if (gi == NG1 + 6) {  // tiles 0,1 of layer 2 complete (groups +4, +5)
+        PUT_TILE(sH1, h1[2], 2);
+        PUT_TILE(sH1, h1[3], 3);
+        h2[0] = osa_tanh4(h2[0]);
+        h2[1] = osa_tanh4(h2[1]);
+      }
+      if (gi == NG1 + 8) {  // output layer on K blocks 0,1 under way; tiles 2,3 of layer 2 complete
+        PUT_TILE(sH2, h2[0], 0);
+        PUT_TILE(sH2, h2[1], 1);
+        h2[2] = osa_tanh4(h2[2]);
+        h2[3] = osa_tanh4(h2[3]);
       }
     }
     PUT_TILE(sH2, h2[2], 2);
     PUT_TILE(sH2, h2[3], 3);
-#undef L1_TILES
-#undef L2_STEP
 
     PTICK(1);
     // ================= loss, dL/d(out) =================
