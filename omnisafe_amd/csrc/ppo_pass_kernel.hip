@@ -216,8 +216,11 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
     return perm_p ? perm_p[pc] : pc;
   };
-  auto fetch = [&](long rr, bool ok, Pre& q) {
-    q.valid = ok;
+  // The gather of the NEXT chunk lands in the SAME registers as the current one: the observation part is
+  // re-issued as soon as layer 1 has consumed it, the per-sample scalars as soon as the loss has (no second
+  // buffer: the kernel is register-bound -- 256 + ~250 AGPR in use -- and every spilled value costs VALU
+  // moves that, on gfx950, add to the MFMA time instead of hiding under it).
+  auto fetch_x = [&](long rr, Pre& q) {
     const float* xrow = obs_p + (int)rr * a.ld_obs;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -233,6 +236,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         q.x[kb].w = xrow[min(col0 + 3, last)];
       }
     }
+  };
+  auto fetch_s = [&](long rr, Pre& q) {
     // 32-bit index arithmetic (host guarantees M * ld < 2^31): 64-bit multiplies per load made the
     // prefetch issue itself cost ~1k cycles.  The actor-only loads sit behind a block-uniform branch.
     const int ri = (int)rr;
@@ -259,9 +264,14 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cm[kb][r] = (16 * kb + 4 * g + r) < nd.obs_dim;
-  Pre cur, nxt;
+  Pre cur;
   long cidx = (long)a.mb0 * nchunk;
-  fetch(row_of(cidx), pos_ok(cidx), cur);  // first gather in flight ...
+  {
+    const long r0 = row_of(cidx);
+    fetch_x(r0, cur);  // first gather in flight ...
+    fetch_s(r0, cur);
+    cur.valid = pos_ok(cidx);
+  }
   long row_nxt = row_of(cidx + 1);
   // ... while the remaining weights stream into LDS (matters for the one-step-per-launch dp mode)
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
@@ -375,11 +385,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       OSA_SB();
       // ---- VALU / memory work placed in the shadow of the MFMA groups that follow
       if (gi == KB) {  // first group of tiles 2,3 issued; tiles 0,1 of layer 1 are complete
-        fetch(row_nxt, pos_ok(cidx + 1), nxt);  // next chunk's gather: in flight until the chunk ends
-        row_nxt = row_of(cidx + 2);
         h1[0] = osa_tanh4(h1[0]);
         h1[1] = osa_tanh4(h1[1]);
       }
+      if (gi == NG1 - 1) fetch_x(row_nxt, cur);  // layer 1 has consumed x: next chunk's rows, in place
       if (gi == NG1 + 1) {  // layer 2 on K blocks 0,1 under way
         PUT_TILE(sH1, h1[0], 0);
         PUT_TILE(sH1, h1[1], 1);
@@ -472,6 +481,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
 
     PTICK(2);
+    fetch_s(row_nxt, cur);  // the loss has consumed the per-sample scalars: next chunk's, in place
+    cur.valid = pos_ok(cidx + 1);
+    row_nxt = row_of(cidx + 2);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       PUT_TILE(sDO, dO[o], o);
@@ -604,7 +616,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       }
       gb = (boff >= 0) ? ((MULTI && ch > 0) ? gb + rs : rs) : 0.f;
     }
-    cur = nxt;
     if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
     }  // chunks
     if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
