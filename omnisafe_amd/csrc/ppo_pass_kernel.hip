@@ -264,6 +264,11 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cm[kb][r] = (16 * kb + 4 * g + r) < nd.obs_dim;
+  float dm[OT][4];  // 1 for this lane's real action dimensions, 0 for padding (static per lane)
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dm[o][r] = (16 * o + 4 * g + r) < nd.act_dim ? 1.f : 0.f;
   Pre cur;
   long cidx = (long)a.mb0 * nchunk;
   {
@@ -420,30 +425,28 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (net == 0) {
+      // Branch-free over the action dimensions (dm = 1 for this lane's real dimensions, 0 for padding): the
+      // divergent `if (d < act_dim && valid)` form cost exec-mask juggling on the critical (actor) block.
       float lp = 0.f;
       f32x4 zv[OT], ivar[OT];
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
+        // Normal.log_prob with sigma = exp(log_std): 1/var = exp(-2 log_std) (one hardware exp2),
+        // log(sigma) = log_std (the reference takes log(exp(log_std)): equal to float32 rounding)
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(sLS + 16 * o + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int d = 16 * o + 4 * g + r;
-          zv[o][r] = 0.f;
-          ivar[o][r] = 0.f;
-          if (d < nd.act_dim && valid) {
-            // Normal.log_prob with sigma = exp(log_std): 1/var = exp(-2 log_std) (one hardware exp2),
-            // log(sigma) = log_std (the reference takes log(exp(log_std)): equal to float32 rounding)
-            const float ls = sLS[d];
-            const float iv = __builtin_amdgcn_exp2f(ls * -2.88539008177792681472f);
-            const float z = cur.act[4 * o + r] - out[o][r];
-            zv[o][r] = z;
-            ivar[o][r] = iv;
-            lp += -0.5f * (z * z) * iv - ls - 0.91893853320467274178f;
-          }
+          const float dmr = dm[o][r];
+          const float iv = __builtin_amdgcn_exp2f(ls[r] * -2.88539008177792681472f) * dmr;
+          const float z = cur.act[4 * o + r] - out[o][r];
+          zv[o][r] = z;
+          ivar[o][r] = iv;
+          lp += -0.5f * (z * z) * iv - ls[r] * dmr - 0.91893853320467274178f * dmr;
         }
       }
       lp = osa_sum_over_groups(lp);
-      if (valid) {
-        const float ratio = __builtin_amdgcn_exp2f((lp - cur.logp) * 1.44269504088896340736f);
+      {
+        const float ratio = valid ? __builtin_amdgcn_exp2f((lp - cur.logp) * 1.44269504088896340736f) : 0.f;
         const float adv = (cur.adv_r - lam * cur.adv_c) * inv_1p_lam;
         float dratio, li;
         if (a.loss_kind == 0) {
@@ -457,8 +460,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           li = -(ratio * adv);
           dratio = -adv;
         }
-        const float dlogp = dratio * ratio * invB;
-        if (g == 0) {
+        const float dlogp = valid ? dratio * ratio * invB : 0.f;
+        if (g == 0 && valid) {
           loss_part += li;
           ratio_part += ratio;
         }
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           for (int r = 0; r < 4; ++r) {
             const float z = zv[o][r], iv = ivar[o][r];
             dO[o][r] = dlogp * z * iv;
-            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) : 0.f;
+            dLS[o][r] = dlogp * (z * z * iv - dm[o][r]);
           }
         }
       }
