@@ -208,7 +208,9 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
  * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above.  A step with
  * B > 64 rows accumulates ceil(B/64) chunks in the accumulator registers before its clip + Adam.  Single
  * process only (world_size == 1: the data-parallel path needs an all-reduce between gradient and
- * Adam and uses osa_ppo_minibatch).  osa_ppo_pass_supported: 1 if (obs_dim, act_dim, hidden) fit. */
+ * Adam and uses osa_ppo_minibatch).  osa_ppo_pass_supported: 1 if (obs_dim, act_dim, hidden) fit.
+ * The observation rows must be 16-byte aligned with ld_obs % 4 == 0 (OSA_EUNSUPPORTED otherwise -- pad
+ * the rows; the same holds for osa_ppo_dp_step / osa_ppo_dp_pass). */
 int osa_ppo_pass_supported(int obs_dim, int act_dim, int hidden);
 int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                  int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
   const float inv_1p_lam = 1.f / (1.f + lam);
-  const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
+  // observation rows are 16-byte aligned with ld % 4 == 0 (checked by the entry points; the host pads
+  // other layouts once per update): one code path, no branch inside the forward scheduling region
+  constexpr bool vec_ok = true;
   const float* __restrict__ tgt = ((net == 1) ? a.tgt_r : a.tgt_c) + roff;
 
   // ---- prefetch machinery: everything this lane needs for its sample of one minibatch.
@@ -979,6 +981,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
   if ((double)M * ld_obs >= 2147483647.0 || (double)M * ld_act >= 2147483647.0) return OSA_EUNSUPPORTED;
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
   OsaPassArgs a;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -1090,6 +1093,7 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && step_index >= 0 && (long)step_index * B < M);
   if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
   OsaPassArgs a;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -1141,6 +1145,7 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(exchange && sync && ld_obs >= obs_dim && ld_act >= act_dim);
   if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
   // all 3 * world workgroups must be co-resident (one per compute unit: ~150 KB of LDS each)
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||

@@ -269,6 +269,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.profile_events.append(('osa_ppo_dp_step', W * M, ev))
         stats_rows.copy_(st['pass_stats'][:stats_rows.shape[0]])
 
+    def _aligned_rows(self, data: dict) -> dict:
+        """The persistent kernels read observation rows with 16-byte loads: rows must be 16-byte aligned
+        with a leading dimension that is a multiple of 4 floats.  buffer.get() of the BASELINE shapes
+        complies (D_o = 60, 72, 376); anything else (e.g. D_o = 27) is padded once per update."""
+        obs = data['obs']
+        if obs.stride(0) % 4 == 0 and obs.data_ptr() % 16 == 0 and obs.stride(1) == 1:
+            return data
+        M, D = obs.shape
+        pad = torch.zeros(M, (D + 3) // 4 * 4, dtype=torch.float32, device=obs.device)
+        pad[:, :D].copy_(obs)
+        out = dict(data)
+        out['obs'] = pad[:, :D]  # a view: shape (M, D), row stride = padded width
+        return out
+
     def snapshot_old_distribution(self, obs: torch.Tensor) -> None:
         """old_distribution = actor(obs) (policy_gradient.py:357)."""
         ac, M = self.ac, obs.shape[0]
@@ -319,11 +333,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
         use_pass = self._pass_fn is not None
         W = dist.world_size()
+        data = self._aligned_rows(data)
         use_repl = (W > 1 and self.ext is None and self.update_critics
                     and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         if use_repl:
-            gathered = self.gather_for_replicated(data, W)
+            gathered = self._aligned_rows(self.gather_for_replicated(data, W))
         # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
         # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
         all_perms = None
