@@ -75,7 +75,7 @@ class OsaError(RuntimeError):
 
 
 def lib_path() -> str:
-    # OSA_LIB_PATH: an alternative build of the same library (tools/build_clocks_lib.sh: phase clocks)
+    # OSA_LIB_PATH: an alternative build of the same library (tools/build_variant_lib.sh: phase clocks)
     return os.environ.get('OSA_LIB_PATH') or _build.LIB_PATH
 
 
