@@ -172,8 +172,9 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
         lg = self._logger
         ratio = summ['per_step']['ratio_mean']
-        for v in ratio:  # min/max/std are over minibatch means, as in the reference (logger.py:277)
-            lg.store({'Train/PolicyRatio': float(v)})
+        # min/max/std are over minibatch means, as in the reference (logger.py:277); one bulk append instead
+        # of 40 960 logger.store calls per epoch
+        lg.extend('Train/PolicyRatio', ratio.tolist())
         lg.store({'Train/Entropy': summ['Train/Entropy'], 'Loss/Loss_pi': summ['Loss/Loss_pi'],
                   'Loss/Loss_reward_critic': summ['Loss/Loss_reward_critic'],
                   'Train/PolicyStd': self._actor_critic.actor.std})

@@ -279,8 +279,7 @@ class CUP(_LagrangeMixin, PPO):
                                  critic_lr=0.0)
         st = out['stats'].double().cpu()
         lg = self._logger
-        for v in st[:, 3]:
-            lg.store({'Train/SecondStepPolicyRatio': float(v)})
+        lg.extend('Train/SecondStepPolicyRatio', st[:, 3].tolist())
         lg.store({'Loss/Loss_pi_c': float(st[:, 2].mean()), 'Train/SecondStepEntropy': float(st[:, 4].mean()),
                   'Train/SecondStepStopIter': out['stop_iter']})
 

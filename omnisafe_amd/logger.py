@@ -91,7 +91,7 @@ class Logger:  # pylint: disable=too-many-instance-attributes
     def extend(self, key: str, values) -> None:
         """Append many scalars at once (per-episode metrics extracted from the device once per epoch)."""
         assert key in self._current_row, f'Key {key} has not been registered'
-        self._data[key].extend(float(v) for v in values)
+        self._data[key].extend(values if isinstance(values, list) else [float(v) for v in values])
 
     def get_stats(self, key: str, min_and_max: bool = False) -> tuple[float, ...]:
         """logger.py:344-374 via dist_statistics_scalar (distributed.py:361-393): global mean (and
