@@ -196,9 +196,14 @@ __device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* _
 
 // Sum over the 4 lane groups g (same sample j in lanes j, j+16, j+32, j+48).
 __device__ __forceinline__ float osa_sum_over_groups(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  // lanes l, l^16, l^32, l^48 (the four lane groups of a sample) -> their sum in all four.  gfx950's
+  // v_permlane{16,32}_swap exchange row pairs inside the VALU: both results together are {own, partner}
+  // (in either order), so their sum is v + v[l ^ 16] -- the same bits as the former ds_bpermute shuffles
+  // without two dependent LDS-pipe round trips.
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // ---- Philox4x32-10 counter-based generator + Box-Muller (device-resident rollout noise) ------------

@@ -125,6 +125,11 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   float* __restrict__ gv = a.adam_v + (long)net * P;
   const bool critic = net != 0;
   const int out_dim = critic ? 1 : nd.act_dim;
+  // 1-2 real outputs (every critic; the actor of the 2-D action spaces): the output layer, its backward and
+  // its weight gradient run on the VALU -- on gfx950 a float32 MFMA costs the same issue cycles as the
+  // equivalent packed VALU math and does not overlap with it, so 48 MFMAs on a 16-wide tile that is 7/8
+  // padding are pure waste (block-uniform switch; wider outputs keep the MFMA tiles)
+  const bool small_out = (OT == 1) && out_dim <= 2;
 
   // ---- load parameters into the LDS master copy (coalesced)
   for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         const int q = gi - NG1, T0 = 2 * ((q >> 1) & 1), kb = 2 * (q >> 2) + (q & 1);
         dst[0] = *reinterpret_cast<const f32x4*>(sW2 + (16 * T0 + i) * PSLD + 16 * kb + 4 * g);
         dst[1] = *reinterpret_cast<const f32x4*>(sW2 + (16 * (T0 + 1) + i) * PSLD + 16 * kb + 4 * g);
-      } else {
+      } else if (!small_out) {
         const int kb = gi - NG1 - 8;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           h2[T0] = OSA_MFMA(w[0][s], h1[kb][s], h2[T0]);
           h2[T0 + 1] = OSA_MFMA(w[1][s], h1[kb][s], h2[T0 + 1]);
         }
-      } else {
+      } else if (!small_out) {
         const int kb = gi - NG1 - 8;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
@@ -417,6 +422,26 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     PUT_TILE(sH2, h2[2], 2);
     PUT_TILE(sH2, h2[3], 3);
+    if (small_out) {
+      // out[d] = b3[d] + sum_f W3[d][f] h2[f]: each lane holds 16 of the 64 features of its sample
+      float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW3 + 16 * t + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sW3 + PSLD + 16 * t + 4 * g);  // zero row if 1 output
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0 = fmaf(w0[r], h2[t][r], p0);
+          p1 = fmaf(w1[r], h2[t][r], p1);
+        }
+      }
+      p0 = osa_sum_over_groups(p0);
+      p1 = osa_sum_over_groups(p1);
+      if (g == 0) {  // lane group 0 holds output dimensions 0..3 of its sample (out[] starts as the bias)
+        out[0][0] += p0;
+        out[0][1] += p1;
+      }
+    }
 
     PTICK(1);
     // ================= loss, dL/d(out) =================
@@ -503,7 +528,20 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
     for (int t = 0; t < HT; ++t) z2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float wt[2][4][HT];
-    {
+    if (small_out) {
+      // z2[f] = sum_d W3[d][f] dO[d] with dO of this lane's sample held by lane group 0 (d = r)
+      const float d0 = __shfl(dO[0][0], j, 64), d1 = __shfl(dO[0][1], j, 64);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)  // first W2^T block, in flight meanwhile
+#pragma unroll
+        for (int t = 0; t < HT; ++t) wt[0][s][t] = sW2[(4 * g + s) * PSLD + 16 * t + i];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW3 + 16 * t + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sW3 + PSLD + 16 * t + 4 * g);
+        z2[t] = w0 * d0 + w1 * d1;
+      }
+    } else {
       float w3t[OT][4][HT];
 #pragma unroll
       for (int o = 0; o < OT; ++o)
@@ -585,16 +623,39 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
           for (int kb = 0; kb < KB; ++kb) g1[kb] = OSA_MFMA(a1[sb][s], b[kb][s], g1[kb]);
       }
+      if (small_out) {
+        // dW3[d][f] = sum_s dO[d][s] h2[f][s] for this lane's column f = 16 wave + cc: lane group g takes
+        // samples 16g .. 16g+15, the four partial sums are combined across the groups
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * PSLD + 16 * g + 4 * k);
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sDO + 16 * g + 4 * k);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(sDO + PSLD + 16 * g + 4 * k);
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * PSLD + 16 * sb + 4 * g);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
-          g3[o] = OSA_MFMA(av.x, b.x, g3[o]);
-          g3[o] = OSA_MFMA(av.y, b.y, g3[o]);
-          g3[o] = OSA_MFMA(av.z, b.z, g3[o]);
-          g3[o] = OSA_MFMA(av.w, b.w, g3[o]);
+          for (int r = 0; r < 4; ++r) {
+            q0 = fmaf(a0[r], hv[r], q0);
+            q1 = fmaf(a1[r], hv[r], q1);
+          }
+        }
+        q0 = osa_sum_over_groups(q0);
+        q1 = osa_sum_over_groups(q1);
+        if (g == 0) {
+          g3[0][0] += q0;
+          g3[0][1] += q1;
+        }
+      } else {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * PSLD + 16 * sb + 4 * g);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * PSLD + 16 * sb + 4 * g);
+            g3[o] = OSA_MFMA(av.x, b.x, g3[o]);
+            g3[o] = OSA_MFMA(av.y, b.y, g3[o]);
+            g3[o] = OSA_MFMA(av.z, b.z, g3[o]);
+            g3[o] = OSA_MFMA(av.w, b.w, g3[o]);
+          }
         }
       }
     }

@@ -266,15 +266,17 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
         acs.append(ac)
     assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
     assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
-    # B <= 64: identical operation order (bit-equal in practice).  B > 64: the pass kernel accumulates
-    # the 64-row chunks in registers, the per-step path reduces per-workgroup slabs -- a different
-    # float32 summation order that Adam's m/sqrt(v) amplifies to ~1e-6 in the parameters.
-    atol = 1e-7 if B <= 64 else 5e-6
+    # B <= 64: the same operation order except for the 1-2-output layers, which the pass kernel evaluates
+    # on the VALU (16-term partial dot products per lane group) and the per-step kernels on MFMA tiles:
+    # float32 summation-order differences of ~1e-7.  B > 64: the pass kernel accumulates the 64-row chunks
+    # in registers, the per-step path reduces per-workgroup slabs -- Adam's m/sqrt(v) amplifies that
+    # order difference to ~1e-6 in the parameters.
+    atol = 5e-7 if B <= 64 else 5e-6
     for name in ('params', 'adam_m', 'adam_v'):
         a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=name)
     s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
-    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=2e-7)
     np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
 
 
