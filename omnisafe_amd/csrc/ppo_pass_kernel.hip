@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     // value is final, in the shadow of the MFMAs that follow, instead of in one block before barrier (A)
 #define PUT_TILE(S, V, T)                                                           \
   _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (S)[(16 * (T) + 4 * g + r_) * PSLD + c] = (V)[r_]
-    // deferred masking of the prefetched observation chunks (padding columns, invalid rows)
+    // deferred masking of the prefetched observation chunks (padding columns)
+    // only the last K block can contain padding columns; rows of a ragged last minibatch were gathered from
+    // clamped (valid, finite) addresses and meet dL/dout = 0 downstream, so they need no masking
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cur.x[kb][r] = (valid && cm[kb][r]) ? cur.x[kb][r] : 0.f;
+    for (int r = 0; r < 4; ++r) cur.x[KB - 1][r] = cm[KB - 1][r] ? cur.x[KB - 1][r] : 0.f;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) PUT_TILE(sX, cur.x[kb], kb);
     // ================= forward (S layout; weights from the LDS master) =================
