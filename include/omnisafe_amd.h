@@ -205,7 +205,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
  * loop (policy_gradient.py:366-382) -- ceil(M/B) dependent minibatch steps over the permutation
  * perm[M] (NULL = identity) -- for all three networks, with the parameters resident in LDS
  * and the Adam moments in registers for the whole pass (see csrc/ppo_pass_kernel.hip).  Same
- * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above.  A step with
+ * arithmetic per step as osa_ppo_minibatch(mode 0); step_stats[ceil(M/B)][16] as above (columns 10..15
+ * additionally receive the three networks' Adam bias-correction factors of the step).  A step with
  * B > 64 rows accumulates ceil(B/64) chunks in the accumulator registers before its clip + Adam.  Single
  * process only (world_size == 1: the data-parallel path needs an all-reduce between gradient and
  * Adam and uses osa_ppo_minibatch).  osa_ppo_pass_supported: 1 if (obs_dim, act_dim, hidden) fit.

@@ -183,13 +183,20 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     vb_ = gv[boff];
   }
   const int step0 = dp ? 0 : a.adam_step[net];
-  double b1pow = 1.0, b2pow = 1.0;
-  if (!dp) {
-    b1pow = pow((double)a.hp.beta1, (double)step0);
-    b2pow = pow((double)a.hp.beta2, (double)step0);
-  }
   const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
+  // Adam's bias corrections of every step of the launch -- step_size = lr / (1 - beta1^t) and
+  // 1 / sqrt(1 - beta2^t), float64 like torch -- are tabulated once (columns 10 + 2 net, 11 + 2 net of the
+  // step's statistics row), 256 steps in parallel, instead of ~60 float64 VALU instructions (a division and
+  // a square root) executed redundantly by every lane in every step.
+  if (!dp) {
+    for (int k = tid; k < a.nmb; k += 256) {
+      const double t = (double)(step0 + k + 1);
+      float* row = a.stats + (long)k * PNSTAT;
+      row[10 + 2 * net] = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+      row[11 + 2 * net] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+    }
+  }
   const bool l2 = critic && a.hp.use_critic_norm;
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
@@ -307,6 +314,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int kb = 0; kb < KB; ++kb) g1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int o = 0; o < OT; ++o) g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ bc_row = a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
+    const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];  // tabulated in the prologue; used by Adam
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
     if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
@@ -894,10 +903,6 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       }
     }
     // ================= Adam on the owned parameters; LDS master updated in place =================
-    b1pow *= (double)beta1;
-    b2pow *= (double)beta2;
-    const float step_size = (float)((double)lr / (1.0 - b1pow));
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
     const float gscale = apply_clip ? coef : 1.f;
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
