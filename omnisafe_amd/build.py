@@ -18,6 +18,9 @@ CSRC = os.path.join(PKG, 'csrc')
 LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libomnisafe_amd.so')
 ARCH = 'gfx950'
+# per-source compiler options.  Pass kernel: let MFMA results land in architectural VGPRs where they are
+# consumed by VALU code (tanh, norms, Adam) instead of AGPRs + v_accvgpr_read moves (-0.8 % step time)
+PER_FILE_FLAGS = {'ppo_pass_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _hipcc() -> str:
@@ -52,7 +55,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))):
             cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
-                   '-Wall', '-Wno-unused-function'] + os.environ.get('OSA_EXTRA_CFLAGS', '').split()
+                   '-Wall', '-Wno-unused-function'] + PER_FILE_FLAGS.get(os.path.basename(src), []) + \
+                os.environ.get('OSA_EXTRA_CFLAGS', '').split()
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 SUF=$1; shift
 python -m omnisafe_amd.build >/dev/null
 L=omnisafe_amd/lib
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c omnisafe_amd/csrc/ppo_pass_kernel.hip -o $L/ppo_pass_kernel_$SUF.hip.o -Wall -Wno-unused-function
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c omnisafe_amd/csrc/ppo_pass_kernel.hip -o $L/ppo_pass_kernel_$SUF.hip.o -Wall -Wno-unused-function
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libomnisafe_amd_$SUF.so $L/buffer_kernels.hip.o $L/mlp_kernels.hip.o $L/rollout_kernels.hip.o $L/ppo_pass_kernel_$SUF.hip.o
 echo $L/libomnisafe_amd_$SUF.so
