@@ -714,11 +714,22 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     float wb = *sbias;
     wb = (boff >= 0) ? wb : 0.f;
     __builtin_amdgcn_sched_barrier(0);
+    // cooperative mode: this rank's UNSCALED gradient tiles are published as soon as they are final -- the
+    // stores drain to memory while the norm is reduced; the clip factor follows in the slab's tail and every
+    // peer forms the same products g_r * clip_r
+    constexpr int NT = HT + KB + OT, XS = NT * 1024 + 256 + PNSTAT;
+    float* __restrict__ xbase = nullptr;
+    f32x4* __restrict__ xs4 = nullptr;
+    if constexpr (coop) {
+      xbase = a.dp_slabs + ((long)((mb - a.mb0) & 1) * 3 + net) * a.dp_world * XS;
+      xs4 = reinterpret_cast<f32x4*>(xbase + (long)rk * XS);
+    }
     f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
       const f32x4 w = w2r[ti];
       if (l2) g2[ti] = g2[ti] + w * c2;
+      if constexpr (coop) xs4[ti * 256 + tid] = g2[ti];
       acc_p = acc_p + w * w;
       acc_g = acc_g + g2[ti] * g2[ti];
     }
@@ -726,6 +737,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int kb = 0; kb < KB; ++kb) {
       const f32x4 w = w1r[kb];
       if (l2) g1[kb] = g1[kb] + w * c2;
+      if constexpr (coop) xs4[(HT + kb) * 256 + tid] = g1[kb];
       acc_p = acc_p + w * w;
       acc_g = acc_g + g1[kb] * g1[kb];
     }
@@ -733,6 +745,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int o = 0; o < OT; ++o) {
       const f32x4 w = w3r[o];
       if (l2) g3[o] = g3[o] + w * c2;
+      if constexpr (coop) xs4[(HT + KB + o) * 256 + tid] = g3[o];
       acc_p = acc_p + w * w;
       acc_g = acc_g + g3[o] * g3[o];
     }
@@ -743,6 +756,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       psq += wb * wb;
       gsq += gb * gb;
     }
+    if constexpr (coop) reinterpret_cast<float*>(xs4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
     // ---- block reduction of (gsq, psq, loss, ratio): wave shuffles, then a fixed-order sum
     gsq = osa_wave_sum_dpp(gsq);
     psq = osa_wave_sum_dpp(psq);
@@ -800,26 +814,13 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     if (net == 0) st_loss -= a.hp.entropy_coef * ent_pre;
     bool apply_clip = a.hp.use_max_grad_norm != 0;
     if constexpr (coop) {
-      // ---- publish this rank's clipped gradient (exchange layout: one f32x4 per thread per tile, so
-      // every store/load instruction of a wave moves 1 KB contiguous)
-      constexpr int NT = HT + KB + OT, XS = NT * 1024 + 256 + PNSTAT;
-      const int W = a.dp_world, par = (mb - a.mb0) & 1;
-      float* __restrict__ xbase = a.dp_slabs + ((long)par * 3 + net) * W * XS;
-      {
-        float* __restrict__ xs = xbase + (long)rk * XS;
-        f32x4* __restrict__ x4 = reinterpret_cast<f32x4*>(xs);
-        const float gs = apply_clip ? coef : 1.f;
-#pragma unroll
-        for (int ti = 0; ti < HT; ++ti) x4[ti * 256 + tid] = g2[ti] * gs;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) x4[(HT + kb) * 256 + tid] = g1[kb] * gs;
-#pragma unroll
-        for (int o = 0; o < OT; ++o) x4[(HT + KB + o) * 256 + tid] = g3[o] * gs;
-        xs[NT * 1024 + tid] = (boff >= 0) ? gb * gs : 0.f;
-        if (tid == 0) {
-          float* t = xs + NT * 1024 + 256;
-          t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent;
-        }
+      // ---- the gradient tiles are on their way (exchange layout: one f32x4 per thread per tile, 1 KB
+      // contiguous per wave instruction); complete the slab with the clip factor and the statistics
+      const int W = a.dp_world;
+      const float gs = apply_clip ? coef : 1.f;
+      if (tid == 0) {
+        float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
+        t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       constexpr int RU = 4;
       for (int r0 = 0; r0 < W; r0 += RU) {
         f32x4 t[RU][NT];
-        float tb[RU];
+        float tb[RU], tg[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
           const float* __restrict__ xr = xbase + (long)min(r0 + u, W - 1) * XS;
@@ -868,17 +869,18 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
           for (int q = 0; q < NT; ++q) t[u][q] = x4[q * 256 + tid];
           tb[u] = xr[NT * 1024 + tid];
+          tg[u] = xr[NT * 1024 + 256 + 5];
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
           if (r0 + u < W) {  // workgroup-uniform
 #pragma unroll
-            for (int ti = 0; ti < HT; ++ti) s2[ti] = s2[ti] + t[u][ti];
+            for (int ti = 0; ti < HT; ++ti) s2[ti] = s2[ti] + t[u][ti] * tg[u];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) s1[kb] = s1[kb] + t[u][HT + kb];
+            for (int kb = 0; kb < KB; ++kb) s1[kb] = s1[kb] + t[u][HT + kb] * tg[u];
 #pragma unroll
-            for (int o = 0; o < OT; ++o) s3[o] = s3[o] + t[u][HT + KB + o];
-            sb_ += tb[u];
+            for (int o = 0; o < OT; ++o) s3[o] = s3[o] + t[u][HT + KB + o] * tg[u];
+            sb_ += tb[u] * tg[u];
           }
         }
       }
