@@ -247,3 +247,11 @@ __device__ __forceinline__ void osa_box_muller(uint32_t a, uint32_t b, float& n0
   n0 = r * c;
   n1 = r * s;
 }
+
+// Defined in ppo_pass_kernel.hip: the gradient of one large minibatch on the persistent kernel's machinery
+// (see there); slabs: [3][nblk][P + 16] partial gradients in the parameter layout.
+int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, const float* obs, int ld_obs,
+                          const float* act, int ld_act, const float* logp, const float* target_value_r,
+                          const float* target_value_c, const float* adv_r, const float* adv_c,
+                          const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
+                          int loss_kind, int nets_mask, int nblk, float* slabs, void* stream);

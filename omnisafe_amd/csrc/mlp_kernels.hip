@@ -1064,6 +1064,31 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   if (nblk > max_blocks) nblk = max_blocks;
   if (nblk > 1) OSA_REQUIRE(ws != nullptr);
   a.nblk = nblk; a.slabs = ws;
+  // Large minibatches: the gradient on the persistent kernel's machinery -- min(nblk, ~CUs/3) workgroups per
+  // network keep the weights in LDS and their partial gradient in registers over several 64-row chunks and
+  // write ONE slab each (this kernel re-reads the weights from L2 for every chunk and read-modify-writes
+  // its slab in global memory per chunk).  Same slab reduce + clip/Adam afterwards.
+  if (!ext && B >= 2048 && nblk > 1 && loss_kind <= 1) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 3) {
+      int pb = cus / 3;
+      if (pb > nblk) pb = nblk;
+      const int prc = osa_pass_partial_grad(obs_dim, act_dim, hidden, params, obs, ld_obs, act, ld_act, logp,
+                                            target_value_r, target_value_c, adv_r, adv_c, idx, B, lagrange,
+                                            hp, loss_kind, a.nets_mask, pb, ws, stream);
+      if (prc == OSA_OK) {
+        a.nblk = pb;
+        const int W = a.nd.P + OSA_NSTAT;
+        hipLaunchKernelGGL(osa_slab_reduce_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
+                           osa_stream(stream), a);
+        hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 1);
+        OSA_CHECK_LAUNCH();
+        return OSA_OK;
+      }
+      if (prc != OSA_EUNSUPPORTED) return prc;
+    }
+  }
   const size_t lds = osa_mb_lds_bytes(a.nd);
 #define OSA_CALL(HT, OT)                                                                          \
   do {                                                                                            \

@@ -64,6 +64,10 @@ struct OsaPassArgs {
   // network: all peers perform identical arithmetic, so their copies stay bit-identical and nothing
   // but gradients ever crosses between compute units.
   int* dp_sync;     // [4]: arrival counters of the three networks + sticky time-out flag; or nullptr
+  // partial-gradient mode of the large-batch step (osa_pass_partial_grad): grid (3, part_stride); workgroup
+  // (net, b) accumulates the 64-row chunks b, b + part_stride, ... of ONE minibatch in its registers and
+  // writes the raw sum (no L2 term, no clip) to slab b of dp_slabs; slab reduce + clip/Adam follow.
+  int part_stride;  // 0 = off
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const int rk = blockIdx.y;  // virtual rank (0 outside the data-parallel mode)
   constexpr bool coop = COOP;
   const bool dp = a.dp_slabs != nullptr && !coop;
-  const long roff = (long)rk * a.M;
+  const bool part = a.part_stride > 0;
+  const long roff = part ? 0 : (long)rk * a.M;
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
   const float* __restrict__ logp_p = a.logp + roff;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       row[11 + 2 * net] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
     }
   }
-  const bool l2 = critic && a.hp.use_critic_norm;
+  const bool l2 = critic && a.hp.use_critic_norm && !part;  // (partial sums get the L2 term once, later)
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
@@ -219,14 +224,17 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     bool valid;
   };
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
-  const int nchunk = MULTI ? (a.B + 63) / 64 : 1;
+  // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
+  const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
+  const int cstride = part ? a.part_stride : 1, cfirst = part ? rk : 0;
+  const int nchunk = part ? (nchunk_all - cfirst + cstride - 1) / cstride : nchunk_all;
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
-    const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
+    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
     const long inb = ch * 64 + 16 * wave + j;
     return (mb < a.mb0 + a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
   };
   auto row_of = [&](long cidx) -> long {  // raw (unconsumed) load of the permutation entry
-    const long mb = cidx / nchunk, ch = cidx - mb * nchunk;
+    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
     const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
     return perm_p ? perm_p[pc] : pc;
   };
@@ -314,8 +322,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int kb = 0; kb < KB; ++kb) g1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int o = 0; o < OT; ++o) g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ bc_row = a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
-    const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];  // tabulated in the prologue; used by Adam
+    float step_size = 0.f, inv_bc2_sqrt = 0.f;  // tabulated in the prologue; used by Adam
+    if (!dp) {
+      const float* __restrict__ bc_row = a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
+      step_size = bc_row[0];
+      inv_bc2_sqrt = bc_row[1];
+    }
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
     if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       // publish the locally clipped gradient of (net, rk) and its statistics; reduce + Adam follow in
       // osa_dp_apply_kernel (clip-then-average order of policy_gradient.py:437-442)
       float* __restrict__ slab = a.dp_slabs + ((long)net * a.dp_world + rk) * (P + PNSTAT);
-      const float gs = a.hp.use_max_grad_norm ? coef : 1.f;
+      const float gs = (a.hp.use_max_grad_norm && !part) ? coef : 1.f;
 #pragma unroll
       for (int ti = 0; ti < HT; ++ti)
 #pragma unroll
@@ -800,7 +812,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         for (int r = 0; r < 4; ++r) slab[nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc] = g3[o][r] * gs;
       if (boff >= 0) slab[boff] = gb * gs;
       if (critic && tid < OUTP) slab[nd.oLS + tid] = 0.f;
-      if (tid == 0) {
+      if (tid == 0 && part) {  // raw sums: osa_slab_reduce_kernel adds the slabs and normalises
+        slab[P + 0] = t_loss;
+        slab[P + 1] = t_ratio;
+      } else if (tid == 0) {
         slab[P + 0] = t_loss * invB - (net == 0 ? a.hp.entropy_coef * ent_pre : 0.f);
         slab[P + 1] = t_ratio * invB;
         slab[P + 2] = t_psq;
@@ -1063,7 +1078,7 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   a.dbg = g_osa_pass_dbg;
-  a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0; a.dp_sync = nullptr;
+  a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0; a.dp_sync = nullptr; a.part_stride = 0;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PASS_CASE(K, O) \
@@ -1174,7 +1189,7 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
-  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = world; a.mb0 = step_index; a.dp_sync = nullptr;
+  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = world; a.mb0 = step_index; a.dp_sync = nullptr; a.part_stride = 0;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
   int rc = OSA_EUNSUPPORTED;
@@ -1232,7 +1247,7 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
-  a.dbg = g_osa_pass_dbg; a.dp_slabs = exchange; a.dp_world = world; a.mb0 = 0; a.dp_sync = sync;
+  a.dbg = g_osa_pass_dbg; a.dp_slabs = exchange; a.dp_world = world; a.mb0 = 0; a.dp_sync = sync; a.part_stride = 0;
   hipStream_t st = osa_stream(stream);
   if (hipMemsetAsync(sync, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
@@ -1245,6 +1260,44 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
 #undef OSA_DPP_CASE
   return OSA_EUNSUPPORTED;
 }
+
+}  // extern "C"
+
+// Large-batch gradient on the persistent kernel's machinery (called by osa_ppo_minibatch_ext): nblk
+// workgroups per network, LDS-resident weights, register accumulators, one raw partial-gradient slab each.
+int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, const float* obs, int ld_obs,
+                          const float* act, int ld_act, const float* logp, const float* target_value_r,
+                          const float* target_value_c, const float* adv_r, const float* adv_c,
+                          const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
+                          int loss_kind, int nets_mask, int nblk, float* slabs, void* stream) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || B <= 64) return OSA_EUNSUPPORTED;
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;
+  OsaPassArgs a;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.params = params; a.adam_m = params; a.adam_v = params; a.adam_step = nullptr;  // untouched in this mode
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = idx; a.M = B; a.B = B; a.nmb = 1; a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask; a.stats = nullptr;
+  a.dbg = nullptr; a.dp_slabs = slabs; a.dp_world = nblk; a.mb0 = 0; a.dp_sync = nullptr;
+  a.part_stride = nblk;
+  const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
+  hipStream_t st = osa_stream(stream);
+#define OSA_PG_CASE(K, O) \
+  if (KB == K && OT == O) return osa_launch_pass<K, O, true>(a, st, nblk)
+  OSA_PG_CASE(1, 1); OSA_PG_CASE(2, 1); OSA_PG_CASE(3, 1); OSA_PG_CASE(4, 1); OSA_PG_CASE(5, 1);
+  OSA_PG_CASE(6, 1); OSA_PG_CASE(1, 2); OSA_PG_CASE(2, 2); OSA_PG_CASE(3, 2); OSA_PG_CASE(4, 2);
+  OSA_PG_CASE(5, 2); OSA_PG_CASE(6, 2);
+#undef OSA_PG_CASE
+  return OSA_EUNSUPPORTED;
+}
+
+extern "C" {
 
 int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream) {
   OSA_REQUIRE(adam_step && nsteps > 0);

@@ -201,12 +201,15 @@ def test_ppolag_update_vs_reference(golden):
                                        err_msg=f'{net}/{k}')
 
 
-def test_large_batch_multiblock_equals_single_pass():
-    """B = 4096 rows split over 64 workgroups + slab reduction == oracle full-batch step."""
+@pytest.mark.parametrize('M,obs_dim,act_dim', [(4096, 60, 2), (5000, 72, 8), (2500, 27, 8)])
+def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
+    """A large minibatch split over up to 64 workgroups + slab reduction == oracle full-batch step: B = 4096
+    and a ragged B = 5000 with an 8-D action space on the persistent kernel's partial-gradient mode
+    (LDS-resident weights, register accumulators), B = 2500 with unaligned 27-float rows on the per-chunk
+    kernel."""
     from omnisafe_amd.update import PPOUpdater
 
     torch.manual_seed(3)
-    M, obs_dim, act_dim = 4096, 60, 2
     ref = O.ActorCritic(obs_dim, act_dim)
     ac = make_ac(obs_dim, act_dim)
     for net in ('actor', 'reward_critic', 'cost_critic'):
