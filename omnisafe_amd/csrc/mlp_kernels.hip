@@ -670,18 +670,16 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_kernel(OsaMbArgs a) {
   const int W = nd.P + OSA_NSTAT;
   if (e >= W) return;
   const float* s = a.slabs + (long)net * a.nblk * W + e;
-  // four independent partial sums (slab b goes to partial b mod 4), combined in a fixed order: four
+  // eight independent partial sums (slab b goes to partial b mod 8), combined in a fixed order: eight
   // times the loads in flight of a single running sum, still deterministic
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int b = 0;
-  for (; b + 4 <= a.nblk; b += 4) {
-    p0 += s[(long)b * W];
-    p1 += s[(long)(b + 1) * W];
-    p2 += s[(long)(b + 2) * W];
-    p3 += s[(long)(b + 3) * W];
+  for (; b + 8 <= a.nblk; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += s[(long)(b + u) * W];
   }
-  for (; b < a.nblk; ++b) p0 += s[(long)b * W];
-  const float acc = (p0 + p1) + (p2 + p3);
+  for (; b < a.nblk; ++b) p[0] += s[(long)b * W];
+  const float acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   if (e < nd.P) {
     a.grads[(long)net * nd.P + e] = acc;
   } else {
