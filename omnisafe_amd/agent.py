@@ -55,6 +55,12 @@ class Agent:  # the reference exposes AlgoWrapper under this name (omnisafe/__in
             dev = f'cuda:{local}'
             self.cfgs.train_cfgs.recurisve_update({'device': dev})
         os.environ['OMNISAFE_DEVICE'] = dev
+        # algo_wrapper.py:160-165: on a GPU device the reference runs the host side on ONE torch thread (the
+        # remaining host work is scalar: Lagrange step, logger); without the cap every tiny CPU reduction
+        # spins up an OpenMP team as large as the host
+        import torch
+
+        torch.set_num_threads(1)
         self.agent = registry.get(self.algo)(env_id=self.env_id, cfgs=self.cfgs)
 
     def learn(self) -> tuple[float, float, float]:

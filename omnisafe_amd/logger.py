@@ -97,16 +97,20 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         """logger.py:344-374 via dist_statistics_scalar (distributed.py:361-393): global mean (and
         population std / min / max) over all ranks' values.  Unlike the reference, min/max use scalar
         reductions (the reference all-reduces a vector whose length may differ per rank)."""
-        vals = torch.tensor(list(self._data[key]), dtype=torch.float32)
         if dist.world_size() == 1:
-            if len(vals) == 0:
+            # float32 numpy reductions: torch CPU ops would open an OpenMP region per call, which costs
+            # milliseconds on many-core hosts and sits on the epoch's critical path (the GPU idles meanwhile)
+            vals = np.asarray(self._data[key], dtype=np.float32)
+            n = vals.size
+            if n == 0:
                 nan = float('nan')
                 return (nan, nan, nan, nan) if min_and_max else (nan,)
-            mean = vals.sum() / len(vals)
+            mean = vals.sum(dtype=np.float32) / np.float32(n)
             if not min_and_max:
-                return (mean.item(),)
-            std = torch.sqrt(((vals - mean) ** 2).sum() / len(vals))
-            return mean.item(), vals.min().item(), vals.max().item(), std.item()
+                return (float(mean),)
+            std = np.sqrt(((vals - mean) ** 2).sum(dtype=np.float32) / np.float32(n))
+            return float(mean), float(vals.min()), float(vals.max()), float(std)
+        vals = torch.tensor(list(self._data[key]), dtype=torch.float32)
         return _dist_stats(vals, min_and_max)
 
     def dump_tabular(self) -> None:

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -385,7 +386,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def summarize(run_out: dict, critic_norm_coef: float, use_critic_norm: bool) -> dict:
         """Per-key means over the optimiser steps of the epoch (what Logger.get_stats averages,
         omnisafe/common/logger.py:359-374), from ONE device->host copy."""
-        s = run_out['stats'].double().cpu()
+        s = run_out['stats'].cpu().numpy().astype(np.float64)  # numpy: no OpenMP region per reduction
         coef = critic_norm_coef if use_critic_norm else 0.0
         loss_r = s[:, 0] + coef * s[:, 5]
         loss_c = s[:, 1] + coef * s[:, 6]
@@ -393,8 +394,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             'Loss/Loss_reward_critic': float(loss_r.mean()), 'Loss/Loss_cost_critic': float(loss_c.mean()),
             'Loss/Loss_pi': float(s[:, 2].mean()), 'Train/PolicyRatio': float(s[:, 3].mean()),
             'Train/PolicyRatio/Min': float(s[:, 3].min()), 'Train/PolicyRatio/Max': float(s[:, 3].max()),
-            'Train/PolicyRatio/Std': float(s[:, 3].std(unbiased=False)) if len(s) > 1 else 0.0,
+            'Train/PolicyRatio/Std': float(s[:, 3].std()) if len(s) > 1 else 0.0,
             'Train/Entropy': float(s[:, 4].mean()),
-            'per_step': {'loss_r': loss_r.numpy(), 'loss_c': loss_c.numpy(), 'loss_pi': s[:, 2].numpy(),
-                         'ratio_mean': s[:, 3].numpy(), 'entropy': s[:, 4].numpy()},
+            'per_step': {'loss_r': loss_r, 'loss_c': loss_c, 'loss_pi': s[:, 2], 'ratio_mean': s[:, 3],
+                         'entropy': s[:, 4]},
         }
