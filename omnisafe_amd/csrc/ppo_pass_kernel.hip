@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const int rk = blockIdx.y;  // virtual rank (0 outside the data-parallel mode)
   constexpr bool coop = COOP;
   const bool dp = a.dp_slabs != nullptr && !coop;
-  const bool part = a.part_stride > 0;
+  const bool part = MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
   const long roff = part ? 0 : (long)rk * a.M;
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
@@ -322,12 +322,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int kb = 0; kb < KB; ++kb) g1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int o = 0; o < OT; ++o) g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float step_size = 0.f, inv_bc2_sqrt = 0.f;  // tabulated in the prologue; used by Adam
-    if (!dp) {
-      const float* __restrict__ bc_row = a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
-      step_size = bc_row[0];
-      inv_bc2_sqrt = bc_row[1];
-    }
+    // tabulated in the prologue, used by Adam; branch-free (the gradient-only modes, which may come without a
+    // statistics buffer, read two floats of the parameter block instead and never use them)
+    const float* __restrict__ bc_row = dp ? gp : a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
+    const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
     if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
