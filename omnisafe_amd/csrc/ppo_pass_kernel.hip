@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int i = j, cc = j;
+  // serial per-step chores (entropy, statistics) go to the first thread of wave 3: waves 0-2 also own the
+  // bias-like parameters, so wave 3 is the one with slack before every barrier
+  const bool leader = tid == 192;
   const int P = nd.P;
   float* __restrict__ gp = a.params + (long)net * P;
   float* __restrict__ gm = a.adam_m + (long)net * P;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const float* __restrict__ bc_row = dp ? gp : a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
     const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
-    if (net == 0 && tid == 0) {  // entropy of the pre-update policy (read before any Adam write)
+    if (net == 0 && leader) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
       ent_pre /= (float)nd.act_dim;
     }
@@ -810,10 +813,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         for (int r = 0; r < 4; ++r) slab[nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc] = g3[o][r] * gs;
       if (boff >= 0) slab[boff] = gb * gs;
       if (critic && tid < OUTP) slab[nd.oLS + tid] = 0.f;
-      if (tid == 0 && part) {  // raw sums: osa_slab_reduce_kernel adds the slabs and normalises
+      if (leader && part) {  // raw sums: osa_slab_reduce_kernel adds the slabs and normalises
         slab[P + 0] = t_loss;
         slab[P + 1] = t_ratio;
-      } else if (tid == 0) {
+      } else if (leader) {
         slab[P + 0] = t_loss * invB - (net == 0 ? a.hp.entropy_coef * ent_pre : 0.f);
         slab[P + 1] = t_ratio * invB;
         slab[P + 2] = t_psq;
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       // contiguous per wave instruction); complete the slab with the clip factor and the statistics
       const int W = a.dp_world;
       const float gs = apply_clip ? coef : 1.f;
-      if (tid == 0) {
+      if (leader) {
         float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
         t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
       }
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       gb = sb_ * invW;
       PTICK(11);
       apply_clip = false;  // already clipped per rank (clip-then-average, policy_gradient.py:437-442)
-      if (tid == 0 && rk == 0) {  // what Logger.get_stats averages across ranks
+      if (leader && rk == 0) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < W; ++r) {
           const float* t = xbase + (long)r * XS + NT * 1024 + 256;
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     PTICK(8);
     // ---- statistics of this optimiser step
-    if (tid == 0 && rk == 0) {
+    if (leader && rk == 0) {
       float* st = a.stats + (long)(mb - a.mb0) * PNSTAT;
       if (net == 0) {
         st[2] = st_loss;
