@@ -313,10 +313,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #endif
   bool coop_dead = false;
 
+  const float invB_full = 1.f / (float)a.B;
   for (int mb = a.mb0; mb < a.mb0 + a.nmb; ++mb) {
     const long mb_lo = (long)mb * a.B;
     const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
-    const float invB = 1.f / (float)Bcur;
+    float invB = invB_full;  // (an IEEE division per step otherwise: ~12 VALU instructions)
+    if (Bcur != a.B) invB = 1.f / (float)Bcur;  // ragged last minibatch
     // weight-gradient accumulators of this optimiser step (summed over its 64-row chunks)
     f32x4 g2[HT], g1[KB], g3[OT];
 #pragma unroll
@@ -447,14 +449,19 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     if (small_out) {
       // out[d] = b3[d] + sum_f W3[d][f] h2[f]: each lane holds 16 of the 64 features of its sample
       float p0 = 0.f, p1 = 0.f;
+      f32x4 w0[HT], w1[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {  // all eight reads in flight before the dot products
+        w0[t] = *reinterpret_cast<const f32x4*>(sW3 + 16 * t + 4 * g);
+        w1[t] = *reinterpret_cast<const f32x4*>(sW3 + PSLD + 16 * t + 4 * g);  // zero row if 1 output
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW3 + 16 * t + 4 * g);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sW3 + PSLD + 16 * t + 4 * g);  // zero row if 1 output
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p0 = fmaf(w0[r], h2[t][r], p0);
-          p1 = fmaf(w1[r], h2[t][r], p1);
+          p0 = fmaf(w0[t][r], h2[t][r], p0);
+          p1 = fmaf(w1[t][r], h2[t][r], p1);
         }
       }
       p0 = osa_sum_over_groups(p0);
