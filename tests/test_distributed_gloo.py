@@ -166,3 +166,62 @@ def _case_seeds_and_sharding(rank, world, tmpdir):
 
 def test_seed_and_step_sharding(tmp_path):
     _run('_case_seeds_and_sharding', tmp_path)
+
+
+# ---------------------------------------------------------------------------------------------
+def _case_replicated_protocol(rank, world, tmpdir):
+    """The replicated-data update: one all-gather of the epoch's rows, then every rank runs the
+    WHOLE global optimiser chain on the same data -- rank r's minibatches drawn from a stream every rank can
+    regenerate -- so the replicas agree without gradient traffic.  Here: the all-gather layout, the
+    regenerated permutation streams and, with the oracle as the local step, bit-equal replicas that match
+    the all-reduce (clip-then-average) semantics."""
+    import np_oracle as O
+    from omnisafe_amd import distributed as dist
+
+    M, D_o, D_a, B, seed = 96, 12, 2, 32, 5
+    g = torch.Generator().manual_seed(1000 + rank)
+    local = {'obs': torch.randn(M, D_o, generator=g), 'act': torch.randn(M, D_a, generator=g),
+             'logp': torch.randn(M, generator=g) - 2, 'adv_r': torch.randn(M, generator=g),
+             'adv_c': torch.randn(M, generator=g), 'target_value_r': torch.randn(M, generator=g),
+             'target_value_c': torch.randn(M, generator=g)}
+    allr = {k: dist.all_gather_rows(v) for k, v in local.items()}
+    for k, v in allr.items():  # rank r occupies rows r*M .. r*M+M-1, for every rank identically
+        assert v.shape[0] == world * M and torch.equal(v[rank * M:(rank + 1) * M], local[k])
+    chk = torch.stack([v.double().sum() for v in allr.values()])
+    ref = chk.clone()
+    dist.broadcast_(ref, src=0)
+    assert torch.equal(chk, ref)
+    # every rank regenerates all ranks' permutation streams (seed + 1000 r + 7919, update.py)
+    perms = []
+    for r in range(world):
+        gen = torch.Generator().manual_seed(seed + 1000 * r + 7919)
+        perms.append(torch.randperm(M, generator=gen))
+    own = torch.randperm(M, generator=torch.Generator().manual_seed(seed + 1000 * rank + 7919))
+    assert torch.equal(perms[rank], own)
+    # global chain on the gathered data with the oracle as the per-rank gradient: identical on all ranks
+    torch.manual_seed(3)
+    ac = O.ActorCritic(D_o, D_a)
+    params = [p for p in ac.reward_critic.parameters()]
+    opt = ac.reward_critic_optimizer
+    for k in range(M // B):
+        grads = []
+        for r in range(world):
+            idx = perms[r][k * B:(k + 1) * B] + r * M
+            opt.zero_grad()
+            loss = torch.nn.functional.mse_loss(ac.reward_critic(allr['obs'][idx])[0] if isinstance(
+                ac.reward_critic(allr['obs'][idx]), tuple) else ac.reward_critic(allr['obs'][idx]),
+                allr['target_value_r'][idx])
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 40.0)  # local clip, then average over the ranks
+            grads.append([p.grad.clone() for p in params])
+        for j, p in enumerate(params):
+            p.grad = sum(gr[j] for gr in grads) / world
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    ref = flat.clone()
+    dist.broadcast_(ref, src=0)
+    assert torch.equal(flat, ref), 'replicas diverged'
+
+
+def test_replicated_data_protocol(tmp_path):
+    _run('_case_replicated_protocol', tmp_path)
