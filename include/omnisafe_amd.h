@@ -253,6 +253,13 @@ int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream)
  * 3 * world <= compute units (OSA_EUNSUPPORTED otherwise: use osa_ppo_dp_step).
  * Replaces: the minibatch loop of PolicyGradient._update under torch.distributed
  * (policy_gradient.py:366-382, 437-442; distributed.py:193-198). */
+/* Optional: the exchange buffer of osa_ppo_dp_pass in UNCACHED device memory (hipExtMallocWithFlags,
+ * hipDeviceMallocUncached).  The kernel recognises such a buffer and hands the gradients over without
+ * the agent-scope L2 write-back / invalidate that ordinary (cached) device memory needs.  The one place
+ * where the library allocates: the memory type cannot be requested through torch.  OSA_EUNSUPPORTED if
+ * the runtime refuses the flag (use an ordinary buffer then). */
+int osa_dp_exchange_alloc(size_t floats, float** out);
+int osa_dp_exchange_free(float* p);
 size_t osa_ppo_dp_pass_ws_floats(int obs_dim, int act_dim, int hidden, int world);
 int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                     int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,

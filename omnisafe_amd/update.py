@@ -16,6 +16,7 @@ networks' gradients, then Adam (clip-then-average order of policy_gradient.py:43
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -139,6 +140,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         M = data['obs'].shape[0]
         st = self._dp
         if st.get('M') != M or st.get('W') != W:
+            self._dp_free()
             st.clear()
             st.update(M=M, W=W, graph=None)
             st['data'] = {k: torch.empty((W * M,) + tuple(data[k].shape[1:]), dtype=torch.float32,
@@ -150,6 +152,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def _dp_state(self, M: int, W: int, nmb: int) -> dict:
         ac, st = self.ac, self._dp
         if st.get('M') != M or st.get('W') != W:
+            self._dp_free()
             st.clear()
             st.update(M=M, W=W, graph=None)
         if 'perm' not in st:
@@ -184,13 +187,33 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         _lib.check(lib.osa_ppo_dp_end_pass(_lib.ptr(ac.adam_step), self._nets_mask() & (7 if self.hp.use_cost else 3),
                                            nmb, _lib.stream_ptr()), 'osa_ppo_dp_end_pass')
 
+    def _dp_free(self) -> None:
+        st = self._dp
+        if st.get('xch') is None and st.get('xch_ptr'):
+            self.lib.osa_dp_exchange_free(st['xch_ptr'])
+        st.pop('xch_ptr', None)
+
+    def __del__(self):
+        try:
+            self._dp_free()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
     def _dp_coop_pass(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor, st: dict) -> bool:
         """osa_ppo_dp_pass: the whole pass as ONE cooperative launch of 3 x W persistent workgroups.
         Returns False when the device cannot hold them (caller falls back to the stepwise path)."""
         ac, lib = self.ac, self.lib
         if 'xch' not in st:
             n = lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
-            st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
+            # uncached device memory for the hand-off (no L2 write-back / invalidate per step); an ordinary
+            # tensor if the runtime refuses (OSA_DP_XCH=cached forces that)
+            p = C.c_void_p()
+            if os.environ.get('OSA_DP_XCH', 'uncached') == 'uncached' and lib.osa_dp_exchange_alloc(
+                    max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
+                st['xch_ptr'], st['xch'] = p.value, None
+            else:
+                st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
+                st['xch_ptr'] = st['xch'].data_ptr()
             st['sync'] = torch.zeros(4, dtype=torch.int32, device=ac.device)
         rc = lib.osa_ppo_dp_pass(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
@@ -199,7 +222,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
             _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
             _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp),
-            self.loss_kind, self._nets_mask(), _lib.ptr(st['xch']), _lib.ptr(st['sync']),
+            self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']),
             _lib.ptr(st['pass_stats']), _lib.stream_ptr())
         if rc == _lib.OSA_EUNSUPPORTED:
             return False
