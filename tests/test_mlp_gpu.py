@@ -286,7 +286,8 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
 @pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),
                                                   (3, 256, 128, True, False), (2, 512, 64, False, True),
                                                   (4, 300, 64, False, True), (3, 256, 128, False, True),
-                                                  (8, 1024, 64, False, True), (1, 200, 64, False, True)])
+                                                  (8, 1024, 64, False, True), (1, 200, 64, False, True),
+                                                  (6, 320, 64, False, True), (16, 128, 64, False, True)])
 def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop):
     """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
     workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
