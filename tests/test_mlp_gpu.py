@@ -353,3 +353,46 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
         np.testing.assert_allclose(getattr(a0, name).cpu().numpy(), getattr(a1, name).cpu().numpy(), rtol=1e-5,
                                    atol=5e-6, err_msg=name)
     assert np.isfinite(results[0][1][:, :10]).all() and (results[0][1][:, 3] > 0).all()
+
+
+def test_full_size_pass_properties():
+    """BASELINE config 2 at full size (M = 65 536 rows, 1024 optimiser steps of 64 rows per pass): size-
+    independent properties of the persistent pass -- run-to-run bit-determinism, the Adam step counters,
+    zero padding staying zero, finite statistics, and permutation equivariance of a pass with the learning
+    rates at 0 (the statistics of step k then depend only on the rows of step k)."""
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(11)
+    M, B, obs_dim, act_dim = 65536, 64, 60, 2
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perm = torch.randperm(M)
+    lam = torch.tensor([0.2], device=DEV)
+    outs = []
+    for rep in range(2):
+        torch.manual_seed(5)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=data['act'] * 0)
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+        out = up.run(data, lam, perms=[perm], actor_lr=3e-4, critic_lr=3e-4)
+        outs.append((ac.params.clone(), ac.adam_m.clone(), ac.adam_v.clone(), out['stats'][:, :10].clone(), ac))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    ac = outs[0][4]
+    assert ac.adam_step.cpu().tolist() == [M // B] * 3
+    assert bool(torch.isfinite(outs[0][0]).all()) and bool(torch.isfinite(outs[0][3]).all())
+    pad = torch.ones(ac.layout.P, dtype=torch.bool, device=DEV)
+    pad[ac.actor._flat_index] = False
+    assert float(ac.params[0][pad].abs().max()) == 0.0 and float(ac.adam_v[0][pad].abs().max()) == 0.0
+    # learning rate 0: parameters fixed, so step k's statistics are a function of its 64 rows only --
+    # reversing the order of the minibatches reverses the rows of the statistics
+    stats = []
+    for p in (perm, perm.reshape(M // B, B).flip(0).reshape(-1)):
+        torch.manual_seed(5)
+        ac0 = make_ac(obs_dim, act_dim)
+        up = PPOUpdater(ac0, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+        stats.append(up.run(data, lam, perms=[p], actor_lr=0.0, critic_lr=0.0)['stats'][:, :5].clone())
+    assert torch.equal(stats[0], stats[1].flip(0))
