@@ -396,6 +396,9 @@ SIBLINGS = [
     ('FOCOPS', 'focops_masked', {'focops_eta': 1e-4}, {'cost_limit': 1.0}),  # trust mask partially active
     ('CUP', 'cup', {}, {'cost_limit': 1.0}),
     ('P3O', 'p3o', {'cost_limit': 1.0, 'kappa': 2.0}, None),
+    # KL early stop (policy_gradient.py:391-397): 4 passes allowed, the threshold is crossed after the second
+    ('PPOLag', 'ppolag_earlystop', {'kl_early_stop': True, 'target_kl': 3e-4, 'update_iters': 4},
+     {'cost_limit': 1.0}),
 ]
 
 

@@ -15,7 +15,7 @@ DEV = 'cuda:0'
 
 FIRST_ORDER = [('PolicyGradient', 'policygradient'), ('PPO', 'ppo'), ('PDO', 'pdo'), ('IPO', 'ipo'),
                ('CPPOPID', 'cppopid'), ('FOCOPS', 'focops'), ('FOCOPS', 'focops_masked'), ('CUP', 'cup'),
-               ('P3O', 'p3o')]
+               ('P3O', 'p3o'), ('PPOLag', 'ppolag_earlystop')]
 TRUST_REGION = [('NaturalPG', 'naturalpg'), ('TRPO', 'trpo'), ('RCPO', 'rcpo'), ('OnCRPO', 'oncrpo_reward'),
                 ('OnCRPO', 'oncrpo_cost'), ('TRPOPID', 'trpopid'), ('PCPO', 'pcpo')]
 # what the golden generator changed relative to the YAML defaults (oracle/make_golden.py::SIBLINGS)
@@ -25,7 +25,8 @@ EXTRA = {'pdo': ({}, {'cost_limit': 1.0}), 'rcpo': ({}, {'cost_limit': 1.0}),
          'trpopid': ({}, {'cost_limit': 1.0}), 'pcpo': ({'cost_limit': 1.0}, None),
          'focops': ({'focops_eta': 0.02}, {'cost_limit': 1.0}),
          'focops_masked': ({'focops_eta': 1e-4}, {'cost_limit': 1.0}), 'cup': ({}, {'cost_limit': 1.0}),
-         'p3o': ({'cost_limit': 1.0, 'kappa': 2.0}, None)}
+         'p3o': ({'cost_limit': 1.0, 'kappa': 2.0}, None),
+         'ppolag_earlystop': ({'kl_early_stop': True, 'target_kl': 3e-4, 'update_iters': 4}, {'cost_limit': 1.0})}
 
 
 def _run_update(name, tag, g, tmp_path, trust_region):
@@ -77,6 +78,8 @@ def test_first_order_sibling_update_vs_reference(golden, tmp_path, name, tag):
                                atol=2e-6)
     np.testing.assert_allclose(_log(algo, 'Loss/Loss_reward_critic').mean(),
                                g['log/Loss/Loss_reward_critic'].mean(), rtol=2e-4)
+    if tag == 'ppolag_earlystop':  # KL early stop: the same pass count as the reference (2 of 4 allowed)
+        assert int(_log(algo, 'Train/StopIter')[-1]) == int(g['log/Train/StopIter'][-1]) == 2
     if tag == 'p3o':
         np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi_cost')[-1], g['log/Loss/Loss_pi_cost'].mean(),
                                    rtol=1e-3)
