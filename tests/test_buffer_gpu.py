@@ -153,3 +153,52 @@ def test_errors():
     buf.store(**step)
     with pytest.raises(AssertionError):
         buf.store(**step)
+
+
+def test_cabi_error_codes():
+    """Error behaviour of the boundary (include/omnisafe_amd.h): integer codes, no exceptions, nothing
+    launched for bad arguments; the Python shim turns them into OsaError."""
+    import ctypes as C
+
+    from omnisafe_amd import _lib
+    from omnisafe_amd.models import HParams, SurrogateExt
+
+    lib = _lib.load(require_gpu=True)
+    EINVAL, EUNSUPPORTED = -1, -3
+    z = torch.zeros(64, 8, device=DEV)
+    # null pointers / non-positive sizes
+    assert lib.osa_gae_scan(None, None, None, None, None, None, None, 4, 4, 0.99, 0.95, 0.95, 0.0, 0,
+                            None, None, None, None, None, None) == EINVAL
+    assert lib.osa_vec_dot(0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None) == EINVAL
+    assert lib.osa_saute_step(4, None, None, None, None, None, None, 0.999, -1.0, None, None, None, 8, None, 0, 7,
+                              None, None, None) == EINVAL
+    # shapes the reference allows but the kernels do not cover: hidden != 64, act_dim > 32, obs too wide for
+    # the persistent kernel
+    out12 = (C.c_int * 12)()
+    assert lib.osa_mlp_layout(60, 2, 128, out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 40, 64, out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 2, 64, out12) == 0 and out12[0] == 64 and out12[1] == 16
+    assert lib.osa_ppo_pass_supported(60, 2, 64) == 1 and lib.osa_ppo_pass_supported(376, 17, 64) == 0
+    # unaligned observation rows are refused by the persistent kernels (the host pads)
+    hp = HParams()
+    obs = torch.zeros(128, 27, device=DEV)
+    v = torch.zeros(128, device=DEV)
+    p = torch.zeros(3, 8448, device=DEV)
+    st = torch.zeros(2, 16, device=DEV)
+    step = torch.zeros(3, dtype=torch.int32, device=DEV)
+    rc = lib.osa_ppo_pass(27, 2, 64, _lib.ptr(p), _lib.ptr(p), _lib.ptr(p), _lib.ptr(step), _lib.ptr(obs), 27,
+                          _lib.ptr(obs), 27, _lib.ptr(v), _lib.ptr(v), _lib.ptr(v), _lib.ptr(v), _lib.ptr(v), None,
+                          128, 64, _lib.ptr(v), C.byref(hp), 0, 7, _lib.ptr(st), None)
+    assert rc == EUNSUPPORTED
+    # extended surrogate: a mask or a penalty needs the whole minibatch in one block
+    ext = SurrogateExt(cost_kappa=1.0)
+    g = torch.zeros(3, 8448, device=DEV)
+    rc = lib.osa_ppo_minibatch_ext(60, 2, 64, _lib.ptr(p), _lib.ptr(p), _lib.ptr(p), _lib.ptr(step), _lib.ptr(g),
+                                   _lib.ptr(z), 60, _lib.ptr(z), 2, _lib.ptr(v), _lib.ptr(v), _lib.ptr(v),
+                                   _lib.ptr(v), _lib.ptr(v), None, 128, _lib.ptr(v), C.byref(hp), 0, 0, 7, 4,
+                                   _lib.ptr(g), _lib.ptr(st), C.byref(ext), None)
+    assert rc == EUNSUPPORTED
+    assert lib.osa_strerror(EINVAL) and lib.osa_strerror(EUNSUPPORTED)
+    with pytest.raises(_lib.OsaError):
+        _lib.check(EINVAL, 'osa_gae_scan')
+    torch.cuda.synchronize()
