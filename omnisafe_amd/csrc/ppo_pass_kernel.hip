@@ -368,12 +368,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
     // The three layers are one sequence of MFMA groups (8 MFMAs on two alternating accumulator tiles, or
     // 4*OT for the output layer); the A fragments of group k+1 are read from the LDS master BEFORE the
-    // MFMAs of group k issue (double buffer; OSA_SB pins LDS reads and MFMAs, everything else may float),
+    // MFMAs of group k issue (double buffer; OSA_SB pins the order of the group's reads and MFMAs),
     // so no MFMA waits for an LDS round trip -- with one wave per SIMD nothing else would hide it.
     //   groups 0 .. 2KB-1        layer 1: tiles (T0, T0+1), T0 = 0 then 2, K block kb over the input
     //   groups 2KB .. 2KB+7      layer 2: (0,kb0) (0,kb1) (2,kb0) (2,kb1) (0,kb2) (0,kb3) (2,kb2) (2,kb3)
     //   groups 2KB+8 .. 2KB+11   output layer, K blocks 0..3
-#define OSA_SB() __builtin_amdgcn_sched_barrier(0x676)
+#define OSA_SB() __builtin_amdgcn_sched_barrier(0)  // (A/B: 0 beats 0x676 = "VALU/SALU/VMEM may cross" and none)
     constexpr int NG1 = 2 * KB, NG = NG1 + 8 + 4;
     auto load_group = [&](int gi, f32x4 (&dst)[2]) {
       if (gi < NG1) {
