@@ -12,10 +12,18 @@
 //     produce), loaded once, written back once;
 //   * gradients never leave registers: MFMA accumulator -> (+2*coef*w) -> block-reduced norm -> clip
 //     -> Adam -> LDS master;
-//   * the next minibatch's rows (gathered by the permutation) are prefetched into registers while the
-//     current one computes.
-// Arithmetic is identical to osa_mb_grad_kernel + osa_finalize_net (same fragment algebra, same
-// operation order per element); tests compare both against the reference's golden vectors.
+//   * the next minibatch's rows (gathered by the permutation) are prefetched into the registers of the
+//     current one as soon as those are consumed.
+// Arithmetic follows osa_mb_grad_kernel + osa_finalize_net (same fragment algebra; the 1-2-output layers
+// run on the VALU here: summation-order differences of ~1e-7); tests compare both against the reference's
+// golden vectors.
+//
+// What bounds the step on gfx950 (measured): float32 MFMAs and VALU instructions do
+// not overlap (in-wave or across waves), so the step costs MFMA cycles + VALU cycles + waits; the kernel is
+// register-bound (256 VGPRs + ~200 AGPRs), and every runtime branch between phases is a scheduling barrier.
+// Modes of the same kernel: plain pass (grid 3), data-parallel gradient step (grid 3 x world, writes
+// slabs), cooperative data-parallel pass (COOP: 3 x world resident workgroups exchanging gradients),
+// partial gradients of one large minibatch (MULTI, grid 3 x nblk).
 #include "mlp_device.h"
 
 #define PSLD 68  // leading dimension (floats) of [feature][sample] tiles and of W2/W3 rows
