@@ -11,11 +11,13 @@ PPO-Lag update with the reference's YAML defaults (batch_size 64, update_iters 4
 optimiser steps x 3 networks) with kl_early_stop OFF so that every epoch does the maximum work (the
 reference would usually stop earlier).  This is BASELINE.json configs[1] ("PPOLag on
 SafetyPointGoal1-v0, 1xMI355X, 4096 vectorized envs, steps_per_epoch=65536"); weak scaling: each rank
-owns 4096 envs, steps_per_epoch = 65 536 x world_size, gradients are all-reduced over RCCL.
+owns 4096 envs, steps_per_epoch = 65 536 x world_size; under data parallelism the rollouts are all-gathered
+once per epoch and every rank runs the whole global optimiser chain (no per-step collective).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     dominant kernel (osa_mb_grad_kernel: fused fwd+bwd+clip+Adam of one 64-row minibatch of
-               all three networks), algorithmic FLOPs / mean launch time measured with HIP events
+  roofline     dominant kernel (osa_ppo_pass_kernel: one persistent launch = one whole pass of 1024 dependent
+               64-row optimiser steps of all three networks), algorithmic FLOPs / mean launch time measured
+               with HIP events in the timed region
   cpu_baseline the oracle (oracle/np_oracle.py, a CPU restatement pinned bit-exact to the reference)
                timed on this box's host cores on a bounded sample of the same workload
 and a "throughput_variant" object: the same workload shape with the large-batch setting the reference
@@ -30,7 +32,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC for RCCL; must precede HIP initialisation
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
