@@ -1,0 +1,121 @@
+"""Live cross-checks of the oracle (and of the product's pure-host classes) against the UNMODIFIED reference,
+imported from /root/reference through oracle/ref_harness.py.  Build container only: skipped where the
+reference is absent (e.g. the GPU box) -- there the committed golden vectors carry the same information."""
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+pytestmark = pytest.mark.reference
+
+
+@pytest.fixture(scope='module')
+def ref():
+    import ref_harness
+
+    return ref_harness.import_reference()
+
+
+def test_discount_cumsum_live(ref):
+    from omnisafe.utils.math import discount_cumsum
+
+    rng = np.random.default_rng(0)
+    for n, d in ((1, 0.99), (17, 0.95), (1000, 0.9405)):
+        x = rng.standard_normal(n).astype(np.float32)
+        want = discount_cumsum(torch.from_numpy(x), d).numpy()
+        assert np.array_equal(O.discount_cumsum(x, d), want)
+
+
+def test_onpolicy_buffer_paths_live(ref):
+    """OnPolicyBuffer.store / finish_path / get of the reference vs the oracle's per-path GAE (bit-exact)."""
+    from omnisafe.common.buffer import OnPolicyBuffer
+
+    from ref_harness import _Box
+
+    rng = np.random.default_rng(1)
+    T, gamma, lam, lam_c = 37, 0.99, 0.95, 0.9
+    buf = OnPolicyBuffer(_Box(-np.inf, np.inf, (3,)), _Box(-1, 1, (2,)), T, gamma, lam, lam_c, 'gae', 0.0,
+                         False, False, device=torch.device('cpu'))
+    d = {k: rng.standard_normal(T).astype(np.float32) for k in ('reward', 'cost', 'value_r', 'value_c', 'logp')}
+    path_end = np.zeros(T, np.uint8)
+    path_end[[9, 10, 25, T - 1]] = 1
+    boot_r = np.where(path_end, rng.standard_normal(T), 0).astype(np.float32)
+    boot_c = np.where(path_end, rng.standard_normal(T), 0).astype(np.float32)
+    for t in range(T):
+        buf.store(obs=torch.zeros(3), act=torch.zeros(2), **{k: torch.tensor(v[t]) for k, v in d.items()})
+        if path_end[t]:
+            buf.finish_path(torch.tensor([boot_r[t]]), torch.tensor([boot_c[t]]))
+    want = {k: buf.data[k].numpy().copy() for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c')}
+    got = O.gae_per_path(d['reward'][:, None], d['cost'][:, None], d['value_r'][:, None], d['value_c'][:, None],
+                         path_end[:, None], boot_r[:, None], boot_c[:, None], gamma, lam, lam_c)
+    for ok, rk in (('adv_r', 'adv_r'), ('adv_c', 'adv_c'), ('tgt_r', 'target_value_r'), ('tgt_c', 'target_value_c')):
+        assert np.array_equal(got[ok][:, 0], want[rk]), ok
+
+
+def test_normalizer_live(ref):
+    from omnisafe.common.normalizer import Normalizer
+
+    rng = np.random.default_rng(2)
+    a, b = Normalizer((5,), clip=5), O.Normalizer((5,), clip=5)
+    for n in (1, 4, 64, 3):
+        x = torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32) * 3 + 1)
+        ya, yb = a.normalize(x.clone()), b.normalize(x.clone())
+        assert torch.equal(ya, yb)
+    for k in ('mean', 'sumsq', 'var', 'std'):
+        assert torch.equal(getattr(a, '_' + k), getattr(b, k)), k
+    assert int(a._count) == int(b.count)
+
+
+def test_lagrange_and_pid_live(ref):
+    """Naive Lagrange (oracle and the product's host class) and the product's PID controller vs the reference."""
+    from omnisafe.common.lagrange import Lagrange as RefLag
+    from omnisafe.common.pid_lagrange import PIDLagrangian as RefPID
+
+    from omnisafe_amd.lagrange import Lagrange
+    from omnisafe_amd.pid_lagrange import PIDLagrangian
+
+    kw = dict(cost_limit=25.0, lagrangian_multiplier_init=0.001, lambda_lr=0.035, lambda_optimizer='Adam')
+    r, o, p = RefLag(**kw), O.Lagrange(**kw), Lagrange(**kw)
+    for jc in (30.0, 80.5, 10.0, 25.0, 60.25):
+        for x in (r, o, p):
+            x.update_lagrange_multiplier(jc)
+        want = float(r.lagrangian_multiplier)
+        assert float(o.lagrangian_multiplier) == want and p.lagrangian_multiplier == want
+    pk = dict(pid_kp=0.1, pid_ki=0.01, pid_kd=0.01, pid_d_delay=10, pid_delta_p_ema_alpha=0.95,
+              pid_delta_d_ema_alpha=0.95, sum_norm=True, diff_norm=False, penalty_max=100,
+              lagrangian_multiplier_init=0.001, cost_limit=25.0)
+    rp, pp = RefPID(**pk), PIDLagrangian(**pk)
+    for jc in (30.0, 80.5, 10.0, 25.0, 60.25, 26.0, 24.0, 90.0, 0.0, 33.0, 41.0, 12.0):
+        rp.pid_update(jc)
+        pp.pid_update(jc)
+        assert rp.lagrangian_multiplier == pp.lagrangian_multiplier
+
+
+def test_conjugate_gradients_live(ref):
+    from omnisafe.utils.math import conjugate_gradients
+
+    torch.manual_seed(0)
+    A = torch.randn(40, 40)
+    A = A @ A.T + 0.5 * torch.eye(40)
+    b = torch.randn(40)
+    fvp = lambda v: A @ v  # noqa: E731
+    assert torch.equal(conjugate_gradients(fvp, b, 15), O.conjugate_gradients(fvp, b, 15))
+
+
+def test_simmer_controller_live(ref):
+    """The product's SimmerPIDController vs the reference's SimmerPIDAgent (host tensors)."""
+    import types
+
+    from omnisafe.common.simmer_agent import SimmerPIDAgent
+
+    from omnisafe_amd.adapter import SimmerPIDController
+
+    cfgs = types.SimpleNamespace(kp=0.05, ki=0.01, kd=0.02, polyak=0.9)
+    bound = 2.0 * torch.ones(4, 1)
+    a, b = SimmerPIDAgent(cfgs=cfgs, budget_bound=bound), SimmerPIDController(cfgs, budget_bound=bound)
+    sa = sb = torch.ones(4, 1)
+    for jc in (1.5, 0.2, 3.0, 0.9, 2.5, 0.0):
+        sa = a.act(safety_budget=sa, observation=torch.tensor(jc))
+        sb = b.act(safety_budget=sb, observation=torch.tensor(jc))
+        assert torch.equal(sa, sb)
