@@ -219,6 +219,16 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
                  const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                  const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                  float* step_stats, void* stream);
+/* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
+ * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);
+ * OSA_EUNSUPPORTED otherwise -- use osa_ppo_minibatch_ext.  ext == NULL: osa_ppo_pass.  With cost_kappa > 0
+ * step_stats[10] of every step receives the penalty value. */
+int osa_ppo_pass_ext(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                 int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                 const float* logp, const float* target_value_r, const float* target_value_c,
+                 const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                 const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                 float* step_stats, const osa_surrogate_ext* ext, void* stream);
 
 /* Data-parallel optimiser step WITHOUT a per-step cross-GPU collective ("replicated data").  The data
  * arrays hold the all-gathered env-major rollouts of all `world` ranks ([world * M] rows, rank r at

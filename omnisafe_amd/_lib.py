@@ -54,6 +54,8 @@ SIGNATURES: dict[str, tuple] = {
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                           _P, _P, _I, _I, _P, _P]),
+    'osa_ppo_pass_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
+                              _P, _P, _I, _I, _P, _P, _P]),
     'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     'osa_actor_fvp_raw': (_I, [_I, _I, _I, _P, _P, _P, _I, _L, _P, _I, _P, _P, _P]),
     'osa_fvp_finish': (_I, [_I, _P, _P, _F, _I, _I, _F, _P, _P]),

@@ -76,6 +76,12 @@ struct OsaPassArgs {
   // (net, b) accumulates the 64-row chunks b, b + part_stride, ... of ONE minibatch in its registers and
   // writes the raw sum (no L2 term, no clip) to slab b of dp_slabs; slab reduce + clip/Adam follow.
   int part_stride;  // 0 = off
+  // extended actor surrogates (EXT instantiations; osa_surrogate_ext of the public header): per-sample
+  // KL(pi_theta || pi_old) term, FOCOPS trust mask, P3O exact penalty
+  const float* old_mean;     // [rows][ld_old_mean]
+  int ld_old_mean;
+  const float* old_log_std;  // [act_dim]
+  float ext_kl_coef, ext_mask_eta, ext_ratio_scale, ext_cost_kappa, ext_cost_excess;
   // 1: dp_slabs lives in device memory allocated uncached (osa_dp_exchange_alloc): every access is served by
   // the device-coherent level, so the hand-off needs no L2 write-back / invalidate (~2.5k cycles per step)
   int dp_uncached;
@@ -98,7 +104,7 @@ struct OsaPassArgs {
 #define PTICK(k) do { } while (0)
 #endif
 
-template <int KB, int OT, bool MULTI, bool COOP>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     f32x4 x[KB];
     float act[4 * OT];
     float logp, adv_r, adv_c, tgt;
+    float old[EXT ? 4 * OT : 1];  // behaviour-policy mean of this lane's action dimensions (EXT)
     bool valid;
   };
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
@@ -287,6 +294,13 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       q.adv_r = advr_p[ri];
       q.adv_c = advc_p[ri];
       q.tgt = 0.f;
+      if constexpr (EXT) {
+        const float* orow = a.old_mean + roff * a.ld_old_mean + ri * a.ld_old_mean;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q.old[4 * o + r] = orow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 4 * OT; ++k) q.act[k] = 0.f;
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const float* __restrict__ bc_row = dp ? gp : a.stats + (long)(mb - a.mb0) * PNSTAT + 10 + 2 * net;
     const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
+    float cost_pen = 0.f;  // P3O penalty value of this step (EXT)
     if (net == 0 && leader) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
       ent_pre /= (float)nd.act_dim;
@@ -512,8 +527,56 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         }
       }
       lp = osa_sum_over_groups(lp);
+      // ---- EXT: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
+      // trust mask with the reference's broadcast semantics (focops.py:84-88: the surrogate term sees the
+      // minibatch MEAN of the mask), P3O's kappa * relu(mean(ratio * A_c) + excess) -- see osa_mb_grad_kernel
+      float kl = 0.f, mask = 1.f, mask_mean = 1.f, cost_w = 0.f;
+      f32x4 dkl_mu[OT], dkl_ls[OT];
+      if constexpr (EXT) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sLS + 16 * o + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // hardware exp2 only: sigma/sigma0 = exp(ls - ls0), log(var_ratio) = 2 (ls - ls0), 1/sigma0 = exp(-ls0)
+            const int d = min(16 * o + 4 * g + r, nd.act_dim - 1);
+            const float ls0 = a.old_log_std[d], dl = ls[r] - ls0;
+            const float q = __builtin_amdgcn_exp2f(dl * 1.44269504088896340736f), var_ratio = q * q;
+            const float isd0 = __builtin_amdgcn_exp2f(ls0 * -1.44269504088896340736f);
+            const float dmu = out[o][r] - cur.old[4 * o + r];
+            const float u = dmu * isd0;
+            kl += 0.5f * (var_ratio + u * u - 1.f - 2.f * dl) * dm[o][r];
+            dkl_mu[o][r] = u * isd0 * dm[o][r];
+            dkl_ls[o][r] = (var_ratio - 1.f) * dm[o][r];
+          }
+        }
+        kl = osa_sum_over_groups(kl);
+      }
+      const float ratio = valid ? __builtin_amdgcn_exp2f((lp - cur.logp) * 1.44269504088896340736f) : 0.f;
+      if constexpr (EXT) {
+        if (a.ext_mask_eta >= 0.f || a.ext_cost_kappa > 0.f) {  // block-uniform; single-chunk minibatches
+          mask = (a.ext_mask_eta < 0.f || (valid && kl <= a.ext_mask_eta)) ? 1.f : 0.f;
+          float pm = (valid && g == 0) ? mask : 0.f;
+          float pc = (valid && g == 0) ? ratio * cur.adv_c : 0.f;
+          pm = osa_wave_sum_dpp(pm);
+          pc = osa_wave_sum_dpp(pc);
+          __syncthreads();  // `red` is free (its previous readers passed barrier C)
+          if (lane == 0) {
+            red[4 * wave + 0] = pm;
+            red[4 * wave + 1] = pc;
+          }
+          __syncthreads();
+          const float tm = red[0] + red[4] + red[8] + red[12], tc = red[1] + red[5] + red[9] + red[13];
+          if (a.ext_mask_eta >= 0.f) mask_mean = tm * invB;
+          if (a.ext_cost_kappa > 0.f) {
+            const float pen = tc * invB + a.ext_cost_excess;
+            if (pen > 0.f) cost_w = a.ext_cost_kappa;
+            cost_pen = a.ext_cost_kappa * fmaxf(pen, 0.f);
+          }
+          __syncthreads();  // `red` is reused by the norm reduction
+        }
+      }
       {
-        const float ratio = valid ? __builtin_amdgcn_exp2f((lp - cur.logp) * 1.44269504088896340736f) : 0.f;
         const float adv = (cur.adv_r - lam * cur.adv_c) * inv_1p_lam;
         float dratio, li;
         if (a.loss_kind == 0) {
@@ -527,6 +590,13 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           li = -(ratio * adv);
           dratio = -adv;
         }
+        float dklw = 0.f;
+        if constexpr (EXT) {
+          const float rs = a.ext_ratio_scale * mask_mean;
+          li = li * rs + a.ext_kl_coef * kl * mask;
+          dratio = dratio * rs + cost_w * cur.adv_c;
+          dklw = valid ? a.ext_kl_coef * mask * invB : 0.f;
+        }
         const float dlogp = valid ? dratio * ratio * invB : 0.f;
         if (g == 0 && valid) {
           loss_part += li;
@@ -539,6 +609,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
             const float z = zv[o][r], iv = ivar[o][r];
             dO[o][r] = dlogp * z * iv;
             dLS[o][r] = dlogp * (z * z * iv - dm[o][r]);
+            if constexpr (EXT) {
+              dO[o][r] += dklw * dkl_mu[o][r];
+              dLS[o][r] += dklw * dkl_ls[o][r];
+            }
           }
         }
       }
@@ -981,6 +1055,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         st[3] = st_ratio;
         st[4] = st_ent;
         st[7] = st_norm;
+        if constexpr (EXT) {
+          if (a.ext_cost_kappa > 0.f) st[10] = cost_pen;  // (this row's bias-correction entry is consumed)
+        }
       } else {
         st[net - 1] = st_loss;
         st[4 + net] = st_psq;
@@ -1049,18 +1126,18 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI, bool COOP = false>
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP>), dim3(3, grid_y), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), dim3(3, grid_y), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1083,13 +1160,25 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
                  const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                  const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                  float* step_stats, void* stream) {
+  return osa_ppo_pass_ext(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act,
+                          logp, target_value_r, target_value_c, adv_r, adv_c, perm, M, B, lagrange, hp,
+                          loss_kind, nets_mask, step_stats, nullptr, stream);
+}
+
+int osa_ppo_pass_ext(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                 int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                 const float* logp, const float* target_value_r, const float* target_value_c,
+                 const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                 const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                 float* step_stats, const osa_surrogate_ext* ext, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
   if ((double)M * ld_obs >= 2147483647.0 || (double)M * ld_act >= 2147483647.0) return OSA_EUNSUPPORTED;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
-  OsaPassArgs a;
+  OsaPassArgs a = {};
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -1105,6 +1194,27 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
   a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0; a.dp_sync = nullptr; a.part_stride = 0; a.dp_uncached = 0;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
+  if (ext) {  // extended actor surrogates: single-chunk minibatches only (mask mean / penalty are per minibatch)
+    if (B > 64) return OSA_EUNSUPPORTED;
+    const bool need_old = ext->kl_coef != 0.f || ext->kl_mask_eta >= 0.f;
+    OSA_REQUIRE(!need_old || (ext->old_mean && ext->old_log_std && ext->ld_old_mean >= act_dim));
+    if (!need_old && ext->cost_kappa <= 0.f && ext->ratio_scale == 1.f) {
+      ext = nullptr;  // nothing extended: the plain instantiation
+    } else {
+      OSA_REQUIRE(ext->old_mean && ext->old_log_std);  // (the kernel reads them unconditionally)
+      a.old_mean = ext->old_mean; a.ld_old_mean = ext->ld_old_mean; a.old_log_std = ext->old_log_std;
+      a.ext_kl_coef = ext->kl_coef; a.ext_mask_eta = ext->kl_mask_eta; a.ext_ratio_scale = ext->ratio_scale;
+      a.ext_cost_kappa = ext->cost_kappa; a.ext_cost_excess = ext->cost_excess;
+#define OSA_PASS_EXT_CASE(K, O) \
+  if (KB == K && OT == O) return osa_launch_pass<K, O, false, false, true>(a, st)
+      OSA_PASS_EXT_CASE(1, 1); OSA_PASS_EXT_CASE(2, 1); OSA_PASS_EXT_CASE(3, 1); OSA_PASS_EXT_CASE(4, 1);
+      OSA_PASS_EXT_CASE(5, 1); OSA_PASS_EXT_CASE(6, 1);
+      OSA_PASS_EXT_CASE(1, 2); OSA_PASS_EXT_CASE(2, 2); OSA_PASS_EXT_CASE(3, 2); OSA_PASS_EXT_CASE(4, 2);
+      OSA_PASS_EXT_CASE(5, 2); OSA_PASS_EXT_CASE(6, 2);
+#undef OSA_PASS_EXT_CASE
+      return OSA_EUNSUPPORTED;
+    }
+  }
 #define OSA_PASS_CASE(K, O) \
   if (KB == K && OT == O) return (B > 64) ? osa_launch_pass<K, O, true>(a, st) : osa_launch_pass<K, O, false>(a, st)
   OSA_PASS_CASE(1, 1); OSA_PASS_CASE(2, 1); OSA_PASS_CASE(3, 1); OSA_PASS_CASE(4, 1);
@@ -1201,7 +1311,8 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && step_index >= 0 && (long)step_index * B < M);
   if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
-  OsaPassArgs a;
+  OsaPassArgs a = {};
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -1299,7 +1410,8 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return OSA_EHIP;
   if (3 * world > cus) return OSA_EUNSUPPORTED;
-  OsaPassArgs a;
+  OsaPassArgs a = {};
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -1336,7 +1448,8 @@ int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, c
                           int loss_kind, int nets_mask, int nblk, float* slabs, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || B <= 64) return OSA_EUNSUPPORTED;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;
-  OsaPassArgs a;
+  OsaPassArgs a = {};
+  a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = params; a.adam_v = params; a.adam_step = nullptr;  // untouched in this mode
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;

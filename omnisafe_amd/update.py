@@ -118,15 +118,21 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if self.profile_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        name, fn = self._pass_fn if getattr(self, '_pass_fn', None) else ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
-        _lib.check(fn(
+        name = 'osa_ppo_pass_kernel'
+        ext = None
+        if self.ext is not None:  # extended actor surrogate (FOCOPS / CUP / P3O) inside the persistent pass
+            self.ext.old_mean = self._old_mean.data_ptr()
+            self.ext.ld_old_mean = self._old_mean.stride(0)
+            self.ext.old_log_std = self._old_log_std.data_ptr()
+            ext = C.byref(self.ext)
+        _lib.check(self.lib.osa_ppo_pass_ext(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
             _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
             _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
             _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
-            C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
-            _lib.stream_ptr()), 'osa_ppo_pass')
+            C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows), ext,
+            _lib.stream_ptr()), 'osa_ppo_pass_ext')
         if ev is not None:
             ev[1].record()
             self.profile_events.append((name, M, ev))
@@ -351,7 +357,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
         self._pass_fn = None
-        if (self.persistent and self.ext is None and self.update_critics and dist.world_size() == 1
+        if (self.persistent and (self.ext is None or B <= 64) and dist.world_size() == 1
                 and B <= self.persistent_max_batch and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)

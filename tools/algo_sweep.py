@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import omnisafe_amd
 from omnisafe_amd import config
 
-ALGOS = ['PolicyGradient', 'PPO', 'PPOLag', 'PDO', 'IPO', 'CPPOPID', 'P3O', 'FOCOPS', 'CUP', 'PPOSaute',
+ALGOS = (sys.argv[1].split(',') if len(sys.argv) > 1 else None) or ['PolicyGradient', 'PPO', 'PPOLag', 'PDO', 'IPO', 'CPPOPID', 'P3O', 'FOCOPS', 'CUP', 'PPOSaute',
          'PPOSimmerPID', 'NaturalPG', 'TRPO', 'TRPOLag', 'RCPO', 'TRPOPID', 'OnCRPO', 'CPO', 'PCPO', 'TRPOSaute',
          'TRPOSimmerPID']
 N, T, EPOCHS, WARM = 4096, 16, 3, 1
