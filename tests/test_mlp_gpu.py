@@ -396,3 +396,47 @@ def test_full_size_pass_properties():
         up = PPOUpdater(ac0, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
         stats.append(up.run(data, lam, perms=[p], actor_lr=0.0, critic_lr=0.0)['stats'][:, :5].clone())
     assert torch.equal(stats[0], stats[1].flip(0))
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,kind', [(60, 2, 'focops'), (28, 8, 'focops'), (72, 2, 'p3o'), (44, 6, 'cup'),
+                                                  (60, 17, 'focops')])
+def test_extended_surrogates_pass_equals_per_minibatch_launches(obs_dim, act_dim, kind):
+    """FOCOPS / CUP / P3O actor losses: the EXT instantiation of the persistent pass vs the per-step kernels
+    (osa_ppo_minibatch_ext) on the same data, incl. wider action spaces (MFMA output tiles instead of the
+    1-2-output VALU path) and a ragged last minibatch; the per-step kernels are pinned to the reference by the
+    sibling goldens."""
+    from omnisafe_amd.models import SurrogateExt
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(obs_dim + act_dim)
+    M, B = 1000, 64
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perms = [torch.randperm(M), torch.randperm(M)]
+    ext_kw = {'focops': dict(kl_coef=1.0, kl_mask_eta=2e-3, ratio_scale=1 / 1.5), 'cup': dict(kl_coef=1.0),
+              'p3o': dict(cost_kappa=2.0, cost_excess=-0.05)}[kind]
+    outs, acs = [], []
+    for persistent in (True, False):
+        torch.manual_seed(99)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01,
+                        persistent=persistent, loss_kind=0 if kind == 'p3o' else 1, ext=SurrogateExt(**ext_kw),
+                        update_critics=kind != 'cup')
+        lam = torch.tensor([0.3], device=DEV)
+        outs.append(up.run(data, lam, perms=perms, actor_lr=3e-3, critic_lr=1e-3))
+        acs.append(ac)
+    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
+    for name in ('params', 'adam_m', 'adam_v'):
+        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-6, err_msg=name)
+    s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
+    np.testing.assert_allclose(s0[:, :5], s1[:, :5], rtol=2e-4, atol=2e-6)
+    if kind == 'p3o':
+        np.testing.assert_allclose(s0[:, 10], s1[:, 10], rtol=2e-4, atol=1e-6)
+        assert (s0[:, 10] > 0).any()  # the penalty is active in some steps
+    if kind == 'focops':  # the trust mask cuts in: with lr 3e-3 the per-sample KL crosses eta within the passes
+        assert not np.allclose(s0[:, 2], 0)
