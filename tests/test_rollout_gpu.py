@@ -341,3 +341,23 @@ def test_saute_simmer_agents_end_to_end(tmp_path, algo_name):
     ep_ret, ep_cost, ep_len = agent.learn()
     assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
     assert len(agent.agent._logger._data) > 0
+
+
+@pytest.mark.parametrize('algo_name,env_id,obs_dim', [('CPO', 'SynthCarGoal1-v0', 72), ('PPOLag', 'SynthHumanoid-v0', 376),
+                                                      ('TRPOLag', 'SynthAnt-v0', 27)])
+def test_baseline_config_shapes_end_to_end(tmp_path, algo_name, env_id, obs_dim):
+    """BASELINE.json configs 3-5 on their observation / action shapes (one GPU): CarGoal1 72/2, Humanoid 376/17
+    (wider than the persistent kernel supports: per-step kernels), Ant 27/8 (unaligned rows: padded once per
+    update).  Two epochs through `Agent.learn()`; finite parameters, sane episode statistics."""
+    import omnisafe_amd
+
+    cfg = {'seed': 1, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 64 * 32, 'vector_env_nums': 64},
+           'algo_cfgs': {'steps_per_epoch': 64 * 32, 'update_iters': 2},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo_name, env_id, custom_cfgs=cfg)
+    ac = agent.agent._actor_critic
+    assert ac.obs_dim == obs_dim
+    before = ac.params.clone()
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
+    assert bool(torch.isfinite(ac.params).all()) and not torch.equal(before, ac.params)
