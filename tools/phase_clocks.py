@@ -11,9 +11,10 @@ ns = types.SimpleNamespace
 mc = ns(actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4), critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4),
         weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning', linear_lr_decay=True)
 dev = 'cuda:0'
-ac = ConstraintActorCritic(Box(-np.inf, np.inf, (60,)), Box(-1, 1, (2,)), mc, 4, device=dev)
+OD, AD = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (60, 2)
+ac = ConstraintActorCritic(Box(-np.inf, np.inf, (OD,)), Box(-1, 1, (AD,)), mc, 4, device=dev)
 M = 65536
-data = {'obs': torch.randn(M, 60, device=dev), 'act': torch.randn(M, 2, device=dev), 'logp': torch.randn(M, device=dev) - 2,
+data = {'obs': torch.randn(M, OD, device=dev), 'act': torch.randn(M, AD, device=dev), 'logp': torch.randn(M, device=dev) - 2,
         'target_value_r': torch.randn(M, device=dev), 'target_value_c': torch.randn(M, device=dev),
         'adv_r': torch.randn(M, device=dev), 'adv_c': torch.randn(M, device=dev)}
 up = PPOUpdater(ac, batch_size=64, update_iters=1, target_kl=0.02, kl_early_stop=False)
@@ -46,6 +47,7 @@ for k in range(1000):
 e1.record(); torch.cuda.synchronize()
 print('us per launch', e0.elapsed_time(e1))
 
+if OD > 96: sys.exit(0)
 # ---- persistent pass kernel
 dbg2 = torch.zeros(48, dtype=torch.int64, device=dev)
 lib.osa_debug_set_pass_clock_buffer(dbg2.data_ptr())
