@@ -151,16 +151,33 @@ __device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* _
   const float* __restrict__ W3 = p + nd.oW3;
 #pragma unroll
   for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(p + nd.ob1 + 16 * t + 4 * g);
+  // software-pipelined over the input K blocks: the x chunk and the four weight fragments of block kb+1 are
+  // requested before the MFMAs of block kb issue (wide inputs -- Humanoid has 24 blocks -- otherwise pay one
+  // L2 round trip per block)
+  f32x4 xn = osa_load_x(xrow, 4 * g, nd.obs_dim, ld, vec_ok);
+  f32x4 wn[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 4 * g);
   for (int kb = 0; kb < nd.KB; ++kb) {
-    const f32x4 x = osa_load_x(xrow, 16 * kb + 4 * g, nd.obs_dim, ld, vec_ok);
+    const f32x4 x = xn;
+    f32x4 w[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) w[t] = wn[t];
+    if (kb + 1 < nd.KB) {
+      xn = osa_load_x(xrow, 16 * (kb + 1) + 4 * g, nd.obs_dim, ld, vec_ok);
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+        wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 16 * (kb + 1) + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 16 * kb + 4 * g);
-      h1[t] = OSA_MFMA(w.x, x.x, h1[t]);
-      h1[t] = OSA_MFMA(w.y, x.y, h1[t]);
-      h1[t] = OSA_MFMA(w.z, x.z, h1[t]);
-      h1[t] = OSA_MFMA(w.w, x.w, h1[t]);
+      h1[t] = OSA_MFMA(w[t].x, x.x, h1[t]);
+      h1[t] = OSA_MFMA(w[t].y, x.y, h1[t]);
+      h1[t] = OSA_MFMA(w[t].z, x.z, h1[t]);
+      h1[t] = OSA_MFMA(w[t].w, x.w, h1[t]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int t = 0; t < HT; ++t) h1[t] = osa_tanh4(h1[t]);

@@ -150,6 +150,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
   float* __restrict__ gbuf = a.grads + (long)net * P;
   const bool critic = net != 0;
   const int mode = a.mode;
+  float gclip = 1.f;
   if (mode != 3) {
     const bool l2 = critic && a.hp.use_critic_norm;
     const float c2 = 2.f * a.hp.critic_norm_coef;
@@ -193,7 +194,11 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
     if (a.hp.use_max_grad_norm) {
       float coef = a.hp.max_grad_norm / (total_norm + 1e-6f);
       coef = coef > 1.f ? 1.f : coef;
-      for (int e = threadIdx.x; e < P; e += blockDim.x) gbuf[e] *= coef;
+      if (mode == 1) {  // the clipped gradient itself is the result (all-reduce follows)
+        for (int e = threadIdx.x; e < P; e += blockDim.x) gbuf[e] *= coef;
+      } else {
+        gclip = coef;   // mode 0: folded into the Adam pass below (one pass over global memory less)
+      }
     }
     if (mode == 1) return;
     __syncthreads();
@@ -227,7 +232,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
     for (int k = 0; k < 8; ++k) {
       const int e = e0 + k * blockDim.x + threadIdx.x;
       if (e < P) {
-        p[e] = osa_adam_update(gv8[k], mv8[k], vv8[k], pv8[k], beta1, beta2, step_size, inv_bc2_sqrt, eps);
+        p[e] = osa_adam_update(gv8[k] * gclip, mv8[k], vv8[k], pv8[k], beta1, beta2, step_size, inv_bc2_sqrt, eps);
         m[e] = mv8[k];
         v[e] = vv8[k];
       }
@@ -558,17 +563,32 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
             *dst = first ? acc[r] : *dst + acc[r];
           }
         }
+        // this lane's 16 sample rows (constant over the K blocks); the 16 gathered x values of block kb+1
+        // are requested before the MFMAs of block kb issue
+        long rows[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rows[q] = sIdx[16 * (q >> 2) + 4 * g + (q & 3)];
+        float xq[16], xnq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          xnq[q] = (rows[q] >= 0 && cc < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + cc] : 0.f;
         for (int kb = 0; kb < nd.KB; ++kb) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const int col = 16 * kb + cc;
 #pragma unroll
+          for (int q = 0; q < 16; ++q) xq[q] = xnq[q];
+          if (kb + 1 < nd.KB) {
+            const int coln = col + 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              xnq[q] = (rows[q] >= 0 && coln < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + coln] : 0.f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
           for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {  // B[k = sample 16sb+4g+s][j = input feature col]
-              const long rr = sIdx[16 * sb + 4 * g + s];
-              const float x = (rr >= 0 && col < nd.obs_dim) ? a.obs[rr * a.ld_obs + col] : 0.f;
-              acc = OSA_MFMA(a1[sb][s], x, acc);
-            }
+            for (int s = 0; s < 4; ++s)  // B[k = sample 16sb+4g+s][j = input feature col]
+              acc = OSA_MFMA(a1[sb][s], xq[4 * sb + s], acc);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -440,3 +440,46 @@ def test_extended_surrogates_pass_equals_per_minibatch_launches(obs_dim, act_dim
         assert (s0[:, 10] > 0).any()  # the penalty is active in some steps
     if kind == 'focops':  # the trust mask cuts in: with lr 3e-3 the per-sample KL crosses eta within the passes
         assert not np.allclose(s0[:, 2], 0)
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,B', [(376, 17, 64), (376, 17, 40), (200, 5, 128)])
+def test_wide_input_minibatch_steps_vs_oracle(obs_dim, act_dim, B):
+    """Wide observations (Humanoid 376 / 17: 24 input K blocks, beyond the persistent kernel) on the per-step
+    kernels: three consecutive optimiser steps of all three networks vs the oracle (losses, parameters)."""
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(obs_dim + B)
+    M = 3 * B
+    ref = O.ActorCritic(obs_dim, act_dim)
+    ac = make_ac(obs_dim, act_dim)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ac, net).load_state_dict(getattr(ref, net).state_dict())
+    cpu = {'obs': torch.randn(M, obs_dim), 'act': torch.randn(M, act_dim), 'target_value_r': torch.randn(M),
+           'target_value_c': torch.randn(M), 'adv_r': torch.randn(M), 'adv_c': torch.randn(M)}
+    with torch.no_grad():
+        cpu['logp'] = ref.actor.dist(cpu['obs']).log_prob(cpu['act']).sum(-1) + 0.2 * torch.randn(M)
+    dev = {k: v.to(DEV) for k, v in cpu.items()}
+    lam = 0.4
+    up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+    up.hp.lr_actor = up.hp.lr_critic = 3e-4
+    assert not up.lib.osa_ppo_pass_supported(obs_dim, act_dim, 64)
+    perm = torch.randperm(M)
+    for k in range(3):
+        idx = perm[k * B:(k + 1) * B]
+        l_r = O.critic_step(ref.reward_critic, ref.reward_critic_optimizer, cpu['obs'][idx], cpu['target_value_r'][idx])
+        l_c = O.critic_step(ref.cost_critic, ref.cost_critic_optimizer, cpu['obs'][idx], cpu['target_value_c'][idx])
+        l_p, ent, ratio = O.actor_step(ref.actor, ref.actor_optimizer, cpu['obs'][idx], cpu['act'][idx], cpu['logp'][idx],
+                                       cpu['adv_r'][idx], cpu['adv_c'][idx], lam)
+        stats = torch.zeros(16, device=DEV)
+        up.minibatch(dev, idx.to(DEV), B, torch.tensor([lam], device=DEV), stats)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[0] + 0.001 * s[5], l_r, rtol=2e-4)
+        np.testing.assert_allclose(s[1] + 0.001 * s[6], l_c, rtol=2e-4)
+        np.testing.assert_allclose(s[2], l_p, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(s[3], float(ratio.mean()), rtol=2e-4)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            # (Adam's m / sqrt(v) turns summation-order noise on near-zero gradients into O(lr * 1e-2) steps:
+            #  a handful of the 24 064 first-layer weights move by a few 1e-6 after three steps)
+            np.testing.assert_allclose(v.cpu().numpy(), getattr(ref, net).state_dict()[k].numpy(), rtol=1e-4,
+                                       atol=2e-5, err_msg=f'{net}/{k}')
