@@ -361,6 +361,20 @@ int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, 
                        float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                        int ld_final, int reset_only, void* stream);
 
+/* Learnable synthetic vector CMDP "SynthReach-v0" (obs_dim >= 6, 2 actions; stand-in for a
+ * Safety-Gymnasium goal task, which is third-party CPU physics outside the reference repo; plays the
+ * role of the reference's tests/simple_env.py:30-90 for learning-curve comparisons): a point moves by
+ * 0.1*clip(action,-1,1) inside [-1.5,1.5]^2, reward = decrease of the distance to the goal, +1 and a
+ * new goal when within 0.15 of it, cost = 1 inside a disc of radius 0.3 around a hazard; never
+ * terminates, truncates every `horizon` steps (gymnasium vector auto-reset convention as above).
+ * state: N x 8 floats (p, goal, hazard, 2 pad), owned by the caller, updated in place.
+ * obs row = [p, goal-p, hazard-p, 0...].  reset_only != 0 draws fresh states and zeroes `steps`. */
+int osa_reach_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+                       int horizon, float* state, int* steps, const float* action, int ld_action,
+                       float* obs, int ld_obs, float* reward, float* cost, uint8_t* terminated,
+                       uint8_t* truncated, float* final_obs, int ld_final, int reset_only,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Trust-region machinery (NaturalPG / TRPO / TRPOLag / CPO actor update)
  *

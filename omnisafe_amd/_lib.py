@@ -71,6 +71,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_action_scale': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _P]),
     'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 19),
     'osa_synth_env_step': (_I, [_U, _U, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'osa_reach_env_step': (_I, [_U, _U, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 

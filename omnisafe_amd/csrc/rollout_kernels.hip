@@ -268,6 +268,97 @@ __global__ __launch_bounds__(256) void osa_synth_env_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Learnable synthetic CMDP "SynthReach" (point reaches resampled goals, one static hazard disc):
+// state[n][8] = p(2) g(2) h(2) pad(2).  Dynamics stated in oracle/np_oracle.py:reach_env_step and
+// compared with it by tests/test_learning_gpu.py; float32, no fused multiply-adds so that the CPU twin
+// the reference trains on sees the same arithmetic.  One wave per env: every lane computes the (tiny)
+// transition, lane k writes column k of the observation row (coalesced 240-byte row stores).
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ float osa_reach_dist(float ux, float uy, float vx, float vy) {
+  const float dx = ux - vx, dy = uy - vy;
+  const float xx = dx * dx, yy = dy * dy;
+  return sqrtf(xx + yy);
+}
+
+__device__ __forceinline__ float osa_reach_obs_col(const float (&s)[6], int k) {
+  float v = 0.f;
+  if (k == 0) v = s[0];
+  if (k == 1) v = s[1];
+  if (k == 2) v = s[2] - s[0];
+  if (k == 3) v = s[3] - s[1];
+  if (k == 4) v = s[4] - s[0];
+  if (k == 5) v = s[5] - s[1];
+  return v;
+}
+
+__device__ __forceinline__ float osa_reach_uniform(uint32_t w) {  // [-1, 1]
+  return 2.f * osa_u01(w) - 1.f;
+}
+
+__global__ __launch_bounds__(64) void osa_reach_env_kernel(
+    unsigned long long seed, unsigned long long step, int N, int D, int horizon,
+    float* __restrict__ state, int* __restrict__ steps, const float* __restrict__ action, int ld_a,
+    float* __restrict__ obs, int ld, float* __restrict__ reward, float* __restrict__ cost,
+    uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated, float* __restrict__ final_obs,
+    int ld_f, int reset_only) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float s[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s[k] = state[(long)n * 8 + k];
+  uint32_t w0[4], w1[4];  // fresh positions for a reset: 6 uniforms
+  osa_philox(seed ^ 0xD1B54A32D192ED03ull, step, ((unsigned long long)n << 20) + 1, w0);
+  osa_philox(seed ^ 0xD1B54A32D192ED03ull, step, ((unsigned long long)n << 20) + 2, w1);
+  const float fresh[6] = {osa_reach_uniform(w0[0]), osa_reach_uniform(w0[1]), osa_reach_uniform(w0[2]),
+                          osa_reach_uniform(w0[3]), osa_reach_uniform(w1[0]), osa_reach_uniform(w1[1])};
+  uint8_t trunc = 0;
+  float r = 0.f, c = 0.f;
+  if (reset_only) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = fresh[k];
+  } else {
+    const float a0 = fminf(fmaxf(action[(long)n * ld_a + 0], -1.f), 1.f);
+    const float a1 = fminf(fmaxf(action[(long)n * ld_a + 1], -1.f), 1.f);
+    const float m0 = 0.1f * a0, m1 = 0.1f * a1;
+    const float qx = fminf(fmaxf(s[0] + m0, -1.5f), 1.5f);
+    const float qy = fminf(fmaxf(s[1] + m1, -1.5f), 1.5f);
+    const float d0 = osa_reach_dist(s[0], s[1], s[2], s[3]);
+    const float d1 = osa_reach_dist(qx, qy, s[2], s[3]);
+    const bool reached = d1 < 0.15f;
+    r = (d0 - d1) + (reached ? 1.f : 0.f);
+    c = (osa_reach_dist(qx, qy, s[4], s[5]) < 0.3f) ? 1.f : 0.f;
+    s[0] = qx;
+    s[1] = qy;
+    if (reached) {
+      s[2] = osa_reach_uniform(w1[2]);
+      s[3] = osa_reach_uniform(w1[3]);
+    }
+    trunc = (steps[n] + 1 >= horizon) ? 1 : 0;
+    if (trunc) {
+      if (final_obs)
+        for (int k = lane; k < D; k += 64) final_obs[(long)n * ld_f + k] = osa_reach_obs_col(s, k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s[k] = fresh[k];
+    }
+  }
+  for (int k = lane; k < D; k += 64) obs[(long)n * ld + k] = osa_reach_obs_col(s, k);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) state[(long)n * 8 + k] = s[k];
+    if (reset_only) {
+      steps[n] = 0;
+    } else {
+      reward[n] = r;
+      cost[n] = c;
+      terminated[n] = 0;
+      truncated[n] = trunc;
+      steps[n] = trunc ? 0 : steps[n] + 1;
+    }
+  }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -357,6 +448,21 @@ int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, 
   hipLaunchKernelGGL(osa_synth_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, N,
                      obs_dim, horizon, cost_p, steps, obs, ld_obs, reward, cost, terminated,
                      truncated, final_obs, ld_final, reset_only);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_reach_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+                       int horizon, float* state, int* steps, const float* action, int ld_action,
+                       float* obs, int ld_obs, float* reward, float* cost, uint8_t* terminated,
+                       uint8_t* truncated, float* final_obs, int ld_final, int reset_only,
+                       void* stream) {
+  OSA_REQUIRE(N > 0 && obs_dim >= 6 && state && steps && obs && ld_obs >= obs_dim);
+  if (!reset_only)
+    OSA_REQUIRE(action && ld_action >= 2 && reward && cost && terminated && truncated && horizon > 0);
+  hipLaunchKernelGGL(osa_reach_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, N,
+                     obs_dim, horizon, state, steps, action, ld_action, obs, ld_obs, reward, cost,
+                     terminated, truncated, final_obs, ld_final, reset_only);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

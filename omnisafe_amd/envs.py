@@ -125,3 +125,85 @@ class SynthVectorEnv:  # pylint: disable=too-many-instance-attributes
 
     def close(self) -> None:
         return None
+
+
+@env_register
+class ReachVectorEnv:  # pylint: disable=too-many-instance-attributes
+    """Learnable synthetic vector CMDP in HBM (osa_reach_env_step): a point reaches resampled goals
+    (reward = progress, +1 per goal) past a hazard disc (cost 1 inside).  Observation/action dims of
+    SafetyPointGoal1 (60 / 2).  Used for learning-curve comparisons against the reference, which trains
+    on the CPU twin of this env kept with the test harness under oracle/."""
+
+    _support_envs = ['SynthReach-v0']
+    need_auto_reset_wrapper = False
+    need_time_limit_wrapper = False
+    need_evaluation = False
+
+    def __init__(self, env_id: str, num_envs: int = 1, device='cuda:0', horizon: int = 50,
+                 seed: int = 0, **_unused) -> None:
+        self._lib = _lib.load(require_gpu=True)
+        self._num_envs = int(num_envs)
+        self._device = torch.device(device)
+        self._obs_dim, self._act_dim = 60, 2
+        self._horizon = int(horizon)
+        self._observation_space = Box(-np.inf, np.inf, (self._obs_dim,))
+        self._action_space = Box(-1.0, 1.0, (self._act_dim,))
+        self._seed = int(seed)
+        self._t = 0
+        self._since_reset = 0
+        N, dev = self._num_envs, self._device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.state = torch.zeros(N, 8, **f32)  # p, goal, hazard, pad
+        self._steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._obs = [torch.empty(N, self._obs_dim, **f32) for _ in range(2)]
+        self._final = torch.zeros(N, self._obs_dim, **f32)
+        self._reward, self._cost = torch.empty(N, **f32), torch.empty(N, **f32)
+        self._term = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._flip = 0
+
+    num_envs = property(lambda self: self._num_envs)
+    observation_space = property(lambda self: self._observation_space)
+    action_space = property(lambda self: self._action_space)
+    max_episode_steps = property(lambda self: self._horizon)
+
+    def set_seed(self, seed: int) -> None:
+        self._seed = int(seed)
+
+    def _launch(self, obs, action, reset_only: int) -> None:
+        ld_a = action.stride(0) if action is not None else 0
+        _lib.check(self._lib.osa_reach_env_step(
+            self._seed & 0xFFFFFFFFFFFFFFFF, self._t, self._num_envs, self._obs_dim, self._horizon,
+            _lib.ptr(self.state), _lib.ptr(self._steps), _lib.ptr(action), ld_a, _lib.ptr(obs),
+            self._obs_dim, _lib.ptr(self._reward), _lib.ptr(self._cost), _lib.ptr(self._term),
+            _lib.ptr(self._trunc), _lib.ptr(self._final), self._obs_dim, reset_only,
+            _lib.stream_ptr()), 'osa_reach_env_step')
+        self._t += 1
+
+    def reset(self, seed: int | None = None, options: dict | None = None):
+        if seed is not None:
+            self.set_seed(seed)
+        self._flip ^= 1
+        obs = self._obs[self._flip]
+        self._launch(obs, None, 1)
+        self._since_reset = 0
+        return obs, {}
+
+    def step(self, action: torch.Tensor):
+        assert action.dtype == torch.float32 and action.shape == (self._num_envs, self._act_dim) \
+            and action.stride(1) == 1
+        self._flip ^= 1
+        obs = self._obs[self._flip]
+        self._launch(obs, action, 0)
+        self._since_reset += 1
+        info: dict[str, Any] = {}
+        if self._since_reset % self._horizon == 0:  # every env truncates on this step
+            info['final_observation'] = self._final
+            info['_final_observation'] = self._trunc
+        return obs, self._reward, self._cost, self._term, self._trunc, info
+
+    def render(self):
+        return None
+
+    def close(self) -> None:
+        return None

@@ -36,5 +36,9 @@ def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
     if new_ids:
         reg._class['OmnisafeAmdSynthVectorEnv'] = amd_envs.SynthVectorEnv  # noqa: SLF001
         reg._support_envs['OmnisafeAmdSynthVectorEnv'] = new_ids  # noqa: SLF001
+    reach_ids = [e for e in amd_envs.ReachVectorEnv._support_envs if e not in known]  # noqa: SLF001
+    if reach_ids:
+        reg._class['OmnisafeAmdReachVectorEnv'] = amd_envs.ReachVectorEnv  # noqa: SLF001
+        reg._support_envs['OmnisafeAmdReachVectorEnv'] = reach_ids  # noqa: SLF001
     del omnisafe
     return swapped

@@ -571,6 +571,80 @@ def gen_config_defaults():
             out[name[:-5]] = yaml.safe_load(open(os.path.join(cfg_dir, name)))['defaults']
     json.dump(out, open(os.path.join(OUT, 'config_defaults.json'), 'w'), indent=1, sort_keys=True)
 
+LEARNING_CFG = {
+    # shared by the reference runs below and tests/test_learning_gpu.py
+    'env_id': 'SynthReach-v0', 'epochs': 10, 'vector_env_nums': 16, 'steps_per_epoch': 4096,
+    'horizon': 50, 'cost_limit': 2.0, 'tail_epochs': 3,
+}
+
+
+def learning_custom_cfgs(algo, seed, device, log_dir, c=None):
+    """custom_cfgs of one learning-curve run; shared with tests/test_learning_gpu.py (which keeps its own
+    copy because tests may not import this generator on the GPU box).  TRPOLag.yaml / CPO.yaml have no
+    env_cfgs key (custom env_cfgs would be rejected), so the env's default horizon (50) applies there."""
+    c = c or LEARNING_CFG
+    cfg = {
+        'seed': seed,
+        'train_cfgs': {'total_steps': c['steps_per_epoch'] * c['epochs'],
+                       'vector_env_nums': c['vector_env_nums'], 'device': device},
+        'algo_cfgs': {'steps_per_epoch': c['steps_per_epoch']},
+        'logger_cfgs': {'log_dir': log_dir, 'save_model_freq': 1000},
+    }
+    if algo == 'CPO':
+        cfg['algo_cfgs']['cost_limit'] = c['cost_limit']
+    else:
+        cfg['lagrange_cfgs'] = {'cost_limit': c['cost_limit']}
+    if algo == 'PPOLag':
+        cfg['env_cfgs'] = {'horizon': c['horizon']}
+    return cfg
+
+
+def gen_learning_curves(algos=('PPOLag', 'TRPOLag', 'CPO'), seeds=(0, 1, 2, 3, 4), merge=True, part=None):
+    """Train the unmodified reference on the learnable point-reach CMDP and record the per-epoch
+    Metrics/EpRet, EpCost (and LagrangeMultiplier) of every seed (progress.csv of the reference's
+    logger): the comparison target for "episode return/cost within +-1 sigma over 3 seeds"."""
+    import csv
+    import json
+
+    import omnisafe
+
+    ref_harness.register_reach_env()
+    c = LEARNING_CFG
+    # part: write a separate file (tools: several single-thread runs in parallel, merged afterwards
+    # by merge_learning_parts)
+    path = os.path.join(OUT, 'learning_reach.json' if part is None else f'_learning_part_{part}.json')
+    out = {'config': dict(c), 'curves': {}}
+    if merge and os.path.exists(path):
+        out['curves'] = json.load(open(path))['curves']
+    for algo in algos:
+        out['curves'].setdefault(algo, {})
+        for seed in seeds:
+            d = tempfile.mkdtemp()
+            cfg = learning_custom_cfgs(algo, seed, 'cpu', d)
+            cfg['train_cfgs']['torch_threads'] = 1
+            cfg['logger_cfgs'].update({'use_wandb': False, 'use_tensorboard': False})
+            omnisafe.Agent(algo, c['env_id'], custom_cfgs=cfg).learn()
+            rows = None
+            for root, _, files in os.walk(d):
+                if 'progress.csv' in files:
+                    rows = list(csv.DictReader(open(os.path.join(root, 'progress.csv'))))
+            keys = ['EpRet', 'EpCost'] + (['LagrangeMultiplier'] if algo != 'CPO' else [])
+            out['curves'][algo][str(seed)] = {k: [float(r[f'Metrics/{k}']) for r in rows] for k in keys}
+            json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
+
+
+def merge_learning_parts():
+    import glob
+    import json
+
+    out = {'config': dict(LEARNING_CFG), 'curves': {}}
+    for f in sorted(glob.glob(os.path.join(OUT, '_learning_part_*.json'))):
+        for algo, seeds in json.load(open(f))['curves'].items():
+            out['curves'].setdefault(algo, {}).update(seeds)
+        os.remove(f)
+    out['curves'] = {a: dict(sorted(s.items(), key=lambda kv: int(kv[0]))) for a, s in out['curves'].items()}
+    json.dump(out, open(os.path.join(OUT, 'learning_reach.json'), 'w'), indent=1, sort_keys=True)
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
@@ -585,6 +659,7 @@ def main():
     gen_sibling_updates()
     gen_saute_simmer()
     gen_config_defaults()
+    gen_learning_curves()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

