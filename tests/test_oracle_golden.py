@@ -165,3 +165,42 @@ def test_ppolag_update_vs_reference(golden):
     assert np.allclose(stats['loss_c'], g['update/loss_c'], rtol=0, atol=0)
     assert np.float32(stats['kl']) == g['update/kl'][-1]
     assert stats['stop_iter'] == int(g['update/stop_iter'][-1])
+
+
+def test_reach_env_statement_known_answers():
+    """Hand-computed transitions of the learnable stand-in task (oracle/np_oracle.py:reach_env_step)."""
+    f = np.float32
+    state = np.array([
+        [0.0, 0.0, 0.3, 0.4, 1.0, 1.0],     # moves towards the goal, far from the hazard
+        [0.0, 0.0, 0.1, 0.0, 0.05, 0.0],    # reaches the goal and sits in the hazard
+        [1.45, -1.45, 0.0, 0.0, -1.0, 1.0],  # clipped at the wall, action clipped to [-1, 1]
+    ], dtype=f)
+    action = np.array([[0.6, 0.8], [1.0, 0.0], [3.0, -3.0]], dtype=f)
+    q, r, c, reached = O.reach_env_step(state, action)
+    np.testing.assert_allclose(q, [[0.06, 0.08], [0.1, 0.0], [1.5, -1.5]], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r[0], 0.5 - 0.4, atol=1e-6)          # |(.3,.4)| = .5 -> |(.24,.32)| = .4
+    assert reached.tolist() == [False, True, False]
+    np.testing.assert_allclose(r[1], 0.1 + 1.0, atol=1e-6)           # progress 0.1 plus the goal bonus
+    assert c.tolist() == [0.0, 1.0, 0.0]
+    assert r[2] < 0                                                  # pushed away from the goal at the origin
+    obs = O.reach_env_obs(np.array([[0.1, 0.2, 0.5, 0.1, -0.3, 0.0]], f), 60)
+    np.testing.assert_allclose(obs[0, :6], [0.1, 0.2, 0.4, -0.1, -0.4, -0.2], atol=1e-7)
+    assert obs.shape == (1, 60) and not obs[0, 6:].any()
+
+
+def test_learning_golden_file_is_complete():
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'learning_reach.json')))
+    cfg = g['config']
+    assert cfg['env_id'] == 'SynthReach-v0' and cfg['epochs'] == 10
+    for algo in ('PPOLag', 'TRPOLag', 'CPO'):
+        curves = g['curves'][algo]
+        assert sorted(map(int, curves)) == list(range(20))
+        for c in curves.values():
+            assert len(c['EpRet']) == len(c['EpCost']) == cfg['epochs']
+            assert np.isfinite(c['EpRet']).all() and np.isfinite(c['EpCost']).all()
+    # the reference learns the task: PPOLag's seed-mean return rises monotonically from ~0 to ~7
+    m = np.mean([c['EpRet'] for c in g['curves']['PPOLag'].values()], axis=0)
+    assert abs(m[0]) < 0.2 and m[-1] > 6 and np.all(np.diff(m) > 0)

@@ -119,3 +119,27 @@ def test_simmer_controller_live(ref):
         sa = a.act(safety_budget=sa, observation=torch.tensor(jc))
         sb = b.act(safety_budget=sb, observation=torch.tensor(jc))
         assert torch.equal(sa, sb)
+
+
+def test_reach_env_twin_live(ref):
+    """The CPU env the reference trains on for the learning curves (oracle/ref_harness.py:
+    register_reach_env) behaves as a reference CMDP: spaces, vector auto-reset convention, horizon."""
+    import ref_harness
+
+    ref_harness.register_reach_env()
+    from omnisafe.envs.core import make
+
+    env = make('SynthReach-v0', num_envs=4, device=torch.device('cpu'), horizon=5)
+    env.set_seed(3)
+    obs, _ = env.reset()
+    assert obs.shape == (4, 60) and env.action_space.shape == (2,)
+    state0 = env._state.copy()
+    for t in range(5):
+        act = torch.full((4, 2), 0.5)
+        q, r, c, reached = O.reach_env_step(env._state, act.numpy())
+        obs, reward, cost, term, trunc, info = env.step(act)
+        np.testing.assert_array_equal(reward.numpy(), r)
+        np.testing.assert_array_equal(cost.numpy(), c)
+        assert bool(trunc.all()) == (t == 4) and not bool(term.any())
+    np.testing.assert_array_equal(info['final_observation'][:, 0:2].numpy(), q)
+    assert not np.array_equal(env._state, state0) and np.all(np.abs(env._state) <= 1)
