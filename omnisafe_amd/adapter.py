@@ -341,3 +341,49 @@ class SimmerAdapter(SauteAdapter):
         self._safety_budget_host = self._controller.act(safety_budget=self._safety_budget_host,
                                                         observation=ep_costs)
         self._sync_budget()
+
+
+class _EarlyTerminatedEnv:
+    """The step() override of the reference's EarlyTerminatedAdapter (early_terminated_adapter.py:50-88) as an
+    env wrapper under the rollout loop: accumulate the cost, and once it exceeds the limit hand back a zero
+    reward, terminated = 1 and the observation of a fresh episode.  The accumulated cost is only cleared
+    there (not on a time-limit reset), as in the reference."""
+
+    need_auto_reset_wrapper = False
+    need_time_limit_wrapper = False
+
+    def __init__(self, env, adapter: 'EarlyTerminatedAdapter', cost_limit: float) -> None:
+        self._env, self._adapter, self._cost_limit = env, adapter, float(cost_limit)
+        self._cost_logger = torch.zeros(1, dtype=torch.float32, device=adapter._device)  # noqa: SLF001
+
+    def __getattr__(self, name):  # spaces, num_envs, set_seed, close, ...
+        return getattr(self._env, name)
+
+    def reset(self, seed=None, options=None):
+        return self._env.reset(seed=seed, options=options)
+
+    def step(self, action: torch.Tensor):
+        next_raw, reward, cost, terminated, truncated, info = self._env.step(action)
+        self._cost_logger += cost.reshape(1).to(torch.float32)
+        if float(self._cost_logger) > self._cost_limit:  # one env, one host read per step (as the reference)
+            # the observation that is thrown away has already gone through ObsNormalize in the reference
+            # (its running statistics saw it, early_terminated_adapter.py:78 -> wrapper.py:231-241)
+            self._adapter._normalize(next_raw, out=self._adapter._scratch_obs)  # noqa: SLF001
+            reward = torch.zeros_like(reward, dtype=torch.float32)
+            terminated = torch.ones(1, dtype=torch.uint8, device=self._cost_logger.device)
+            next_raw, _ = self._env.reset()
+            self._cost_logger.zero_()
+        return next_raw, reward, cost, terminated, truncated, info
+
+
+class EarlyTerminatedAdapter(OnPolicyAdapter):
+    """early_terminated_adapter.py:27-88: episodes end as soon as their accumulated cost exceeds
+    ``algo_cfgs.cost_limit``.  Single environment only, like the reference (:42)."""
+
+    def __init__(self, env_id: str, num_envs: int, seed: int, cfgs, env=None) -> None:
+        assert num_envs == 1, 'EarlyTerminatedAdapter only supports num_envs=1.'
+        super().__init__(env_id, num_envs, seed, cfgs, env=env)
+        self._scratch_obs = torch.empty(1, self._obs_dim, dtype=torch.float32, device=self._device)
+        self._cost_limit = float(cfgs.algo_cfgs.cost_limit)
+        self._env = _EarlyTerminatedEnv(self._env, self, self._cost_limit)
+

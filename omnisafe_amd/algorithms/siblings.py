@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import distributed as dist
-from ..adapter import SauteAdapter, SimmerAdapter
+from ..adapter import EarlyTerminatedAdapter, SauteAdapter, SimmerAdapter
 from ..lagrange import Lagrange
 from ..models import SurrogateExt
 from ..pid_lagrange import PIDLagrangian
@@ -329,3 +329,26 @@ class PPOSimmerPID(_SimmerMixin, PPO):
 @register
 class TRPOSimmerPID(_SimmerMixin, TRPO):
     pass
+
+
+class _EarlyTerminatedMixin:
+    """_init_env of ppo_early_terminated.py:40-66 / trpo_early_terminated.py."""
+
+    def _init_env(self) -> None:
+        c = self._cfgs
+        self._env = EarlyTerminatedAdapter(self._env_id, c.train_cfgs.vector_env_nums, self._seed, c)
+        assert c.algo_cfgs.steps_per_epoch % (dist.world_size() * c.train_cfgs.vector_env_nums) == 0, (
+            'The number of steps per epoch is not divisible by the number of environments.')
+        self._steps_per_epoch = (c.algo_cfgs.steps_per_epoch // dist.world_size()
+                                 // c.train_cfgs.vector_env_nums)
+
+
+@register
+class PPOEarlyTerminated(_EarlyTerminatedMixin, PPO):
+    pass
+
+
+@register
+class TRPOEarlyTerminated(_EarlyTerminatedMixin, TRPO):
+    pass
+

@@ -154,11 +154,15 @@ _TRPOSIMMER = _derive(_TRPO, dict(_SAUTE, upper_budget=25.0))
 for _d in (_PPOSIMMER, _TRPOSIMMER):
     _d['control_cfgs'] = {'kp': 0.0005, 'ki': 1e-05, 'kd': 0.0, 'polyak': 0.995}
 
+_PPOET = _derive(_PPO, {'cost_limit': 25.0})     # PPOEarlyTerminated.yaml = PPO.yaml + cost_limit
+_TRPOET = _derive(_TRPO, {'cost_limit': 25.0})
+
 DEFAULTS = {'PPOLag': _PPOLAG, 'TRPOLag': _TRPOLAG, 'CPO': _CPO, 'PPO': _PPO, 'TRPO': _TRPO,
             'PolicyGradient': _PG, 'NaturalPG': _NPG, 'PDO': _PDO, 'RCPO': _RCPO, 'IPO': _IPO,
             'OnCRPO': _ONCRPO, 'CPPOPID': _CPPOPID, 'TRPOPID': _TRPOPID, 'PCPO': _PCPO,
             'FOCOPS': _FOCOPS, 'CUP': _CUP, 'P3O': _P3O, 'PPOSaute': _PPOSAUTE, 'TRPOSaute': _TRPOSAUTE,
-            'PPOSimmerPID': _PPOSIMMER, 'TRPOSimmerPID': _TRPOSIMMER}
+            'PPOSimmerPID': _PPOSIMMER, 'TRPOSimmerPID': _TRPOSIMMER,
+            'PPOEarlyTerminated': _PPOET, 'TRPOEarlyTerminated': _TRPOET}
 
 
 def get_default_kwargs(algo: str) -> dict:

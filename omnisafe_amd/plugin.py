@@ -12,7 +12,7 @@ from __future__ import annotations
 
 ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag', 'CPO', 'PDO', 'RCPO', 'IPO',
                'OnCRPO', 'CPPOPID', 'TRPOPID', 'PCPO', 'FOCOPS', 'CUP', 'P3O', 'PPOSaute', 'TRPOSaute',
-               'PPOSimmerPID', 'TRPOSimmerPID')
+               'PPOSimmerPID', 'TRPOSimmerPID', 'PPOEarlyTerminated', 'TRPOEarlyTerminated')
 
 
 def install(algorithms: tuple[str, ...] | None = None) -> list[str]:

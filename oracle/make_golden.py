@@ -247,6 +247,7 @@ def gen_rollout_and_ppolag_update():
         algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
     env_core.step, env_core.reset = orig_step, orig_reset
     out['rollout/reset_obs'] = resets[-1]
+    out['rollout/resets'] = np.stack(resets)  # every reset() in call order (early termination resets mid-epoch)
     for k in steps[0]:
         out[f'rollout/{k}'] = np.stack([s[k] for s in steps])
     vec_eps = [e for e in rec.normals if e.dim() == 2]
@@ -503,6 +504,7 @@ def _record_rollout(algo, T, seed):
         algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
     env_core.step, env_core.reset = orig_step, orig_reset
     out['rollout/reset_obs'] = resets[-1]
+    out['rollout/resets'] = np.stack(resets)  # every reset() in call order (early termination resets mid-epoch)
     for k in steps[0]:
         out[f'rollout/{k}'] = np.stack([s[k] for s in steps])
     vec_eps = [e for e in rec.normals if e.dim() == 2]
@@ -556,6 +558,44 @@ def gen_saute_simmer():
         np.savez(os.path.join(OUT, f'{tag}_rollout.npz'), **out)
         print(tag, 'unsafe steps:', int((out['buffer/reward'] == np.float32(-0.5)).sum()),
               'EpBudget', out.get('rollout/ep_budget_window'))
+
+
+def gen_early_terminated():
+    """EarlyTerminatedAdapter rollout of the reference (single env, as it requires): 400 steps on the
+    synthetic env with cost_limit 1.5, so that episodes end both by the time limit (every 16 steps) and
+    by early termination (second unit of accumulated cost; the accumulator survives time-limit resets)."""
+    import omnisafe
+
+    N, T, horizon = 1, 400, 16
+    ref_harness.register_synth_env()
+    ref_harness.DEFAULT_HORIZON = horizon  # PPOEarlyTerminated.yaml has no env_cfgs key
+    d = tempfile.mkdtemp()
+    cfg = {'seed': 0,
+           'train_cfgs': {'total_steps': N * T * 4, 'vector_env_nums': N, 'torch_threads': 1, 'device': 'cpu'},
+           'algo_cfgs': {'steps_per_epoch': N * T, 'update_iters': 2, 'cost_limit': 1.5},
+           'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
+    algo = omnisafe.Agent('PPOEarlyTerminated', 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+    out = {'N': N, 'T': T, 'horizon': horizon, 'cost_limit': np.float32(1.5)}
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(algo._actor_critic, net)).items():
+            out[f'init/{net}/{k}'] = v
+    rec = _record_rollout(algo, T, seed=7)
+    for k, v in rec.items():  # a single reference env returns unbatched tensors: restore the env axis
+        if k in ('rollout/action', 'rollout/obs', 'rollout/final_obs'):
+            v = v.reshape(T, N, -1)
+        elif k in ('rollout/reward', 'rollout/cost', 'rollout/terminated', 'rollout/truncated'):
+            v = v.reshape(T, N)
+        elif k == 'rollout/reset_obs':
+            v = v.reshape(N, -1)
+        elif k == 'rollout/resets':
+            v = v.reshape(v.shape[0], N, -1)
+        elif k == 'rollout/eps':
+            v = v.reshape(T, N, -1)
+        out[k] = v
+    np.savez(os.path.join(OUT, 'early_terminated_rollout.npz'), **out)
+    print('early terminated: resets', out['rollout/resets'].shape[0] - 1, 'truncations',
+          int(out['rollout/truncated'].sum()), 'episodes', len(out['rollout/ep_len_window']),
+          'zeroed rewards', int((out['buffer/reward'] == 0).sum()))
 
 
 def gen_config_defaults():
@@ -658,6 +698,7 @@ def main():
     gen_trust_region_updates()
     gen_sibling_updates()
     gen_saute_simmer()
+    gen_early_terminated()
     gen_config_defaults()
     gen_learning_curves()
     for f in sorted(os.listdir(OUT)):

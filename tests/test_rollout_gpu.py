@@ -361,3 +361,83 @@ def test_baseline_config_shapes_end_to_end(tmp_path, algo_name, env_id, obs_dim)
     ep_ret, ep_cost, ep_len = agent.learn()
     assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
     assert bool(torch.isfinite(ac.params).all()) and not torch.equal(before, ac.params)
+
+
+class _TraceEnvWithResets(TraceEnv):
+    """TraceEnv whose reset() serves the reference's recorded resets in call order (the early-terminated
+    adapter resets the env in the middle of an epoch) and does not rewind the trace."""
+
+    def __init__(self, g):
+        super().__init__(g)
+        self.n_resets = 0
+
+    def reset(self, seed=None, options=None):
+        obs = torch.from_numpy(self.g['rollout/resets'][self.n_resets]).to(DEV)
+        self.n_resets += 1
+        return obs, {}
+
+
+def test_early_terminated_rollout_on_reference_trace(golden):
+    """EarlyTerminatedAdapter (early_terminated_adapter.py:50-88) replayed on the raw env trace of a
+    reference PPOEarlyTerminated rollout: 14 early terminations (zero reward, terminated, mid-epoch
+    reset, no bootstrap) interleaved with 18 time-limit truncations."""
+    from omnisafe_amd.adapter import EarlyTerminatedAdapter
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from test_mlp_gpu import make_ac
+
+    g = golden('early_terminated_rollout.npz')
+    N, T = int(g['N']), int(g['T'])
+    env = _TraceEnvWithResets(g)
+    adapter = EarlyTerminatedAdapter('trace', N, 0, _cfgs(cost_limit=float(g['cost_limit'])), env=env)
+    ac = make_ac(60, 2, g, 'init/')
+    eps_iter = iter(g['rollout/eps'])
+    plain_step = ac.step
+
+    def step_with_recorded_noise(obs, deterministic=False, eps=None, out=None, nets_mask=7):
+        if out is not None and 'act' in out and not deterministic:
+            eps = torch.from_numpy(next(eps_iter)).to(DEV)
+        return plain_step(obs, deterministic=deterministic, eps=eps, out=out, nets_mask=nets_mask)
+
+    ac.step = step_with_recorded_noise
+    buf = VectorOnPolicyBuffer(adapter.observation_space, adapter.action_space, T, 0.99, 0.95, 0.95,
+                               'gae', 0.0, True, True, num_envs=N, device=DEV)
+    logger = _LoggerStub()
+    adapter.rollout(T, ac, buf, logger)
+    assert env.n_resets == g['rollout/resets'].shape[0] == 15  # epoch start + 14 early terminations
+    buf.compute_advantages()
+    b = {k: v.cpu().numpy() for k, v in buf.data.items()}
+    assert np.array_equal(b['reward'], g['buffer/reward']) and np.array_equal(b['cost'], g['buffer/cost'])
+    # early-terminated steps: reward zeroed although the env returned a non-zero one
+    early = (b['reward'][:, 0] == 0) & (g['rollout/reward'][:, 0] != 0)
+    assert early.sum() == 14
+    pe = (g['rollout/truncated'][:, 0].astype(bool) | early).astype(np.uint8)
+    pe[-1] = 1
+    assert np.array_equal(b['path_end'][:, 0], pe)
+    assert not b['boot_r'][early, 0].any() and not b['boot_c'][early, 0].any()  # terminated: no bootstrap
+    for k in ('obs', 'act', 'value_r', 'value_c', 'logp'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in ('adv_r', 'adv_c', 'target_value_r', 'target_value_c'):
+        np.testing.assert_allclose(b[k], g[f'buffer/{k}'], rtol=1e-4, atol=1e-4, err_msg=k)
+    norm = adapter.save()['obs_normalizer']
+    assert int(norm._count) == int(g['rollout/norm_count']) == 1 + T + 14 + 18
+    np.testing.assert_allclose(norm.mean.cpu().numpy(), g['rollout/norm_mean'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(norm.std.cpu().numpy(), g['rollout/norm_std'], rtol=1e-5)
+    np.testing.assert_allclose(logger.data['Metrics/EpRet'], g['rollout/ep_ret_window'], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(np.float32(logger.data['Metrics/EpCost']), g['rollout/ep_cost_window'])
+    assert np.array_equal(np.float32(logger.data['Metrics/EpLen']), g['rollout/ep_len_window'])
+    with pytest.raises(AssertionError, match='only supports num_envs=1'):
+        EarlyTerminatedAdapter('trace', 2, 0, _cfgs(cost_limit=1.0), env=env)
+
+
+@pytest.mark.parametrize('algo_name', ['PPOEarlyTerminated', 'TRPOEarlyTerminated'])
+def test_early_terminated_agents_end_to_end(tmp_path, algo_name):
+    import omnisafe_amd
+
+    cfg = {'seed': 4, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 512, 'vector_env_nums': 1},
+           'algo_cfgs': {'steps_per_epoch': 512, 'update_iters': 2, 'cost_limit': 2.5},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}}
+    agent = omnisafe_amd.Agent(algo_name, 'SynthTiny-v0', custom_cfgs=cfg)
+    ep_ret, ep_cost, ep_len = agent.learn()
+    # cost arrives in units of 1 with p = 0.05 per step: an episode ends when the accumulator reaches 3
+    # (it may start above zero: it survives the epoch's reset); the 1000-step time limit is never reached
+    assert np.isfinite(ep_ret) and 0 < ep_cost <= 3.0 and ep_len < 512
