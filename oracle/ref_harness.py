@@ -249,13 +249,14 @@ def register_synth_env():
 
 
 _REACH_REGISTERED = False
+_REACH_CLS = None
 
 
 def register_reach_env():
     """Register ``SynthReach-v0`` (obs 60 / act 2) with the reference's env registry: the CPU twin of
     omnisafe_amd's device env of the same id.  Dynamics from oracle/np_oracle.py; resets and goal
     resampling draw from a numpy Generator seeded by ``set_seed``."""
-    global _REACH_REGISTERED
+    global _REACH_REGISTERED, _REACH_CLS
     install()
     import numpy as np
     import torch
@@ -266,7 +267,7 @@ def register_reach_env():
     import np_oracle
 
     if _REACH_REGISTERED:
-        return None
+        return _REACH_CLS
 
     @env_register
     class ReachRefEnv(CMDP):  # pylint: disable=too-many-instance-attributes
@@ -342,4 +343,5 @@ def register_reach_env():
             return None
 
     _REACH_REGISTERED = True
+    _REACH_CLS = ReachRefEnv
     return ReachRefEnv

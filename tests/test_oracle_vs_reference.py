@@ -126,10 +126,11 @@ def test_reach_env_twin_live(ref):
     register_reach_env) behaves as a reference CMDP: spaces, vector auto-reset convention, horizon."""
     import ref_harness
 
-    ref_harness.register_reach_env()
-    from omnisafe.envs.core import make
+    from omnisafe.envs.core import CMDP
 
-    env = make('SynthReach-v0', num_envs=4, device=torch.device('cpu'), horizon=5)
+    cls = ref_harness.register_reach_env()  # instantiated directly: omnisafe_amd.install() (another test)
+    assert issubclass(cls, CMDP)            # may have pointed the id at the device env in this process
+    env = cls('SynthReach-v0', num_envs=4, device=torch.device('cpu'), horizon=5)
     env.set_seed(3)
     obs, _ = env.reset()
     assert obs.shape == (4, 60) and env.action_space.shape == (2,)
