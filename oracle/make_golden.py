@@ -618,10 +618,12 @@ LEARNING_CFG = {
 }
 
 
-def learning_custom_cfgs(algo, seed, device, log_dir, c=None):
-    """custom_cfgs of one learning-curve run; shared with tests/test_learning_gpu.py (which keeps its own
-    copy because tests may not import this generator on the GPU box).  TRPOLag.yaml / CPO.yaml have no
-    env_cfgs key (custom env_cfgs would be rejected), so the env's default horizon (50) applies there."""
+def learning_custom_cfgs(algo, seed, device, log_dir, defaults, c=None):
+    """custom_cfgs of one learning-curve run, derived from the algorithm's YAML defaults so that the cost
+    limit lands where that algorithm reads it.  tests/test_learning_gpu.py keeps a copy of this function
+    (tests may not import this generator on the GPU box) and feeds it omnisafe_amd's defaults, which a CPU
+    test pins to the reference's YAML files.  No env_cfgs: several YAMLs have no such key and would reject
+    it; the env's default horizon (50) applies."""
     c = c or LEARNING_CFG
     cfg = {
         'seed': seed,
@@ -630,12 +632,14 @@ def learning_custom_cfgs(algo, seed, device, log_dir, c=None):
         'algo_cfgs': {'steps_per_epoch': c['steps_per_epoch']},
         'logger_cfgs': {'log_dir': log_dir, 'save_model_freq': 1000},
     }
-    if algo == 'CPO':
-        cfg['algo_cfgs']['cost_limit'] = c['cost_limit']
-    else:
+    if 'cost_limit' in defaults.get('lagrange_cfgs', {}):
         cfg['lagrange_cfgs'] = {'cost_limit': c['cost_limit']}
-    if algo == 'PPOLag':
-        cfg['env_cfgs'] = {'horizon': c['horizon']}
+    if 'cost_limit' in defaults['algo_cfgs']:
+        cfg['algo_cfgs']['cost_limit'] = c['cost_limit']
+    if 'safety_budget' in defaults['algo_cfgs']:  # Saute / Simmer: budget = the limit, episodes of 50 steps
+        cfg['algo_cfgs'].update({'safety_budget': c['cost_limit'], 'max_ep_len': c['horizon']})
+        if 'upper_budget' in defaults['algo_cfgs']:
+            cfg['algo_cfgs']['upper_budget'] = 2 * c['cost_limit']
     return cfg
 
 
@@ -660,7 +664,10 @@ def gen_learning_curves(algos=('PPOLag', 'TRPOLag', 'CPO'), seeds=(0, 1, 2, 3, 4
         out['curves'].setdefault(algo, {})
         for seed in seeds:
             d = tempfile.mkdtemp()
-            cfg = learning_custom_cfgs(algo, seed, 'cpu', d)
+            from omnisafe.utils.config import get_default_kwargs_yaml
+
+            defaults = get_default_kwargs_yaml(algo, c['env_id'], 'on-policy').todict()
+            cfg = learning_custom_cfgs(algo, seed, 'cpu', d, defaults)
             cfg['train_cfgs']['torch_threads'] = 1
             cfg['logger_cfgs'].update({'use_wandb': False, 'use_tensorboard': False})
             omnisafe.Agent(algo, c['env_id'], custom_cfgs=cfg).learn()
@@ -668,7 +675,7 @@ def gen_learning_curves(algos=('PPOLag', 'TRPOLag', 'CPO'), seeds=(0, 1, 2, 3, 4
             for root, _, files in os.walk(d):
                 if 'progress.csv' in files:
                     rows = list(csv.DictReader(open(os.path.join(root, 'progress.csv'))))
-            keys = ['EpRet', 'EpCost'] + (['LagrangeMultiplier'] if algo != 'CPO' else [])
+            keys = ['EpRet', 'EpCost'] + (['LagrangeMultiplier'] if 'Metrics/LagrangeMultiplier' in rows[0] else [])
             out['curves'][algo][str(seed)] = {k: [float(r[f'Metrics/{k}']) for r in rows] for k in keys}
             json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
 
