@@ -618,6 +618,11 @@ LEARNING_CFG = {
 }
 
 
+LEARNING_ALGOS = ('PPOLag', 'TRPOLag', 'CPO', 'PolicyGradient', 'PPO', 'NaturalPG', 'TRPO', 'PDO', 'RCPO', 'CPPOPID',
+                  'TRPOPID', 'PCPO', 'FOCOPS', 'CUP', 'IPO', 'P3O', 'OnCRPO', 'PPOSaute', 'TRPOSaute',
+                  'PPOSimmerPID', 'TRPOSimmerPID')
+
+
 def learning_custom_cfgs(algo, seed, device, log_dir, defaults, c=None):
     """custom_cfgs of one learning-curve run, derived from the algorithm's YAML defaults so that the cost
     limit lands where that algorithm reads it.  tests/test_learning_gpu.py keeps a copy of this function
@@ -643,7 +648,7 @@ def learning_custom_cfgs(algo, seed, device, log_dir, defaults, c=None):
     return cfg
 
 
-def gen_learning_curves(algos=('PPOLag', 'TRPOLag', 'CPO'), seeds=(0, 1, 2, 3, 4), merge=True, part=None):
+def gen_learning_curves(algos=LEARNING_ALGOS, seeds=tuple(range(20)), merge=True, part=None):
     """Train the unmodified reference on the learnable point-reach CMDP and record the per-epoch
     Metrics/EpRet, EpCost (and LagrangeMultiplier) of every seed (progress.csv of the reference's
     logger): the comparison target for "episode return/cost within +-1 sigma over 3 seeds"."""
@@ -690,7 +695,7 @@ def merge_learning_parts():
             out['curves'].setdefault(algo, {}).update(seeds)
         os.remove(f)
     out['curves'] = {a: dict(sorted(s.items(), key=lambda kv: int(kv[0]))) for a, s in out['curves'].items()}
-    json.dump(out, open(os.path.join(OUT, 'learning_reach.json'), 'w'), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(OUT, 'learning_reach.json'), 'w'), sort_keys=True, separators=(',', ':'))
 
 
 def main():
