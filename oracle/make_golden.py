@@ -718,4 +718,18 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    # `make_golden.py`                         everything, serially (the 420 learning runs take ~8 CPU-hours)
+    # `make_golden.py learning ALGO SEED`      one learning run -> tests/golden/_learning_part_ALGO_SEED.json
+    #                                          (how the committed fixture was made: 8 of these in parallel,
+    #                                          OMP_NUM_THREADS=1 each)
+    # `make_golden.py merge-learning`          fold the part files into tests/golden/learning_reach.json
+    if len(sys.argv) >= 4 and sys.argv[1] == 'learning':
+        ref_harness.import_reference()
+        gen_learning_curves(algos=(sys.argv[2],), seeds=(int(sys.argv[3]),), merge=False,
+                            part=f'{sys.argv[2]}_{sys.argv[3]}')
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
+        if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there
+            os.replace(os.path.join(OUT, 'learning_reach.json'), os.path.join(OUT, '_learning_part_0prev.json'))
+        merge_learning_parts()
+    else:
+        main()

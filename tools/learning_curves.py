@@ -13,17 +13,18 @@ from test_learning_gpu import GOLDEN, train_reach  # noqa: E402
 
 algo = sys.argv[1] if len(sys.argv) > 1 else 'PPOLag'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # first seed (other seeds = other env layouts)
 g = json.load(open(GOLDEN))
 cfg = g['config']
 ours = {}
-for seed in range(n):
+for seed in range(first, first + n):
     ours[str(seed)] = train_reach(algo, seed, cfg, tempfile.mkdtemp())
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump({'config': cfg, 'curves': ours}, open(os.path.join(ROOT, 'gpurun_out', f'learning_{algo}.json'), 'w'),
+json.dump({'config': cfg, 'curves': ours}, open(os.path.join(ROOT, 'gpurun_out', f'learning_{algo}.json' if first == 0 else f'learning_{algo}_from{first}.json'), 'w'),
           indent=1)
 ref = g['curves'].get(algo)
 for key in ('EpRet', 'EpCost', 'LagrangeMultiplier'):
-    if key not in ours['0']:  # CPO has no multiplier
+    if key not in next(iter(ours.values())):  # CPO has no multiplier
         continue
     o = np.array([c[key] for c in ours.values()])
     print(key, 'ours mean/std per epoch:', np.round(o.mean(0), 3).tolist(), np.round(o.std(0, ddof=1), 3).tolist())
