@@ -5,7 +5,6 @@ Tolerances: policy gradient rtol 1e-3 / atol 2e-6; Fisher-vector 
 (JVP->VJP vs the reference's autograd double backward); CG solution rtol 2e-2 of its norm (15
 iterations amplify float32 noise); accepted line-search index and CPO case identical; post-update
 parameters atol 2e-4 (they are theta_old + a step of norm ~0.3)."""
-import types
 
 import numpy as np
 import pytest
