@@ -144,3 +144,24 @@ def test_reach_env_twin_live(ref):
         assert bool(trunc.all()) == (t == 4) and not bool(term.any())
     np.testing.assert_array_equal(info['final_observation'][:, 0:2].numpy(), q)
     assert not np.array_equal(env._state, state0) and np.all(np.abs(env._state) <= 1)
+
+
+def test_learning_runs_get_the_same_custom_cfgs_on_both_sides(ref, tmp_path):
+    """The learning-curve comparison feeds the reference (oracle/make_golden.py:learning_custom_cfgs, from the
+    YAML defaults) and omnisafe_amd (tests/test_learning_gpu.py:reach_custom_cfgs, from omnisafe_amd's
+    defaults) the same custom_cfgs for every algorithm, device aside."""
+    import json
+
+    import make_golden
+    import test_learning_gpu as tl
+    from omnisafe.utils.config import get_default_kwargs_yaml
+
+    cfg = json.load(open(tl.GOLDEN))['config']
+    assert cfg == make_golden.LEARNING_CFG
+    for algo in make_golden.LEARNING_ALGOS:
+        defaults = get_default_kwargs_yaml(algo, cfg['env_id'], 'on-policy').todict()
+        theirs = make_golden.learning_custom_cfgs(algo, 3, 'cpu', str(tmp_path), defaults)
+        ours = tl.reach_custom_cfgs(algo, 3, cfg, str(tmp_path))
+        assert theirs['train_cfgs'].pop('device') == 'cpu' and ours['train_cfgs'].pop('device') == tl.DEV
+        assert theirs == ours, algo
+    assert sorted(make_golden.LEARNING_ALGOS) == sorted(['PPOLag', 'TRPOLag', 'CPO'] + tl.SIBLINGS)
