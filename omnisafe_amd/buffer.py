@@ -98,6 +98,13 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         return self._standardized_adv_c
 
     @property
+    def buffers(self) -> list['_EnvBufferView']:
+        """Per-env views with the attributes the reference's ``OnPolicyBuffer`` objects expose
+        (vector_onpolicy_buffer.py:77-89: ``vector_buffer.buffers[idx].data[key]``, ``.ptr``,
+        ``.path_start_idx``).  There is one storage block, so these are strided views of it."""
+        return [_EnvBufferView(self, idx) for idx in range(self._num_buffers)]
+
+    @property
     def stats(self) -> torch.Tensor:
         """Device statistics [sum_r, sum_c, n, sumsq_r, mean_r, mean_c, std_r, -] of the last get()."""
         return self._stats
@@ -196,3 +203,26 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         self.ptr = 0
         self.data['path_end'].zero_()
         return dict(o)
+
+
+class _EnvBufferView:
+    """What ``VectorOnPolicyBuffer.buffers[idx]`` looks like to code written against the reference:
+    ``data[key]`` is env ``idx``'s (size, ...) column of the time-major block (a view: writes go through),
+    ``ptr`` the shared write pointer, ``path_start_idx`` the step after the env's last finished path."""
+
+    def __init__(self, owner: VectorOnPolicyBuffer, idx: int) -> None:
+        self._owner, self._idx = owner, idx
+
+    @property
+    def data(self) -> dict[str, torch.Tensor]:
+        return {k: v[:, self._idx] for k, v in self._owner.data.items()}
+
+    @property
+    def ptr(self) -> int:
+        return self._owner.ptr
+
+    @property
+    def path_start_idx(self) -> int:
+        ends = self._owner.data['path_end'][:self._owner.ptr, self._idx].nonzero()
+        return int(ends[-1]) + 1 if ends.numel() else 0
+

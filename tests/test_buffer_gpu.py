@@ -202,3 +202,56 @@ def test_cabi_error_codes():
     with pytest.raises(_lib.OsaError):
         _lib.check(EINVAL, 'osa_gae_scan')
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('advantage_estimator', ['gae', 'vtrace', 'gae-rtg', 'plain'])
+def test_vector_onpolicy_buffer_like_the_reference_test(advantage_estimator):
+    """The reference's own test of this class (tests/test_buffer.py:29-168: obs/act dim 1, size 100,
+    gamma = lam = lam_c = 0.9, two envs, the four estimators, (num_envs, 1)-shaped scalars) run against the
+    drop-in: same constructor keywords, `buffers[idx].data[key][ptr - 1]` after every store, `path_start_idx
+    == ptr` after finish_path, shapes of get() -- plus what the reference's test leaves out, the values."""
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from omnisafe_amd.spaces import Box
+
+    size, num_envs = 100, 2
+    vector_buffer = VectorOnPolicyBuffer(
+        obs_space=Box(low=-1, high=1, shape=(1,)), act_space=Box(low=-1, high=1, shape=(1,)), size=size,
+        gamma=0.9, lam=0.9, advantage_estimator=advantage_estimator, standardized_adv_r=True,
+        standardized_adv_c=True, lam_c=0.9, penalty_coefficient=0.0, device=torch.device(DEV), num_envs=num_envs)
+    assert vector_buffer.num_buffers == num_envs
+    assert vector_buffer.standardized_adv_c is True and vector_buffer.standardized_adv_r is True
+    assert len(vector_buffer.buffers) == num_envs
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    keys = ('obs', 'act', 'reward', 'cost', 'value_r', 'value_c', 'logp')
+    stored = {k: [] for k in keys}
+    for _ in range(size):
+        step = {k: torch.rand((num_envs, 1), generator=gen).to(DEV) for k in keys}
+        vector_buffer.store(**step)
+        for k in keys:
+            stored[k].append(step[k].cpu().numpy().reshape(num_envs))
+        for idx, buffer in enumerate(vector_buffer.buffers):
+            for k in keys:
+                assert torch.allclose(buffer.data[k][buffer.ptr - 1].reshape(-1), step[k][idx]), k
+    last = torch.randn(num_envs, 2, generator=gen)
+    for idx, buffer in enumerate(vector_buffer.buffers):
+        vector_buffer.finish_path(last[idx, :1].to(DEV), last[idx, 1:].to(DEV), idx)
+        assert buffer.path_start_idx == buffer.ptr == size
+    data = vector_buffer.get()
+    assert data['obs'].shape == (size * num_envs, 1) and data['act'].shape == (size * num_envs, 1)
+    assert set(data) == {'obs', 'act', 'logp', 'target_value_r', 'target_value_c', 'adv_r', 'adv_c',
+                         'discounted_ret'}
+    # values: the oracle's per-path arithmetic (pinned to the reference's OnPolicyBuffer) on the same numbers
+    s = {k: np.stack(v) for k, v in stored.items()}  # (T, N)
+    pe = np.zeros((size, num_envs), bool)
+    pe[-1] = True
+    br = np.zeros((size, num_envs), np.float32)
+    bc = np.zeros((size, num_envs), np.float32)
+    br[-1], bc[-1] = last[:, 0].numpy(), last[:, 1].numpy()
+    ref = O.gae_time_major(s['reward'], s['cost'], s['value_r'], s['value_c'], pe, br, bc, 0.9, 0.9, 0.9,
+                           estimator=advantage_estimator)
+    assert np.array_equal(data['target_value_r'].cpu().numpy(), O.env_major(ref['tgt_r']))
+    assert np.array_equal(data['target_value_c'].cpu().numpy(), O.env_major(ref['tgt_c']))
+    a_r, a_c, _ = O.buffer_get(ref['adv_r'], ref['adv_c'])
+    np.testing.assert_allclose(data['adv_r'].cpu().numpy(), a_r, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(data['adv_c'].cpu().numpy(), a_c, rtol=2e-5, atol=2e-6)
+    assert np.array_equal(data['logp'].cpu().numpy(), O.env_major(s['logp']))
