@@ -441,3 +441,37 @@ def test_early_terminated_agents_end_to_end(tmp_path, algo_name):
     # cost arrives in units of 1 with p = 0.05 per step: an episode ends when the accumulator reaches 3
     # (it may start above zero: it survives the epoch's reset); the 1000-step time limit is never reached
     assert np.isfinite(ep_ret) and 0 < ep_cost <= 3.0 and ep_len < 512
+
+
+@pytest.mark.parametrize('shape', [(), (10,), (10, 10)])
+def test_normalizer_like_the_reference_test(shape):
+    """The reference's own test of this class (tests/test_normalizer.py:24-52): 1000 single samples, then
+    1000 batches of 10, of standard normal data; running mean / std within 1e-2 of the sample statistics
+    (here also within 1e-5 of them: the running update is exact up to float32 rounding)."""
+    from omnisafe_amd.normalizer import Normalizer
+
+    gen = torch.Generator(device='cpu').manual_seed(len(shape))
+    norm = Normalizer(shape, device=DEV)
+    assert norm.mean.shape == shape
+    data_lst = []
+    for _ in range(1000):
+        data = torch.randn(shape, generator=gen)
+        data_lst.append(data)
+        out = norm(data.to(DEV))
+        assert out.shape == shape
+    data = torch.stack(data_lst)
+    assert torch.allclose(data.mean(dim=0), norm.mean.cpu(), atol=1e-2)
+    assert torch.allclose(data.std(dim=0), norm.std.cpu(), atol=1e-2)
+    assert torch.allclose(data.mean(dim=0), norm.mean.cpu(), atol=1e-5)
+    assert torch.allclose(data.std(dim=0), norm.std.cpu(), rtol=1e-4)
+    norm = Normalizer(shape, device=DEV)
+    data_lst = []
+    for _ in range(1000):
+        data = torch.randn(10, *shape, generator=gen)
+        data_lst.append(data)
+        norm(data.to(DEV))
+    data = torch.cat(data_lst)
+    assert torch.allclose(data.mean(dim=0), norm.mean.cpu(), atol=1e-2)
+    assert torch.allclose(data.std(dim=0), norm.std.cpu(), atol=1e-2)
+    assert torch.allclose(data.std(dim=0), norm.std.cpu(), rtol=1e-4)
+    assert int(norm._count) == 10000 and norm.state_dict()['_mean'].shape == shape
