@@ -46,8 +46,8 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         self._actor_critic.set_seed(self._seed)
         if dist.world_size() > 1:
             self._actor_critic.sync_params()
-        if getattr(c.model_cfgs, 'exploration_noise_anneal', False):
-            raise NotImplementedError('exploration_noise_anneal (gaussian actor) is not accelerated')
+        if getattr(c.model_cfgs, 'exploration_noise_anneal', False):  # policy_gradient.py:101-105
+            self._actor_critic.set_annealing(epochs=[0, c.train_cfgs.epochs], std=list(c.model_cfgs.std_range))
 
     def _init(self) -> None:
         """policy_gradient.py:107-131."""
@@ -129,6 +129,8 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
             self._update()
             torch.cuda.synchronize(self._device)
             self._logger.store({'Time/Update': time.time() - update_time})
+            if getattr(c.model_cfgs, 'exploration_noise_anneal', False):  # policy_gradient.py:271-272
+                self._actor_critic.annealing(epoch)
             if c.model_cfgs.actor.lr is not None:
                 self._actor_critic.actor_scheduler.step()
             self._logger.store({

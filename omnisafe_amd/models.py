@@ -146,6 +146,12 @@ class NetView:
         lay = self._o.layout
         return float(torch.exp(self._block()[lay.oLS:lay.oLS + lay.act_dim]).mean())
 
+    @std.setter
+    def std(self, std: float) -> None:
+        """gaussian_learning_actor.py:136-139: log_std.fill_(log(std)), float32 like the reference."""
+        assert self._net == ACTOR
+        self.log_std.fill_(float(torch.log(torch.tensor(std))))
+
     @property
     def log_std(self) -> torch.Tensor:
         lay = self._o.layout
@@ -269,6 +275,28 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
         if single:
             return act[0], v_r[0], v_c[0], logp[0]
         return act, v_r, v_c, logp
+
+    def __call__(self, obs: torch.Tensor, deterministic: bool = False):
+        """nn.Module.forward of the reference (actor_critic.py:141-155) = step."""
+        return self.step(obs, deterministic=deterministic)
+
+    def set_annealing(self, epochs: list[int], std: list[float]) -> None:
+        """actor_critic.py:157-171: piecewise-linear schedule of the exploration std over the epochs
+        (omnisafe/utils/schedule.py:37-82: outside the end points the last value applies)."""
+        idxes = list(epochs)
+        assert idxes == sorted(idxes)
+        self._std_endpoints = list(zip(epochs, std))
+        self._std_outside = std[-1]
+
+    def annealing(self, epoch: int) -> None:
+        """actor_critic.py:173-183."""
+        value = self._std_outside
+        for (left_t, left), (right_t, right) in zip(self._std_endpoints[:-1], self._std_endpoints[1:]):
+            if left_t <= epoch < right_t:
+                alpha = float(epoch - left_t) / (right_t - left_t)
+                value = left + alpha * (right - left)
+                break
+        self.actor.std = value
 
     def values(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """Critic values only (bootstrap V(s) at truncation / epoch end)."""

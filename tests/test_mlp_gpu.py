@@ -483,3 +483,41 @@ def test_wide_input_minibatch_steps_vs_oracle(obs_dim, act_dim, B):
             #  a handful of the 24 064 first-layer weights move by a few 1e-6 after three steps)
             np.testing.assert_allclose(v.cpu().numpy(), getattr(ref, net).state_dict()[k].numpy(), rtol=1e-4,
                                        atol=2e-5, err_msg=f'{net}/{k}')
+
+
+@pytest.mark.parametrize('linear_lr_decay', [True, False])
+@pytest.mark.parametrize('lr', [None, 1e-3])
+def test_constraint_actor_critic_like_the_reference_test(linear_lr_decay, lr):
+    """The reference's own test of this class (tests/test_model.py:127-178): a single unbatched observation
+    through the module's call operator, output shapes, and the std annealing schedule
+    (actor_critic.py:157-183: linear from 0.5 at epoch 1 to 0.1 at epoch 10, 0.1 outside)."""
+    import types
+
+    from omnisafe_amd.models import ConstraintActorCritic
+    from omnisafe_amd.spaces import Box
+
+    ns = types.SimpleNamespace
+    obs_dim, act_dim = 10, 5
+    model_cfgs = ns(weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
+                    linear_lr_decay=linear_lr_decay, exploration_noise_anneal=False, std_range=[0.5, 0.1],
+                    actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr),
+                    critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr))
+    cac = ConstraintActorCritic(obs_space=Box(low=-1.0, high=1.0, shape=(obs_dim,)),
+                                act_space=Box(low=-1.0, high=1.0, shape=(act_dim,)), model_cfgs=model_cfgs,
+                                epochs=10, device=DEV)
+    obs = torch.randn(obs_dim, dtype=torch.float32)
+    act, value_r, value_c, logp = cac(obs)
+    assert act.shape == torch.Size([act_dim])
+    assert value_r.shape == torch.Size([]) and value_c.shape == torch.Size([]) and logp.shape == torch.Size([])
+    cac.set_annealing(epochs=[1, 10], std=[0.5, 0.1])
+    cac.annealing(5)
+    want = 0.5 + (5 - 1) / 9 * (0.1 - 0.5)
+    assert cac.actor.std == pytest.approx(want, rel=1e-6)
+    assert torch.allclose(cac.actor.log_std.cpu(), torch.full((act_dim,), float(np.log(want))), rtol=1e-6)
+    for epoch, std in ((0, 0.1), (1, 0.5), (10, 0.1), (12, 0.1)):
+        cac.annealing(epoch)
+        assert cac.actor.std == pytest.approx(std, rel=1e-6)
+    # the annealed std is what the next step samples with: logp of the mean action = -sum(log std) - d/2 log 2pi
+    cac.annealing(5)
+    act_det, _, _, logp_det = cac(obs, deterministic=True)
+    assert float(logp_det) == pytest.approx(-act_dim * (np.log(want) + 0.5 * np.log(2 * np.pi)), rel=1e-5)

@@ -475,3 +475,22 @@ def test_normalizer_like_the_reference_test(shape):
     assert torch.allclose(data.std(dim=0), norm.std.cpu(), atol=1e-2)
     assert torch.allclose(data.std(dim=0), norm.std.cpu(), rtol=1e-4)
     assert int(norm._count) == 10000 and norm.state_dict()['_mean'].shape == shape
+
+
+def test_exploration_noise_anneal_end_to_end(tmp_path):
+    """model_cfgs.exploration_noise_anneal (policy_gradient.py:101-105, 271-272): after every update the
+    actor's std is reset to the schedule's value for that epoch."""
+    import omnisafe_amd
+
+    cfg = {'seed': 3, 'train_cfgs': {'device': DEV, 'total_steps': 3 * 64 * 20, 'vector_env_nums': 64},
+           'algo_cfgs': {'steps_per_epoch': 64 * 20, 'update_iters': 2},
+           'model_cfgs': {'exploration_noise_anneal': True, 'std_range': [0.5, 0.1]},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 10}}
+    agent = omnisafe_amd.Agent('PPOLag', 'SynthTiny-v0', custom_cfgs=cfg)
+    agent.learn()
+    assert agent.agent._actor_critic.actor.std == pytest.approx(0.5 + 2 / 3 * (0.1 - 0.5), rel=1e-6)
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(str(tmp_path), '*', '*', 'progress.csv'))[0])))
+    # Train/PolicyStd of epoch e is logged during its update, i.e. before that epoch's annealing: epoch 1
+    # starts from the value set after epoch 0 (0.5) and epoch 2 from 0.5 - 0.4/3, each moved a little by Adam
+    assert abs(float(rows[1]['Train/PolicyStd']) - 0.5) < 0.02
+    assert abs(float(rows[2]['Train/PolicyStd']) - (0.5 - 0.4 / 3)) < 0.02
