@@ -168,13 +168,10 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             st['slabs'] = torch.empty(self.lib.osa_ppo_dp_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W),
                                       dtype=torch.float32, device=dev)
             st['lr'] = torch.zeros(2, dtype=torch.float32, device=dev)
-            # one generator per virtual rank, seeded like the ranks' own (seed + 1000 * rank): every rank
-            # draws the SAME W permutations without communicating
-            st['gens'] = []
-            for r in range(W):
-                gen = torch.Generator(device=dev)
-                gen.manual_seed(self.seed + 1000 * r + 7919)
-                st['gens'].append(gen)
+            # one generator, seeded from the (rank-independent) config seed: every rank draws the SAME W
+            # permutations without communicating
+            st['gen'] = torch.Generator(device=dev)
+            st['gen'].manual_seed(self.seed + 7919)
             st['graph'] = None
         return st
 
@@ -255,9 +252,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         st = self._dp_state(M, W, nmb)
         if perms_all is not None:
             st['perm'].copy_(perms_all.reshape(W, M))
-        else:
-            for r in range(W):
-                st['perm'][r].copy_(torch.randperm(M, generator=st['gens'][r], device=ac.device))
+        else:  # W uniform shuffles in one batched sort of random 62-bit keys (3 launches instead of ~4 W)
+            keys = torch.randint(0, 1 << 62, (W, M), generator=st['gen'], device=ac.device, dtype=torch.int64)
+            st['perm'].copy_(keys.argsort(dim=1))
         if coop is None:
             coop = self.dp_mode != 'replicated-steps'
         if coop:
