@@ -240,6 +240,31 @@ def cpu_baseline(args):
             'rollout_s': round(t_roll, 3), 'ms_per_minibatch_step': round(per_mb * 1e3, 4)}
 
 
+def cpu_baseline_reference(args):
+    """The UNMODIFIED reference on this box's host cores (kind "reference"): oracle/ref_cpu_baseline.py runs
+    `omnisafe.Agent('PPOLag', ..., device=cpu).learn()` for one epoch of this benchmark's shape with
+    update_iters lowered to 1 (the bounded sample) in its own process and reads Time/Rollout / Time/Update /
+    Time/FPS from the reference's progress.csv.  The package comes from /root/reference or from the archive
+    staged by `__graft_entry__.build()` (oracle/_ref/omnisafe_ref.zip); None if neither exists."""
+    import subprocess
+
+    threads = max(1, min(os.cpu_count() or 1, 16))  # the reference's own default torch_threads (PPOLag.yaml)
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py'), '--envs', str(args.envs),
+           '--steps-per-env', str(args.steps_per_env), '--batch-size', str(args.batch_size),
+           '--update-iters', str(args.update_iters), '--sample-iters', '1', '--threads', str(threads),
+           '--algo', args.algo]
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
+        res = json.loads(line)
+        return None if 'error' in res else res
+    except Exception as exc:  # noqa: BLE001 - the baseline is a reported extra, never fatal
+        return {'error': f'{type(exc).__name__}: {exc}'}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -292,7 +317,14 @@ def main():
             'ms_per_step': round(v_dt / v_steps * 1e3, 3),
             'roofline': roofline_from_events(v_events, 16384)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args)
+        port = cpu_baseline(args)
+        ref = cpu_baseline_reference(args)
+        if ref is not None and 'error' not in ref:
+            out['cpu_baseline'] = ref           # the unmodified reference on this box's host cores
+            out['cpu_baseline_port'] = port     # the oracle port (vectorised numpy rollout: flatters the CPU)
+        else:
+            out['cpu_baseline'] = port
+            out['cpu_baseline_reference_error'] = ref
     else:
         out['cpu_baseline'] = None
     if rank == 0:

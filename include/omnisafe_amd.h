@@ -46,6 +46,9 @@ extern "C" {
 const char* osa_strerror(int code);
 int osa_version(void);            /* ABI version, currently 1 */
 const char* osa_build_arch(void); /* "gfx950" */
+/* sha256 (first 32 hex digits) of this header and of the kernel sources the library was built from; the
+ * Python binding refuses a library whose digest differs from the sources next to it. */
+const char* osa_abi_digest(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Rollout buffer (replaces omnisafe/common/buffer/{onpolicy_buffer,vector_onpolicy_buffer}.py)
@@ -256,11 +259,14 @@ int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream)
  * workgroups stay resident for all ceil(M/B) steps; workgroup (net, r) keeps its own LDS/register copy
  * of the network and of the Adam moments, computes rank r's locally clipped gradient, publishes it in
  * `exchange` (osa_ppo_dp_pass_ws_floats floats), meets its `world` peers at an agent-scope arrival
- * counter (sync: int[4], counters + sticky time-out flag sync[3] that the caller should check; a peer
- * that never arrives is flagged after a bounded spin instead of hanging the device), then sums the
+ * counter (sync: int[4]: sync[0..2] arrival counters, reset by every call; sync[3] STICKY time-out flag,
+ * never reset by the library -- the caller zeroes all four words once at allocation and reads sync[3]
+ * at its next host synchronisation; a peer that never arrives is flagged after a bounded spin instead of
+ * hanging the device), then sums the
  * gradients in rank order and applies Adam locally -- every peer does identical arithmetic, rank 0's
- * copy is written back at the end and adam_step advances by the number of steps.  Requires
- * 3 * world <= compute units (OSA_EUNSUPPORTED otherwise: use osa_ppo_dp_step).
+ * copy is written back at the end and adam_step advances by the number of steps.  Launched with
+ * hipLaunchCooperativeKernel, i.e. the runtime verifies that all 3 * world workgroups are co-resident
+ * (OSA_EUNSUPPORTED otherwise: use osa_ppo_dp_step).
  * Replaces: the minibatch loop of PolicyGradient._update under torch.distributed
  * (policy_gradient.py:366-382, 437-442; distributed.py:193-198). */
 /* Optional: the exchange buffer of osa_ppo_dp_pass in UNCACHED device memory (hipExtMallocWithFlags,

@@ -23,6 +23,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_strerror': (C.c_char_p, [_I]),
     'osa_version': (_I, []),
     'osa_build_arch': (C.c_char_p, []),
+    'osa_abi_digest': (C.c_char_p, []),
     'osa_buffer_store_step': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I,
                                    _P, _P, _P, _P, _P, _P]),
     'osa_gae_scan': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
@@ -89,14 +90,40 @@ def load(require_gpu: bool = False):
     global _LIB
     if _LIB is None:
         path = lib_path()
-        if not os.path.exists(path):
+        own = path == _build.LIB_PATH  # OSA_LIB_PATH variants (tools/) are taken as they are
+
+        def build(force: bool) -> None:
             try:
-                _build.build_library(verbose=False)
+                _build.build_library(force=force, verbose=False)
             except Exception as exc:  # pragma: no cover
                 raise OsaError(
-                    f'libomnisafe_amd.so is missing and could not be built ({exc}); '
+                    f'libomnisafe_amd.so is missing or stale and could not be built ({exc}); '
                     'run `python -m omnisafe_amd.build` -- there is no CPU fallback') from exc
+
+        def digest(lib) -> str:
+            try:
+                lib.osa_abi_digest.restype = C.c_char_p
+                return lib.osa_abi_digest().decode()
+            except AttributeError:
+                return 'none'
+
+        if own and not os.path.exists(path):
+            build(False)
         lib = C.CDLL(path)
+        if own:
+            # ctypes cannot check prototypes, and the library is git-ignored but travels with the working
+            # tree: refuse to bind one that was not built from the sources next to it (content digest, not
+            # file times) -- rebuild it where hipcc exists, fail loudly where it does not
+            want = _build.source_digest()
+            if digest(lib) != want:
+                import _ctypes
+
+                _ctypes.dlclose(lib._handle)  # noqa: SLF001
+                build(True)
+                lib = C.CDLL(path)
+                if digest(lib) != want:
+                    raise OsaError(f'{path} was built from other sources (digest {digest(lib)}, expected '
+                                   f'{want}); run `python -m omnisafe_amd.build --force`')
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res

@@ -44,7 +44,7 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         self._actor_critic = ConstraintActorCritic(self._env.observation_space, self._env.action_space,
                                                    c.model_cfgs, c.train_cfgs.epochs, device=self._device)
         self._actor_critic.set_seed(self._seed)
-        if dist.world_size() > 1:
+        if dist.collectives_active():
             self._actor_critic.sync_params()
         if getattr(c.model_cfgs, 'exploration_noise_anneal', False):  # policy_gradient.py:101-105
             self._actor_critic.set_annealing(epochs=[0, c.train_cfgs.epochs], std=list(c.model_cfgs.std_range))

@@ -184,11 +184,11 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         _lib.check(self._lib.osa_adv_stats_phase1(_lib.ptr(b['adv_r']), _lib.ptr(b['adv_c']), M,
                                                   _lib.ptr(self._ws), _lib.ptr(self._stats), st),
                    'osa_adv_stats_phase1')
-        if dist.world_size() > 1:
+        if dist.collectives_active():
             dist.all_reduce_sum_(self._stats[0:3])
         _lib.check(self._lib.osa_adv_stats_phase2(_lib.ptr(b['adv_r']), M, _lib.ptr(self._ws),
                                                   _lib.ptr(self._stats), st), 'osa_adv_stats_phase2')
-        if dist.world_size() > 1:
+        if dist.collectives_active():
             dist.all_reduce_sum_(self._stats[3:4])
         o = self._out
         _lib.check(self._lib.osa_buffer_get(

@@ -34,8 +34,33 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+ABI_INFO = 'abi_info.hip'  # defines osa_abi_digest(); recompiled whenever any other source changes
+
+
+def source_digest() -> str:
+    """sha256 over the header and every kernel source (content, not mtimes: the library travels to the GPU
+    box with the working tree and file times do not survive that).  Compiled into the library
+    (osa_abi_digest) and compared by _lib.load(): a stale or foreign libomnisafe_amd.so is rebuilt or
+    refused instead of being called through prototypes it does not have."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = [f for f in sources() if os.path.basename(f) != ABI_INFO]
+    files += sorted(glob.glob(os.path.join(CSRC, '*.h')))
+    files += sorted(glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    for k in sorted(PER_FILE_FLAGS):
+        h.update((k + ' '.join(PER_FILE_FLAGS[k])).encode())
+    return h.hexdigest()[:32]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    stamp = os.path.join(LIB_DIR, 'abi_digest.txt')
+    if not os.path.exists(stamp) or open(stamp).read().strip() != source_digest():
         return True
     lib_m = os.path.getmtime(LIB_PATH)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(
@@ -48,14 +73,19 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
+    digest = source_digest()
+    stamp = os.path.join(LIB_DIR, 'abi_digest.txt')
+    digest_changed = not os.path.exists(stamp) or open(stamp).read().strip() != digest
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src) + '.o')
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+        is_info = os.path.basename(src) == ABI_INFO
+        if force or not os.path.exists(obj) or (is_info and digest_changed) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))):
             cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
                    '-Wall', '-Wno-unused-function'] + PER_FILE_FLAGS.get(os.path.basename(src), []) + \
+                ([f'-DOSA_ABI_DIGEST="{digest}"'] if is_info else []) + \
                 os.environ.get('OSA_EXTRA_CFLAGS', '').split()
             if verbose:
                 print(' '.join(cmd), flush=True)
@@ -65,6 +95,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(stamp, 'w') as f:
+        f.write(digest + '\n')
     return LIB_PATH
 
 

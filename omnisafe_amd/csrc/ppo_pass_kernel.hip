@@ -1137,6 +1137,31 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       return OSA_EHIP;
     attr_set = true;
   }
+  if constexpr (COOP) {
+    // the 3 x world workgroups meet at an arrival counter every step, so they MUST be co-resident: a
+    // cooperative launch makes the runtime verify that (occupancy x CUs >= grid) instead of inferring it
+    // from the CU count, and refuses the launch otherwise
+    static bool coop_refused = false;  // runtime without cooperative launches: checked plain launch below
+    if (!coop_refused) {
+      OsaPassArgs arg = a;
+      void* kargs[] = {&arg};
+      const hipError_t e = hipLaunchCooperativeKernel(
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), dim3(3, grid_y),
+          dim3(256), kargs, (unsigned)lds, stream);
+      if (e == hipSuccess) return OSA_OK;
+      (void)hipGetLastError();
+      if (e == hipErrorCooperativeLaunchTooLarge) return OSA_EUNSUPPORTED;  // caller takes the stepwise path
+      coop_refused = true;
+    }
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), 256, lds) !=
+            hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return OSA_EHIP;
+    if ((long)per_cu * cus < 3L * grid_y) return OSA_EUNSUPPORTED;
+  }
   hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), dim3(3, grid_y), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
@@ -1425,7 +1450,10 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   a.dbg = g_osa_pass_dbg; a.dp_slabs = exchange; a.dp_world = world; a.mb0 = 0; a.dp_sync = sync; a.part_stride = 0; a.dp_uncached = osa_is_exchange_ptr(exchange) ? 1 : 0;
   hipStream_t st = osa_stream(stream);
-  if (hipMemsetAsync(sync, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  // sync[0..2]: per-network arrival counters of this pass; sync[3]: STICKY "a peer never arrived" flag --
+  // it survives the per-pass reset so that a timeout in any pass of an update is still visible when the
+  // host reads it (the caller zeroes all four words once, at allocation)
+  if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \

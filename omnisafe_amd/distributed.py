@@ -32,6 +32,16 @@ def rank() -> int:
     return dist.get_rank() if is_initialized() else 0
 
 
+def collectives_active() -> bool:
+    """True when the exchange steps of the path must be issued: world_size > 1, or a process group exists
+    and OSA_DIST_FORCE_COLLECTIVES=1 -- a world of ONE rank then still runs every RCCL call of the
+    multi-GPU path (init, all-reduce, all-gather, broadcast, the DP update modes), which is how the
+    single-GPU test box exercises the `nccl` backend (tests/test_rccl_gpu.py)."""
+    if not is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('OSA_DIST_FORCE_COLLECTIVES', '0') == '1'
+
+
 def init_from_env(device: torch.device | str | None = None) -> bool:
     """Join the process group described by torchrun's environment (RANK/WORLD_SIZE/MASTER_*), as the
     reference does in setup_distributed (omnisafe/utils/distributed.py:59-104).  Returns True when
@@ -39,7 +49,7 @@ def init_from_env(device: torch.device | str | None = None) -> bool:
     if is_initialized():
         return world_size() > 1
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1:
+    if ws <= 1 and os.environ.get('OSA_DIST_FORCE_COLLECTIVES', '0') != '1':
         return False
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -53,11 +63,11 @@ def init_from_env(device: torch.device | str | None = None) -> bool:
     if use_gpu and backend == 'nccl':
         kwargs['device_id'] = torch.device(device)
     dist.init_process_group(backend=backend, **kwargs)
-    return True
+    return ws > 1
 
 
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
-    if world_size() > 1:
+    if collectives_active():
         if not t.is_contiguous():
             tmp = t.contiguous()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
@@ -69,21 +79,22 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
 
 def all_reduce_avg_(t: torch.Tensor) -> torch.Tensor:
     """SUM then divide by world size (avg_grads / avg_tensor semantics, distributed.py:160-198)."""
-    ws = world_size()
-    if ws > 1:
+    if collectives_active():
         all_reduce_sum_(t)
-        t.div_(ws)
+        ws = world_size()
+        if ws > 1:
+            t.div_(ws)
     return t
 
 
 def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
-    if world_size() > 1:
+    if collectives_active():
         dist.broadcast(t, src=src)
     return t
 
 
 def barrier() -> None:
-    if world_size() > 1:
+    if collectives_active():
         dist.barrier()
 
 
@@ -91,7 +102,7 @@ def all_gather_rows(t: torch.Tensor, out: torch.Tensor | None = None) -> torch.T
     """Concatenate every rank's tensor along dim 0 (rank r occupies rows r*n .. r*n+n-1).  Used once per
     epoch by the replicated-data update path to hand every rank the whole rollout."""
     ws = world_size()
-    if ws == 1:
+    if not collectives_active():
         if out is None:
             return t
         out.copy_(t)

@@ -97,7 +97,7 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         """logger.py:344-374 via dist_statistics_scalar (distributed.py:361-393): global mean (and
         population std / min / max) over all ranks' values.  Unlike the reference, min/max use scalar
         reductions (the reference all-reduces a vector whose length may differ per rank)."""
-        if dist.world_size() == 1:
+        if not dist.collectives_active():
             # float32 numpy reductions: torch CPU ops would open an OpenMP region per call, which costs
             # milliseconds on many-core hosts and sits on the epoch's critical path (the GPU idles meanwhile)
             vals = np.asarray(self._data[key], dtype=np.float32)

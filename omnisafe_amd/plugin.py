@@ -15,6 +15,9 @@ ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag'
                'PPOSimmerPID', 'TRPOSimmerPID', 'PPOEarlyTerminated', 'TRPOEarlyTerminated')
 
 
+_saved_entries: dict[str, type] = {}  # the reference's own classes, kept for uninstall()
+
+
 def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
     """Replace the reference's registry entries; returns the names that were swapped."""
     import omnisafe  # the reference; must be importable by the caller's environment
@@ -27,7 +30,10 @@ def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
     swapped = []
     for name in (algorithms or ACCELERATED):
         if name in amd_registry.REGISTRY._module_dict and name in ref_registry.REGISTRY._module_dict:  # noqa: SLF001
-            ref_registry.REGISTRY._module_dict[name] = amd_registry.get(name)  # noqa: SLF001
+            ours = amd_registry.get(name)
+            if ref_registry.REGISTRY._module_dict[name] is not ours:  # noqa: SLF001
+                _saved_entries.setdefault(name, ref_registry.REGISTRY._module_dict[name])  # noqa: SLF001
+            ref_registry.REGISTRY._module_dict[name] = ours  # noqa: SLF001
             swapped.append(name)
     # make the synthetic ids valid env ids for the reference's config checks (envs/core.py:362-386)
     reg = ref_env_core.ENV_REGISTRY
@@ -42,3 +48,15 @@ def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
         reg._support_envs['OmnisafeAmdReachVectorEnv'] = reach_ids  # noqa: SLF001
     del omnisafe
     return swapped
+
+
+def uninstall() -> list[str]:
+    """Put the reference's own classes back (A/B runs of the same script: reference path vs HIP path)."""
+    from omnisafe.algorithms import registry as ref_registry
+
+    restored = []
+    for name, cls in list(_saved_entries.items()):
+        ref_registry.REGISTRY._module_dict[name] = cls  # noqa: SLF001
+        restored.append(name)
+    _saved_entries.clear()
+    return restored

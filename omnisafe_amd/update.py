@@ -70,6 +70,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # optional profiling: list collecting (start, end) HIP events around every update launch on
         # torch's current stream (bench.py turns this on for the timed region)
         self.profile_events: list | None = None
+        self.last_path: str | None = None
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
@@ -79,8 +80,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
                   stats_row: torch.Tensor) -> None:
         ac, lib, st = self.ac, self.lib, _lib.stream_ptr()
-        ws = dist.world_size()
-        mode = 0 if ws == 1 else 1
+        dp = dist.collectives_active()
+        mode = 1 if dp else 0  # 1: gradients only (clipped locally); all-reduce + Adam follow below
         ev = None
         if self.profile_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -102,7 +103,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if ev is not None:
             ev[1].record()
             self.profile_events.append(('osa_mb_grad_kernel', B, ev))
-        if ws > 1:
+        if dp:
             dist.all_reduce_avg_(ac.grads)  # C1: one flat message for pi, V_r, V_c
             _lib.check(lib.osa_adam_apply(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params),
                                           _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
@@ -234,7 +235,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         return True
 
     def check_dp_sync(self) -> None:
-        """Raise if a cooperative pass flagged a peer workgroup that never arrived (host sync)."""
+        """Raise if ANY cooperative pass since allocation flagged a peer workgroup that never arrived (host
+        sync).  sync[3] is sticky: osa_ppo_dp_pass resets only the arrival counters sync[0..2], so a time-out
+        in an early pass of an update is still visible here.  After a time-out this rank has applied Adam
+        steps to incompletely averaged gradients: its replica is no longer trustworthy, hence an error and
+        not a silent fallback."""
         st = self._dp
         if 'sync' in st and int(st['sync'][3]) != 0:
             raise RuntimeError('osa_ppo_dp_pass: a peer workgroup timed out (workgroups not co-resident?); '
@@ -354,18 +359,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
         self._pass_fn = None
-        if (self.persistent and (self.ext is None or B <= 64) and dist.world_size() == 1
+        if (self.persistent and (self.ext is None or B <= 64) and not dist.collectives_active()
                 and B <= self.persistent_max_batch and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
         use_pass = self._pass_fn is not None
         W = dist.world_size()
         data = self._aligned_rows(data)
-        use_repl = (W > 1 and self.ext is None and self.update_critics
+        use_repl = (dist.collectives_active() and self.ext is None and self.update_critics
                     and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         if use_repl:
             gathered = self._aligned_rows(self.gather_for_replicated(data, W))
+        # which machinery ran (tests assert the timed path, not a fallback)
+        self.last_path = 'replicated' if use_repl else ('persistent' if use_pass else 'per-step')
         # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
         # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
         all_perms = None
@@ -398,6 +405,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 kl_dev = self.kl(obs)
                 if self.kl_early_stop:
                     final_kl = float(kl_dev)  # the one host sync per pass
+                    if use_repl:  # the stream is drained anyway: see a lost peer before the KL decision
+                        self.check_dp_sync()
                     if final_kl > self.target_kl:
                         break
         if use_repl:

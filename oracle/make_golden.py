@@ -403,73 +403,106 @@ SIBLINGS = [
 ]
 
 
+def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, update_iters=2):
+    """One reference `_update()` of `algo_name` on a reference-collected buffer of N x T transitions of
+    `env_id`: inputs (initial parameters, `buf.get()` output, EpCost window, recorded permutations) and
+    outputs (parameters of all three networks, multiplier, logged statistics) -> tests/golden/<out_name>."""
+    import omnisafe
+    from omnisafe.utils.config import get_default_kwargs_yaml
+
+    base = get_default_kwargs_yaml(algo_name, env_id, 'on-policy').todict()
+    trust_region = 'cg_iters' in base['algo_cfgs']
+    ea = dict({'update_iters': update_iters, 'batch_size': 128 if trust_region else 64, 'kl_early_stop': False},
+              **extra)
+    ref_harness.register_synth_env()
+    ref_harness.DEFAULT_HORIZON = horizon
+    d = tempfile.mkdtemp()
+    cfg = {'seed': 0,
+           'train_cfgs': {'total_steps': N * T * 4, 'vector_env_nums': N, 'torch_threads': 8, 'device': 'cpu'},
+           'algo_cfgs': dict({'steps_per_epoch': N * T}, **ea),
+           'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
+    if lag:
+        cfg['lagrange_cfgs'] = lag
+    algo = omnisafe.Agent(algo_name, env_id, custom_cfgs=cfg).agent
+    ac = algo._actor_critic
+    out = {'N': N, 'T': T, 'algo': algo_name, 'env_id': env_id}
+    torch.manual_seed(31)
+    algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+    out['ep_cost_window'] = np.asarray(list(algo._logger._data['Metrics/EpCost']), np.float32)
+    out['Jc'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'init/{net}/{k}'] = v
+    captured = {}
+    orig_get = algo._buf.get
+
+    def spy_get():
+        r = orig_get()
+        if not captured:  # CUP calls get() twice (the buffer is empty the second time around)
+            captured.update({k: v.clone() for k, v in r.items()})
+        return {k: v.clone() for k, v in captured.items()}
+
+    algo._buf.get = spy_get
+    if hasattr(algo, '_lagrange'):
+        lm = algo._lagrange.lagrangian_multiplier
+        out['lambda_before'] = np.float32(float(lm))
+    with _Recorder() as rec:
+        torch.manual_seed(33)
+        algo._update()
+    for k, v in captured.items():
+        out[f'data/{k}'] = _np(v)
+    if hasattr(algo, '_lagrange'):
+        out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    # RandomSampler draws two permutations per pass (see gen_rollout_and_ppolag_update)
+    out['perms'] = np.stack([_np(p) for p in rec.perms[::2]]) if rec.perms else np.zeros((0, N * T), np.int64)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'post/{net}/{k}'] = v
+    for key, val in algo._logger._data.items():
+        if key.startswith(('Loss/', 'Train/', 'Misc/', 'Metrics/LagrangeMultiplier', 'Value/Adv')):
+            vals = list(val) if not isinstance(val, (int, float)) else [val]
+            if len(vals) and all(isinstance(x, (int, float, np.floating)) for x in vals):
+                out['log/' + key] = np.asarray(vals, np.float32)
+    np.savez(os.path.join(OUT, out_name), **out)
+    return out
+
+
 def gen_sibling_updates(only=None):
-    """One reference `_update()` per sibling algorithm on a reference-collected buffer: inputs (initial
-    parameters, `buf.get()` output, EpCost window, recorded permutations) and outputs (parameters,
-    multiplier, logged statistics) -> tests/golden/sibling_<tag>.npz."""
+    """One reference `_update()` per sibling algorithm (SafetyPointGoal1 shapes, M = 160)
+    -> tests/golden/sibling_<tag>.npz."""
     N, T, horizon = 4, 40, 16
     for algo_name, tag, extra, lag in SIBLINGS:
         if only and tag not in only:
             continue
-        import omnisafe
-        from omnisafe.utils.config import get_default_kwargs_yaml
-
-        base = get_default_kwargs_yaml(algo_name, 'SynthPointGoal1-v0', 'on-policy').todict()
-        trust_region = 'cg_iters' in base['algo_cfgs']
-        ea = dict({'update_iters': 2, 'batch_size': 128 if trust_region else 64, 'kl_early_stop': False},
-                  **extra)
-        ref_harness.register_synth_env()
-        ref_harness.DEFAULT_HORIZON = horizon
-        d = tempfile.mkdtemp()
-        cfg = {'seed': 0,
-               'train_cfgs': {'total_steps': N * T * 4, 'vector_env_nums': N, 'torch_threads': 8, 'device': 'cpu'},
-               'algo_cfgs': dict({'steps_per_epoch': N * T}, **ea),
-               'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
-        if lag:
-            cfg['lagrange_cfgs'] = lag
-        algo = omnisafe.Agent(algo_name, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
-        ac = algo._actor_critic
-        out = {'N': N, 'T': T, 'algo': algo_name}
-        torch.manual_seed(31)
-        algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
-        out['ep_cost_window'] = np.asarray(list(algo._logger._data['Metrics/EpCost']), np.float32)
-        out['Jc'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])
-        for net in ('actor', 'reward_critic', 'cost_critic'):
-            for k, v in _state(getattr(ac, net)).items():
-                out[f'init/{net}/{k}'] = v
-        captured = {}
-        orig_get = algo._buf.get
-
-        def spy_get():
-            r = orig_get()
-            if not captured:  # CUP calls get() twice (the buffer is empty the second time around)
-                captured.update({k: v.clone() for k, v in r.items()})
-            return {k: v.clone() for k, v in captured.items()}
-
-        algo._buf.get = spy_get
-        if hasattr(algo, '_lagrange'):
-            lm = algo._lagrange.lagrangian_multiplier
-            out['lambda_before'] = np.float32(float(lm))
-        with _Recorder() as rec:
-            torch.manual_seed(33)
-            algo._update()
-        for k, v in captured.items():
-            out[f'data/{k}'] = _np(v)
-        if hasattr(algo, '_lagrange'):
-            out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
-        # RandomSampler draws two permutations per pass (see gen_rollout_and_ppolag_update)
-        out['perms'] = np.stack([_np(p) for p in rec.perms[::2]]) if rec.perms else np.zeros((0, N * T), np.int64)
-        for net in ('actor', 'reward_critic', 'cost_critic'):
-            for k, v in _state(getattr(ac, net)).items():
-                out[f'post/{net}/{k}'] = v
-        for key, val in algo._logger._data.items():
-            if key.startswith(('Loss/', 'Train/', 'Misc/', 'Metrics/LagrangeMultiplier', 'Value/Adv')):
-                vals = list(val) if not isinstance(val, (int, float)) else [val]
-                if len(vals) and all(isinstance(x, (int, float, np.floating)) for x in vals):
-                    out['log/' + key] = np.asarray(vals, np.float32)
-        np.savez(os.path.join(OUT, f'sibling_{tag}.npz'), **out)
+        out = _gen_update_golden(algo_name, 'SynthPointGoal1-v0', f'sibling_{tag}.npz', N, T, horizon, extra, lag)
         print('sibling', tag, {k: out[k] for k in ('Jc', 'lambda_before', 'lambda_after') if k in out},
               'perms', out['perms'].shape)
+
+
+# (tag, algorithm, env id, extra algo_cfgs, extra lagrange_cfgs): one whole reference `_update()` at the
+# observation / action shapes of every BASELINE.json config, M = 16 x 256 = 4096 transitions.
+#   config 2  PPOLag  SafetyPointGoal1 60/2      config 3  CPO     SafetyCarGoal1 72/2
+#   config 4  PPOLag  SafetyHumanoidVelocity 376/17 (wide input)
+#   config 5  TRPOLag SafetyAntVelocity 27/8 (rows not 16-byte aligned: the padding path; D_a = 8)
+# The multiplier starts at 0.5 so that the cost advantage carries weight in the surrogate; CPO's limit
+# sits just below the rollout's mean episode cost so that the constraint is active.
+CONFIG_SHAPES = [
+    ('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    ('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', {'cost_limit': 0.73}, None),
+    ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+]
+
+
+def gen_config_shape_updates(only=None):
+    N, T, horizon = 16, 256, 16
+    for tag, algo_name, env_id, extra, lag in CONFIG_SHAPES:
+        if only and tag not in only:
+            continue
+        out = _gen_update_golden(algo_name, env_id, f'{tag}.npz', N, T, horizon, extra, lag)
+        print(tag, {k: out[k] for k in ('Jc', 'lambda_before', 'lambda_after') if k in out}, 'perms',
+              out['perms'].shape, {k: out[k] for k in out if k.startswith('log/Misc')})
 
 
 def _record_rollout(algo, T, seed):
@@ -709,6 +742,7 @@ def main():
     gen_rollout_and_ppolag_update()
     gen_trust_region_updates()
     gen_sibling_updates()
+    gen_config_shape_updates()
     gen_saute_simmer()
     gen_early_terminated()
     gen_config_defaults()
@@ -727,6 +761,10 @@ if __name__ == '__main__':
         ref_harness.import_reference()
         gen_learning_curves(algos=(sys.argv[2],), seeds=(int(sys.argv[3]),), merge=False,
                             part=f'{sys.argv[2]}_{sys.argv[3]}')
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'config-shapes':
+        ref_harness.import_reference()
+        torch.set_num_threads(1)
+        gen_config_shape_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
         if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there
             os.replace(os.path.join(OUT, 'learning_reach.json'), os.path.join(OUT, '_learning_part_0prev.json'))

@@ -27,7 +27,10 @@ import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get('OMNISAFE_REFERENCE_ROOT', '/root/reference')
+_DEFAULT_ROOT = os.environ.get('OMNISAFE_REFERENCE_ROOT', '/root/reference')
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGED_ARCHIVE = os.path.join(_HERE, '_ref', 'omnisafe_ref.zip')  # written by oracle/stage_reference.py
+REFERENCE_ROOT = _DEFAULT_ROOT
 
 _STUB_PREFIXES = (
     'gymnasium', 'safety_gymnasium', 'wandb', 'tensorboard', 'pytorch_lightning', 'moviepy',
@@ -36,8 +39,40 @@ _STUB_PREFIXES = (
 )
 
 
+def _unpack_staged() -> str | None:
+    """GPU box: /root/reference does not exist there; the build container staged the unmodified package
+    as oracle/_ref/omnisafe_ref.zip (git-ignored build output).  The reference reads its YAML files
+    through the file system (omnisafe/utils/config.py:250-262), so the archive is unpacked into a scratch
+    directory outside the repository instead of being imported in place."""
+    if not os.path.exists(STAGED_ARCHIVE):
+        return None
+    cached = os.environ.get('OSA_REF_UNPACKED')
+    if cached and os.path.isdir(os.path.join(cached, 'omnisafe')):
+        return cached
+    import tempfile
+    import zipfile
+
+    root = tempfile.mkdtemp(prefix='osa_reference_')
+    with zipfile.ZipFile(STAGED_ARCHIVE) as z:
+        z.extractall(root)
+    os.environ['OSA_REF_UNPACKED'] = root  # child processes (torchrun ranks, subprocess benches) reuse it
+    return root
+
+
+def reference_root() -> str | None:
+    """Directory that holds the unmodified `omnisafe/` package, or None."""
+    global REFERENCE_ROOT
+    if os.path.isdir(os.path.join(_DEFAULT_ROOT, 'omnisafe')):
+        REFERENCE_ROOT = _DEFAULT_ROOT
+        return REFERENCE_ROOT
+    root = _unpack_staged()
+    if root:
+        REFERENCE_ROOT = root
+    return root
+
+
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'omnisafe'))
+    return reference_root() is not None
 
 
 class _Box:
@@ -113,7 +148,7 @@ def install() -> None:
     if _installed:
         return
     if not reference_available():
-        raise RuntimeError(f'reference not found at {REFERENCE_ROOT}')
+        raise RuntimeError(f'reference not found at {_DEFAULT_ROOT} and no staged archive at {STAGED_ARCHIVE}')
     sys.meta_path.append(_StubFinder())
     tb = types.ModuleType('torch.utils.tensorboard')
     tbw = types.ModuleType('torch.utils.tensorboard.writer')

@@ -13,19 +13,21 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
-    config.addinivalue_line('markers', 'reference: needs /root/reference (build container only)')
+    config.addinivalue_line('markers', 'reference: executes the unmodified reference (/root/reference or oracle/_ref/omnisafe_ref.zip)')
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
 
     have_gpu = torch.cuda.is_available()
-    have_ref = os.path.isdir('/root/reference/omnisafe')
+    import ref_harness
+
+    have_ref = ref_harness.reference_available()  # /root/reference, or the archive staged by build()
     for item in items:
         if 'gpu' in item.keywords and not have_gpu:
             item.add_marker(pytest.mark.skip(reason='no GPU in this container'))
         if 'reference' in item.keywords and not have_ref:
-            item.add_marker(pytest.mark.skip(reason='/root/reference not present'))
+            item.add_marker(pytest.mark.skip(reason='reference not present'))
 
 
 @pytest.fixture(scope='session')

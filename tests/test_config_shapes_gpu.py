@@ -1,0 +1,81 @@
+"""GPU parity at the observation / action shapes of EVERY BASELINE.json config, M = 4096 transitions, against
+one whole `_update()` of the unmodified reference per config (tests/golden/config{2..5}_*.npz, written by
+oracle/make_golden.py::gen_config_shape_updates): same initial parameters, same `buf.get()` output, same
+EpCost window, same minibatch permutations -> parameters of all three networks, multiplier, logged
+statistics.
+
+  config 2  PPOLag  60/2    128 chained Adam steps of 64 rows          (persistent pass kernel)
+  config 3  CPO     72/2    CG + FVP + CPO case algebra + line search, then 64 critic steps of 128 rows
+  config 4  PPOLag  376/17  the wide-input path (W1 does not fit the 64x96 LDS tile of the narrow kernel)
+  config 5  TRPOLag 27/8    rows that are not 16-byte aligned (padded once per update), D_a = 8
+
+Tolerances (float32; the reference sums in CPU-sgemm order, the kernels in MFMA-tile order):
+  first-order family: parameters after 128 chained Adam steps  atol 2e-5 (each step moves a parameter by
+    <= lr = 3e-4; Adam's m/sqrt(v) turns 1e-7 gradient differences into ~1e-7 .. 1e-6 parameter differences per
+    step where v is small, and they accumulate along the chain); losses rtol 2e-3; KL rtol 1e-2;
+  trust-region family: accepted line-search index and CPO case identical; actor atol 3e-4 (theta_old + a step
+    of norm ~0.3 whose direction comes out of 15 float32 CG iterations); critics atol 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_siblings_gpu import _check_params, _log, _run_update
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+LAG = {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}
+FIRST_ORDER = [('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', ({}, LAG)),
+               ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', ({}, LAG))]
+TRUST_REGION = [('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', ({'cost_limit': 0.73}, None)),
+                ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', ({}, LAG))]
+
+
+def _max_err(ac, g, net):
+    return max(float(np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']).max())
+               for k, v in getattr(ac, net).state_dict().items())
+
+
+@pytest.mark.parametrize('tag,name,env_id,extra', FIRST_ORDER)
+def test_first_order_update_at_config_shape(golden, tmp_path, tag, name, env_id, extra):
+    g = golden(f'{tag}.npz')
+    assert g['data/obs'].shape[0] == 4096
+    algo, ac = _run_update(name, tag, g, tmp_path, trust_region=False, env_id=env_id, extra=extra)
+    assert algo._last_update_steps == 2 * 64
+    print(tag, 'max |param - reference|:', {n: _max_err(ac, g, n) for n in ('actor', 'reward_critic', 'cost_critic')})
+    _check_params(ac, g, ('actor', 'reward_critic', 'cost_critic'), 2e-5)
+    # the parameters moved by much more than the tolerance (the comparison is not vacuous)
+    moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
+    assert moved > 5e-3
+    np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    np.testing.assert_allclose(_log(algo, 'Train/KL')[-1], g['log/Train/KL'][-1], rtol=1e-2, atol=1e-7)
+    np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi').mean(), g['log/Loss/Loss_pi'].mean(), rtol=2e-3,
+                               atol=2e-6)
+    for key in ('Loss/Loss_reward_critic', 'Loss/Loss_cost_critic'):
+        np.testing.assert_allclose(_log(algo, key).mean(), g['log/' + key].mean(), rtol=2e-4)
+    np.testing.assert_allclose(_log(algo, 'Train/Entropy').mean(), g['log/Train/Entropy'].mean(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('tag,name,env_id,extra', TRUST_REGION)
+def test_trust_region_update_at_config_shape(golden, tmp_path, tag, name, env_id, extra):
+    g = golden(f'{tag}.npz')
+    assert g['data/obs'].shape[0] == 4096
+    algo, ac = _run_update(name, tag, g, tmp_path, trust_region=True, env_id=env_id, extra=extra)
+    print(tag, 'max |param - reference|:', {n: _max_err(ac, g, n) for n in ('actor', 'reward_critic', 'cost_critic')})
+    assert int(_log(algo, 'Misc/AcceptanceStep')[-1]) == int(g['log/Misc/AcceptanceStep'][-1])
+    for key, rtol in (('Misc/Alpha', 1e-2), ('Misc/xHx', 1e-2), ('Misc/gradient_norm', 1e-3),
+                      ('Misc/H_inv_g', 1e-2), ('Misc/FinalStepNorm', 2e-2)):
+        np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
+    if name == 'CPO':
+        info = algo._last_actor_update
+        assert info['case'] == int(g['log/Misc/OptimCase'][-1]) == 2  # constraint active, both projections evaluated
+        for key, rtol in (('Misc/q', 1e-2), ('Misc/r', 5e-2), ('Misc/s', 1e-2), ('Misc/cost_gradient_norm', 1e-3),
+                          ('Misc/A', 1e-2), ('Misc/B', 5e-2), ('Misc/Lambda_star', 5e-2)):
+            np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, atol=1e-6, err_msg=key)
+    else:
+        np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    _check_params(ac, g, ('actor',), 3e-4)
+    _check_params(ac, g, ('reward_critic', 'cost_critic'), 2e-5)
+    moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
+    assert moved > 5e-3

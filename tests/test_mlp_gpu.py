@@ -398,6 +398,63 @@ def test_full_size_pass_properties():
     assert torch.equal(stats[0], stats[1].flip(0))
 
 
+def test_full_size_pass_vs_oracle():
+    """The thing bench.py times, against the oracle: ONE full-size pass of BASELINE config 2 (M = 65 536
+    rows, batch 64 -> 1024 CHAINED optimiser steps of all three networks in one persistent launch) vs
+    np_oracle.ppolag_update (pinned to the reference's `_update()`), same data, same permutation, same
+    initial parameters.
+
+    Drift tolerance: both sides compute in float32 but sum in different orders (CPU sgemm vs MFMA tiles), so
+    every step's gradient differs by ~1e-7 relative; Adam turns that into parameter differences of up to
+    ~lr * 1e-3 per step where sqrt(v) is small, and 1024 dependent steps accumulate them.  Parameters move
+    by up to 0.2 over the pass; required: max |theta - theta_oracle| <= 3e-4 (actor, lr 3e-4 with
+    |update| <= lr per step) and <= 3e-4 (critics), the per-step losses within rtol 2e-3 for >= 99.5 % of the
+    1024 steps and in the mean within 1e-4 relative, the final KL within 2 %."""
+    import np_oracle as O
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(17)
+    M, B, obs_dim, act_dim = 65536, 64, 60, 2
+    ac = make_ac(obs_dim, act_dim)
+    obs = torch.randn(M, obs_dim, device=DEV).clamp_(-5, 5)
+    act, _, _, logp = ac.step(obs)  # behaviour policy = initial policy: ratios start at 1
+    data = {'obs': obs, 'act': act.clone(), 'logp': logp.clone(),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.rand(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perm = torch.randperm(M)
+    lam = 0.35
+    ref = O.ActorCritic(obs_dim, act_dim, actor_lr=3e-4, critic_lr=3e-4)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ref, net).load_state_dict({k: v.cpu() for k, v in getattr(ac, net).state_dict().items()})
+    init = {k: v.cpu().clone() for k, v in ac.actor.state_dict().items()}
+    cpu = {k: v.cpu() for k, v in data.items()}
+    torch.set_num_threads(8)
+    st = O.ppolag_update(ref, cpu, lam, [perm], batch_size=B, update_iters=1, kl_early_stop=False)
+    torch.set_num_threads(1)
+    up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+    out = up.run(data, torch.tensor([lam], device=DEV), perms=[perm], actor_lr=3e-4, critic_lr=3e-4)
+    assert out['steps'] == M // B == len(st['loss_pi'])
+    assert up.last_path == 'persistent'  # the kernel bench.py times, not the per-step fallback
+    errs = {}
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        want = getattr(ref, net).state_dict()
+        errs[net] = max(float((v.cpu() - want[k]).abs().max()) for k, v in getattr(ac, net).state_dict().items())
+    moved = max(float((v.cpu() - init[k]).abs().max()) for k, v in ac.actor.state_dict().items())
+    print('full-size pass vs oracle: max |theta - theta_oracle| =', errs, 'actor moved by', moved)
+    assert moved > 0.02
+    assert errs['actor'] <= 3e-4 and errs['reward_critic'] <= 3e-4 and errs['cost_critic'] <= 3e-4, errs
+    s = out['stats'].double().cpu().numpy()
+    l2 = 0.001
+    for col, l2col, key in ((0, 5, 'loss_r'), (1, 6, 'loss_c'), (2, None, 'loss_pi')):
+        mine = s[:, col] + (l2 * s[:, l2col] if l2col is not None else 0.0)
+        want = np.asarray(st[key], np.float64)
+        close = np.isclose(mine, want, rtol=2e-3, atol=2e-5)
+        assert close.mean() >= 0.995, (key, close.mean())
+        np.testing.assert_allclose(mine.mean(), want.mean(), rtol=1e-4, atol=1e-6, err_msg=key)
+    np.testing.assert_allclose(s[:, 3], np.asarray(st['ratio_mean']), rtol=2e-4)
+    np.testing.assert_allclose(out['kl'], st['kl'], rtol=2e-2)
+
+
 @pytest.mark.parametrize('obs_dim,act_dim,kind', [(60, 2, 'focops'), (28, 8, 'focops'), (72, 2, 'p3o'), (44, 6, 'cup'),
                                                   (60, 17, 'focops')])
 def test_extended_surrogates_pass_equals_per_minibatch_launches(obs_dim, act_dim, kind):

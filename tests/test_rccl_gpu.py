@@ -1,0 +1,163 @@
+"""GPU: the `nccl` (= RCCL on ROCm) backend for real, on the single GPU of the test box.
+
+The reference selects `nccl` whenever the device is a GPU (omnisafe/utils/distributed.py:75-80,100) and
+all-reduces gradients per parameter tensor (:167-198).  omnisafe_amd/distributed.py selects the same
+backend; the multi-rank tests (tests/test_dp_gpu.py, tests/test_distributed_gloo.py) must use gloo
+because RCCL refuses two ranks on one device.  Here a world of ONE rank with
+OSA_DIST_FORCE_COLLECTIVES=1 initialises the RCCL process group and then issues every collective of the
+multi-GPU path on device tensors -- `all_reduce` (flat gradients, fp64 statistics),
+`all_gather_into_tensor` (the per-epoch rollout gather of the replicated mode), `broadcast` (initial
+parameters) -- and runs whole PPOLag / TRPOLag / CPO epochs in each data-parallel mode on top of it.
+It also measures the per-call latency floor of each collective and the per-optimiser-step time of the
+`allreduce` mode (gradient kernel -> RCCL all-reduce -> Adam), written to
+gpurun_out/rccl_world1_timing.json (copied to profiles/ by hand).  No 1 -> 8 GPU curve can be measured on
+this box; a world of one only proves the calls, their arguments and their ordering on the stream.
+"""
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _env(port, dp_mode):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      OSA_DIST_FORCE_COLLECTIVES='1', OSA_DP_MODE=dp_mode, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('OSA_DIST_BACKEND', None)
+    sys.path.insert(0, ROOT)
+
+
+def _time_us(fn, iters=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def _collectives_worker(_rank, port, out_path):
+    _env(port, 'allreduce')
+    from omnisafe_amd import distributed as dist
+
+    assert dist.init_from_env('cuda:0') is False  # a world of one: "not distributed" for the caller
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'
+    assert dist.world_size() == 1 and dist.rank() == 0 and dist.collectives_active()
+    dev = torch.device('cuda:0')
+    res = {'backend': torch.distributed.get_backend(), 'world_size': 1}
+    # C1: the flat gradient message of one optimiser step (3 networks x 8448 padded floats, config 2)
+    g = torch.randn(3, 8448, device=dev)
+    want = g.clone()
+    dist.all_reduce_avg_(g)
+    assert torch.equal(g, want)
+    res['all_reduce_grads_101KB_us'] = _time_us(lambda: dist.all_reduce_avg_(g))
+    # Humanoid-sized message (3 x 29 696 floats)
+    gh = torch.randn(3, 29696, device=dev)
+    res['all_reduce_grads_356KB_us'] = _time_us(lambda: dist.all_reduce_avg_(gh))
+    # C4: fp64 advantage statistics, a slice of the stats vector
+    stats = torch.arange(8, dtype=torch.float64, device=dev)
+    dist.all_reduce_sum_(stats[0:3])
+    assert stats.tolist() == list(range(8))
+    res['all_reduce_stats_24B_us'] = _time_us(lambda: dist.all_reduce_sum_(stats[0:3]))
+    # non-contiguous input goes through a contiguous staging copy
+    nc = torch.randn(6, 4, device=dev)[:, 1]
+    want = nc.clone()
+    dist.all_reduce_sum_(nc)
+    assert torch.equal(nc, want)
+    # the per-epoch rollout gather of the replicated mode: all_gather_into_tensor
+    obs = torch.randn(65536, 60, device=dev)
+    out = torch.empty(65536, 60, device=dev)
+    got = dist.all_gather_rows(obs, out=out)
+    assert got is out and torch.equal(out, obs)
+    res['all_gather_obs_15.7MB_us'] = _time_us(lambda: dist.all_gather_rows(obs, out=out), iters=50)
+    assert torch.equal(dist.all_gather_rows(obs[:100]), obs[:100])
+    # C5: initial parameters
+    p = torch.randn(3, 8448, device=dev)
+    want = p.clone()
+    dist.broadcast_(p, src=0)
+    assert torch.equal(p, want)
+    res['broadcast_params_101KB_us'] = _time_us(lambda: dist.broadcast_(p, src=0))
+    dist.barrier()
+    # ---- the `allreduce` data-parallel mode on config-2 shapes: per-step gradient kernel -> ONE flat RCCL
+    # all-reduce -> Adam (the reference's structure with 1 message per step instead of 19)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_mlp_gpu import make_ac
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(3)
+    M, B = 65536, 64
+    ac = make_ac(60, 2)
+    data = {'obs': torch.randn(M, 60, device=dev), 'act': torch.randn(M, 2, device=dev),
+            'logp': torch.randn(M, device=dev) * 0.1 - 2.8, 'target_value_r': torch.randn(M, device=dev),
+            'target_value_c': torch.randn(M, device=dev), 'adv_r': torch.randn(M, device=dev),
+            'adv_c': torch.randn(M, device=dev)}
+    lam = torch.tensor([0.2], device=dev)
+    for mode in ('allreduce', 'replicated', 'replicated-steps'):
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, dp_mode=mode)
+        up.run(data, lam, actor_lr=3e-4, critic_lr=3e-4)  # warm-up (graph capture, LDS attributes)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out_ = up.run(data, lam, actor_lr=3e-4, critic_lr=3e-4)
+        b.record()
+        torch.cuda.synchronize()
+        assert out_['steps'] == M // B and bool(torch.isfinite(ac.params).all())
+        assert up.last_path == ('per-step' if mode == 'allreduce' else 'replicated')
+        res[f'dp_mode_{mode}_us_per_step_world1'] = a.elapsed_time(b) * 1e3 / out_['steps']
+    torch.distributed.destroy_process_group()
+    with open(out_path, 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+def test_rccl_world1_collectives_and_dp_modes(tmp_path):
+    out = str(tmp_path / 'rccl.json')
+    mp.spawn(_collectives_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = json.load(open(out))
+    assert res['backend'] == 'nccl'
+    print('RCCL world-1 timings:', json.dumps(res))
+    dst = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(dst, exist_ok=True)
+    json.dump(res, open(os.path.join(dst, 'rccl_world1_timing.json'), 'w'), indent=1)
+
+
+def _agent_worker(_rank, port, algo, dp_mode, tmpdir):
+    _env(port, dp_mode)
+    import omnisafe_amd
+    from omnisafe_amd import distributed as dist
+
+    cfg = {'seed': 4, 'train_cfgs': {'device': 'cuda:0', 'total_steps': 2 * 128 * 16, 'vector_env_nums': 128},
+           'algo_cfgs': {'steps_per_epoch': 128 * 16, 'update_iters': 2},
+           'logger_cfgs': {'log_dir': tmpdir, 'verbose': False}, 'env_cfgs': {'horizon': 8, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo, 'SynthPointGoal1-v0', custom_cfgs=cfg)
+    assert torch.distributed.get_backend() == 'nccl' and dist.collectives_active()
+    p0 = agent.agent._actor_critic.params.clone()
+    ep_ret, ep_cost, ep_len = agent.learn()
+    p = agent.agent._actor_critic.params
+    assert bool(torch.isfinite(p).all()) and not torch.equal(p, p0)
+    assert ep_len == 8.0 and 1.0 < ep_cost < 4.0
+    if algo == 'PPOLag':
+        assert agent.agent._updater.last_path == ('per-step' if dp_mode == 'allreduce' else 'replicated')
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('algo,dp_mode', [('PPOLag', 'allreduce'), ('PPOLag', 'replicated'),
+                                          ('PPOLag', 'replicated-steps'), ('TRPOLag', 'allreduce'),
+                                          ('CPO', 'allreduce')])
+def test_agents_over_rccl_world1(tmp_path, algo, dp_mode):
+    mp.spawn(_agent_worker, args=(_free_port(), algo, dp_mode, str(tmp_path)), nprocs=1, join=True)

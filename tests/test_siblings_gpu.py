@@ -29,18 +29,18 @@ EXTRA = {'pdo': ({}, {'cost_limit': 1.0}), 'rcpo': ({}, {'cost_limit': 1.0}),
          'ppolag_earlystop': ({'kl_early_stop': True, 'target_kl': 3e-4, 'update_iters': 4}, {'cost_limit': 1.0})}
 
 
-def _run_update(name, tag, g, tmp_path, trust_region):
+def _run_update(name, tag, g, tmp_path, trust_region, env_id='SynthPointGoal1-v0', extra=None):
     import omnisafe_amd
 
     N, T = int(g['N']), int(g['T'])
-    extra_algo, lag = EXTRA.get(tag, ({}, None))
+    extra_algo, lag = extra if extra is not None else EXTRA.get(tag, ({}, None))
     cfg = {'seed': 0, 'train_cfgs': {'device': DEV, 'total_steps': 4 * N * T, 'vector_env_nums': N},
            'algo_cfgs': dict({'steps_per_epoch': N * T, 'update_iters': 2, 'kl_early_stop': False,
                               'batch_size': 128 if trust_region else 64}, **extra_algo),
            'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}}
     if lag:
         cfg['lagrange_cfgs'] = lag
-    algo = omnisafe_amd.Agent(name, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
+    algo = omnisafe_amd.Agent(name, env_id, custom_cfgs=cfg).agent
     ac = algo._actor_critic
     for net in ('actor', 'reward_critic', 'cost_critic'):
         sd = {k[len('init/') + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
