@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variant', action='store_true')
     ap.add_argument('--algo', default='PPOLag')
+    # passes of the reference's update actually executed by the cpu_baseline leg (of --update-iters): 4 passes
+    # + the rollout are ~13 s on the GPU box's host (2.7 s rollout + 2.55 s per pass at 16 threads)
+    ap.add_argument('--ref-sample-iters', type=int, default=4)
     return ap.parse_args()
 
 
@@ -243,7 +246,7 @@ def cpu_baseline(args):
 def cpu_baseline_reference(args):
     """The UNMODIFIED reference on this box's host cores (kind "reference"): oracle/ref_cpu_baseline.py runs
     `omnisafe.Agent('PPOLag', ..., device=cpu).learn()` for one epoch of this benchmark's shape with
-    update_iters lowered to 1 (the bounded sample) in its own process and reads Time/Rollout / Time/Update /
+    update_iters lowered to --ref-sample-iters (the bounded sample) in its own process and reads Time/Rollout / Time/Update /
     Time/FPS from the reference's progress.csv.  The package comes from /root/reference or from the archive
     staged by `__graft_entry__.build()` (oracle/_ref/omnisafe_ref.zip); None if neither exists."""
     import subprocess
@@ -251,7 +254,7 @@ def cpu_baseline_reference(args):
     threads = max(1, min(os.cpu_count() or 1, 16))  # the reference's own default torch_threads (PPOLag.yaml)
     cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py'), '--envs', str(args.envs),
            '--steps-per-env', str(args.steps_per_env), '--batch-size', str(args.batch_size),
-           '--update-iters', str(args.update_iters), '--sample-iters', '1', '--threads', str(threads),
+           '--update-iters', str(args.update_iters), '--sample-iters', str(args.ref_sample_iters), '--threads', str(threads),
            '--algo', args.algo]
     try:
         env = dict(os.environ, OMP_NUM_THREADS=str(threads))

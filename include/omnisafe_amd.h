@@ -78,6 +78,21 @@ int osa_gae_scan(const float* reward, const float* cost, const float* value_r, c
                  float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
                  float* discounted_ret, void* stream);
 
+/* The same sweep parallel over TIME -- the wavefront backward scan with LDS staging: a workgroup owns 16
+ * consecutive envs, walks the time axis backwards in tiles of 64 steps staged in LDS with coalesced row
+ * segments, and scans each env's 64 steps across the 64 lanes of a wave (Hillis-Steele scan of the affine
+ * maps y_t = x_t + c_t y_{t+1}, carries chained from tile to tile).  For few envs / long horizons (e.g.
+ * vector_env_nums = 4, T = 5000) where osa_gae_scan leaves the chip idle; the caller picks by (T, N).
+ * Same float32 deltas; the float64 recurrences are associated as a tree instead of a chain, so outputs equal
+ * osa_gae_scan's to float64 rounding before the final float32 rounding (tests: rtol 1e-5).  Estimators gae,
+ * gae-rtg, plain (v-trace is a float32 chain: OSA_EUNSUPPORTED, use osa_gae_scan).
+ * Replaces: the same reference code as osa_gae_scan. */
+int osa_gae_scan_tiled(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                       const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
+                       double gamma, double lam, double lam_c, float penalty_coef, int estimator,
+                       float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
+                       float* discounted_ret, void* stream);
+
 /* Advantage statistics of VectorOnPolicyBuffer.get (vector_onpolicy_buffer.py:131-136 ->
  * omnisafe/utils/distributed.py:382-392), split in two phases so the cross-rank all-reduce (RCCL) can
  * sit between them.  stats is 8 doubles on the device:

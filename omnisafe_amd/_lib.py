@@ -27,6 +27,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_buffer_store_step': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I,
                                    _P, _P, _P, _P, _P, _P]),
     'osa_gae_scan': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
+    'osa_gae_scan_tiled': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
     'osa_reduce_ws_bytes': (C.c_size_t, []),
     'osa_adv_stats_phase1': (_I, [_P, _P, _L, _P, _P, _P]),
     'osa_adv_stats_phase2': (_I, [_P, _L, _P, _P, _P]),

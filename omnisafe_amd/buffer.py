@@ -35,6 +35,7 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         standardized_adv_c: bool,
         num_envs: int = 1,
         device: torch.device | str = 'cuda:0',
+        gae_variant: str | None = None,
     ) -> None:
         if num_envs < 1:
             raise ValueError('num_envs must be greater than 0.')  # vector_onpolicy_buffer.py:74-75
@@ -48,6 +49,14 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         self._size = int(size)
         self._gamma, self._lam, self._lam_c = float(gamma), float(lam), float(lam_c)
         self._estimator = _EST[advantage_estimator]
+        # which backward-scan kernel finishes the paths: 'sequential' (one lane per env, bit-exact to the
+        # reference), 'tiled' (time-parallel wavefront scan with LDS staging, tolerance-exact) or 'auto'
+        # (by (T, N): see gae_variant_for).  Extension to the reference signature; env OSA_GAE_VARIANT.
+        import os
+
+        self._gae_variant = gae_variant or os.environ.get('OSA_GAE_VARIANT', 'auto')
+        if self._gae_variant not in ('auto', 'sequential', 'tiled'):
+            raise ValueError(f'gae_variant must be auto, sequential or tiled, not {self._gae_variant!r}')
         self._penalty_coefficient = float(penalty_coefficient)
         self._standardized_adv_r = bool(standardized_adv_r)
         self._standardized_adv_c = bool(standardized_adv_c)
@@ -163,10 +172,27 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         self.data['boot_c'][t] = torch.where(m, last_value_c.to(self._device, torch.float32), 0.0)
 
     # ------------------------------------------------------------------ get
+    @staticmethod
+    def gae_variant_for(T: int, N: int, estimator: int) -> str:
+        """The (T, N) rule of 'auto' (measured on MI355X, profiles/r2_gae_bandwidth.md): the lane-per-env
+        kernel needs many envs to fill the chip and pays one dependent float64 chain of length T per lane; the
+        time-parallel tiled kernel has N/16 workgroups and scans 64 steps per wave pass.  Few envs or long
+        horizons -> tiled; v-trace (a float32 chain) always sequential."""
+        if estimator == _EST['vtrace']:
+            return 'sequential'
+        return 'tiled' if (T >= 128 and N < 32768) else 'sequential'
+
     def compute_advantages(self) -> None:
-        """K5: one backward scan over the (T, N) buffer (osa_gae_scan)."""
+        """K5: one backward scan over the (T, N) buffer (osa_gae_scan / osa_gae_scan_tiled)."""
         b, T, N = self.data, self._size, self._num_buffers
-        _lib.check(self._lib.osa_gae_scan(
+        variant = self._gae_variant
+        if variant == 'auto':
+            variant = self.gae_variant_for(T, N, self._estimator)
+        elif variant == 'tiled' and self._estimator == _EST['vtrace']:
+            variant = 'sequential'
+        self.last_gae_variant = variant
+        fn = self._lib.osa_gae_scan_tiled if variant == 'tiled' else self._lib.osa_gae_scan
+        _lib.check(fn(
             _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),
             _lib.ptr(b['path_end']), _lib.ptr(b['boot_r']), _lib.ptr(b['boot_c']), T, N, self._gamma,
             self._lam, self._lam_c, self._penalty_coefficient, self._estimator, _lib.ptr(b['adv_r']),

@@ -157,6 +157,215 @@ __global__ __launch_bounds__(256) void osa_gae_scan_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5b  the same dual GAE scan, parallel over TIME: the wavefront backward scan with LDS staging.
+//
+// The lane-per-env kernel above needs N >= ~32 k envs to fill the chip and walks T sequentially; for few
+// envs / long horizons (BASELINE config 1: N = 4, T = 5000) almost every lane of the GPU idles.  Here a
+// workgroup owns NB = 16 consecutive envs and walks the time axis backwards in tiles of 64 steps:
+//   1. the tile (64 steps x 16 envs of r, c, v_r, v_c, path_end, boot_r, boot_c) is fetched with coalesced
+//      row segments (16 envs x 4 B = 64 B per step and array; the next tile's loads are issued into registers
+//      before the current one is processed) and staged in LDS;
+//   2. each wave takes 4 of the envs; for one env the 64 lanes ARE the 64 time steps (lane 0 = latest).
+//      Every recurrence y_t = x_t + c_t * y_{t+1} (c_t = gamma*lambda, or 0 where a path ends) is an affine
+//      map, so the strip is a Hillis-Steele scan of (c, x) pairs in 6 shuffle rounds; because c_t is either 0
+//      or one constant d, the composed coefficient of a window of o steps is d^o or 0, decided per lane from
+//      the wave's ballot of path ends -- only the x parts travel through the shuffles.  The carry of the tile
+//      (lane 63) continues into the next (earlier) tile;
+//   3. results go back through LDS and leave with the same coalesced row segments.
+// Arithmetic: float32 deltas exactly as the lane-per-env kernel; the recurrences in float64 but associated
+// as a tree instead of a chain, so results agree with the bit-exact kernel to float64 rounding (then rounded
+// to float32: identical in all but ~1e-7 of the elements; tests require rtol 1e-5).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double osa_shfl_up_f64(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_up(lo, o, 64);
+  hi = __shfl_up(hi, o, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double osa_readlane63_f64(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// inclusive scan of y_l = x_l + (reset_l ? 0 : d) * y_{l-1} over the 64 lanes; `resets` = ballot of reset_l,
+// dpow[k] = d^(2^k), dlane = d^(lane+1); carry = y_{-1}.  Returns y_l.
+__device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long resets, const double (&dpow)[6],
+                                                    double dlane, double carry, int lane) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int o = 1 << k;
+    const double up = osa_shfl_up_f64(x, o);
+    // window of lane l before this round: lanes [l-o+1 .. l]
+    const unsigned long long win = (o == 64 ? ~0ull : ((1ull << o) - 1ull)) << ((lane - o + 1) & 63);
+    if (lane >= o && (resets & win) == 0ull) {
+      const double m = dpow[k] * up;
+      x = x + m;
+    }
+  }
+  const unsigned long long all = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+  if ((resets & all) == 0ull) {
+    const double m = dlane * carry;
+    x = x + m;
+  }
+  return x;
+}
+
+template <int EST, int NB>
+__global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
+    const float* __restrict__ reward, const float* __restrict__ cost,
+    const float* __restrict__ value_r, const float* __restrict__ value_c,
+    const uint8_t* __restrict__ path_end, const float* __restrict__ boot_r,
+    const float* __restrict__ boot_c, int T, int N, float g32, double d_g, double d_r, double d_c,
+    float pc, float* __restrict__ adv_r, float* __restrict__ adv_c, float* __restrict__ tgt_r,
+    float* __restrict__ tgt_c, float* __restrict__ disc_ret) {
+#pragma clang fp contract(off)
+  constexpr int TT = 64, LD = NB + 1, EPW = NB / 4, PER = TT * NB / 256;  // envs per wave, elements per thread
+  __shared__ float s_in[7][TT][LD];   // r, c, v_r, v_c, boot_r, boot_c, path_end (as 0/1)
+  __shared__ float s_out[5][TT][LD];  // adv_r, adv_c, tgt_r, tgt_c, disc_ret
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * NB;
+  // powers of the three coefficients: d^(2^k) for the scan rounds, d^(lane+1) for the carry
+  double pw_r[6], pw_c[6], pw_g[6];
+  pw_r[0] = d_r; pw_c[0] = d_c; pw_g[0] = d_g;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) {
+    pw_r[k] = pw_r[k - 1] * pw_r[k - 1];
+    pw_c[k] = pw_c[k - 1] * pw_c[k - 1];
+    pw_g[k] = pw_g[k - 1] * pw_g[k - 1];
+  }
+  double dl_r = 1.0, dl_c = 1.0, dl_g = 1.0;  // d^(lane+1) by binary exponentiation
+  {
+    const int e = lane + 1;
+    double br = d_r, bc = d_c, bg = d_g;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      if ((e >> k) & 1) { dl_r *= br; dl_c *= bc; dl_g *= bg; }
+      br *= br; bc *= bc; bg *= bg;
+    }
+  }
+  // per-env carries of this wave (wave-uniform values)
+  double ca_r[EPW], ca_c[EPW], cret[EPW], crtg_r[EPW], crtg_c[EPW];
+  float cnv_r[EPW], cnv_c[EPW];
+#pragma unroll
+  for (int q = 0; q < EPW; ++q) {
+    ca_r[q] = ca_c[q] = cret[q] = crtg_r[q] = crtg_c[q] = 0.0;
+    cnv_r[q] = cnv_c[q] = 0.f;
+  }
+  const int ntiles = (T + TT - 1) / TT;
+  float pre[7][PER];
+  auto fetch = [&](int j) {  // tile j: rows tt = 0.. <-> t = t_hi - tt, t_hi = T-1-64j
+    const int t_hi = T - 1 - j * TT;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+      const int t = t_hi - tt, n = n0 + e;
+      const bool ok = t >= 0 && n < N;
+      const long g = ok ? (long)t * N + n : 0;
+      pre[0][k] = ok ? reward[g] : 0.f;
+      pre[1][k] = ok ? cost[g] : 0.f;
+      pre[2][k] = ok ? value_r[g] : 0.f;
+      pre[3][k] = ok ? value_c[g] : 0.f;
+      const bool pe = ok && path_end[g] != 0;
+      pre[4][k] = pe ? boot_r[g] : 0.f;
+      pre[5][k] = pe ? boot_c[g] : 0.f;
+      pre[6][k] = pe ? 1.f : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+#pragma unroll
+      for (int a = 0; a < 7; ++a) s_in[a][tt][e] = pre[a][k];
+    }
+  };
+  fetch(0);
+  stage();
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const int t_hi = T - 1 - j * TT;
+    const int nvalid = t_hi + 1 < TT ? t_hi + 1 : TT;
+    if (j + 1 < ntiles) fetch(j + 1);  // in flight while this tile is scanned
+#pragma unroll
+    for (int q = 0; q < EPW; ++q) {
+      const int e = wave * EPW + q;
+      const float r = s_in[0][lane][e], c = s_in[1][lane][e];
+      const float vr = s_in[2][lane][e], vc = s_in[3][lane][e];
+      const float br = s_in[4][lane][e], bc = s_in[5][lane][e];
+      // a path ends after step t; the last row of the buffer without a flag = bootstrap 0 (as the
+      // lane-per-env kernel, whose carries start at 0)
+      const bool pe = s_in[6][lane][e] != 0.f || (j == 0 && lane == 0);
+      const unsigned long long resets = __ballot(pe);
+      const float nxt_r = lane == 0 ? cnv_r[q] : s_in[2][(lane + 63) & 63][e];
+      const float nxt_c = lane == 0 ? cnv_c[q] : s_in[3][(lane + 63) & 63][e];
+      const float nv_r = pe ? br : nxt_r, nv_c = pe ? bc : nxt_c;
+      const float pcost = pc * c;
+      const float r_pen = r - pcost;
+      const float gr = g32 * nv_r, gc = g32 * nv_c;
+      const float sr = r_pen + gr, sc = c + gc;
+      const float delta_r = sr - vr, delta_c = sc - vc;
+      // discounted return: x = r (+ gamma * bootstrap where a path ends)
+      double x_ret = (double)r;
+      if (pe) { const double m = d_g * (double)br; x_ret = x_ret + m; }
+      const double ret = osa_affine_scan64(x_ret, resets, pw_g, dl_g, cret[q], lane);
+      double o_ar, o_ac, o_tr, o_tc;
+      if (EST == OSA_EST_GAE || EST == OSA_EST_GAE_RTG) {
+        o_ar = osa_affine_scan64((double)delta_r, resets, pw_r, dl_r, ca_r[q], lane);
+        o_ac = osa_affine_scan64((double)delta_c, resets, pw_c, dl_c, ca_c[q], lane);
+        ca_r[q] = osa_readlane63_f64(o_ar);
+        ca_c[q] = osa_readlane63_f64(o_ac);
+      } else {
+        o_ar = (double)delta_r;
+        o_ac = (double)delta_c;
+      }
+      if (EST == OSA_EST_GAE) {
+        o_tr = o_ar + (double)vr;
+        o_tc = o_ac + (double)vc;
+      } else {
+        double x_r = (double)r_pen, x_c = (double)c;
+        if (pe) {
+          const float pb = pc * bc;
+          const double m1 = d_g * (double)(br - pb);
+          x_r = x_r + m1;
+          const double m2 = d_g * (double)bc;
+          x_c = x_c + m2;
+        }
+        o_tr = osa_affine_scan64(x_r, resets, pw_g, dl_g, crtg_r[q], lane);
+        o_tc = osa_affine_scan64(x_c, resets, pw_g, dl_g, crtg_c[q], lane);
+        crtg_r[q] = osa_readlane63_f64(o_tr);
+        crtg_c[q] = osa_readlane63_f64(o_tc);
+      }
+      cret[q] = osa_readlane63_f64(ret);
+      cnv_r[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vr), 63));
+      cnv_c[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vc), 63));
+      s_out[0][lane][e] = (float)o_ar;
+      s_out[1][lane][e] = (float)o_ac;
+      s_out[2][lane][e] = (float)o_tr;
+      s_out[3][lane][e] = (float)o_tc;
+      s_out[4][lane][e] = (float)ret;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+      const int t = t_hi - tt, n = n0 + e;
+      if (tt < nvalid && n < N) {
+        const long g = (long)t * N + n;
+        adv_r[g] = s_out[0][tt][e];
+        adv_c[g] = s_out[1][tt][e];
+        tgt_r[g] = s_out[2][tt][e];
+        tgt_c[g] = s_out[3][tt][e];
+        disc_ret[g] = s_out[4][tt][e];
+      }
+    }
+    if (j + 1 < ntiles) stage();
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6  statistics: deterministic two-stage float64 reductions
 // ------------------------------------------------------------------------------------------------
 #define OSA_RED_BLOCKS 512
@@ -345,6 +554,31 @@ int osa_gae_scan(const float* reward, const float* cost, const float* value_r, c
   else if (estimator == OSA_EST_PLAIN) OSA_GAE_LAUNCH(OSA_EST_PLAIN);
   else OSA_GAE_LAUNCH(OSA_EST_VTRACE);
 #undef OSA_GAE_LAUNCH
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_gae_scan_tiled(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                       const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
+                       double gamma, double lam, double lam_c, float penalty_coef, int estimator,
+                       float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
+                       float* discounted_ret, void* stream) {
+  OSA_REQUIRE(T > 0 && N > 0);
+  OSA_REQUIRE(reward && cost && value_r && value_c && path_end && boot_r && boot_c);
+  OSA_REQUIRE(adv_r && adv_c && target_value_r && target_value_c && discounted_ret);
+  if (estimator < OSA_EST_GAE || estimator > OSA_EST_PLAIN) return OSA_EUNSUPPORTED;  // v-trace: float32 chain
+  const float g32 = (float)gamma;
+  const double d_g = gamma, d_r = gamma * lam, d_c = gamma * lam_c;
+  constexpr int NB = 16;
+  const int blocks = (N + NB - 1) / NB;
+#define OSA_GAE_TILE_LAUNCH(E)                                                                     \
+  hipLaunchKernelGGL((osa_gae_tile_scan_kernel<E, NB>), dim3(blocks), dim3(256), 0, osa_stream(stream), \
+                     reward, cost, value_r, value_c, path_end, boot_r, boot_c, T, N, g32, d_g, d_r, d_c,  \
+                     penalty_coef, adv_r, adv_c, target_value_r, target_value_c, discounted_ret)
+  if (estimator == OSA_EST_GAE) OSA_GAE_TILE_LAUNCH(OSA_EST_GAE);
+  else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_TILE_LAUNCH(OSA_EST_GAE_RTG);
+  else OSA_GAE_TILE_LAUNCH(OSA_EST_PLAIN);
+#undef OSA_GAE_TILE_LAUNCH
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

@@ -1141,7 +1141,8 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     // the 3 x world workgroups meet at an arrival counter every step, so they MUST be co-resident: a
     // cooperative launch makes the runtime verify that (occupancy x CUs >= grid) instead of inferring it
     // from the CU count, and refuses the launch otherwise
-    static bool coop_refused = false;  // runtime without cooperative launches: checked plain launch below
+    // (OSA_DP_PLAIN_LAUNCH=1: A/B switch of tools/dp_timing.py -- plain launch behind the occupancy check)
+    static bool coop_refused = getenv("OSA_DP_PLAIN_LAUNCH") != nullptr && getenv("OSA_DP_PLAIN_LAUNCH")[0] == '1';
     if (!coop_refused) {
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};

@@ -488,7 +488,7 @@ def gen_sibling_updates(only=None):
 # sits just below the rollout's mean episode cost so that the constraint is active.
 CONFIG_SHAPES = [
     ('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
-    ('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', {'cost_limit': 0.73}, None),
+    ('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', {'cost_limit': 0.71}, None),
     ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', {},
      {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
     ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),

@@ -9,12 +9,12 @@ statistics.
   config 4  PPOLag  376/17  the wide-input path (W1 does not fit the 64x96 LDS tile of the narrow kernel)
   config 5  TRPOLag 27/8    rows that are not 16-byte aligned (padded once per update), D_a = 8
 
-Tolerances (float32; the reference sums in CPU-sgemm order, the kernels in MFMA-tile order):
-  first-order family: parameters after 128 chained Adam steps  atol 2e-5 (each step moves a parameter by
-    <= lr = 3e-4; Adam's m/sqrt(v) turns 1e-7 gradient differences into ~1e-7 .. 1e-6 parameter differences per
-    step where v is small, and they accumulate along the chain); losses rtol 2e-3; KL rtol 1e-2;
-  trust-region family: accepted line-search index and CPO case identical; actor atol 3e-4 (theta_old + a step
-    of norm ~0.3 whose direction comes out of 15 float32 CG iterations); critics atol 2e-5.
+Tolerances (float32; the reference sums in CPU-sgemm order, the kernels in MFMA-tile order).  Measured on
+MI355X (round 2): max |theta - theta_reference| = 4e-8 (config 2), 1.6e-7 (config 4), 3e-8 / 4e-6 (config 5
+actor / critics), <1e-7 (config 3).  Required, with ~10x margin:
+  first-order family: parameters after 128 chained Adam steps  atol 2e-6; losses rtol 2e-3; KL rtol 1e-2;
+  trust-region family: accepted line-search index and CPO case identical; actor atol 5e-5 (theta_old + a step
+    of norm ~0.33 whose direction comes out of 15 float32 CG iterations); critics atol 2e-5.
 """
 import numpy as np
 import pytest
@@ -28,7 +28,7 @@ DEV = 'cuda:0'
 LAG = {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}
 FIRST_ORDER = [('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', ({}, LAG)),
                ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', ({}, LAG))]
-TRUST_REGION = [('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', ({'cost_limit': 0.73}, None)),
+TRUST_REGION = [('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', ({'cost_limit': 0.71}, None)),
                 ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', ({}, LAG))]
 
 
@@ -44,7 +44,7 @@ def test_first_order_update_at_config_shape(golden, tmp_path, tag, name, env_id,
     algo, ac = _run_update(name, tag, g, tmp_path, trust_region=False, env_id=env_id, extra=extra)
     assert algo._last_update_steps == 2 * 64
     print(tag, 'max |param - reference|:', {n: _max_err(ac, g, n) for n in ('actor', 'reward_critic', 'cost_critic')})
-    _check_params(ac, g, ('actor', 'reward_critic', 'cost_critic'), 2e-5)
+    _check_params(ac, g, ('actor', 'reward_critic', 'cost_critic'), 2e-6)
     # the parameters moved by much more than the tolerance (the comparison is not vacuous)
     moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
     assert moved > 5e-3
@@ -69,13 +69,16 @@ def test_trust_region_update_at_config_shape(golden, tmp_path, tag, name, env_id
         np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
     if name == 'CPO':
         info = algo._last_actor_update
-        assert info['case'] == int(g['log/Misc/OptimCase'][-1]) == 2  # constraint active, both projections evaluated
+        assert info['case'] == int(g['log/Misc/OptimCase'][-1]) == 1  # constraint violated but recoverable: both
+        # projections (lambda_a, lambda_b) are evaluated and nu* > 0 (cpo.py:300-322)
+        assert float(g['log/Misc/Nu_star'][-1]) > 1.0
+        np.testing.assert_allclose(_log(algo, 'Misc/Nu_star')[-1], g['log/Misc/Nu_star'][-1], rtol=5e-2)
         for key, rtol in (('Misc/q', 1e-2), ('Misc/r', 5e-2), ('Misc/s', 1e-2), ('Misc/cost_gradient_norm', 1e-3),
                           ('Misc/A', 1e-2), ('Misc/B', 5e-2), ('Misc/Lambda_star', 5e-2)):
             np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, atol=1e-6, err_msg=key)
     else:
         np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
-    _check_params(ac, g, ('actor',), 3e-4)
+    _check_params(ac, g, ('actor',), 5e-5)
     _check_params(ac, g, ('reward_critic', 'cost_critic'), 2e-5)
     moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
     assert moved > 5e-3

@@ -406,10 +406,10 @@ def test_full_size_pass_vs_oracle():
 
     Drift tolerance: both sides compute in float32 but sum in different orders (CPU sgemm vs MFMA tiles), so
     every step's gradient differs by ~1e-7 relative; Adam turns that into parameter differences of up to
-    ~lr * 1e-3 per step where sqrt(v) is small, and 1024 dependent steps accumulate them.  Parameters move
-    by up to 0.2 over the pass; required: max |theta - theta_oracle| <= 3e-4 (actor, lr 3e-4 with
-    |update| <= lr per step) and <= 3e-4 (critics), the per-step losses within rtol 2e-3 for >= 99.5 % of the
-    1024 steps and in the mean within 1e-4 relative, the final KL within 2 %."""
+    ~lr * 1e-3 per step where sqrt(v) is small, and 1024 dependent steps accumulate them.  Measured on
+    MI355X: max |theta - theta_oracle| = 1.0e-7 (actor), 1.3e-7 / 2.1e-7 (critics) while the parameters move
+    by 0.02.  Required: <= 2e-6 for every network (10x the measurement), the per-step losses within rtol 2e-3
+    for >= 99.5 % of the 1024 steps and in the mean within 1e-4 relative, the final KL within 2 %."""
     import np_oracle as O
     from omnisafe_amd.update import PPOUpdater
 
@@ -441,8 +441,8 @@ def test_full_size_pass_vs_oracle():
         errs[net] = max(float((v.cpu() - want[k]).abs().max()) for k, v in getattr(ac, net).state_dict().items())
     moved = max(float((v.cpu() - init[k]).abs().max()) for k, v in ac.actor.state_dict().items())
     print('full-size pass vs oracle: max |theta - theta_oracle| =', errs, 'actor moved by', moved)
-    assert moved > 0.02
-    assert errs['actor'] <= 3e-4 and errs['reward_critic'] <= 3e-4 and errs['cost_critic'] <= 3e-4, errs
+    assert moved > 0.01
+    assert errs['actor'] <= 2e-6 and errs['reward_critic'] <= 2e-6 and errs['cost_critic'] <= 2e-6, errs
     s = out['stats'].double().cpu().numpy()
     l2 = 0.001
     for col, l2col, key in ((0, 5, 'loss_r'), (1, 6, 'loss_c'), (2, None, 'loss_pi')):
