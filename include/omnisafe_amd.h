@@ -328,7 +328,9 @@ int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params
 /* Normalizer._push (omnisafe/common/normalizer.py:109-139) with a batch of the rows of x selected by
  * mask (NULL = all N rows; zero selected rows = no-op): Chan/Golub/LeVeque merge of the batch mean and
  * centred sum of squares into the running state, var = sumsq/(count-1), std = max(sqrt(var), 1e-2).
- * State: mean/sumsq/var/std float32[D], count int64[1] (all device).  ws: osa_normalizer_ws_doubles. */
+ * State: mean/sumsq/var/std float32[D], count int64[1] (all device).  ws: osa_normalizer_ws_doubles(N, D)
+ * doubles, ZERO-INITIALISED ONCE by the caller (its last word is the arrival ticket of the single-launch
+ * reduction; every call leaves it at zero again). */
 size_t osa_normalizer_ws_doubles(int N, int D);
 int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mask, float* mean,
                         float* sumsq, float* var, float* std_, long* count, double* ws,

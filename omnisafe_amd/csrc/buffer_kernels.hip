@@ -167,46 +167,91 @@ __global__ __launch_bounds__(256) void osa_gae_scan_kernel(
 //      before the current one is processed) and staged in LDS;
 //   2. each wave takes 4 of the envs; for one env the 64 lanes ARE the 64 time steps (lane 0 = latest).
 //      Every recurrence y_t = x_t + c_t * y_{t+1} (c_t = gamma*lambda, or 0 where a path ends) is an affine
-//      map, so the strip is a Hillis-Steele scan of (c, x) pairs in 6 shuffle rounds; because c_t is either 0
-//      or one constant d, the composed coefficient of a window of o steps is d^o or 0, decided per lane from
-//      the wave's ballot of path ends -- only the x parts travel through the shuffles.  The carry of the tile
-//      (lane 63) continues into the next (earlier) tile;
+//      map, so the strip is a scan of (c, x) pairs in 6 DPP rounds (row_shr 1/2/4/8, row_bcast 15/31); because
+//      c_t is either 0 or one constant d, the composed coefficient of a window of k steps is d^k or 0,
+//      decided per lane from the wave's ballot of path ends -- only the x parts travel between lanes.  The
+//      carry of the tile (lane 63) continues into the next (earlier) tile;
 //   3. results go back through LDS and leave with the same coalesced row segments.
 // Arithmetic: float32 deltas exactly as the lane-per-env kernel; the recurrences in float64 but associated
 // as a tree instead of a chain, so results agree with the bit-exact kernel to float64 rounding (then rounded
 // to float32: identical in all but ~1e-7 of the elements; tests require rtol 1e-5).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double osa_shfl_up_f64(double v, int o) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_up(lo, o, 64);
-  hi = __shfl_up(hi, o, 64);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double osa_readlane63_f64(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
+// DPP move of a double (two dwords); lanes without a valid source receive +0.0
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double osa_dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 
-// inclusive scan of y_l = x_l + (reset_l ? 0 : d) * y_{l-1} over the 64 lanes; `resets` = ballot of reset_l,
-// dpow[k] = d^(2^k), dlane = d^(lane+1); carry = y_{-1}.  Returns y_l.
-__device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long resets, const double (&dpow)[6],
-                                                    double dlane, double carry, int lane) {
-#pragma clang fp contract(off)
+// Per-lane powers of one recurrence coefficient d, computed once per kernel.
+struct OsaScanPow {
+  double o1, o2, o4, o8;  // d^1, d^2, d^4, d^8 (wave-uniform)
+  double row;             // d^((lane & 15) + 1): joins the prefix that ends right before the lane's row of 16
+  double half;            // d^(lane - 31) for lanes >= 32: joins the prefix of lanes 0..31
+  double all;             // d^(lane + 1): joins the carry of the previous tile
+};
+__device__ __forceinline__ double osa_powi(double d, int e) {
+  double r = 1.0, b = d;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int o = 1 << k;
-    const double up = osa_shfl_up_f64(x, o);
-    // window of lane l before this round: lanes [l-o+1 .. l]
-    const unsigned long long win = (o == 64 ? ~0ull : ((1ull << o) - 1ull)) << ((lane - o + 1) & 63);
-    if (lane >= o && (resets & win) == 0ull) {
-      const double m = dpow[k] * up;
-      x = x + m;
-    }
+  for (int k = 0; k < 7; ++k) {
+    if ((e >> k) & 1) r *= b;
+    b *= b;
   }
-  const unsigned long long all = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-  if ((resets & all) == 0ull) {
-    const double m = dlane * carry;
+  return r;
+}
+__device__ __forceinline__ OsaScanPow osa_scan_pow(double d, int lane) {
+  OsaScanPow p;
+  p.o1 = d; p.o2 = d * d; p.o4 = p.o2 * p.o2; p.o8 = p.o4 * p.o4;
+  p.row = osa_powi(d, (lane & 15) + 1);
+  p.half = osa_powi(d, lane >= 32 ? lane - 31 : 0);
+  p.all = osa_powi(d, lane + 1);
+  return p;
+}
+
+// Inclusive scan of y_l = x_l + (reset_l ? 0 : d) * y_{l-1} over the 64 lanes of a wave (lane 0 first),
+// y_{-1} = carry.  `resets` = ballot of reset_l.  Because the coefficient of every step is either d or 0,
+// the composed coefficient of a window of k steps is d^k if the window holds no reset and 0 otherwise:
+// only the x parts move between lanes -- on the DPP network: row_shr 1, 2, 4, 8 inside each row of 16
+// lanes, then row_bcast:15 and row_bcast:31 across rows (the gfx9 wave64 scan sequence).
+__device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long resets, const OsaScanPow& p,
+                                                    double carry, int lane) {
+#pragma clang fp contract(off)
+  const int lr = lane & 15;
+#define OSA_SCAN_ROW_STEP(O, CTRL, PW)                                                              \
+  {                                                                                                 \
+    const double up = osa_dpp_f64<CTRL, 0xf>(x);                                                    \
+    /* window of this lane before the step: lanes [lane-O+1 .. lane], all inside its row if lr >= O */ \
+    const bool open = lr >= (O) && ((resets >> ((lane - (O) + 1) & 63)) & ((1ull << (O)) - 1ull)) == 0ull; \
+    const double m = (open ? (PW) : 0.0) * up;                                                      \
+    x = x + m;                                                                                      \
+  }
+  OSA_SCAN_ROW_STEP(1, 0x111, p.o1)
+  OSA_SCAN_ROW_STEP(2, 0x112, p.o2)
+  OSA_SCAN_ROW_STEP(4, 0x114, p.o4)
+  OSA_SCAN_ROW_STEP(8, 0x118, p.o8)
+#undef OSA_SCAN_ROW_STEP
+  {  // rows 1 and 3 take the total of the row before them (its lane 15)
+    const double up = osa_dpp_f64<0x142, 0xa>(x);
+    const int rs = lane & ~15;
+    const bool open = ((lane >> 4) & 1) && ((resets >> rs) & ((2ull << lr) - 1ull)) == 0ull;
+    const double m = (open ? p.row : 0.0) * up;
+    x = x + m;
+  }
+  {  // rows 2 and 3 take the total of lanes 0..31 (lane 31)
+    const double up = osa_dpp_f64<0x143, 0xc>(x);
+    const bool open = lane >= 32 && ((resets >> 32) & ((2ull << (lane - 32)) - 1ull)) == 0ull;
+    const double m = (open ? p.half : 0.0) * up;
+    x = x + m;
+  }
+  {
+    const unsigned long long all = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const double m = ((resets & all) == 0ull ? p.all : 0.0) * carry;
     x = x + m;
   }
   return x;
@@ -226,25 +271,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
   __shared__ float s_out[5][TT][LD];  // adv_r, adv_c, tgt_r, tgt_c, disc_ret
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * NB;
-  // powers of the three coefficients: d^(2^k) for the scan rounds, d^(lane+1) for the carry
-  double pw_r[6], pw_c[6], pw_g[6];
-  pw_r[0] = d_r; pw_c[0] = d_c; pw_g[0] = d_g;
-#pragma unroll
-  for (int k = 1; k < 6; ++k) {
-    pw_r[k] = pw_r[k - 1] * pw_r[k - 1];
-    pw_c[k] = pw_c[k - 1] * pw_c[k - 1];
-    pw_g[k] = pw_g[k - 1] * pw_g[k - 1];
-  }
-  double dl_r = 1.0, dl_c = 1.0, dl_g = 1.0;  // d^(lane+1) by binary exponentiation
-  {
-    const int e = lane + 1;
-    double br = d_r, bc = d_c, bg = d_g;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      if ((e >> k) & 1) { dl_r *= br; dl_c *= bc; dl_g *= bg; }
-      br *= br; bc *= bc; bg *= bg;
-    }
-  }
+  const OsaScanPow pw_r = osa_scan_pow(d_r, lane), pw_c = osa_scan_pow(d_c, lane), pw_g = osa_scan_pow(d_g, lane);
   // per-env carries of this wave (wave-uniform values)
   double ca_r[EPW], ca_c[EPW], cret[EPW], crtg_r[EPW], crtg_c[EPW];
   float cnv_r[EPW], cnv_c[EPW];
@@ -290,7 +317,8 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
     if (j + 1 < ntiles) fetch(j + 1);  // in flight while this tile is scanned
 #pragma unroll
     for (int q = 0; q < EPW; ++q) {
-      const int e = wave * EPW + q;
+      const int e = q * 4 + wave;  // envs interleaved over the waves: few envs still use all four
+      if (n0 + e >= N) continue;   // wave-uniform
       const float r = s_in[0][lane][e], c = s_in[1][lane][e];
       const float vr = s_in[2][lane][e], vc = s_in[3][lane][e];
       const float br = s_in[4][lane][e], bc = s_in[5][lane][e];
@@ -309,11 +337,11 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
       // discounted return: x = r (+ gamma * bootstrap where a path ends)
       double x_ret = (double)r;
       if (pe) { const double m = d_g * (double)br; x_ret = x_ret + m; }
-      const double ret = osa_affine_scan64(x_ret, resets, pw_g, dl_g, cret[q], lane);
+      const double ret = osa_affine_scan64(x_ret, resets, pw_g, cret[q], lane);
       double o_ar, o_ac, o_tr, o_tc;
       if (EST == OSA_EST_GAE || EST == OSA_EST_GAE_RTG) {
-        o_ar = osa_affine_scan64((double)delta_r, resets, pw_r, dl_r, ca_r[q], lane);
-        o_ac = osa_affine_scan64((double)delta_c, resets, pw_c, dl_c, ca_c[q], lane);
+        o_ar = osa_affine_scan64((double)delta_r, resets, pw_r, ca_r[q], lane);
+        o_ac = osa_affine_scan64((double)delta_c, resets, pw_c, ca_c[q], lane);
         ca_r[q] = osa_readlane63_f64(o_ar);
         ca_c[q] = osa_readlane63_f64(o_ac);
       } else {
@@ -332,8 +360,8 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
           const double m2 = d_g * (double)bc;
           x_c = x_c + m2;
         }
-        o_tr = osa_affine_scan64(x_r, resets, pw_g, dl_g, crtg_r[q], lane);
-        o_tc = osa_affine_scan64(x_c, resets, pw_g, dl_g, crtg_c[q], lane);
+        o_tr = osa_affine_scan64(x_r, resets, pw_g, crtg_r[q], lane);
+        o_tc = osa_affine_scan64(x_c, resets, pw_g, crtg_c[q], lane);
         crtg_r[q] = osa_readlane63_f64(o_tr);
         crtg_c[q] = osa_readlane63_f64(o_tc);
       }

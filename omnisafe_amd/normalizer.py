@@ -49,7 +49,7 @@ class Normalizer:
     def _workspace(self, N: int) -> torch.Tensor:
         need = self._lib.osa_normalizer_ws_doubles(N, self._D)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.float64, device=self.device)
+            self._ws = torch.zeros(need, dtype=torch.float64, device=self.device)  # ticket word starts at 0
         return self._ws
 
     def push(self, data: torch.Tensor, mask: torch.Tensor | None = None) -> None:

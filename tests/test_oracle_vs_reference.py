@@ -85,11 +85,18 @@ def test_lagrange_and_pid_live(ref):
     pk = dict(pid_kp=0.1, pid_ki=0.01, pid_kd=0.01, pid_d_delay=10, pid_delta_p_ema_alpha=0.95,
               pid_delta_d_ema_alpha=0.95, sum_norm=True, diff_norm=False, penalty_max=100,
               lagrangian_multiplier_init=0.001, cost_limit=25.0)
-    rp, pp = RefPID(**pk), PIDLagrangian(**pk)
-    for jc in (30.0, 80.5, 10.0, 25.0, 60.25, 26.0, 24.0, 90.0, 0.0, 33.0, 41.0, 12.0):
-        rp.pid_update(jc)
-        pp.pid_update(jc)
-        assert rp.lagrangian_multiplier == pp.lagrangian_multiplier
+    costs = (30.0, 80.5, 10.0, 25.0, 60.25, 26.0, 24.0, 90.0, 0.0, 33.0, 41.0, 12.0, 25.5, 700.0, 3.0, 28.0)
+    # all three output ranges (sum_norm / diff_norm / penalty_max ceiling) and delay lines that wrap around
+    for over in ({}, {'pid_d_delay': 3}, {'sum_norm': False, 'diff_norm': True, 'pid_d_delay': 2},
+                 {'sum_norm': False, 'diff_norm': False, 'penalty_max': 2, 'pid_kp': 0.5, 'pid_d_delay': 1},
+                 {'pid_ki': 0.2, 'pid_kd': 0.3, 'pid_delta_p_ema_alpha': 0.5, 'pid_delta_d_ema_alpha': 0.7,
+                  'lagrangian_multiplier_init': 0.4}):
+        kw_pid = dict(pk, **over)
+        rp, pp = RefPID(**kw_pid), PIDLagrangian(**kw_pid)
+        for jc in costs:
+            rp.pid_update(jc)
+            pp.pid_update(jc)
+            assert rp.lagrangian_multiplier == pp.lagrangian_multiplier, (over, jc)
 
 
 def test_conjugate_gradients_live(ref):
