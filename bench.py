@@ -50,7 +50,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=2)  # epoch 1 eager, epoch 2 captures the rollout hipGraph
     ap.add_argument('--envs', type=int, default=4096)
     ap.add_argument('--steps-per-env', type=int, default=16)
     ap.add_argument('--batch-size', type=int, default=64)
@@ -306,10 +306,10 @@ def main():
     if world == 1 and not args.no_variant and rank == 0:
         del algo
         torch.cuda.empty_cache()
-        v_algo = make_algo(args, world, 16384, 8, 6, log_dir)
-        v_steps = 5
+        v_algo = make_algo(args, world, 16384, 8, 14, log_dir)
+        v_steps = 10
         v_events = []
-        run_epochs(v_algo, 1, lambda: torch.cuda.synchronize(dev))
+        run_epochs(v_algo, 3, lambda: torch.cuda.synchronize(dev))  # eager epoch, capture epoch, one replay
         v_algo._updater.profile_events = v_events
         v_dt = timed(v_algo, v_steps, 0, world, dev)
         v_algo._updater.profile_events = None
@@ -317,7 +317,8 @@ def main():
             'workload': 'same shapes, batch_size=16384, update_iters=8 (large-batch setting of PPOLag.yaml '
                         'GPU-env blocks)',
             'value': round(per_gpu_steps * v_steps / v_dt, 1), 'unit': 'env-steps/s',
-            'ms_per_step': round(v_dt / v_steps * 1e3, 3),
+            'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
+            'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
             'roofline': roofline_from_events(v_events, 16384)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         port = cpu_baseline(args)

@@ -139,14 +139,17 @@ int osa_mlp_layout(int obs_dim, int act_dim, int hidden, int* out12);
  * log_prob gaussian_learning_actor.py:81-129; VCritic.forward v_critic.py:89-92) for N observation
  * rows: act = mean + exp(log_std) * eps (or mean if deterministic), logp = sum_d Normal.log_prob,
  * value_r, value_c.  eps: optional external standard-normal noise [N][act_dim] (parity tests);
- * when NULL the kernel draws Philox4x32-10 + Box-Muller normals keyed by (seed, offset, row, dim).
+ * when NULL the kernel draws Philox4x32-10 + Box-Muller normals keyed by (seed, offset + *offset_base, row,
+ * dim).  offset_base (device pointer, may be NULL = 0) is the part of the stream position that lives in
+ * device memory: a captured hipGraph of a whole rollout replays with frozen by-value offsets 1..T and the
+ * caller advances *offset_base by T between replays.
  * nets_mask: bit0 actor, bit1 reward critic, bit2 cost critic (bootstrap calls need critics only).
  * Any output pointer may be NULL.  mean_out optionally receives the distribution mean. */
 int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
                     int ld_obs, int N, const float* eps, unsigned long long seed,
-                    unsigned long long offset, int deterministic, int nets_mask, float* act,
-                    int ld_act, float* value_r, float* value_c, float* logp, float* mean_out,
-                    int ld_mean, void* stream);
+                    unsigned long long offset, const unsigned long long* offset_base, int deterministic,
+                    int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
+                    float* mean_out, int ld_mean, void* stream);
 
 /* Hyper-parameters of one optimiser step; field names follow algo_cfgs / model_cfgs of
  * omnisafe/configs/on-policy/PPOLag.yaml. */
@@ -173,7 +176,9 @@ typedef struct osa_ppo_hparams {
  * mode 0: gradient + local clip + Adam;  1: gradient + local clip (caller all-reduces grads[3][P]
  * and calls osa_adam_apply -- clip-then-average order of policy_gradient.py:437-442);  2: raw grads.
  * B <= 64*max_blocks rows are processed by ceil(B/64) workgroups per network (ws: at least
- * osa_minibatch_ws_floats floats when more than one is used).  step_stats[16] receives
+ * osa_minibatch_ws_floats floats when more than one is used, ZERO-INITIALISED ONCE by the caller: its tail
+ * holds the arrival tickets of the fused slab-reduce + clip/Adam launch, which every call leaves at zero).
+ * step_stats[16] receives
  *   [0] mse_r [1] mse_c [2] loss_pi [3] mean ratio [4] entropy [5] sum p^2 (V_r) [6] sum p^2 (V_c)
  *   [7] |g_pi| [8] |g_Vr| [9] |g_Vc|   (logged Loss_*_critic = mse + critic_norm_coef * sum p^2). */
 size_t osa_minibatch_ws_floats(int obs_dim, int act_dim, int hidden, int max_blocks);
@@ -378,8 +383,10 @@ int osa_saute_step(int N, const float* cost, const float* reward, const uint8_t*
  * reference): obs ~ N(0,1)^obs_dim, reward ~ N(0,1), cost ~ Bernoulli(cost_p), never terminates,
  * truncates every `horizon` steps with gymnasium's vector auto-reset convention (the returned obs is
  * the post-reset obs; the pre-reset obs goes to final_obs).  reset_only != 0 draws initial
- * observations and zeroes the step counters. */
-int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+ * observations and zeroes the step counters.  Random draws are keyed by (seed, step + *step_base, env, k);
+ * step_base: device pointer or NULL (same role as osa_policy_step's offset_base: graph replay). */
+int osa_synth_env_step(unsigned long long seed, unsigned long long step,
+                       const unsigned long long* step_base, int N, int obs_dim,
                        int horizon, float cost_p, int* steps, float* obs, int ld_obs, float* reward,
                        float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                        int ld_final, int reset_only, void* stream);
@@ -392,7 +399,8 @@ int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, 
  * terminates, truncates every `horizon` steps (gymnasium vector auto-reset convention as above).
  * state: N x 8 floats (p, goal, hazard, 2 pad), owned by the caller, updated in place.
  * obs row = [p, goal-p, hazard-p, 0...].  reset_only != 0 draws fresh states and zeroes `steps`. */
-int osa_reach_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+int osa_reach_env_step(unsigned long long seed, unsigned long long step,
+                       const unsigned long long* step_base, int N, int obs_dim,
                        int horizon, float* state, int* steps, const float* action, int ld_action,
                        float* obs, int ld_obs, float* reward, float* cost, uint8_t* terminated,
                        uint8_t* truncated, float* final_obs, int ld_final, int reset_only,

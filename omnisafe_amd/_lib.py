@@ -34,7 +34,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_buffer_get': (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                             _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'osa_mlp_layout': (_I, [_I, _I, _I, _P]),
-    'osa_policy_step': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _I, _I, _P, _I, _P, _P, _P, _P, _I,
+    'osa_policy_step': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I,
                              _P]),
     'osa_minibatch_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
     'osa_ppo_minibatch': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
@@ -72,8 +72,8 @@ SIGNATURES: dict[str, tuple] = {
     'osa_normalizer_apply': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _P]),
     'osa_action_scale': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _P]),
     'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 19),
-    'osa_synth_env_step': (_I, [_U, _U, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
-    'osa_reach_env_step': (_I, [_U, _U, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'osa_synth_env_step': (_I, [_U, _U, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'osa_reach_env_step': (_I, [_U, _U, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 

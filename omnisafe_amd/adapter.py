@@ -154,10 +154,59 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                 self._ep_rows[k] = torch.zeros(T, N, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ rollout
+    # The device part of an epoch's rollout is a FIXED sequence of launches on fixed device buffers when the
+    # env is device-resident (`env.graph_safe`): which kernels run at step t depends only on t, T and the
+    # horizon.  From the second epoch on it is therefore captured once as a hipGraph and replayed with ONE
+    # host call per epoch instead of ~9 launches x T steps (the large-batch configuration of the benchmark is
+    # otherwise bound by the host's launch rate, not by the GPU).  What changes between epochs lives in
+    # device memory: the Philox stream positions of the env and of the policy noise (`commit()` /
+    # `commit_rng()` advance their device-resident parts inside the graph), the normaliser state, the
+    # network parameters.  OSA_ROLLOUT_GRAPH=0 disables it.
+    _graph_safe_hooks = True
+
     def rollout(self, steps_per_epoch: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer,
                 logger) -> None:
         """onpolicy_adapter.py:58-136."""
-        lib, N, T = self._lib, self._num_envs, int(steps_per_epoch)
+        import os
+
+        T = int(steps_per_epoch)
+        use_graph = (os.environ.get('OSA_ROLLOUT_GRAPH', '1') != '0' and self._graph_safe_hooks
+                     and getattr(self._env, 'graph_safe', False) and hasattr(agent, 'commit_rng'))
+        if not use_graph:
+            self._rollout_device(T, agent, buffer)
+            self._flush_logs(logger, buffer)
+            return
+        st = self.__dict__.setdefault('_rollout_graph', {})
+        key = (T, buffer.data['obs'].data_ptr(), agent.params.data_ptr(), self._num_envs)
+        if st.get('key') != key:  # first epoch (also sets kernel attributes, which must not happen under capture)
+            st.clear()
+            st.update(key=key, graph=None, failed=False)
+            self._rollout_device(T, agent, buffer)
+        elif st['graph'] is None and not st['failed']:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):  # records the launches without executing them
+                    self._rollout_device(T, agent, buffer)
+                st['graph'] = g
+                buffer.ptr = 0
+                g.replay()
+                buffer.ptr = T
+            except Exception:  # pragma: no cover - capture refused: stay on eager launches
+                st['failed'], st['graph'] = True, None
+                buffer.ptr = 0
+                self._rollout_device(T, agent, buffer)
+        elif st['graph'] is not None:
+            assert buffer.ptr == 0
+            st['graph'].replay()
+            buffer.ptr = T
+        else:
+            self._rollout_device(T, agent, buffer)
+        self.last_rollout_graphed = st.get('graph') is not None
+        self._flush_logs(logger, buffer)
+
+    def _rollout_device(self, T: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer) -> None:
+        """Everything of the rollout that runs on the device (no host synchronisation inside)."""
+        lib, N = self._lib, self._num_envs
         assert buffer.size == T and buffer.num_buffers == N and buffer.ptr == 0
         self._reset_log()
         self._ensure_episode_rows(T)
@@ -209,7 +258,10 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(b['boot_c'][t]), _lib.ptr(ep['done'][t]), _lib.ptr(ep['ret'][t]),
                 _lib.ptr(ep['cost'][t]), _lib.ptr(ep['len'][t]), st), 'osa_rollout_post_step')
             buffer.advance()
-        self._flush_logs(logger, buffer)
+        if hasattr(self._env, 'commit'):  # fold the epoch's stream positions into their device-resident parts
+            self._env.commit()
+        if hasattr(agent, 'commit_rng'):
+            agent.commit_rng()
 
     def _flush_logs(self, logger, buffer: VectorOnPolicyBuffer) -> None:
         """One device->host transfer per epoch: finished episodes in (step, env) order
@@ -351,6 +403,7 @@ class _EarlyTerminatedEnv:
 
     need_auto_reset_wrapper = False
     need_time_limit_wrapper = False
+    graph_safe = False  # one host read of the accumulated cost per step decides what is launched next
 
     def __init__(self, env, adapter: 'EarlyTerminatedAdapter', cost_limit: float) -> None:
         self._env, self._adapter, self._cost_limit = env, adapter, float(cost_limit)
@@ -379,6 +432,8 @@ class _EarlyTerminatedEnv:
 class EarlyTerminatedAdapter(OnPolicyAdapter):
     """early_terminated_adapter.py:27-88: episodes end as soon as their accumulated cost exceeds
     ``algo_cfgs.cost_limit``.  Single environment only, like the reference (:42)."""
+
+    _graph_safe_hooks = False
 
     def __init__(self, env_id: str, num_envs: int, seed: int, cfgs, env=None) -> None:
         assert num_envs == 1, 'EarlyTerminatedAdapter only supports num_envs=1.'

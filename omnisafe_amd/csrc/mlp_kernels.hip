@@ -67,11 +67,12 @@ template <int HT, int OT>
 __global__ __launch_bounds__(256) void osa_policy_step_kernel(
     OsaNet nd, const float* __restrict__ params, const float* __restrict__ obs, int ld, int N,
     const float* __restrict__ eps, unsigned long long seed, unsigned long long offset,
-    int deterministic, int nets_mask, float* __restrict__ act, int ld_act,
-    float* __restrict__ value_r, float* __restrict__ value_c, float* __restrict__ logp,
-    float* __restrict__ mean_out, int ld_mean) {
+    const unsigned long long* __restrict__ offset_base, int deterministic, int nets_mask,
+    float* __restrict__ act, int ld_act, float* __restrict__ value_r, float* __restrict__ value_c,
+    float* __restrict__ logp, float* __restrict__ mean_out, int ld_mean) {
   const int net = blockIdx.y;
   if (!((nets_mask >> net) & 1)) return;
+  if (offset_base) offset += *offset_base;  // device-resident part of the Philox stream position
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const long row = (long)blockIdx.x * 64 + 16 * wave + j;
   const bool valid = row < N;
@@ -725,6 +726,65 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_kernel(OsaMbArgs a) {
   }
 }
 
+// Large-batch step, second (and last) launch: the slab reduction of osa_slab_reduce_kernel spread over
+// ceil((P+16)/1024) workgroups per network, then the LAST workgroup of each network to arrive (release fence ->
+// agent-scope ticket -> acquire fence) runs the whole-network part -- L2 term, gradient norm, clip, Adam --
+// exactly as osa_finalize_kernel did in a third launch (same 1024-thread reduction order: bit-identical).
+// ticket: int[3], zero before the first call; every call leaves it at zero.
+__global__ __launch_bounds__(1024) void osa_slab_reduce_finalize_kernel(OsaMbArgs a, int* ticket) {
+  __shared__ float red[32];
+  __shared__ int s_last;
+  const OsaNet& nd = a.nd;
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = nd.P + OSA_NSTAT;
+  if (e < W) {
+    const float* s = a.slabs + (long)net * a.nblk * W + e;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
+    int b = 0;
+    for (; b + 8 <= a.nblk; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += s[(long)(b + u) * W];
+    }
+    for (; b < a.nblk; ++b) p[0] += s[(long)b * W];
+    const float acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (e < nd.P) {
+      a.grads[(long)net * nd.P + e] = acc;
+    } else {
+      const int k = e - nd.P;
+      const float invB = 1.f / (float)a.B;
+      if (net == 0) {
+        if (k == 0) {
+          float ent = 0.f;
+          for (int d = 0; d < nd.act_dim; ++d) ent += 1.41893853320467274178f + a.params[nd.oLS + d];
+          ent /= (float)nd.act_dim;
+          a.stats[2] = acc * invB - a.hp.entropy_coef * ent;
+          a.stats[4] = ent;
+        } else if (k == 1) {
+          a.stats[3] = acc * invB;
+        }
+      } else if (k == 0) {
+        a.stats[net - 1] = acc * invB;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(ticket + net, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
+    if (s_last) __hip_atomic_store(ticket + net, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < a.nd.act_dim)
+    a.grads[a.nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)a.nd.act_dim;
+  __syncthreads();
+  osa_finalize_net(a, net, red);
+}
+
 __global__ __launch_bounds__(1024) void osa_finalize_kernel(OsaMbArgs a, int add_entropy_grad) {
   __shared__ float red[32];
   const int net = blockIdx.y;
@@ -999,9 +1059,9 @@ int osa_mlp_layout(int obs_dim, int act_dim, int hidden, int* out12) {
 
 int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
                     int ld_obs, int N, const float* eps, unsigned long long seed,
-                    unsigned long long offset, int deterministic, int nets_mask, float* act,
-                    int ld_act, float* value_r, float* value_c, float* logp, float* mean_out,
-                    int ld_mean, void* stream) {
+                    unsigned long long offset, const unsigned long long* offset_base, int deterministic,
+                    int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
+                    float* mean_out, int ld_mean, void* stream) {
   const int rc = osa_check_dims(obs_dim, act_dim, hidden);
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && obs && N > 0 && ld_obs >= obs_dim);
@@ -1010,7 +1070,7 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
   const dim3 grid((N + 63) / 64, 3);
 #define OSA_CALL(HT, OT)                                                                          \
   hipLaunchKernelGGL((osa_policy_step_kernel<HT, OT>), grid, dim3(256), 0, osa_stream(stream), nd, \
-                     params, obs, ld_obs, N, eps, seed, offset, deterministic, nets_mask, act,    \
+                     params, obs, ld_obs, N, eps, seed, offset, offset_base, deterministic, nets_mask, act, \
                      ld_act, value_r, value_c, logp, mean_out, ld_mean)
   OSA_DISPATCH_OT(nd, OSA_CALL);
 #undef OSA_CALL
@@ -1021,7 +1081,7 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
 size_t osa_minibatch_ws_floats(int obs_dim, int act_dim, int hidden, int max_blocks) {
   if (osa_check_dims(obs_dim, act_dim, hidden) != OSA_OK || max_blocks < 1) return 0;
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
-  return (size_t)3 * max_blocks * (nd.P + OSA_NSTAT);
+  return (size_t)3 * max_blocks * (nd.P + OSA_NSTAT) + 4;  // slabs + arrival tickets (int[3]) of the fused reduce
 }
 
 int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
@@ -1082,6 +1142,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   if (nblk > max_blocks) nblk = max_blocks;
   if (nblk > 1) OSA_REQUIRE(ws != nullptr);
   a.nblk = nblk; a.slabs = ws;
+  // arrival tickets of the fused slab reduce + finalize launch live behind the slabs
+  int* tickets = ws ? reinterpret_cast<int*>(ws + (size_t)3 * max_blocks * (a.nd.P + OSA_NSTAT)) : nullptr;
   // Large minibatches: the gradient on the persistent kernel's machinery -- min(nblk, ~CUs/3) workgroups per
   // network keep the weights in LDS and their partial gradient in registers over several 64-row chunks and
   // write ONE slab each (this kernel re-reads the weights from L2 for every chunk and read-modify-writes
@@ -1098,9 +1160,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
       if (prc == OSA_OK) {
         a.nblk = pb;
         const int W = a.nd.P + OSA_NSTAT;
-        hipLaunchKernelGGL(osa_slab_reduce_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
-                           osa_stream(stream), a);
-        hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 1);
+        hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 1023) / 1024, 3), dim3(1024), 0,
+                           osa_stream(stream), a, tickets);
         OSA_CHECK_LAUNCH();
         return OSA_OK;
       }
@@ -1125,9 +1186,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
 #undef OSA_CALL
   if (nblk > 1) {
     const int W = a.nd.P + OSA_NSTAT;
-    hipLaunchKernelGGL(osa_slab_reduce_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
-                       osa_stream(stream), a);
-    hipLaunchKernelGGL(osa_finalize_kernel, dim3(1, 3), dim3(1024), 0, osa_stream(stream), a, 1);
+    hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 1023) / 1024, 3), dim3(1024), 0,
+                       osa_stream(stream), a, tickets);
   }
   OSA_CHECK_LAUNCH();
   return OSA_OK;

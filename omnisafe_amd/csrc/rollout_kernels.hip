@@ -242,10 +242,11 @@ __global__ __launch_bounds__(256) void osa_saute_step_kernel(
 // handed back as final_observation).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void osa_synth_env_kernel(
-    unsigned long long seed, unsigned long long step, int N, int D, int horizon, float cost_p,
-    int* __restrict__ steps, float* __restrict__ obs, int ld, float* __restrict__ reward,
-    float* __restrict__ cost, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-    float* __restrict__ final_obs, int ld_f, int reset_only) {
+    unsigned long long seed, unsigned long long step, const unsigned long long* __restrict__ step_base, int N,
+    int D, int horizon, float cost_p, int* __restrict__ steps, float* __restrict__ obs, int ld,
+    float* __restrict__ reward, float* __restrict__ cost, uint8_t* __restrict__ terminated,
+    uint8_t* __restrict__ truncated, float* __restrict__ final_obs, int ld_f, int reset_only) {
+  if (step_base) step += *step_base;  // device-resident part of the Philox stream position
   const int n = blockIdx.x;  // one workgroup per env row; threads over feature pairs
   uint8_t trunc = 0;
   if (!reset_only) trunc = (steps[n] + 1 >= horizon) ? 1 : 0;
@@ -312,11 +313,13 @@ __device__ __forceinline__ float osa_reach_uniform(uint32_t w) {  // [-1, 1]
 }
 
 __global__ __launch_bounds__(64) void osa_reach_env_kernel(
-    unsigned long long seed, unsigned long long step, int N, int D, int horizon,
-    float* __restrict__ state, int* __restrict__ steps, const float* __restrict__ action, int ld_a,
+    unsigned long long seed, unsigned long long step, const unsigned long long* __restrict__ step_base, int N,
+    int D, int horizon, float* __restrict__ state, int* __restrict__ steps,
+    const float* __restrict__ action, int ld_a,
     float* __restrict__ obs, int ld, float* __restrict__ reward, float* __restrict__ cost,
     uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated, float* __restrict__ final_obs,
     int ld_f, int reset_only) {
+  if (step_base) step += *step_base;
   const int n = blockIdx.x, lane = threadIdx.x;
   float s[6];
 #pragma unroll
@@ -453,20 +456,22 @@ int osa_saute_step(int N, const float* cost, const float* reward, const uint8_t*
   return OSA_OK;
 }
 
-int osa_synth_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+int osa_synth_env_step(unsigned long long seed, unsigned long long step,
+                       const unsigned long long* step_base, int N, int obs_dim,
                        int horizon, float cost_p, int* steps, float* obs, int ld_obs, float* reward,
                        float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                        int ld_final, int reset_only, void* stream) {
   OSA_REQUIRE(N > 0 && obs_dim > 0 && steps && obs && ld_obs >= obs_dim);
   if (!reset_only) OSA_REQUIRE(reward && cost && terminated && truncated && horizon > 0);
-  hipLaunchKernelGGL(osa_synth_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, N,
+  hipLaunchKernelGGL(osa_synth_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, step_base, N,
                      obs_dim, horizon, cost_p, steps, obs, ld_obs, reward, cost, terminated,
                      truncated, final_obs, ld_final, reset_only);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }
 
-int osa_reach_env_step(unsigned long long seed, unsigned long long step, int N, int obs_dim,
+int osa_reach_env_step(unsigned long long seed, unsigned long long step,
+                       const unsigned long long* step_base, int N, int obs_dim,
                        int horizon, float* state, int* steps, const float* action, int ld_action,
                        float* obs, int ld_obs, float* reward, float* cost, uint8_t* terminated,
                        uint8_t* truncated, float* final_obs, int ld_final, int reset_only,
@@ -474,7 +479,7 @@ int osa_reach_env_step(unsigned long long seed, unsigned long long step, int N, 
   OSA_REQUIRE(N > 0 && obs_dim >= 6 && state && steps && obs && ld_obs >= obs_dim);
   if (!reset_only)
     OSA_REQUIRE(action && ld_action >= 2 && reward && cost && terminated && truncated && horizon > 0);
-  hipLaunchKernelGGL(osa_reach_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, N,
+  hipLaunchKernelGGL(osa_reach_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, step_base, N,
                      obs_dim, horizon, state, steps, action, ld_action, obs, ld_obs, reward, cost,
                      terminated, truncated, final_obs, ld_final, reset_only);
   OSA_CHECK_LAUNCH();

@@ -72,7 +72,11 @@ class SynthVectorEnv:  # pylint: disable=too-many-instance-attributes
         self._observation_space = Box(-np.inf, np.inf, (self._obs_dim,))
         self._action_space = Box(-1.0, 1.0, (self._act_dim,))
         self._seed = int(seed)
-        self._t = 0            # global step counter (Philox stream position)
+        # Philox stream position = *_t_base (device) + _t (host, passed by value).  commit() folds the host part
+        # into the device part: a captured hipGraph of an epoch replays with the same by-value positions
+        # 0..T while the device part advances, so every epoch still draws fresh numbers
+        self._t = 0
+        self._t_base = torch.zeros(1, dtype=torch.int64, device=torch.device(device))
         self._since_reset = 0  # all envs reset together -> truncation steps are known on the host
         N, dev = self._num_envs, self._device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -94,8 +98,8 @@ class SynthVectorEnv:  # pylint: disable=too-many-instance-attributes
 
     def _launch(self, obs, reset_only: int) -> None:
         _lib.check(self._lib.osa_synth_env_step(
-            self._seed & 0xFFFFFFFFFFFFFFFF, self._t, self._num_envs, self._obs_dim, self._horizon,
-            self._cost_p, _lib.ptr(self._steps), _lib.ptr(obs), self._obs_dim, _lib.ptr(self._reward),
+            self._seed & 0xFFFFFFFFFFFFFFFF, self._t, _lib.ptr(self._t_base), self._num_envs, self._obs_dim,
+            self._horizon, self._cost_p, _lib.ptr(self._steps), _lib.ptr(obs), self._obs_dim, _lib.ptr(self._reward),
             _lib.ptr(self._cost), _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final),
             self._obs_dim, reset_only, _lib.stream_ptr()), 'osa_synth_env_step')
         self._t += 1
@@ -119,6 +123,14 @@ class SynthVectorEnv:  # pylint: disable=too-many-instance-attributes
             info['final_observation'] = self._final
             info['_final_observation'] = self._trunc
         return obs, self._reward, self._cost, self._term, self._trunc, info
+
+
+    graph_safe = True  # every step is a fixed sequence of launches on device tensors (no host-side data flow)
+
+    def commit(self) -> None:
+        """Fold the host part of the stream position into the device part (end of an epoch; capturable)."""
+        self._t_base += self._t
+        self._t = 0
 
     def render(self):
         return None
@@ -149,7 +161,8 @@ class ReachVectorEnv:  # pylint: disable=too-many-instance-attributes
         self._observation_space = Box(-np.inf, np.inf, (self._obs_dim,))
         self._action_space = Box(-1.0, 1.0, (self._act_dim,))
         self._seed = int(seed)
-        self._t = 0
+        self._t = 0            # host part of the Philox stream position (see SynthVectorEnv)
+        self._t_base = torch.zeros(1, dtype=torch.int64, device=self._device)
         self._since_reset = 0
         N, dev = self._num_envs, self._device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -173,8 +186,8 @@ class ReachVectorEnv:  # pylint: disable=too-many-instance-attributes
     def _launch(self, obs, action, reset_only: int) -> None:
         ld_a = action.stride(0) if action is not None else 0
         _lib.check(self._lib.osa_reach_env_step(
-            self._seed & 0xFFFFFFFFFFFFFFFF, self._t, self._num_envs, self._obs_dim, self._horizon,
-            _lib.ptr(self.state), _lib.ptr(self._steps), _lib.ptr(action), ld_a, _lib.ptr(obs),
+            self._seed & 0xFFFFFFFFFFFFFFFF, self._t, _lib.ptr(self._t_base), self._num_envs, self._obs_dim,
+            self._horizon, _lib.ptr(self.state), _lib.ptr(self._steps), _lib.ptr(action), ld_a, _lib.ptr(obs),
             self._obs_dim, _lib.ptr(self._reward), _lib.ptr(self._cost), _lib.ptr(self._term),
             _lib.ptr(self._trunc), _lib.ptr(self._final), self._obs_dim, reset_only,
             _lib.stream_ptr()), 'osa_reach_env_step')
@@ -201,6 +214,14 @@ class ReachVectorEnv:  # pylint: disable=too-many-instance-attributes
             info['final_observation'] = self._final
             info['_final_observation'] = self._trunc
         return obs, self._reward, self._cost, self._term, self._trunc, info
+
+
+    graph_safe = True  # every step is a fixed sequence of launches on device tensors (no host-side data flow)
+
+    def commit(self) -> None:
+        """Fold the host part of the stream position into the device part (end of an epoch; capturable)."""
+        self._t_base += self._t
+        self._t = 0
 
     def render(self):
         return None

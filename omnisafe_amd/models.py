@@ -212,7 +212,8 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
         if self.actor_lr is not None:
             self.actor_scheduler = _ActorSchedule(float(self.actor_lr), epochs,
                                                   bool(getattr(model_cfgs, 'linear_lr_decay', True)))
-        self._rng_offset = 0
+        self._rng_offset = 0  # host part of the Philox stream position (by value); see commit_rng
+        self._rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.seed = 0
 
     # ------------------------------------------------------------------ init
@@ -269,12 +270,19 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
         self._rng_offset += 1
         _lib.check(self._lib.osa_policy_step(
             self.obs_dim, self.act_dim, self.hidden, _lib.ptr(self.params), _lib.ptr(x), x.stride(0), N,
-            _lib.ptr(e), self.seed, self._rng_offset, int(deterministic), nets_mask, _lib.ptr(act),
+            _lib.ptr(e), self.seed, self._rng_offset, _lib.ptr(self._rng_base), int(deterministic), nets_mask,
+            _lib.ptr(act),
             self.act_dim, _lib.ptr(v_r), _lib.ptr(v_c), _lib.ptr(logp), None, 0, _lib.stream_ptr()),
             'osa_policy_step')
         if single:
             return act[0], v_r[0], v_c[0], logp[0]
         return act, v_r, v_c, logp
+
+    def commit_rng(self) -> None:
+        """Fold the host part of the noise stream position into the device part (end of an epoch; a plain
+        tensor add, so it is capturable: see OnPolicyAdapter's rollout graph)."""
+        self._rng_base += self._rng_offset
+        self._rng_offset = 0
 
     def __call__(self, obs: torch.Tensor, deterministic: bool = False):
         """nn.Module.forward of the reference (actor_critic.py:141-155) = step."""

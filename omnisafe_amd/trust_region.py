@@ -31,7 +31,7 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         dev, P = ac.device, ac.layout.P
         f32 = dict(dtype=torch.float32, device=dev)
         nws = self.lib.osa_minibatch_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, max_blocks)
-        self._ws = torch.empty(nws, **f32)
+        self._ws = torch.zeros(nws, **f32)  # tail = arrival tickets (start at 0)
         self._stats = torch.zeros(16, **f32)
         self._eval_ws = torch.empty(4096, dtype=torch.float64, device=dev)
         self._scal = torch.zeros(4, **f32)

@@ -61,7 +61,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.max_blocks = int(max_blocks)
         dev = ac.device
         nws = self.lib.osa_minibatch_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, self.max_blocks)
-        self._ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dev)
+        self._ws = torch.zeros(max(nws, 1), dtype=torch.float32, device=dev)  # tail = arrival tickets (start at 0)
         self._kl_ws = torch.empty(1024, dtype=torch.float64, device=dev)
         self._kl = torch.zeros(1, dtype=torch.float32, device=dev)
         self._old_mean: torch.Tensor | None = None

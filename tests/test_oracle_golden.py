@@ -197,7 +197,8 @@ def test_learning_golden_file_is_complete():
     assert cfg['env_id'] == 'SynthReach-v0' and cfg['epochs'] == 10
     for algo in ('PPOLag', 'TRPOLag', 'CPO'):
         curves = g['curves'][algo]
-        assert sorted(map(int, curves)) == list(range(20))
+        # 20 seeds per algorithm; CPO has 80 (round 2: large-sample follow-up of its episode-cost tail)
+        assert sorted(map(int, curves)) == list(range(80 if algo == 'CPO' else 20))
         for c in curves.values():
             assert len(c['EpRet']) == len(c['EpCost']) == cfg['epochs']
             assert np.isfinite(c['EpRet']).all() and np.isfinite(c['EpCost']).all()

@@ -494,3 +494,43 @@ def test_exploration_noise_anneal_end_to_end(tmp_path):
     # starts from the value set after epoch 0 (0.5) and epoch 2 from 0.5 - 0.4/3, each moved a little by Adam
     assert abs(float(rows[1]['Train/PolicyStd']) - 0.5) < 0.02
     assert abs(float(rows[2]['Train/PolicyStd']) - (0.5 - 0.4 / 3)) < 0.02
+
+
+@pytest.mark.parametrize('algo_name,env_id', [('PPOLag', 'SynthPointGoal1-v0'), ('PPOSaute', 'SynthReach-v0'),
+                                              ('TRPOLag', 'SynthAnt-v0')])
+def test_rollout_graph_replay_equals_eager_launches(tmp_path, monkeypatch, algo_name, env_id):
+    """The hipGraph of an epoch's rollout (captured on the second epoch, replayed afterwards) against the same
+    agent run with eager launches: bit-identical buffers, normaliser state, episode metrics and parameters
+    after every one of 5 epochs (rollout + update), i.e. the device-resident Philox stream positions advance
+    exactly as the host counters do, and truncation steps (final observations, bootstrap values) replay."""
+    import omnisafe_amd
+
+    def run(graph):
+        monkeypatch.setenv('OSA_ROLLOUT_GRAPH', '1' if graph else '0')
+        cfg = {'seed': 7, 'train_cfgs': {'device': DEV, 'total_steps': 5 * 64 * 24, 'vector_env_nums': 64},
+               'algo_cfgs': {'steps_per_epoch': 64 * 24, 'update_iters': 2},
+               'logger_cfgs': {'log_dir': str(tmp_path / ('g' if graph else 'e')), 'verbose': False}}
+        if env_id != 'SynthReach-v0':
+            cfg['env_cfgs'] = {'horizon': 10, 'cost_p': 0.2}  # truncations at steps 10 and 20 of the 24
+        algo = omnisafe_amd.Agent(algo_name, env_id, custom_cfgs=cfg).agent
+        snaps = []
+        for _ in range(5):
+            algo._env.rollout(steps_per_epoch=algo._steps_per_epoch, agent=algo._actor_critic, buffer=algo._buf,
+                              logger=algo._logger)
+            snap = {k: v.clone() for k, v in algo._buf.data.items()}
+            snap['norm_mean'] = algo._env._obs_normalizer._mean.clone()
+            snap['ep_cost'] = torch.tensor(list(algo._logger._data['Metrics/EpCost']))
+            algo._update()
+            snap['params'] = algo._actor_critic.params.clone()
+            snaps.append(snap)
+            algo._logger.dump_tabular()
+        return algo, snaps
+
+    a_g, s_g = run(True)
+    a_e, s_e = run(False)
+    assert a_g._env.last_rollout_graphed is True and not getattr(a_e._env, 'last_rollout_graphed', False)
+    for ep, (g, e) in enumerate(zip(s_g, s_e)):
+        for k in g:
+            assert torch.equal(g[k].cpu(), e[k].cpu()), (ep, k)
+    # epochs differ from each other (fresh noise every epoch, not a replay of the captured numbers)
+    assert not torch.equal(s_g[2]['act'], s_g[3]['act']) and not torch.equal(s_g[3]['reward'], s_g[4]['reward'])
