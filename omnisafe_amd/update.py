@@ -71,6 +71,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # torch's current stream (bench.py turns this on for the timed region)
         self.profile_events: list | None = None
         self.last_path: str | None = None
+        self._use_wide = False
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
@@ -120,6 +121,19 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         name = 'osa_ppo_pass_kernel'
+        if self._use_wide:  # wide observations: W1 and its Adam moments streamed from L2 (wide_pass_kernel.hip)
+            _lib.check(self.lib.osa_ppo_wide_pass(
+                ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
+                _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+                _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+                _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
+                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
+                _lib.stream_ptr()), 'osa_ppo_wide_pass')
+            if ev is not None:
+                ev[1].record()
+                self.profile_events.append(('osa_wide_pass_kernel', M, ev))
+            return
         ext = None
         if self.ext is not None:  # extended actor surrogate (FOCOPS / CUP / P3O) inside the persistent pass
             self.ext.old_mean = self._old_mean.data_ptr()
@@ -363,6 +377,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 and B <= self.persistent_max_batch and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
+        self._use_wide = False
+        if (self._pass_fn is None and self.persistent and self.ext is None and not dist.collectives_active()
+                and B <= 64 and self.loss_kind in (0, 1)
+                and bool(self.lib.osa_ppo_wide_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
+            self._pass_fn = ('osa_wide_pass_kernel', self.lib.osa_ppo_wide_pass)
+            self._use_wide = True
         use_pass = self._pass_fn is not None
         W = dist.world_size()
         data = self._aligned_rows(data)
@@ -372,7 +392,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if use_repl:
             gathered = self._aligned_rows(self.gather_for_replicated(data, W))
         # which machinery ran (tests assert the timed path, not a fallback)
-        self.last_path = 'replicated' if use_repl else ('persistent' if use_pass else 'per-step')
+        self.last_path = 'replicated' if use_repl else (
+            ('persistent-wide' if self._use_wide else 'persistent') if use_pass else 'per-step')
         # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
         # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
         all_perms = None

@@ -243,7 +243,10 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
 
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
                                                 (90, 17, 512, 64), (5, 1, 130, 64), (60, 2, 1000, 128),
-                                                (72, 2, 700, 200)])
+                                                (72, 2, 700, 200),
+                                                # wide observations: osa_ppo_wide_pass (W1 streamed from L2)
+                                                (376, 17, 1024, 64), (376, 17, 200, 64), (100, 3, 300, 64),
+                                                (200, 20, 256, 32), (512, 32, 192, 64), (97, 1, 130, 48)])
 def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     """osa_ppo_pass (one persistent launch per pass, weights in LDS, Adam moments in registers) vs
     osa_ppo_minibatch (one launch per optimiser step): same parameters, moments and statistics after
@@ -254,7 +257,7 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
             'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
             'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
-    acs, outs = [], []
+    acs, outs, paths = [], [], []
     perms = [torch.randperm(M), torch.randperm(M)]
     for persistent in (True, False):
         torch.manual_seed(99)
@@ -266,8 +269,10 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
                         entropy_coef=0.01, persistent=persistent)
         lam = torch.tensor([0.3], device=DEV)
         outs.append(up.run(data, lam, perms=perms, actor_lr=3e-4, critic_lr=1e-3))
+        paths.append(up.last_path)
         acs.append(ac)
     assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
+    assert paths == ['persistent-wide' if obs_dim > 96 else 'persistent', 'per-step']
     assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
     # B <= 64: the same operation order except for the 1-2-output layers, which the pass kernel evaluates
     # on the VALU (16-term partial dot products per lane group) and the per-step kernels on MFMA tiles:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""us per optimiser step of the wide-observation persistent pass (osa_ppo_wide_pass) vs the per-step kernels,
+BASELINE config 4 shapes (376 / 17, batch 64) and two other widths; one pass of M rows each.
+
+    python tools/wide_pass_timing.py [M]
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+from test_mlp_gpu import make_ac  # noqa: E402
+
+from omnisafe_amd.update import PPOUpdater  # noqa: E402
+
+DEV = 'cuda:0'
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+res = {}
+for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32)):
+    torch.manual_seed(0)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'logp': torch.randn(M, device=DEV) * 0.1 - 20.0, 'target_value_r': torch.randn(M, device=DEV),
+            'target_value_c': torch.randn(M, device=DEV), 'adv_r': torch.randn(M, device=DEV),
+            'adv_c': torch.randn(M, device=DEV)}
+    lam = torch.tensor([0.2], device=DEV)
+    for persistent in (True, False):
+        ac = make_ac(obs_dim, act_dim)
+        up = PPOUpdater(ac, batch_size=64, update_iters=1, target_kl=0.02, kl_early_stop=False,
+                        persistent=persistent)
+        perm = [torch.randperm(M)]
+        up.run(data, lam, perms=perm, actor_lr=3e-4, critic_lr=3e-4)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = up.run(data, lam, perms=perm, actor_lr=3e-4, critic_lr=3e-4)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / out['steps']
+        res[f'{obs_dim}/{act_dim} {up.last_path}'] = round(us, 2)
+        print(f'{obs_dim}/{act_dim}: {up.last_path:16s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2_wide_pass_timing.json'), 'w'), indent=1)
