@@ -242,20 +242,24 @@ int osa_ppo_pass(int obs_dim, int act_dim, int hidden, float* params, float* ada
                  const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                  const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                  float* step_stats, void* stream);
-/* The same persistent pass for WIDE observations (97 <= obs_dim <= 512, e.g. SafetyHumanoidVelocity 376/17;
+/* The same persistent pass for WIDE observations (65 <= obs_dim <= 512; callers prefer osa_ppo_pass where it
+ * is supported; e.g. SafetyHumanoidVelocity 376/17;
  * model builder omnisafe/utils/model.py:73-111 takes any sizes): the first layer's weights and Adam moments do
  * not fit one compute unit, so they stay in (L2-resident) global memory -- W1 fragments are streamed by the
  * forward pass, the W1 gradient is accumulated in MFMA accumulator registers and norm + clip + Adam are applied
  * by the lanes that hold it; the other layers live in LDS / registers as in osa_ppo_pass (see
  * csrc/wide_pass_kernel.hip).  B <= 64, loss_kind 0/1, single process; same arguments, statistics and
- * arithmetic per step as osa_ppo_pass / osa_ppo_minibatch(mode 0).  OSA_EUNSUPPORTED otherwise. */
+ * arithmetic per step as osa_ppo_pass / osa_ppo_minibatch(mode 0), plus ws: osa_ppo_wide_pass_ws_floats
+ * floats of scratch (a tiled private copy of the first layer, of its Adam moments and of its gradient for the
+ * duration of the launch; contents undefined afterwards).  OSA_EUNSUPPORTED otherwise. */
 int osa_ppo_wide_pass_supported(int obs_dim, int act_dim, int hidden);
+size_t osa_ppo_wide_pass_ws_floats(int obs_dim, int act_dim, int hidden);
 int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                       int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
                       const float* logp, const float* target_value_r, const float* target_value_c,
                       const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                       const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                      float* step_stats, void* stream);
+                      float* ws, float* step_stats, void* stream);
 /* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
  * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);
  * OSA_EUNSUPPORTED otherwise -- use osa_ppo_minibatch_ext.  ext == NULL: osa_ppo_pass.  With cost_kappa > 0

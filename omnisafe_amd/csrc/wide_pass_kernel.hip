@@ -59,17 +59,39 @@ struct OsaWideArgs {
   int loss_kind;
   int nets_mask;
   float* stats;  // [nmb][WNSTAT]
+  // [3][4][H * INP]: per network a TILED private copy of W1, of its two Adam moments, and the W1 gradient of the
+  // step in flight.  Tile (ft, kb) = features 16 ft .. +15 x inputs 16 kb .. +15 is 1 KB contiguous, element
+  // (c, i) at c * 16 + i: a wave's 16-byte accesses to one tile are then 8 full cache lines instead of 16
+  // half lines of 16 different rows (measured: the row-major version was bound by line touches, 36 k cycles
+  // per step for the Adam pass alone).  Built at the start of the launch, written back at its end.
+  float* ws;
 };
 
-// KB4 = ceil(KB / 4): the W1 gradient is held as 4 * KB4 accumulator tiles (tiles >= KB stay zero)
-template <int KB4, int OT>
+// Phase clocks (tools/wide_pass_timing.py --phases with a -DOSA_WIDE_CLOCKS build, tools/build_variant_lib.sh):
+// mean s_memtime cycles per step of thread 0 of network `net`, written over columns 0..6 of statistics row
+// nmb-1-net at the end of the launch (debug builds only).
+#ifdef OSA_WIDE_CLOCKS
+#define WTICK(k)                                   \
+  do {                                             \
+    if (tid == 0) {                                \
+      const long long now_ = clock64();            \
+      wdbg[k] += now_ - wlast;                     \
+      wlast = now_;                                \
+    }                                              \
+  } while (0)
+#else
+#define WTICK(k) do { } while (0)
+#endif
+
+template <int OT>
 __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int H = 64, HT = 4, OUTP = 16 * OT, KBM = 4 * KB4;
+  constexpr int H = 64, HT = 4, OUTP = 16 * OT;
   const OsaNet& nd = a.nd;
   const int net = blockIdx.x;
   if (!((a.nets_mask >> net) & 1)) return;
   const int KB = nd.KB, INP = nd.INP, P = nd.P;
+  const int KB4 = (KB + 3) / 4;  // slabs of 4 K blocks (64 input features)
   // ---- LDS carve-up (offsets are multiples of 4 floats)
   float* sW2 = smem;                      // [H][WSLD]
   float* sW3 = sW2 + H * WSLD;            // [OUTP][WSLD]
@@ -91,11 +113,36 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   float* __restrict__ gp = a.params + (long)net * P;
   float* __restrict__ gm = a.adam_m + (long)net * P;
   float* __restrict__ gv = a.adam_v + (long)net * P;
-  float* __restrict__ W1 = gp + nd.oW1;
-  float* __restrict__ M1 = gm + nd.oW1;
-  float* __restrict__ V1 = gv + nd.oW1;
+  const int NW1 = H * INP;
+  float* __restrict__ W1 = a.ws + (long)net * 4 * NW1;  // tiled copies (see OsaWideArgs::ws)
+  float* __restrict__ M1 = W1 + NW1;
+  float* __restrict__ V1 = M1 + NW1;
+  float* __restrict__ G1 = V1 + NW1;
+  // ---- row-major parameter block -> tiled private copy (once per launch)
+  for (int e = tid; e < NW1; e += 256) {
+    const int t_ = e >> 8, c_ = (e >> 4) & 15, i_ = e & 15, ft_ = t_ / KB, kb_ = t_ - ft_ * KB;
+    const int src = nd.oW1 + (16 * ft_ + c_) * INP + 16 * kb_ + i_;
+    W1[e] = gp[src];
+    M1[e] = gm[src];
+    V1[e] = gv[src];
+  }
   const bool critic = net != 0;
-  const bool vec_ok = (a.ld_obs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs) & 15) == 0);
+  // Observation chunks: rows are 16-byte aligned with ld % 4 == 0 (checked by the entry point), so a chunk is
+  // ONE unconditional 16-byte load from an address clamped into the row, masked when it is used.  (The generic
+  // osa_load_x branches per lane and the compiler then waits for every single load inside its branch: measured
+  // 7 k cycles per slab of four loads in the first version of this kernel.)
+  const int ld_obs = a.ld_obs, obs_dim = nd.obs_dim;
+  auto load_chunk = [&](const float* __restrict__ xr, int col0) -> f32x4 {
+    const int cl = (col0 + 4 <= ld_obs) ? col0 : ld_obs - 4;
+    return *reinterpret_cast<const f32x4*>(xr + cl);
+  };
+  auto mask_chunk = [&](f32x4 v, int col0) -> f32x4 {
+    v.x = (col0 + 0 < obs_dim) ? v.x : 0.f;
+    v.y = (col0 + 1 < obs_dim) ? v.y : 0.f;
+    v.z = (col0 + 2 < obs_dim) ? v.z : 0.f;
+    v.w = (col0 + 3 < obs_dim) ? v.w : 0.f;
+    return v;
+  };
 
   // ---- small parameters -> LDS master copy
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * WSLD + (e & 63)] = gp[nd.oW2 + e];
@@ -110,7 +157,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   }
   // ---- ownership (as osa_ppo_pass_kernel): W2[(16w+4g+r)][16ti+cc], W3[(16o+4g+r)][16w+cc], one
   // bias-like scalar per thread; W1[(16w+4g+r)][16kb+cc] lives in global memory
-  f32x4 m2[HT], v2[HT], m3[OT], v3[OT];
   float mb_ = 0.f, vb_ = 0.f;
   int boff = -1;
   float* sbias = sB1;
@@ -119,22 +165,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   else if (tid < 2 * H + OUTP) { boff = nd.ob3 + tid - 2 * H; sbias = sB3 + tid - 2 * H; }
   else if (tid < 2 * H + 2 * OUTP) { boff = nd.oLS + tid - 2 * H - OUTP; sbias = sLS + tid - 2 * H - OUTP; }
   if (critic && boff >= nd.oLS) boff = -1;  // critics have no log_std
-#pragma unroll
-  for (int ti = 0; ti < HT; ++ti)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
-      m2[ti][r] = gm[off];
-      v2[ti][r] = gv[off];
-    }
-#pragma unroll
-  for (int o = 0; o < OT; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
-      m3[o][r] = gm[off];
-      v3[o][r] = gv[off];
-    }
   if (boff >= 0) {
     mb_ = gm[boff];
     vb_ = gv[boff];
@@ -155,24 +185,62 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
   const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
-  // the W1 elements this lane owns (D layout of the weight-gradient tiles): rows 16 wave + 4 g + r, columns
-  // 16 kb + cc
-  const long w1row0 = (long)(16 * wave + 4 * g) * INP + cc;
+  // the W1 elements this lane owns (D layout of the TRANSPOSED weight-gradient tiles): row 16 wave + cc,
+  // columns 16 kb + 4 g .. + 3 = 16 bytes at offset cc * 16 + 4 g of tile (wave, kb) of the tiled copies
+  const int w1own = wave * KB * 256 + cc * 16 + 4 * g;
   __syncthreads();  // LDS master copy + bias-correction table complete
+#ifdef OSA_WIDE_CLOCKS
+  long long wdbg[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long wlast = clock64();
+#endif
 
 #define WPUT_TILE(S, V, T)                                                           \
   _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (S)[(16 * (T) + 4 * g + r_) * WSLD + c] = (V)[r_]
 
+  long row_nxt;
+  {
+    const int B0 = (int)min((long)a.B, a.M);
+    const long p0 = (16 * wave + j < B0) ? 16 * wave + j : 0;
+    row_nxt = a.perm ? a.perm[p0] : p0;
+  }
   for (int mb = 0; mb < a.nmb; ++mb) {
     const long mb_lo = (long)mb * a.B;
     const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
     const float invB = 1.f / (float)Bcur;
     const int c = 16 * wave + j;  // this lane's sample column
     const bool valid = c < Bcur;
-    // invalid columns of a ragged minibatch gather a valid row (finite values) and meet dL/dout = 0
-    const long pos = mb_lo + (valid ? c : 0);
-    const long row = a.perm ? a.perm[pos] : pos;
-    const float* __restrict__ xrow = a.obs + row * a.ld_obs;
+    // invalid columns of a ragged minibatch gather a valid row (finite values) and meet dL/dout = 0.
+    // The permutation entries of the NEXT step (this lane's sample, and the sample whose rows this thread will
+    // pull into the L2) are requested now and used one step / half a step later: perm -> row -> first chunk is
+    // a chain of two dependent HBM round trips that otherwise opens every step.
+    const long row = row_nxt;
+    const float* __restrict__ xrow = a.obs + row * ld_obs;
+    long row_nn = row, prow = row;
+    const bool have_next = mb + 1 < a.nmb;
+    if (have_next) {
+      const long nlo = mb_lo + a.B;
+      const int nB = (int)(min(nlo + a.B, a.M) - nlo);
+      const long np = nlo + ((c < nB) ? c : 0), pp = nlo + min(tid >> 2, nB - 1);
+      row_nn = a.perm ? a.perm[np] : np;
+      prow = a.perm ? a.perm[pp] : pp;
+    }
+    // this lane's per-sample scalars: unconditional loads issued now (clamped indices), masked where they are
+    // used -- a load inside a divergent branch is waited for inside that branch
+    float s_act[4 * OT], s_logp = 0.f, s_advr = 0.f, s_advc = 0.f, s_tgt = 0.f;
+    if (net == 0) {  // block-uniform
+      const float* __restrict__ arow = a.act + row * a.ld_act;
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_act[4 * o + r] = arow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
+      s_logp = a.logp[row];
+      s_advr = a.adv_r[row];
+      s_advc = a.adv_c[row];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * OT; ++k) s_act[k] = 0.f;
+      s_tgt = tgt[row];
+    }
     const float* bc_row = a.stats + (long)mb * WNSTAT + 10 + 2 * net;
     const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
     float ent_pre = 0.f;
@@ -184,30 +252,81 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     f32x4 h1[HT], h2[HT], out[OT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
-    {  // layer 1: W1 fragments and x chunks streamed from global memory (L2), one K block ahead
-      f32x4 xn = osa_load_x(xrow, 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
-      f32x4 wn[HT];
+    // layer 1: W1 is staged through LDS in slabs of 4 K blocks (64 rows x 64 columns; the two X^T slab buffers
+    // of the dW1 phase are free now), loaded ONCE per step by the whole workgroup -- each wave reading its own
+    // A fragments from L2 would fetch W1 four times -- and double-buffered: the next slab and the next x chunks
+    // are in flight while the 64 MFMAs of the current slab issue.  The loader threads also accumulate sum w^2.
+    float w1sq = 0.f;
+    {
+      f32x4 wl[4], xc[4];
+      auto load_slab = [&](int s4) {  // 16 tiles (4 feature tiles x 4 K blocks) = 1024 f32x4, 4 per thread
 #pragma unroll
-      for (int t = 0; t < HT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 4 * g);
-      for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 x = xn;
-        f32x4 w[HT];
-#pragma unroll
-        for (int t = 0; t < HT; ++t) w[t] = wn[t];
-        if (kb + 1 < KB) {
-          xn = osa_load_x(xrow, 16 * (kb + 1) + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-            wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 16 * (kb + 1) + 4 * g);
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 256 * q, t16 = e >> 6, kb_ = 4 * s4 + (t16 & 3);
+          wl[q] = (kb_ < KB) ? *reinterpret_cast<const f32x4*>(W1 + (((t16 >> 2) * KB + kb_) << 8) + 4 * (e & 63))
+                             : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto load_x = [&](int s4) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < 4; ++q) xc[q] = load_chunk(xrow, 16 * (4 * s4 + q) + 4 * g);
+      };
+      load_slab(0);
+      load_x(0);
+      for (int s4 = 0; s4 < KB4; ++s4) {
+        float* slab = sXs + (s4 & 1) * 64 * WSLD;
 #pragma unroll
-          for (int t = 0; t < HT; ++t) h1[t] = OSA_MFMA(w[t][s], x[s], h1[t]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 256 * q, t16 = e >> 6, f4 = e & 63;  // tile (ft, q'), element (c, 4 i4)
+          *reinterpret_cast<f32x4*>(slab + (16 * (t16 >> 2) + (f4 >> 2)) * WSLD + 16 * (t16 & 3) + 4 * (f4 & 3)) = wl[q];
+          if (critic) w1sq += (wl[q].x * wl[q].x + wl[q].y * wl[q].y) + (wl[q].z * wl[q].z + wl[q].w * wl[q].w);
+        }
+        f32x4 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = mask_chunk(xc[q], 16 * (4 * s4 + q) + 4 * g);
+        __syncthreads();
+        if (s4 + 1 < KB4) {
+          load_slab(s4 + 1);
+          load_x(s4 + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 w[HT];
+#pragma unroll
+          for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(slab + (16 * t + i) * WSLD + 16 * q + 4 * g);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) h1[t] = OSA_MFMA(w[t][s_], x[q][s_], h1[t]);
+        }
       }
     }
+    // touch every 128-byte line of the NEXT step's observation rows (4 threads per row; their permutation
+    // entries, requested at the top of the step, have arrived by now): the gather of a permuted minibatch misses
+    // the L2 (a pass streams 100 MB of rows) and an HBM round trip per slab is what the one-slab-ahead register
+    // prefetch cannot hide.  The values are consumed at the end of the step.
+    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f;
+    if (have_next) {
+      const float* __restrict__ pr = a.obs + prow * ld_obs;
+      const int last = obs_dim - 1, pl = tid & 3;
+      pf0 = pr[min(32 * pl, last)];
+      pf1 = pr[min(32 * (pl + 4), last)];
+      pf2 = pr[min(32 * (pl + 8), last)];
+      pf3 = pr[min(32 * (pl + 12), last)];
+      // ... and the lines of that sample's scalars (action row, logp, advantages / value target)
+      if (net == 0) {
+        const float* __restrict__ q_ = (pl == 0) ? a.act + prow * a.ld_act : (pl == 1) ? a.logp + prow
+                                       : (pl == 2) ? a.adv_r + prow : a.adv_c + prow;
+        pf0 += *q_;
+      } else if (pl == 0) {
+        pf0 += tgt[prow];
+      }
+    }
+    WTICK(0);
+    // <dW1, W1> = sum_{f,s} dz1[f][s] (a1[f][s] - b1[f]) needs the pre-activations (critics' L2 term, below)
+    f32x4 pre1[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) pre1[t] = h1[t] - *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       h1[t] = osa_tanh4(h1[t]);
@@ -252,7 +371,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     if (net == 0) {
       float lp = 0.f;
       f32x4 zv[OT], ivar[OT];
-      const float* __restrict__ arow = a.act + row * a.ld_act;
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
 #pragma unroll
@@ -263,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
           if (d < nd.act_dim && valid) {
             const float sd = expf(sLS[d]);
             const float var = sd * sd;
-            const float z = arow[d] - out[o][r];
+            const float z = s_act[4 * o + r] - out[o][r];
             zv[o][r] = z;
             ivar[o][r] = 1.f / var;
             lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
@@ -271,9 +389,9 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
         }
       }
       lp = osa_sum_over_groups(lp);
-      const float ratio = valid ? expf(lp - a.logp[row]) : 0.f;
+      const float ratio = valid ? expf(lp - s_logp) : 0.f;
       if (valid) {
-        const float adv = (a.adv_r[row] - lam * a.adv_c[row]) / (1.f + lam);  // ppo_lag.py:101-102
+        const float adv = (s_advr - lam * s_advc) / (1.f + lam);  // ppo_lag.py:101-102
         float dratio, li;
         if (a.loss_kind == 0) {  // base/ppo.py:66-78
           const float lo = 1.f - a.hp.clip, hi = 1.f + a.hp.clip;
@@ -302,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
         }
       }
     } else if (valid) {
-      const float diff = out[0][0] - tgt[row];
+      const float diff = out[0][0] - s_tgt;
       if (g == 0) {
         loss_part = diff * diff;
         dO[0][0] = 2.f * diff * invB;
@@ -310,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     }
     // ================= backward through the hidden layers (S layout) =================
     f32x4 z2[HT], z1[HT];
+    f32x4 gw4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -337,7 +456,9 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
       }
       z1[t] = acc * (1.f - h1[t] * h1[t]);
       WPUT_TILE(sZ1, z1[t], t);
+      gw4 = gw4 + z1[t] * pre1[t];  // <dW1, W1> = <dz1, W1 x> (critics' L2 term, see the norm below)
     }
+    const float gw = (gw4.x + gw4.y) + (gw4.z + gw4.w);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       WPUT_TILE(sDO, dO[o], o);
@@ -346,10 +467,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     // first X^T slab of the dW1 contraction: requested before the barrier, staged after it
     f32x4 xs[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xs[q] = osa_load_x(xrow, 16 * q + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+    for (int q = 0; q < 4; ++q) xs[q] = load_chunk(xrow, 16 * q + 4 * g);
     __syncthreads();  // (A) tiles complete
+    WTICK(1);
     // ================= weight gradients (registers) =================
-    f32x4 g2[HT], g3[OT], g1[KBM];
+    f32x4 g2[HT], g3[OT];
     f32x4 a1[4];
     {
       f32x4 a2[4];
@@ -404,35 +526,50 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     }
     if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
+    WTICK(2);
     // ---- dW1[f][k] = sum_s dz1[f][s] x[s][k]: X^T restaged in slabs of 4 K blocks (64 input features),
     // double-buffered; the next slab's rows are requested before the current slab's MFMAs issue
-#pragma unroll
+    // Every finished 16x16 tile leaves its squared norm in a register and goes to the L2-resident gradient
+    // scratch (one 16-byte store per lane): holding all KB tiles in accumulators until the clip factor is
+    // known needs 4 KB registers per lane and made the compiler spill for KB >= 16.
+    f32x4 g1sq = {0.f, 0.f, 0.f, 0.f};
     for (int s4 = 0; s4 < KB4; ++s4) {
       float* slab = sXs + (s4 & 1) * 64 * WSLD;
-      if (4 * s4 < KB) {  // block-uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) WPUT_TILE(slab, xs[q], q);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 xm = mask_chunk(xs[q], 16 * (4 * s4 + q) + 4 * g);
+        WPUT_TILE(slab, xm, q);
       }
       __syncthreads();
-      if (4 * (s4 + 1) < KB) {
+      if (s4 + 1 < KB4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          xs[q] = osa_load_x(xrow, 16 * (4 * (s4 + 1) + q) + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+        for (int q = 0; q < 4; ++q) xs[q] = load_chunk(xrow, 16 * (4 * (s4 + 1) + q) + 4 * g);
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        f32x4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(slab + (16 * q + i) * WSLD + 16 * sb + 4 * g);
+        // D[i = input 4g+r][j = feature cc] = sum_s X^T[i][s] dz1[j][s]: the lane then holds 4 CONSECUTIVE
+        // inputs of one feature row of W1 -- one 16-byte access per tile and array in the Adam pass
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = OSA_MFMA(b[q][s_], a1[sb][s_], acc[q]);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kb = 4 * s4 + q;
-        g1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kb < KB) {
-#pragma unroll
-          for (int sb = 0; sb < 4; ++sb) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(slab + (16 * q + i) * WSLD + 16 * sb + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) g1[kb] = OSA_MFMA(a1[sb][s], b[s], g1[kb]);
-          }
+        if (kb < KB) {  // block-uniform
+          g1sq = g1sq + acc[q] * acc[q];
+          *reinterpret_cast<f32x4*>(G1 + w1own + 256 * kb) = acc[q];
         }
       }
     }
+    WTICK(3);
     // ================= + 2 coef w (critics), squared norms =================
     f32x4 w2r[HT], w3r[OT];
 #pragma unroll
@@ -460,24 +597,16 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
       acc_p = acc_p + w * w;
       acc_g = acc_g + g3[o] * g3[o];
     }
-    if (critic) {  // block-uniform: the L2 term and sum p^2 need W1's values (L2 hits)
-#pragma unroll
-      for (int kb = 0; kb < KBM; ++kb) {
-        if (kb < KB) {
-          f32x4 w;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = W1[w1row0 + (long)r * INP + 16 * kb];
-          if (l2) g1[kb] = g1[kb] + w * c2;
-          acc_p = acc_p + w * w;
-          acc_g = acc_g + g1[kb] * g1[kb];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < KBM; ++kb) acc_g = acc_g + g1[kb] * g1[kb];
-    }
+    acc_g = acc_g + g1sq;
     float gsq = (acc_g.x + acc_g.y) + (acc_g.z + acc_g.w);
     float psq = (acc_p.x + acc_p.y) + (acc_p.z + acc_p.w);
+    if (critic) {
+      // W1's share of |g + 2 c w|^2 and of sum w^2 without reading W1 a second time:
+      //   |g1 + c2 w1|^2 = |g1|^2 + 2 c2 <g1, w1> + c2^2 |w1|^2,   <g1, w1> = sum_{f,s} dz1[f][s] (a1[f][s] - b1[f])
+      // (dW1 = dz1 x^T, so <dz1 x^T, W1> = <dz1, W1 x>); sum w1^2 was accumulated by the slab loaders
+      psq += w1sq;
+      if (l2) gsq += 2.f * c2 * gw + c2 * c2 * w1sq;
+    }
     if (boff >= 0) {
       if (l2) gb += c2 * wb;
       psq += wb * wb;
@@ -494,6 +623,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
       red[4 * wave + 3] = ratio_part;
     }
     __syncthreads();  // (B)
+    WTICK(4);
     const float t_gsq = red[0] + red[4] + red[8] + red[12];
     const float t_psq = red[1] + red[5] + red[9] + red[13];
     const float t_loss = red[2] + red[6] + red[10] + red[14];
@@ -505,41 +635,79 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
       gscale = gscale > 1.f ? 1.f : gscale;
     }
     // ================= Adam =================
-    // W1: this lane's 4 x KB elements, read-modify-write in global memory (L2-resident)
+    // W1: this lane's 4 x KB elements (one 16-byte access per K block and array): gradient from the scratch,
+    // weights and moments read-modify-written in global memory (all L2-resident); the critics' L2 term joins
+    // the gradient here.  Four K blocks per trip, the next trip's 16 loads in flight during the arithmetic.
+    {
+      f32x4 cw[4], cm[4], cv[4], cg[4], nw[4], nm[4], nv[4], ng[4];
+      auto fetch = [&](int kb0, f32x4 (&w)[4], f32x4 (&m)[4], f32x4 (&v)[4], f32x4 (&gg)[4]) {
 #pragma unroll
-    for (int kb = 0; kb < KBM; ++kb) {
-      if (kb < KB) {
-        f32x4 w, m, v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long off = w1row0 + (long)r * INP + 16 * kb;
-          w[r] = W1[off];
-          m[r] = M1[off];
-          v[r] = V1[off];
+        for (int q = 0; q < 4; ++q) {
+          const int off = w1own + 256 * min(kb0 + q, KB - 1);
+          w[q] = *reinterpret_cast<const f32x4*>(W1 + off);
+          m[q] = *reinterpret_cast<const f32x4*>(M1 + off);
+          v[q] = *reinterpret_cast<const f32x4*>(V1 + off);
+          gg[q] = *reinterpret_cast<const f32x4*>(G1 + off);
         }
-        w = osa_adam_update4(g1[kb] * gscale, m, v, w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+      };
+      fetch(0, nw, nm, nv, ng);
+      for (int kb0 = 0; kb0 < KB; kb0 += 4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long off = w1row0 + (long)r * INP + 16 * kb;
-          W1[off] = w[r];
-          M1[off] = m[r];
-          V1[off] = v[r];
+        for (int q = 0; q < 4; ++q) { cw[q] = nw[q]; cm[q] = nm[q]; cv[q] = nv[q]; cg[q] = ng[q]; }
+        if (kb0 + 4 < KB) fetch(kb0 + 4, nw, nm, nv, ng);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (kb0 + q < KB) {  // block-uniform
+            const int off = w1own + 256 * (kb0 + q);
+            f32x4 gg = cg[q];
+            if (l2) gg = gg + cw[q] * c2;
+            const f32x4 w = osa_adam_update4(gg * gscale, cm[q], cv[q], cw[q], beta1, beta2, step_size,
+                                             inv_bc2_sqrt, aeps);
+            *reinterpret_cast<f32x4*>(W1 + off) = w;
+            *reinterpret_cast<f32x4*>(M1 + off) = cm[q];
+            *reinterpret_cast<f32x4*>(V1 + off) = cv[q];
+          }
         }
       }
     }
+    WTICK(5);
+    // W2 / W3: weights from the LDS master copy, moments read-modify-written in global memory (L2): 24 KB per
+    // step and network -- registers are what this kernel is short of
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
-      const f32x4 w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w2r[ti], beta1, beta2, step_size,
-                                       inv_bc2_sqrt, aeps);
+      f32x4 m, v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * WSLD + 16 * ti + cc] = w[r];
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+        m[r] = gm[off];
+        v[r] = gv[off];
+      }
+      const f32x4 w = osa_adam_update4(g2[ti] * gscale, m, v, w2r[ti], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+        sW2[(16 * wave + 4 * g + r) * WSLD + 16 * ti + cc] = w[r];
+        gm[off] = m[r];
+        gv[off] = v[r];
+      }
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-      const f32x4 w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w3r[o], beta1, beta2, step_size,
-                                       inv_bc2_sqrt, aeps);
+      f32x4 m, v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * WSLD + 16 * wave + cc] = w[r];
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+        m[r] = gm[off];
+        v[r] = gv[off];
+      }
+      const f32x4 w = osa_adam_update4(g3[o] * gscale, m, v, w3r[o], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+        sW3[(16 * o + 4 * g + r) * WSLD + 16 * wave + cc] = w[r];
+        gm[off] = m[r];
+        gv[off] = v[r];
+      }
     }
     if (boff >= 0) {
       float mv_ = mb_, vv_ = vb_;
@@ -560,12 +728,28 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
         st[7 + net] = total_norm;
       }
     }
+    asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));  // the prefetched lines have arrived
+    row_nxt = row_nn;
     // (C) frees tiles and `red`; it also orders this step's W1 stores before the next step's W1 fragment
     // loads by the other waves: workgroup scope suffices, the four waves share one CU and its vector L1
     __syncthreads();
+    WTICK(6);
   }
 #undef WPUT_TILE
-  // ---- write back the LDS master copy and the register-resident Adam state
+#ifdef OSA_WIDE_CLOCKS
+  __syncthreads();
+  if (tid == 0 && a.nmb >= 3)  // network `net` -> row nmb-1-net, columns 0..6: mean cycles per step and phase
+    for (int k = 0; k < 7; ++k) a.stats[(long)(a.nmb - 1 - net) * WNSTAT + k] = (float)wdbg[k] / (float)a.nmb;
+#endif
+  // ---- write back: tiled W1 / moments -> row-major parameter block, LDS master copy, bias-like Adam state
+  __syncthreads();
+  for (int e = tid; e < NW1; e += 256) {
+    const int t_ = e >> 8, c_ = (e >> 4) & 15, i_ = e & 15, ft_ = t_ / KB, kb_ = t_ - ft_ * KB;
+    const int dst = nd.oW1 + (16 * ft_ + c_) * INP + 16 * kb_ + i_;
+    gp[dst] = W1[e];
+    gm[dst] = M1[e];
+    gv[dst] = V1[e];
+  }
   for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * WSLD + (e & 63)];
   for (int e = tid; e < OUTP * H; e += 256) gp[nd.oW3 + e] = sW3[(e >> 6) * WSLD + (e & 63)];
   if (tid < H) {
@@ -576,22 +760,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     gp[nd.ob3 + tid] = sB3[tid];
     if (!critic) gp[nd.oLS + tid] = sLS[tid];
   }
-#pragma unroll
-  for (int ti = 0; ti < HT; ++ti)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
-      gm[off] = m2[ti][r];
-      gv[off] = v2[ti][r];
-    }
-#pragma unroll
-  for (int o = 0; o < OT; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
-      gm[off] = m3[o][r];
-      gv[off] = v3[o][r];
-    }
   if (boff >= 0) {
     gm[boff] = mb_;
     gv[boff] = vb_;
@@ -606,26 +774,33 @@ static size_t osa_wide_lds_bytes(int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB4, int OT>
+template <int OT>
 static int osa_launch_wide(const OsaWideArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = osa_wide_lds_bytes(OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_pass_kernel<KB4, OT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_pass_kernel<OT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((osa_wide_pass_kernel<KB4, OT>), dim3(3), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_wide_pass_kernel<OT>), dim3(3), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
 extern "C" {
 
 int osa_ppo_wide_pass_supported(int obs_dim, int act_dim, int hidden) {
-  if (hidden != 64 || obs_dim < 97 || obs_dim > 512 || act_dim < 1 || act_dim > 32) return 0;
+  // (from 65 inputs: the few narrow shapes osa_ppo_pass cannot hold in LDS, e.g. 90 inputs x 17 actions, come here)
+  if (hidden != 64 || obs_dim < 65 || obs_dim > 512 || act_dim < 1 || act_dim > 32) return 0;
   return 1;
+}
+
+size_t osa_ppo_wide_pass_ws_floats(int obs_dim, int act_dim, int hidden) {
+  if (!osa_ppo_wide_pass_supported(obs_dim, act_dim, hidden)) return 0;
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  return (size_t)3 * 4 * nd.H * nd.INP;
 }
 
 int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -633,13 +808,16 @@ int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float
                       const float* logp, const float* target_value_r, const float* target_value_c,
                       const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                       const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                      float* step_stats, void* stream) {
+                      float* ws, float* step_stats, void* stream) {
   if (!osa_ppo_wide_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;  // larger batches: per-step kernels
-  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && ws);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad the rows
+  if ((double)M * ld_obs >= 2147483647.0 * 4) return OSA_EUNSUPPORTED;
   OsaWideArgs a = {};
+  a.ws = ws;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -652,14 +830,9 @@ int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   hipStream_t st = osa_stream(stream);
-  const int KB4 = (a.nd.KB + 3) / 4, OT = a.nd.OUTP / 16;
-#define OSA_WIDE_CASE(K, O) \
-  if (KB4 == K && OT == O) return osa_launch_wide<K, O>(a, st)
-  OSA_WIDE_CASE(2, 1); OSA_WIDE_CASE(3, 1); OSA_WIDE_CASE(4, 1); OSA_WIDE_CASE(5, 1); OSA_WIDE_CASE(6, 1);
-  OSA_WIDE_CASE(7, 1); OSA_WIDE_CASE(8, 1);
-  OSA_WIDE_CASE(2, 2); OSA_WIDE_CASE(3, 2); OSA_WIDE_CASE(4, 2); OSA_WIDE_CASE(5, 2); OSA_WIDE_CASE(6, 2);
-  OSA_WIDE_CASE(7, 2); OSA_WIDE_CASE(8, 2);
-#undef OSA_WIDE_CASE
+  const int OT = a.nd.OUTP / 16;
+  if (OT == 1) return osa_launch_wide<1>(a, st);
+  if (OT == 2) return osa_launch_wide<2>(a, st);
   return OSA_EUNSUPPORTED;
 }
 

@@ -128,7 +128,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
                 _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
                 _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
-                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
+                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(self._wide_ws), _lib.ptr(stats_rows),
                 _lib.stream_ptr()), 'osa_ppo_wide_pass')
             if ev is not None:
                 ev[1].record()
@@ -383,6 +383,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 and bool(self.lib.osa_ppo_wide_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_wide_pass_kernel', self.lib.osa_ppo_wide_pass)
             self._use_wide = True
+            if getattr(self, '_wide_ws', None) is None:
+                n = self.lib.osa_ppo_wide_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden)
+                self._wide_ws = torch.empty(n, dtype=torch.float32, device=ac.device)
         use_pass = self._pass_fn is not None
         W = dist.world_size()
         data = self._aligned_rows(data)

@@ -272,14 +272,20 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
         paths.append(up.last_path)
         acs.append(ac)
     assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
-    assert paths == ['persistent-wide' if obs_dim > 96 else 'persistent', 'per-step']
+    from omnisafe_amd import _lib
+
+    narrow = bool(_lib.load().osa_ppo_pass_supported(obs_dim, act_dim, 64))
+    assert paths == ['persistent' if narrow else 'persistent-wide', 'per-step']
+    assert narrow == (obs_dim <= 96 and not (obs_dim > 80 and act_dim > 16))
     assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
     # B <= 64: the same operation order except for the 1-2-output layers, which the pass kernel evaluates
     # on the VALU (16-term partial dot products per lane group) and the per-step kernels on MFMA tiles:
     # float32 summation-order differences of ~1e-7.  B > 64: the pass kernel accumulates the 64-row chunks
     # in registers, the per-step path reduces per-workgroup slabs -- Adam's m/sqrt(v) amplifies that
     # order difference to ~1e-6 in the parameters.
-    atol = 5e-7 if B <= 64 else 5e-6
+    # wide inputs: 376-term dot products; Adam's m / sqrt(v) turns ~1e-7 gradient differences into up to ~2e-6
+    # in single parameters with small v (measured: 1 element of 1e5 at 1.6e-6)
+    atol = (5e-7 if narrow else 5e-6) if B <= 64 else 5e-6
     for name in ('params', 'adam_m', 'adam_v'):
         a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=name)

@@ -11,7 +11,7 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')]
 from test_mlp_gpu import make_ac  # noqa: E402
 
 from omnisafe_amd.update import PPOUpdater  # noqa: E402
@@ -39,6 +39,12 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32)):
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / out['steps']
+        if persistent and 'clocks' in os.environ.get('OSA_LIB_PATH', ''):
+            st = out['stats'].cpu().numpy()
+            names = ['fwd L1', 'fwd rest+loss+bwd', 'dW2/dW3/bias', 'dW1', 'norm+barrier', 'Adam W1', 'Adam rest+barrier']
+            for net in range(3):
+                row = st[out['steps'] - 1 - net, :7]
+                print(f'   net {net} cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(names, row)) + f'  total={row.sum():.0f}')
         res[f'{obs_dim}/{act_dim} {up.last_path}'] = round(us, 2)
         print(f'{obs_dim}/{act_dim}: {up.last_path:16s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
