@@ -28,6 +28,69 @@ from .models import ConstraintActorCritic
 from .normalizer import Normalizer
 
 
+class _EnvWrapper:
+    """omnisafe/envs/core.py:185-297 (Wrapper): forwards everything it does not override."""
+
+    graph_safe = False  # host-side decisions per step
+
+    def __init__(self, env, device) -> None:
+        self._env, self._device = env, torch.device(device)
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+    def reset(self, seed=None, options=None):
+        return self._env.reset(seed=seed, options=options)
+
+    def step(self, action):
+        return self._env.step(action)
+
+
+class TimeLimit(_EnvWrapper):
+    """omnisafe/envs/wrapper.py:31-107: truncated = (steps since reset >= time_limit); single env."""
+
+    need_time_limit_wrapper = False
+
+    def __init__(self, env, time_limit: int, device) -> None:
+        super().__init__(env, device)
+        assert int(env.num_envs) == 1, 'TimeLimit only supports single environment'
+        self._time, self._time_limit = 0, int(time_limit)
+
+    def reset(self, seed=None, options=None):
+        self._time = 0
+        return self._env.reset(seed=seed, options=options)
+
+    def step(self, action):
+        obs, reward, cost, terminated, truncated, info = self._env.step(action)
+        self._time += 1
+        truncated = torch.tensor(self._time >= self._time_limit, dtype=torch.bool, device=self._device)
+        return obs, reward, cost, terminated, truncated, info
+
+
+class AutoReset(_EnvWrapper):
+    """omnisafe/envs/wrapper.py:110-176: on terminated / truncated the env is reset, the returned observation is
+    the first of the new episode and the true last one goes to info['final_observation']; single env (one host
+    read of the two flags per step, as in the reference)."""
+
+    need_auto_reset_wrapper = False
+
+    def __init__(self, env, device) -> None:
+        super().__init__(env, device)
+        assert int(env.num_envs) == 1, 'AutoReset only supports single environment'
+
+    def step(self, action):
+        obs, reward, cost, terminated, truncated, info = self._env.step(action)
+        if bool(torch.as_tensor(terminated).any()) or bool(torch.as_tensor(truncated).any()):
+            new_obs, new_info = self._env.reset()
+            assert 'final_observation' not in new_info, 'info dict cannot contain key "final_observation" '
+            assert 'final_info' not in new_info, 'info dict cannot contain key "final_info" '
+            new_info = dict(new_info)
+            new_info['final_observation'] = obs
+            new_info['final_info'] = info
+            obs, info = new_obs, new_info
+        return obs, reward, cost, terminated, truncated, info
+
+
 class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
     def __init__(self, env_id: str, num_envs: int, seed: int, cfgs, env=None) -> None:
         self._lib = _lib.load(require_gpu=True)
@@ -39,10 +102,14 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             env_cfgs = cfgs.env_cfgs.todict() if hasattr(cfgs.env_cfgs, 'todict') else dict(cfgs.env_cfgs)
         self._env = env if env is not None else envs_mod.make(env_id, num_envs=num_envs,
                                                                device=self._device, **env_cfgs)
-        if getattr(self._env, 'need_auto_reset_wrapper', False) or getattr(
-                self._env, 'need_time_limit_wrapper', False):
-            raise NotImplementedError('TimeLimit/AutoReset wrappers are not on the accelerated path: '
-                                      'the env must auto-reset (gymnasium vector convention)')
+        # online_adapter.py:120-132: TimeLimit, then AutoReset, for envs that ask for them (single env, as in the
+        # reference: wrapper.py:52,147); vector envs implement the gymnasium auto-reset convention themselves
+        if getattr(self._env, 'need_time_limit_wrapper', False):
+            assert self._env.max_episode_steps, ('You must define max_episode_steps as an integer\n'
+                                                 'or cancel the use of the time_limit wrapper.')
+            self._env = TimeLimit(self._env, time_limit=int(self._env.max_episode_steps), device=self._device)
+        if getattr(self._env, 'need_auto_reset_wrapper', False):
+            self._env = AutoReset(self._env, device=self._device)
         a = cfgs.algo_cfgs
         self._num_envs = int(self._env.num_envs)
         self._raw_obs_dim = int(self._env.observation_space.shape[0])

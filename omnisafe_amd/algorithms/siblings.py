@@ -171,6 +171,7 @@ class PCPO(CPO):
         x = s.conjugate_gradients(g)
         assert torch.isfinite(x).all(), 'x is not finite'
         H_inv_g = s.fvp(x)  # (sic) pcpo.py:78: named H_inv_g, computed as F x
+        s.fvp_calls += 1  # the reference evaluates (and logs the KL of) F x twice: pcpo.py:79 and :80
         xHx = float(s.dot(x, H_inv_g))
         assert xHx >= 0, 'xHx is negative'
         f = np.float32
@@ -186,11 +187,17 @@ class PCPO(CPO):
         c1 = np.sqrt(f(2 * a.target_kl) / (f(q) + f(1e-8)))
         c2 = max((np.sqrt(f(2 * a.target_kl) / f(q)) * f(r) + f(ep_costs)) / f(sc), f(0.0))
         step_direction = s.lincomb(float(c1), H_inv_g, -float(c2), p)
+        before = self._eval_at(data, theta_old, torch.zeros_like(step_direction), 'adv_r', self._lambda_zero)
         step, accept_step = self._cpo_search_step(data, theta_old, step_direction, g, loss_reward_before,
                                                   loss_cost_before, total_steps=200, violation_c=ep_costs,
                                                   optim_case=0)
-        s.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
         final = s.evaluate_candidates(data, theta_old, step, [1.0], 'adv_r', self._lambda_zero).numpy()
+        # the reference's `_loss_pi` calls in order (pcpo.py:69, cpo.py:125 per tried candidate, pcpo.py:129)
+        self._store_loss_pi_call(before[0], before[3], theta_old)
+        for frac, row in self._tried:
+            self._store_loss_pi_call(row[0], row[3], s.lincomb(1.0, theta_old, frac, step_direction))
+        s.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
+        self._store_loss_pi_call(final[0, 0], final[0, 3], ac.params[0])
         self._last_actor_update = dict(g=g, x=x, b=b, p=p, xHx=xHx, alpha=alpha, q=q, r=r, s=sc,
                                        step_direction=step_direction, final_step=step, accept_step=accept_step,
                                        loss_reward_before=loss_reward_before, loss_cost_before=loss_cost_before)
@@ -199,9 +206,7 @@ class PCPO(CPO):
             'Misc/Alpha': alpha, 'Misc/FinalStepNorm': float(step.norm()), 'Misc/xHx': xHx,
             'Misc/H_inv_g': float(x.norm()), 'Misc/gradient_norm': float(g.norm()),
             'Misc/cost_gradient_norm': float(b.norm()), 'Misc/Lambda_star': 1.0, 'Misc/Nu_star': 1.0,
-            'Misc/OptimCase': 1, 'Misc/A': 1.0, 'Misc/B': 1.0, 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc,
-            'Train/PolicyRatio': float(final[0, 3]),
-            'Train/Entropy': float(1.4189385332 + ac.actor.log_std.mean())})
+            'Misc/OptimCase': 1, 'Misc/A': 1.0, 'Misc/B': 1.0, 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc})
 
 
 @register

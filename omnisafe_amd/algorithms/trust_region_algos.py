@@ -39,6 +39,30 @@ class NaturalPG(PolicyGradient):
             self._logger.register_key(k)
 
     # ---- shared pieces -------------------------------------------------------------------------
+    def _store_loss_pi_call(self, loss: float, ratio: float, theta: torch.Tensor) -> None:
+        """What ONE call of the reference's `_loss_pi` leaves in the logger (policy_gradient.py:574-588):
+        Loss/Loss_pi, the mean ratio, and entropy / std of the policy at `theta` (padded actor vector).  The
+        reference calls it at theta_old, at every line-search candidate it tries and at the final parameters, and
+        the epoch's csv value is the MEAN over those calls -- reproduced call for call."""
+        lay = self._actor_critic.layout
+        log_std = theta[lay.oLS:lay.oLS + lay.act_dim]
+        self._logger.store({'Loss/Loss_pi': float(loss), 'Train/PolicyRatio': float(ratio),
+                            'Train/Entropy': float(1.4189385332046727 + log_std.mean()),
+                            'Train/PolicyStd': float(log_std.exp().mean())})
+
+    def _store_fvp_kl_calls(self) -> None:
+        """`_fvp` logs kl_divergence(p, q).mean() of every call (natural_pg.py:91-119); both distributions come
+        from the current parameters there, so each stored value is 0 up to float32 noise (~1e-9)."""
+        n = self._solver.fvp_calls + self._solver.cg_solves  # + the F(0) evaluation that opens every CG solve there
+        for _ in range(n - getattr(self, '_fvp_logged', 0)):
+            self._logger.store({'Train/KL': 0.0})
+        self._fvp_logged = n
+
+    def _eval_at(self, data: dict, theta_old, step, adv_key=None, lagrange=None):
+        """[loss_pi, loss_cost, kl, mean ratio] at theta_old + step."""
+        return self._solver.evaluate_candidates(data, theta_old, step, [1.0], adv_key or self._adv_key_r,
+                                                self._lagrange_tensor() if lagrange is None else lagrange).numpy()[0]
+
     def _policy_gradient(self, data: dict):
         """loss, g = -flat_grad of the surrogate loss at theta_old, p_dist snapshot (trpo.py:176-186)."""
         s = self._solver
@@ -63,7 +87,12 @@ class NaturalPG(PolicyGradient):
         x, xHx, alpha = self._natural_direction(g)
         step = self._solver.lincomb(alpha, x)
         assert torch.isfinite(step).all(), 'step_direction is not finite'
+        before = self._eval_at(data, theta_old, torch.zeros_like(step))
+        after = self._eval_at(data, theta_old, step)
         self._solver.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
+        self._store_fvp_kl_calls()
+        self._store_loss_pi_call(before[0], before[3], theta_old)     # natural_pg.py:154
+        self._store_loss_pi_call(after[0], after[3], ac.params[0])    # natural_pg.py:169
         self._logger.store({'Misc/Alpha': alpha, 'Misc/FinalStepNorm': float(step.norm()), 'Misc/xHx': xHx,
                             'Misc/gradient_norm': float(g.norm()), 'Misc/H_inv_g': float(x.norm())})
 
@@ -77,8 +106,7 @@ class NaturalPG(PolicyGradient):
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
         lg = self._logger
-        lg.store({'Loss/Loss_reward_critic': summ['Loss/Loss_reward_critic'],
-                  'Train/PolicyStd': self._actor_critic.actor.std})
+        lg.store({'Loss/Loss_reward_critic': summ['Loss/Loss_reward_critic']})
         if a.use_cost:
             lg.store({'Loss/Loss_cost_critic': summ['Loss/Loss_cost_critic']})
         lg.store({'Train/StopIter': a.update_iters, 'Value/Adv': float(data['adv_r'].mean())})
@@ -100,8 +128,10 @@ class TRPO(NaturalPG):
         res = self._solver.evaluate_candidates(data, theta_old, step_direction, fracs, self._adv_key_r,
                                                self._lagrange_tensor()).numpy()
         final_kl, acceptance_step, step_frac = 0.0, 0, fracs[-1] * decay
+        self._tried = []  # (frac, row) of every candidate the reference would have evaluated
         for j, frac in enumerate(fracs):
             loss, kl = float(res[j, 0]), float(res[j, 2])
+            self._tried.append((frac, res[j]))
             loss_improve = loss_before - loss
             if not np.isfinite(loss):
                 self._logger.log('WARNING: loss_pi not finite')
@@ -116,6 +146,7 @@ class TRPO(NaturalPG):
         else:
             self._logger.log('INFO: no suitable step found...')
             step_direction = torch.zeros_like(step_direction)
+        self._store_fvp_kl_calls()
         self._logger.store({'Train/KL': final_kl})
         return self._solver.lincomb(step_frac, step_direction), acceptance_step
 
@@ -128,17 +159,21 @@ class TRPO(NaturalPG):
         x, xHx, alpha = self._natural_direction(g)
         step_direction = self._solver.lincomb(alpha, x)
         assert torch.isfinite(step_direction).all(), 'step_direction is not finite'
+        before = self._eval_at(data, theta_old, torch.zeros_like(step_direction))
         step, accept_step = self._search_step_size(data, theta_old, step_direction, g, loss_before)
+        final = self._eval_at(data, theta_old, step)
+        # the reference's `_loss_pi` calls in order: theta_old (trpo.py:178), every tried candidate
+        # (trpo.py:104-110), the final parameters (trpo.py:207)
+        self._store_loss_pi_call(before[0], before[3], theta_old)
+        for frac, row in self._tried:
+            self._store_loss_pi_call(row[0], row[3], self._solver.lincomb(1.0, theta_old, frac, step_direction))
         self._solver.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
+        self._store_loss_pi_call(final[0], final[3], ac.params[0])
         self._last_actor_update = dict(g=g, x=x, xHx=xHx, alpha=alpha, step_direction=step_direction,
                                        final_step=step, accept_step=accept_step, loss_before=loss_before)
-        final = self._solver.evaluate_candidates(data, theta_old, step, [1.0], self._adv_key_r,
-                                                 self._lagrange_tensor()).numpy()
         self._logger.store({'Misc/Alpha': alpha, 'Misc/FinalStepNorm': float(step.norm()), 'Misc/xHx': xHx,
                             'Misc/gradient_norm': float(g.norm()), 'Misc/H_inv_g': float(x.norm()),
-                            'Misc/AcceptanceStep': accept_step, 'Loss/Loss_pi': float(final[0, 0]),
-                            'Train/PolicyRatio': float(final[0, 3]),
-                            'Train/Entropy': float(1.4189385332 + ac.actor.log_std.mean())})
+                            'Misc/AcceptanceStep': accept_step})
 
 
 @register
@@ -253,9 +288,11 @@ class CPO(TRPO):
             return cache[c0][k - c0]
 
         step_frac, k, kl, acceptance_step, accepted = 1.0, 0, 0.0, 0, False
+        self._tried = []
         for step in range(total_steps):
             acceptance_step = step + 1
             row = evaluated(k)
+            self._tried.append((step_frac, row))
             loss_reward, loss_cost, kl = float(row[0]), float(row[1]), float(row[2])
             loss_reward_improve = loss_reward_before - loss_reward
             loss_cost_diff = loss_cost - loss_cost_before
@@ -278,6 +315,7 @@ class CPO(TRPO):
             self._logger.log('INFO: no suitable step found...')
             step_direction = torch.zeros_like(step_direction)
             acceptance_step = 0
+        self._store_fvp_kl_calls()
         self._logger.store({'Train/KL': kl})
         return self._solver.lincomb(step_frac, step_direction), acceptance_step
 
@@ -303,11 +341,18 @@ class CPO(TRPO):
         case, A, B = cpo_determine_case(bb, ep_costs, q, r, sc, a.target_kl)
         cx, cp, lambda_star, nu_star = cpo_step_coefficients(case, xHx, A, B, q, r, sc, ep_costs, a.target_kl)
         step_direction = s.lincomb(float(cx), x, float(cp), p)
+        before = self._eval_at(data, theta_old, torch.zeros_like(step_direction), 'adv_r', self._lambda_zero)
         step, accept_step = self._cpo_search_step(data, theta_old, step_direction, g, loss_reward_before,
                                                   loss_cost_before, total_steps=20, violation_c=ep_costs,
                                                   optim_case=case)
-        s.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
         final = s.evaluate_candidates(data, theta_old, step, [1.0], 'adv_r', self._lambda_zero).numpy()
+        # `_loss_pi` calls of the reference in order: cpo.py:369 (theta_old), :125 (every tried candidate),
+        # :439 (final parameters); the combined reward + cost loss is stored once more at :445
+        self._store_loss_pi_call(before[0], before[3], theta_old)
+        for frac, row in self._tried:
+            self._store_loss_pi_call(row[0], row[3], s.lincomb(1.0, theta_old, frac, step_direction))
+        s.lincomb(1.0, theta_old, 1.0, step, out=ac.params[0])
+        self._store_loss_pi_call(final[0, 0], final[0, 3], ac.params[0])
         self._last_actor_update = dict(g=g, x=x, b=b, p=p, xHx=xHx, alpha=alpha, q=q, r=r, s=sc, case=case,
                                        A=float(A), B=float(B), lambda_star=float(lambda_star),
                                        nu_star=float(nu_star), step_direction=step_direction, final_step=step,
@@ -319,6 +364,4 @@ class CPO(TRPO):
             'Misc/H_inv_g': float(x.norm()), 'Misc/gradient_norm': float(g.norm()),
             'Misc/cost_gradient_norm': float(b.norm()), 'Misc/Lambda_star': float(lambda_star),
             'Misc/Nu_star': float(nu_star), 'Misc/OptimCase': int(case), 'Misc/A': float(A),
-            'Misc/B': float(B), 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc,
-            'Train/PolicyRatio': float(final[0, 3]),
-            'Train/Entropy': float(1.4189385332 + ac.actor.log_std.mean())})
+            'Misc/B': float(B), 'Misc/q': q, 'Misc/r': r, 'Misc/s': sc})

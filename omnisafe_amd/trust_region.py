@@ -41,6 +41,7 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         self._old_log_std = torch.zeros(ac.layout.OUTP, **f32)
         self._fvp_obs: torch.Tensor | None = None
         self.fvp_calls = 0
+        self.cg_solves = 0  # the reference's CG evaluates F(0) once more per solve (math.py:116-118: r = b - Ax(x))
 
     # ------------------------------------------------------------------ gradient
     def actor_loss_grad(self, data: dict, adv_key_r: str, adv_key_c: str, lagrange: torch.Tensor):
@@ -102,6 +103,7 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
                             residual_tol: float = 1e-10, eps: float = 1e-6) -> torch.Tensor:
         """omnisafe/utils/math.py:86-132 with F = self.fvp; returns a new padded vector x."""
         lib, P, st = self.lib, self.ac.layout.P, _lib.stream_ptr()
+        self.cg_solves += 1
         x, r, p, z = (self._vecs[k] for k in ('x', 'r', 'p', 'z'))
         _lib.check(lib.osa_cg_init(P, _lib.ptr(b), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p),
                                    _lib.ptr(self._scal), st), 'osa_cg_init')

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_siblings_gpu import _check_params, _log, _run_update
+from test_siblings_gpu import _check_loss_pi_call_log, _check_params, _log, _run_update
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -78,6 +78,7 @@ def test_trust_region_update_at_config_shape(golden, tmp_path, tag, name, env_id
             np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, atol=1e-6, err_msg=key)
     else:
         np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    _check_loss_pi_call_log(algo, g)
     _check_params(ac, g, ('actor',), 5e-5)
     _check_params(ac, g, ('reward_critic', 'cost_critic'), 2e-5)
     moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())

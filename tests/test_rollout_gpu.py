@@ -534,3 +534,83 @@ def test_rollout_graph_replay_equals_eager_launches(tmp_path, monkeypatch, algo_
             assert torch.equal(g[k].cpu(), e[k].cpu()), (ep, k)
     # epochs differ from each other (fresh noise every epoch, not a replay of the captured numbers)
     assert not torch.equal(s_g[2]['act'], s_g[3]['act']) and not torch.equal(s_g[3]['reward'], s_g[4]['reward'])
+
+
+class _CountEnv:
+    """Single, NON-auto-resetting env that asks for the TimeLimit and AutoReset wrappers (the shape of a
+    caller-side Safety-Gymnasium shim, envs/safety_gymnasium_env.py:160-210, single-env case): obs = [steps since
+    reset, episode index, 0, 0], reward 1, cost 0.5, terminates by itself after 5 steps in every third episode."""
+    need_auto_reset_wrapper = True
+    need_time_limit_wrapper = True
+    need_evaluation = False
+    num_envs = 1
+    max_episode_steps = 7
+
+    def __init__(self):
+        from omnisafe_amd.spaces import Box
+
+        self.observation_space = Box(-np.inf, np.inf, (4,))
+        self.action_space = Box(-2.0, 2.0, (2,))
+        self.k, self.ep, self.resets = 0, -1, 0
+
+    def set_seed(self, seed):
+        pass
+
+    def _obs(self):
+        return torch.tensor([float(self.k), float(self.ep), 0.0, 0.0], device=DEV)
+
+    def reset(self, seed=None, options=None):
+        self.k, self.ep, self.resets = 0, self.ep + 1, self.resets + 1
+        return self._obs(), {}
+
+    def step(self, action):
+        assert action.shape[-1] == 2
+        self.k += 1
+        term = self.ep % 3 == 2 and self.k >= 5
+        return (self._obs(), torch.tensor(1.0, device=DEV), torch.tensor(0.5, device=DEV),
+                torch.tensor(term, device=DEV), torch.tensor(False, device=DEV), {})
+
+    def close(self):
+        pass
+
+
+def test_time_limit_and_auto_reset_wrappers():
+    """online_adapter.py:120-132 + wrapper.py:31-176 for a single env that needs both wrappers: episodes are cut
+    after max_episode_steps = 7 (truncation: bootstrap with V(final observation)) or end by themselves (termination:
+    bootstrap 0); the observation after an episode end is the first of the new episode."""
+    from omnisafe_amd.adapter import AutoReset, OnPolicyAdapter, TimeLimit
+    from omnisafe_amd.buffer import VectorOnPolicyBuffer
+    from test_mlp_gpu import make_ac
+
+    env = _CountEnv()
+    adapter = OnPolicyAdapter('count', 1, 0, _cfgs(obs_normalize=False), env=env)
+    assert isinstance(adapter._env, AutoReset) and isinstance(adapter._env._env, TimeLimit)
+    T = 24
+    torch.manual_seed(2)
+    ac = make_ac(4, 2)
+    buf = VectorOnPolicyBuffer(adapter.observation_space, adapter.action_space, T, 0.99, 0.95, 0.95, 'gae', 0.0, True,
+                               True, num_envs=1, device=DEV)
+    logger = _LoggerStub()
+    adapter.rollout(T, ac, buf, logger)
+    b = {k: v.cpu().numpy() for k, v in buf.data.items()}
+    # episodes: 0 (7 steps, truncated), 1 (7, truncated), 2 (5, terminated), 3 (5 of 7 steps when the epoch ends)
+    ends = [6, 13, 18, 23]
+    assert b['path_end'][:, 0].nonzero()[0].tolist() == ends
+    assert logger.data['Metrics/EpLen'] == [7.0, 7.0, 5.0] and logger.data['Metrics/EpRet'] == [7.0, 7.0, 5.0]
+    assert logger.data['Metrics/EpCost'] == [3.5, 3.5, 2.5]
+    want_obs = [[k, 0] for k in range(7)] + [[k, 1] for k in range(7)] + [[k, 2] for k in range(5)] + \
+               [[k, 3] for k in range(5)]
+    np.testing.assert_array_equal(b['obs'][:, 0, :2], np.asarray(want_obs, np.float32))
+    # bootstraps: V(final observation) at truncations, 0 at the termination, V(next observation) at the epoch end
+    v = lambda o: ac.values(torch.tensor([o], dtype=torch.float32, device=DEV))  # noqa: E731
+    for t, o in ((6, [7.0, 0.0, 0.0, 0.0]), (13, [7.0, 1.0, 0.0, 0.0]), (23, [5.0, 3.0, 0.0, 0.0])):
+        vr, vc = v(o)
+        np.testing.assert_allclose(b['boot_r'][t, 0], float(vr[0]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(b['boot_c'][t, 0], float(vc[0]), rtol=1e-5, atol=1e-6)
+    assert b['boot_r'][18, 0] == 0.0 and b['boot_c'][18, 0] == 0.0
+    assert env.resets == 1 + 3  # the epoch's reset + one per finished episode
+    # a vector env asking for the wrappers is refused like in the reference (single env only)
+    env2 = _CountEnv()
+    env2.num_envs = 2
+    with pytest.raises(AssertionError, match='single environment'):
+        OnPolicyAdapter('count', 2, 0, _cfgs(obs_normalize=False), env=env2)

@@ -66,6 +66,22 @@ def _log(algo, key):
     return np.asarray(list(algo._logger._data[key]), np.float64)
 
 
+def _check_loss_pi_call_log(algo, g):
+    """The csv values of the trust-region family: the reference stores Loss/Loss_pi, Train/PolicyRatio,
+    Train/Entropy (and PolicyStd) at EVERY `_loss_pi` call -- theta_old, each tried line-search candidate, the
+    final parameters -- and Train/KL at every `_fvp` call; the logged epoch value is the mean over those stores.
+    Same number of stores, same values."""
+    for key, rtol, atol in (('Loss/Loss_pi', 2e-3, 3e-6), ('Train/Entropy', 1e-5, 0), ('Train/PolicyRatio', 1e-4, 0),
+                            ('Train/PolicyStd', 1e-5, 0)):
+        if 'log/' + key in g:
+            mine, want = _log(algo, key), g['log/' + key]
+            assert len(mine) == len(want), (key, len(mine), len(want))
+            np.testing.assert_allclose(mine, want, rtol=rtol, atol=atol, err_msg=key)
+    mine, want = _log(algo, 'Train/KL'), g['log/Train/KL']
+    assert len(mine) == len(want)
+    np.testing.assert_allclose(mine.mean(), want.mean(), rtol=2e-2, atol=1e-8)  # FVP calls store ~0 (1e-9 noise)
+
+
 @pytest.mark.parametrize('name,tag', FIRST_ORDER)
 def test_first_order_sibling_update_vs_reference(golden, tmp_path, name, tag):
     g = golden(f'sibling_{tag}.npz')
@@ -107,6 +123,7 @@ def test_trust_region_sibling_update_vs_reference(golden, tmp_path, name, tag):
         np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
     if 'log/Misc/AcceptanceStep' in g:
         assert int(_log(algo, 'Misc/AcceptanceStep')[-1]) == int(g['log/Misc/AcceptanceStep'][-1])
+    _check_loss_pi_call_log(algo, g)
     if tag == 'pcpo':
         for key, rtol in (('Misc/q', 1e-2), ('Misc/r', 5e-2), ('Misc/s', 1e-2), ('Misc/cost_gradient_norm', 1e-3)):
             np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, atol=1e-4, err_msg=key)
