@@ -334,13 +334,13 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         """One device->host transfer per epoch: finished episodes in (step, env) order
         (_log_metrics, :159-174) and the mean critic outputs (logger.store Value/*, :88-92)."""
         ep = self._ep_rows
-        window = 100
-        if hasattr(logger, '_headers_windows'):
-            window = logger._headers_windows.get('Metrics/EpRet') or 100  # noqa: SLF001
+        # the three windowed keys only ever keep the last `window` episodes: copy no more than those to the host;
+        # un-windowed extras (Metrics/EpBudget of Saute / Simmer) average EVERY episode of the epoch
+        window = logger.window_length('Metrics/EpRet') if hasattr(logger, 'window_length') else None
         idx = ep['done'].reshape(-1).nonzero().reshape(-1)  # host sync (once per epoch)
         if idx.numel() > 0:
-            idx = idx[-window:]
-            vals = torch.stack([ep[k].reshape(-1)[idx] for k in ('ret', 'cost', 'len')]).cpu()
+            widx = idx if window is None else idx[-window:]
+            vals = torch.stack([ep[k].reshape(-1)[widx] for k in ('ret', 'cost', 'len')]).cpu()
             logger.extend('Metrics/EpRet', vals[0].tolist())
             logger.extend('Metrics/EpCost', vals[1].tolist())
             logger.extend('Metrics/EpLen', vals[2].tolist())

@@ -200,8 +200,15 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(b['discounted_ret']), _lib.stream_ptr()), 'osa_gae_scan')
 
     def get(self) -> dict[str, torch.Tensor]:
-        """Finish all paths, standardise, and return the env-major batch (reference key set)."""
+        """Finish all paths, standardise, and return the env-major batch (reference key set).
+
+        The buffer must be full (`ptr == size`): the reference's `get()` is only ever called then
+        (policy_gradient.py:345-349) and a partially filled buffer would feed stale rows of the previous epoch
+        into the advantages and their statistics.  The returned tensors alias the buffer's staging block: the
+        next `get()` overwrites them (the reference returns fresh concatenations)."""
         from . import distributed as dist
+
+        assert self.ptr == self._size, f'get() on a partially filled buffer (ptr {self.ptr} of {self._size})'
 
         b, T, N = self.data, self._size, self._num_buffers
         M = T * N

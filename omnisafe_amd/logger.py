@@ -73,6 +73,10 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         self._headers_windows[key] = window_length
         self._data[key] = deque(maxlen=window_length) if window_length is not None else []
 
+    def window_length(self, key: str) -> int | None:
+        """The window a key was registered with (None = all values of the epoch are kept)."""
+        return self._headers_windows.get(key)
+
     def store(self, data: dict[str, Any] | None = None, /, **kwargs: Any) -> None:
         """logger.py:253-282: scalars appended; tensors/arrays contribute their mean."""
         if data is not None:

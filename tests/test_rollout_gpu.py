@@ -107,6 +107,9 @@ class _LoggerStub:
         self.data = {}
         self._headers_windows = {'Metrics/EpRet': 100}
 
+    def window_length(self, key):
+        return self._headers_windows.get(key)
+
     def extend(self, k, v):
         self.data.setdefault(k, []).extend(v)
 
