@@ -44,6 +44,8 @@ def main() -> int:
     ap.add_argument('--sample-iters', type=int, default=2)
     ap.add_argument('--threads', type=int, default=16)
     args = ap.parse_args()
+    if args.sample_iters <= 0:
+        args.sample_iters = args.update_iters
     import ref_harness
 
     if not ref_harness.reference_available():
@@ -51,16 +53,25 @@ def main() -> int:
         return 1
     omnisafe = ref_harness.import_reference()
     ref_harness.register_synth_env()
+    from omnisafe.utils.config import get_default_kwargs_yaml
+
+    has_env_cfgs = 'env_cfgs' in get_default_kwargs_yaml(args.algo, args.env_id, 'on-policy').todict()
+    ref_harness.DEFAULT_HORIZON = args.steps_per_env  # TRPOLag.yaml / CPO.yaml have no env_cfgs key to carry it
     spe = args.envs * args.steps_per_env
     log_dir = tempfile.mkdtemp(prefix='osa_refbase_')
     cfg = {'seed': 0,
            'train_cfgs': {'device': 'cpu', 'torch_threads': args.threads, 'vector_env_nums': args.envs,
                           'total_steps': spe, 'parallel': 1},
            'algo_cfgs': {'steps_per_epoch': spe, 'batch_size': args.batch_size,
-                         'update_iters': args.sample_iters, 'kl_early_stop': False},
+                         'update_iters': args.sample_iters},
            'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': log_dir,
-                           'save_model_freq': 10 ** 9},
-           'env_cfgs': {'horizon': args.steps_per_env, 'cost_p': 0.05}}
+                           'save_model_freq': 10 ** 9}}
+    if has_env_cfgs:
+        cfg['env_cfgs'] = {'horizon': args.steps_per_env, 'cost_p': 0.05}
+    if args.batch_size <= 0:  # keep the algorithm's YAML default
+        del cfg['algo_cfgs']['batch_size']
+    if 'kl_early_stop' in get_default_kwargs_yaml(args.algo, args.env_id, 'on-policy').todict()['algo_cfgs']:
+        cfg['algo_cfgs']['kl_early_stop'] = False
     sink = io.StringIO()
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
@@ -93,7 +104,8 @@ def main() -> int:
         'kind': 'reference',
         'sample': (f'unmodified omnisafe.Agent({args.algo!r}, device=cpu, torch_threads={args.threads}).learn(), '
                    f'1 epoch of the benchmark shape ({args.envs} envs x {args.steps_per_env} steps = {spe} '
-                   f'env-steps, batch_size {args.batch_size}) with update_iters={args.sample_iters}: '
+                   f'env-steps, batch_size {args.batch_size if args.batch_size > 0 else "= YAML default"}) with '
+                   f'update_iters={args.sample_iters}: '
                    f'Time/Rollout {t_roll:.2f} s, Time/Update {t_upd:.2f} s, Time/FPS {fps:.0f} (its own csv); '
                    f'buffer.get() {t_get[0]:.2f} s of the update; value = {spe} / (Time/Rollout + get + '
                    f'(Time/Update - get) x {args.update_iters}/{args.sample_iters}), i.e. only the minibatch '
