@@ -83,6 +83,14 @@ struct OsaWideArgs {
 #define WTICK(k) do { } while (0)
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release, which on
+// gfx950 waits for EVERY outstanding vector-memory operation (one vmcnt for loads and stores): inside the slab
+// loops that would drain the Adam / gradient stores just issued, and the loads that are meant to stay in flight
+// across the barrier, before each barrier.  The slab loops only hand LDS tiles between the waves.
+__device__ __forceinline__ void osa_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int OT>
 __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -197,6 +205,8 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
 #define WPUT_TILE(S, V, T)                                                           \
   _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (S)[(16 * (T) + 4 * g + r_) * WSLD + c] = (V)[r_]
 
+  bool pending = false;  // W1's Adam step of the previous optimiser step not applied yet
+  float p_gscale = 1.f, p_step_size = 0.f, p_inv_bc2_sqrt = 1.f;
   long row_nxt;
   {
     const int B0 = (int)min((long)a.B, a.M);
@@ -252,41 +262,69 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     f32x4 h1[HT], h2[HT], out[OT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
-    // layer 1: W1 is staged through LDS in slabs of 4 K blocks (64 rows x 64 columns; the two X^T slab buffers
-    // of the dW1 phase are free now), loaded ONCE per step by the whole workgroup -- each wave reading its own
-    // A fragments from L2 would fetch W1 four times -- and double-buffered: the next slab and the next x chunks
-    // are in flight while the 64 MFMAs of the current slab issue.  The loader threads also accumulate sum w^2.
+    // layer 1, fused with the W1 part of the PREVIOUS step's Adam update.  W1 is staged through LDS in slabs of
+    // 4 K blocks (64 rows x 64 columns; the two X^T slab buffers of the dW1 phase are free now).  Every W1
+    // element is owned by exactly one lane (tile layout, see w1own), so the lane that applies the pending Adam
+    // step to its 4 x 16 bytes of a slab is also the one that writes them into the LDS slab: the forward pass
+    // needs no W1 read of its own, and the memory traffic of Adam (w, m, v, g in, w, m, v out: the bandwidth-
+    // bound part of the step, 21 k cycles on its own) streams one slab ahead under the 64 MFMAs of the current
+    // slab.  The owners also accumulate sum w^2 of the weights this step's forward pass uses.
     float w1sq = 0.f;
     {
-      f32x4 wl[4], xc[4];
-      auto load_slab = [&](int s4) {  // 16 tiles (4 feature tiles x 4 K blocks) = 1024 f32x4, 4 per thread
+      f32x4 xc[4], pw[4], pm[4], pv[4], pg[4];
+      auto fetch_own = [&](int s4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int e = tid + 256 * q, t16 = e >> 6, kb_ = 4 * s4 + (t16 & 3);
-          wl[q] = (kb_ < KB) ? *reinterpret_cast<const f32x4*>(W1 + (((t16 >> 2) * KB + kb_) << 8) + 4 * (e & 63))
-                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int off = w1own + 256 * min(4 * s4 + q, KB - 1);
+          pw[q] = *reinterpret_cast<const f32x4*>(W1 + off);
+          if (pending) {  // block-uniform
+            pm[q] = *reinterpret_cast<const f32x4*>(M1 + off);
+            pv[q] = *reinterpret_cast<const f32x4*>(V1 + off);
+            pg[q] = *reinterpret_cast<const f32x4*>(G1 + off);
+          }
         }
       };
       auto load_x = [&](int s4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xc[q] = load_chunk(xrow, 16 * (4 * s4 + q) + 4 * g);
       };
-      load_slab(0);
+      fetch_own(0);
       load_x(0);
       for (int s4 = 0; s4 < KB4; ++s4) {
         float* slab = sXs + (s4 & 1) * 64 * WSLD;
+        // all arithmetic first (the 16 loads were issued a whole slab of MFMAs ago), then all stores: a store
+        // issued between two waits for loads makes the next wait drain it (loads and stores share one counter)
+        if (pending) {  // block-uniform
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 gg = pg[q];
+            if (l2) gg = gg + pw[q] * c2;
+            pw[q] = osa_adam_update4(gg * p_gscale, pm[q], pv[q], pw[q], beta1, beta2, p_step_size, p_inv_bc2_sqrt, aeps);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kb = 4 * s4 + q;
+            if (kb < KB) {  // block-uniform
+              const int off = w1own + 256 * kb;
+              *reinterpret_cast<f32x4*>(W1 + off) = pw[q];
+              *reinterpret_cast<f32x4*>(M1 + off) = pm[q];
+              *reinterpret_cast<f32x4*>(V1 + off) = pv[q];
+            }
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int e = tid + 256 * q, t16 = e >> 6, f4 = e & 63;  // tile (ft, q'), element (c, 4 i4)
-          *reinterpret_cast<f32x4*>(slab + (16 * (t16 >> 2) + (f4 >> 2)) * WSLD + 16 * (t16 & 3) + 4 * (f4 & 3)) = wl[q];
-          if (critic) w1sq += (wl[q].x * wl[q].x + wl[q].y * wl[q].y) + (wl[q].z * wl[q].z + wl[q].w * wl[q].w);
+          const f32x4 w = (4 * s4 + q < KB) ? pw[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(slab + (16 * wave + cc) * WSLD + 16 * q + 4 * g) = w;
+          if (critic) w1sq += (w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w);
         }
         f32x4 x[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) x[q] = mask_chunk(xc[q], 16 * (4 * s4 + q) + 4 * g);
-        __syncthreads();
+        osa_lds_barrier();
         if (s4 + 1 < KB4) {
-          load_slab(s4 + 1);
+          fetch_own(s4 + 1);
           load_x(s4 + 1);
         }
 #pragma unroll
@@ -540,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
         const f32x4 xm = mask_chunk(xs[q], 16 * (4 * s4 + q) + 4 * g);
         WPUT_TILE(slab, xm, q);
       }
-      __syncthreads();
+      osa_lds_barrier();
       if (s4 + 1 < KB4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xs[q] = load_chunk(xrow, 16 * (4 * (s4 + 1) + q) + 4 * g);
@@ -635,41 +673,12 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
       gscale = gscale > 1.f ? 1.f : gscale;
     }
     // ================= Adam =================
-    // W1: this lane's 4 x KB elements (one 16-byte access per K block and array): gradient from the scratch,
-    // weights and moments read-modify-written in global memory (all L2-resident); the critics' L2 term joins
-    // the gradient here.  Four K blocks per trip, the next trip's 16 loads in flight during the arithmetic.
-    {
-      f32x4 cw[4], cm[4], cv[4], cg[4], nw[4], nm[4], nv[4], ng[4];
-      auto fetch = [&](int kb0, f32x4 (&w)[4], f32x4 (&m)[4], f32x4 (&v)[4], f32x4 (&gg)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int off = w1own + 256 * min(kb0 + q, KB - 1);
-          w[q] = *reinterpret_cast<const f32x4*>(W1 + off);
-          m[q] = *reinterpret_cast<const f32x4*>(M1 + off);
-          v[q] = *reinterpret_cast<const f32x4*>(V1 + off);
-          gg[q] = *reinterpret_cast<const f32x4*>(G1 + off);
-        }
-      };
-      fetch(0, nw, nm, nv, ng);
-      for (int kb0 = 0; kb0 < KB; kb0 += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cw[q] = nw[q]; cm[q] = nm[q]; cv[q] = nv[q]; cg[q] = ng[q]; }
-        if (kb0 + 4 < KB) fetch(kb0 + 4, nw, nm, nv, ng);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (kb0 + q < KB) {  // block-uniform
-            const int off = w1own + 256 * (kb0 + q);
-            f32x4 gg = cg[q];
-            if (l2) gg = gg + cw[q] * c2;
-            const f32x4 w = osa_adam_update4(gg * gscale, cm[q], cv[q], cw[q], beta1, beta2, step_size,
-                                             inv_bc2_sqrt, aeps);
-            *reinterpret_cast<f32x4*>(W1 + off) = w;
-            *reinterpret_cast<f32x4*>(M1 + off) = cm[q];
-            *reinterpret_cast<f32x4*>(V1 + off) = cv[q];
-          }
-        }
-      }
-    }
+    // W1: clip factor and bias corrections of this step are carried into the next step's fused Adam + forward
+    // loop (or the tail pass after the last step)
+    pending = true;
+    p_gscale = gscale;
+    p_step_size = step_size;
+    p_inv_bc2_sqrt = inv_bc2_sqrt;
     WTICK(5);
     // W2 / W3: weights from the LDS master copy, moments read-modify-written in global memory (L2): 24 KB per
     // step and network -- registers are what this kernel is short of
@@ -736,6 +745,39 @@ __global__ __launch_bounds__(256, 1) void osa_wide_pass_kernel(OsaWideArgs a) {
     WTICK(6);
   }
 #undef WPUT_TILE
+  // ---- tail: W1's Adam step of the last optimiser step (4 K blocks per trip, the next trip's loads in flight)
+  if (pending) {
+    f32x4 cw[4], cm[4], cv[4], cg[4], nw[4], nm[4], nv[4], ng[4];
+    auto fetch = [&](int kb0, f32x4 (&w)[4], f32x4 (&m)[4], f32x4 (&v)[4], f32x4 (&gg)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int off = w1own + 256 * min(kb0 + q, KB - 1);
+        w[q] = *reinterpret_cast<const f32x4*>(W1 + off);
+        m[q] = *reinterpret_cast<const f32x4*>(M1 + off);
+        v[q] = *reinterpret_cast<const f32x4*>(V1 + off);
+        gg[q] = *reinterpret_cast<const f32x4*>(G1 + off);
+      }
+    };
+    fetch(0, nw, nm, nv, ng);
+    for (int kb0 = 0; kb0 < KB; kb0 += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { cw[q] = nw[q]; cm[q] = nm[q]; cv[q] = nv[q]; cg[q] = ng[q]; }
+      if (kb0 + 4 < KB) fetch(kb0 + 4, nw, nm, nv, ng);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (kb0 + q < KB) {  // block-uniform
+          const int off = w1own + 256 * (kb0 + q);
+          f32x4 gg = cg[q];
+          if (l2) gg = gg + cw[q] * c2;
+          const f32x4 w = osa_adam_update4(gg * p_gscale, cm[q], cv[q], cw[q], beta1, beta2, p_step_size,
+                                           p_inv_bc2_sqrt, aeps);
+          *reinterpret_cast<f32x4*>(W1 + off) = w;
+          *reinterpret_cast<f32x4*>(M1 + off) = cm[q];
+          *reinterpret_cast<f32x4*>(V1 + off) = cv[q];
+        }
+      }
+    }
+  }
 #ifdef OSA_WIDE_CLOCKS
   __syncthreads();
   if (tid == 0 && a.nmb >= 3)  // network `net` -> row nmb-1-net, columns 0..6: mean cycles per step and phase
