@@ -121,15 +121,16 @@ def timed(algo, steps, warmup, world, dev):
 
 def pmc_traffic(kernel_name):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction);
+    (profiles/r2_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction);
     PMC counters cannot be read from inside the process, so this is the offline measurement of the
     same command.  None if no matching entry."""
-    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    for k, v in json.load(open(path)).items():
-        if k.startswith(kernel_name):
-            return v['traffic_bytes_per_launch']
+    for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):  # newest committed PMC passes first
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        for k, v in json.load(open(path)).items():
+            if k.startswith(kernel_name):
+                return v['traffic_bytes_per_launch']
     return None
 
 

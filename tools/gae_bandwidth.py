@@ -55,7 +55,7 @@ def main():
     from omnisafe_amd.spaces import Box
 
     shapes = [tuple(int(x) for x in s.split(',')) for s in args.shapes] if args.shapes else DEFAULT_SHAPES
-    if args.pmc_run:
+    if args.pmc_run and not args.shapes:
         shapes = [s for s in shapes if s[0] * s[1] >= (1 << 24)] or shapes[-1:]
     dev = torch.device('cuda:0')
     # copy bandwidth of this box (read + write bytes / time)

@@ -1,15 +1,19 @@
 # End-of-round measurement set on one MI355X (run through gpurun): GPU tests, default bench, 2-rank code-path
-# check, rocprofv3 kernel stats of the default bench, and the two PMC passes (separate runs, kernel-trace only).
+# check, rocprofv3 kernel stats of the default bench, the PMC passes (separate runs, --kernel-trace only:
+# FETCH_SIZE, WRITE_SIZE, one SQ pass), the same two traffic passes for the buffer kernels at M = 16 M.
 set -x
-cd /root/repo
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3
 timeout 600 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json
-OSA_DIST_BACKEND=gloo OSA_SINGLE_DEVICE_RANKS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_2rank_1gpu.json 2> gpurun_out/bench_2rank.err; tail -c 400 gpurun_out/bench_2rank_1gpu.json
+OSA_DIST_BACKEND=gloo OSA_SINGLE_DEVICE_RANKS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 2 > gpurun_out/bench_2rank_1gpu.json 2> gpurun_out/bench_2rank.err; tail -c 400 gpurun_out/bench_2rank_1gpu.json
 cd /tmp && export TMPDIR=/tmp
-rm -rf /root/repo/gpurun_out/prof_final /root/repo/gpurun_out/pmc_FETCH_SIZE /root/repo/gpurun_out/pmc_WRITE_SIZE
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_final -- python /root/repo/bench.py --steps 2 --warmup 1 > /root/repo/gpurun_out/prof_final.log 2>&1
+rm -rf $R/gpurun_out/prof_final $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE $R/gpurun_out/pmc_sq $R/gpurun_out/pmc_gae_FETCH_SIZE $R/gpurun_out/pmc_gae_WRITE_SIZE
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python $R/bench.py --steps 2 --warmup 2 > $R/gpurun_out/prof_final.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /root/repo/gpurun_out/pmc_$c -- python /root/repo/bench.py --steps 1 --warmup 1 --update-iters 4 --no-cpu-baseline --no-variant > /root/repo/gpurun_out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 1 --warmup 2 --update-iters 4 --no-cpu-baseline --no-variant > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_gae_$c -- python $R/tools/gae_bandwidth.py --pmc-run --shapes 16,1048576 4096,4096 > $R/gpurun_out/pmc_gae_$c.log 2>&1
 done
-ls /root/repo/gpurun_out/prof_final/* /root/repo/gpurun_out/pmc_FETCH_SIZE/* | head
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 1 --warmup 2 --update-iters 2 --no-cpu-baseline --no-variant > $R/gpurun_out/pmc_sq.log 2>&1
+ls $R/gpurun_out/prof_final/* $R/gpurun_out/pmc_FETCH_SIZE/* $R/gpurun_out/pmc_gae_FETCH_SIZE/* | head

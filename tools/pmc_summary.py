@@ -1,5 +1,5 @@
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
-profiles/r1_pmc_traffic.{md,json}: HBM-side bytes per launch of every libomnisafe_amd kernel.
+profiles/r2_pmc_traffic.{md,json} (default; pass another base name as third argument): HBM-side bytes per launch of every libomnisafe_amd kernel.
 
     python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 
@@ -49,4 +49,4 @@ def main(fetch_dir, write_dir, out_base):
 
 if __name__ == '__main__':
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, 'profiles', 'r1_pmc_traffic'))
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, 'profiles', 'r2_pmc_traffic'))
