@@ -177,7 +177,8 @@ typedef struct osa_ppo_hparams {
  * and calls osa_adam_apply -- clip-then-average order of policy_gradient.py:437-442);  2: raw grads.
  * B <= 64*max_blocks rows are processed by ceil(B/64) workgroups per network (ws: at least
  * osa_minibatch_ws_floats floats when more than one is used, ZERO-INITIALISED ONCE by the caller: its tail
- * holds the arrival tickets of the fused slab-reduce + clip/Adam launch, which every call leaves at zero).
+ * holds the partial norms and the arrival / finish counters of the fused slab-reduce + clip/Adam launch, which
+ * every call leaves re-armed at zero; use one ws with ONE value of max_blocks).
  * step_stats[16] receives
  *   [0] mse_r [1] mse_c [2] loss_pi [3] mean ratio [4] entropy [5] sum p^2 (V_r) [6] sum p^2 (V_c)
  *   [7] |g_pi| [8] |g_Vr| [9] |g_Vc|   (logged Loss_*_critic = mse + critic_norm_coef * sum p^2). */

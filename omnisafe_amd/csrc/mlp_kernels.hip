@@ -726,33 +726,51 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_kernel(OsaMbArgs a) {
   }
 }
 
-// Large-batch step, second (and last) launch: the slab reduction of osa_slab_reduce_kernel spread over
-// ceil((P+16)/1024) workgroups per network, then the LAST workgroup of each network to arrive (release fence ->
-// agent-scope ticket -> acquire fence) runs the whole-network part -- L2 term, gradient norm, clip, Adam --
-// exactly as osa_finalize_kernel did in a third launch (same 1024-thread reduction order: bit-identical).
-// ticket: int[3], zero before the first call; every call leaves it at zero.
-__global__ __launch_bounds__(1024) void osa_slab_reduce_finalize_kernel(OsaMbArgs a, int* ticket) {
+// Large-batch step, second (and last) launch.  Grid (ceil((P+16)/256), 3): every workgroup reduces 256 elements
+// of the slabs (coalesced, 8 independent partial sums), forms gradient + L2 term and its share of |g|^2 and
+// sum p^2, and publishes the two partial sums; then ALL workgroups of the network meet at an arrival counter
+// (release fence -> agent-scope add -> bounded spin -> acquire fence: the ~100 workgroups of a launch are a
+// fraction of the chip, co-resident by construction), add the partials in block order (every workgroup gets the
+// same total norm, bit for bit) and apply clip + Adam to THEIR OWN 256 parameters.  Round 1 used two more
+// launches (slab reduce 7 us, then norm + clip + Adam by one 1024-thread block per network: 12 us).
+// sync: int[8] per launch site, zero before the first call; the last workgroup to FINISH resets it.
+//   sync[net] arrival counter, sync[4 + net] finish counter, sync[3] sticky time-out flag.
+__global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs a, float* partials, int* sync) {
   __shared__ float red[32];
-  __shared__ int s_last;
+  __shared__ float s_tot[2];
   const OsaNet& nd = a.nd;
   const int net = blockIdx.y;
   if (!((a.nets_mask >> net) & 1)) return;
+  const int P = nd.P, W = P + OSA_NSTAT, nblk = gridDim.x;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int W = nd.P + OSA_NSTAT;
+  const bool critic = net != 0;
+  const int step = a.adam_step[net] + 1;  // read before anybody can advance it (the last finisher does)
+  float* __restrict__ p = a.params + (long)net * P;
+  float gval = 0.f, pval = 0.f, gsq = 0.f, psq = 0.f;
   if (e < W) {
     const float* s = a.slabs + (long)net * a.nblk * W + e;
-    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
     int b = 0;
     for (; b + 8 <= a.nblk; b += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] += s[(long)(b + u) * W];
+      for (int u = 0; u < 8; ++u) q[u] += s[(long)(b + u) * W];
     }
-    for (; b < a.nblk; ++b) p[0] += s[(long)b * W];
-    const float acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    if (e < nd.P) {
-      a.grads[(long)net * nd.P + e] = acc;
+    for (; b < a.nblk; ++b) q[0] += s[(long)b * W];
+    const float acc = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    if (e < P) {
+      pval = p[e];
+      gval = acc;
+      if (net == 0 && a.hp.entropy_coef != 0.f && e >= nd.oLS && e < nd.oLS + nd.act_dim)
+        gval -= a.hp.entropy_coef / (float)nd.act_dim;
+      if (critic && e >= nd.oLS) {  // critics have no log_std; keep the slot inert
+        gval = 0.f;
+      } else {
+        if (critic && a.hp.use_critic_norm) gval += 2.f * a.hp.critic_norm_coef * pval;
+        if (critic) psq = pval * pval;
+      }
+      gsq = gval * gval;
     } else {
-      const int k = e - nd.P;
+      const int k = e - P;
       const float invB = 1.f / (float)a.B;
       if (net == 0) {
         if (k == 0) {
@@ -769,20 +787,78 @@ __global__ __launch_bounds__(1024) void osa_slab_reduce_finalize_kernel(OsaMbArg
       }
     }
   }
+  gsq = osa_block_sum_f(gsq, red);
+  psq = osa_block_sum_f(psq, red);
+  float* part = partials + ((long)net * nblk + blockIdx.x) * 2;
+  if (threadIdx.x == 0) {
+    part[0] = gsq;
+    part[1] = psq;
+  }
+  // ---- grid barrier of this network's workgroups
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(ticket + net, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
-    if (s_last) __hip_atomic_store(ticket + net, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int seen = __hip_atomic_fetch_add(sync + net, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    int spins = 0;
+    while (seen < nblk) {
+      __builtin_amdgcn_s_sleep(1);
+      seen = __hip_atomic_load(sync + net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1 << 22)) {  // never hang the device: flag it (the caller checks sync[3])
+        __hip_atomic_store(sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
   }
   __syncthreads();
-  if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (net == 0 && a.hp.entropy_coef != 0.f && threadIdx.x < a.nd.act_dim)
-    a.grads[a.nd.oLS + threadIdx.x] -= a.hp.entropy_coef / (float)a.nd.act_dim;
+  if (threadIdx.x == 0) {
+    float tg = 0.f, tp = 0.f;
+    const float* pp = partials + (long)net * nblk * 2;
+    for (int k = 0; k < nblk; ++k) {  // block order: identical totals in every workgroup
+      tg += pp[2 * k];
+      tp += pp[2 * k + 1];
+    }
+    s_tot[0] = tg;
+    s_tot[1] = tp;
+  }
   __syncthreads();
-  osa_finalize_net(a, net, red);
+  const float total_norm = sqrtf(s_tot[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.stats[7 + net] = total_norm;
+    if (critic) a.stats[4 + net] = s_tot[1];
+  }
+  float coef = 1.f;
+  if (a.hp.use_max_grad_norm && a.mode != 2) {
+    coef = a.hp.max_grad_norm / (total_norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+  }
+  if (e < P) {
+    if (a.mode != 0) {  // 1: the locally clipped gradient is the result (all-reduce follows); 2: raw gradient
+      a.grads[(long)net * P + e] = gval * coef;
+    } else {
+      const double b1 = a.hp.beta1, b2 = a.hp.beta2;
+      const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+      const float step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
+      const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
+      float* __restrict__ m = a.adam_m + (long)net * P;
+      float* __restrict__ v = a.adam_v + (long)net * P;
+      float mv = m[e], vv = v[e];
+      p[e] = osa_adam_update(gval * coef, mv, vv, pval, a.hp.beta1, a.hp.beta2, step_size, inv_bc2_sqrt,
+                             a.hp.adam_eps);
+      m[e] = mv;
+      v[e] = vv;
+    }
+  }
+  // ---- the last workgroup to finish advances the step counter and re-arms the counters
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int done = __hip_atomic_fetch_add(sync + 4 + net, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (done == nblk) {
+      if (a.mode == 0) a.adam_step[net] = step;
+      __hip_atomic_store(sync + net, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 4 + net, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ __launch_bounds__(1024) void osa_finalize_kernel(OsaMbArgs a, int add_entropy_grad) {
@@ -1081,7 +1157,8 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
 size_t osa_minibatch_ws_floats(int obs_dim, int act_dim, int hidden, int max_blocks) {
   if (osa_check_dims(obs_dim, act_dim, hidden) != OSA_OK || max_blocks < 1) return 0;
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
-  return (size_t)3 * max_blocks * (nd.P + OSA_NSTAT) + 4;  // slabs + arrival tickets (int[3]) of the fused reduce
+  // slabs + the fused reduce/finalize launch's partial norms [3][ceil((P+16)/256)][2] + its counters (int[8])
+  return (size_t)3 * max_blocks * (nd.P + OSA_NSTAT) + (size_t)3 * ((nd.P + OSA_NSTAT + 255) / 256) * 2 + 8;
 }
 
 int osa_ppo_minibatch(int obs_dim, int act_dim, int hidden, float* params, float* adam_m,
@@ -1142,8 +1219,10 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   if (nblk > max_blocks) nblk = max_blocks;
   if (nblk > 1) OSA_REQUIRE(ws != nullptr);
   a.nblk = nblk; a.slabs = ws;
-  // arrival tickets of the fused slab reduce + finalize launch live behind the slabs
-  int* tickets = ws ? reinterpret_cast<int*>(ws + (size_t)3 * max_blocks * (a.nd.P + OSA_NSTAT)) : nullptr;
+  // partial norms and counters of the fused slab reduce + clip/Adam launch live behind the slabs
+  const int rblk = (a.nd.P + OSA_NSTAT + 255) / 256;
+  float* partials = ws ? ws + (size_t)3 * max_blocks * (a.nd.P + OSA_NSTAT) : nullptr;
+  int* tickets = ws ? reinterpret_cast<int*>(partials + (size_t)3 * rblk * 2) : nullptr;
   // Large minibatches: the gradient on the persistent kernel's machinery -- min(nblk, ~CUs/3) workgroups per
   // network keep the weights in LDS and their partial gradient in registers over several 64-row chunks and
   // write ONE slab each (this kernel re-reads the weights from L2 for every chunk and read-modify-writes
@@ -1160,8 +1239,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
       if (prc == OSA_OK) {
         a.nblk = pb;
         const int W = a.nd.P + OSA_NSTAT;
-        hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 1023) / 1024, 3), dim3(1024), 0,
-                           osa_stream(stream), a, tickets);
+        hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
+                           osa_stream(stream), a, partials, tickets);
         OSA_CHECK_LAUNCH();
         return OSA_OK;
       }
@@ -1186,8 +1265,8 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
 #undef OSA_CALL
   if (nblk > 1) {
     const int W = a.nd.P + OSA_NSTAT;
-    hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 1023) / 1024, 3), dim3(1024), 0,
-                       osa_stream(stream), a, tickets);
+    hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
+                       osa_stream(stream), a, partials, tickets);
   }
   OSA_CHECK_LAUNCH();
   return OSA_OK;

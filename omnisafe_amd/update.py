@@ -259,6 +259,13 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             raise RuntimeError('osa_ppo_dp_pass: a peer workgroup timed out (workgroups not co-resident?); '
                                'set OSA_DP_MODE=replicated-steps')
 
+    def check_reduce_sync(self) -> None:
+        """The fused slab-reduce + clip/Adam launch of the large-batch step meets its workgroups at a grid
+        barrier with a bounded spin; a time-out is flagged in the workspace tail (sticky) instead of hanging."""
+        if int(self._ws.view(torch.int32)[-5]) != 0:
+            raise RuntimeError('osa_ppo_minibatch: the workgroups of the slab reduction did not all arrive '
+                               '(device shared with another long-running kernel?)')
+
     def run_pass_replicated(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor,
                             stats_rows: torch.Tensor, perms_all: torch.Tensor | None = None,
                             use_graph: bool = True, coop: bool | None = None) -> None:
@@ -435,6 +442,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                         break
         if use_repl:
             self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
+        if not use_repl and not use_pass and B > 64:
+            self.check_reduce_sync()
         used = stats[:step]
         out = {'stop_iter': update_counts, 'steps': step, 'stats': used}
         if self.update_actor:
