@@ -1,5 +1,5 @@
 """GPU tool: per-phase s_memtime cycles of the persistent pass kernel (needs the clocks build:
-bash tools/build_variant_lib.sh clocks -DOSA_PASS_CLOCKS; OSA_LIB_PATH=omnisafe_amd/lib/libomnisafe_amd_clocks.so python tools/pass_phases.py)."""
+bash tools/build_variant_lib.sh clocks ppo_pass_kernel.hip -DOSA_PASS_CLOCKS; OSA_LIB_PATH=omnisafe_amd/lib/libomnisafe_amd_clocks.so python tools/pass_phases.py)."""
 import os, sys, types
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
