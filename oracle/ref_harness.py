@@ -1,10 +1,13 @@
-"""TEST INFRASTRUCTURE ONLY -- lets the *unmodified* reference (PKU-Alignment/omnisafe at
-/root/reference) execute in the build container so it can pin the oracle and generate golden vectors.
+"""TEST INFRASTRUCTURE ONLY -- lets the *unmodified* reference (PKU-Alignment/omnisafe) execute: in the build
+container from /root/reference (to pin the oracle and generate golden vectors), on the GPU box -- which has no
+/root/reference -- from the archive oracle/_ref/omnisafe_ref.zip that oracle/stage_reference.py writes at build
+time (git-ignored build output; unpacked into a scratch directory here).
 
-Nothing in the product (``omnisafe_amd/``) imports this file.  It is used by
-``oracle/make_golden.py`` (fixture generator, runs only where /root/reference exists) and by the
-``-m "not gpu"`` tests that cross-check ``oracle/np_oracle.py`` against the live reference when it is
-present.  /root/reference does not exist on the GPU box; every user of this module must skip there.
+Nothing in the product (``omnisafe_amd/``) imports this file.  Users: ``oracle/make_golden.py`` (fixture
+generator), the ``-m "not gpu"`` tests that cross-check ``oracle/np_oracle.py`` against the live reference,
+``tests/test_reference_facade_gpu.py`` (the reference's own ``omnisafe.Agent`` driving the plugin on the GPU) and
+``oracle/ref_cpu_baseline.py`` (bench.py's ``cpu_baseline``, kind "reference").  Every user skips (or reports the
+baseline as unavailable) when neither source of the reference exists.
 
 What it does:
   1. appends a meta-path finder that fabricates empty stand-in modules for the reference's third-party
