@@ -261,6 +261,24 @@ int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float
                       const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                       const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                       float* ws, float* step_stats, void* stream);
+/* osa_ppo_wide_pass with the first layer SPLIT over cooperating compute units (csrc/wide_split_kernel.hip):
+ * a network is 1 + ceil(KB / 6) workgroups of one cooperative launch -- every helper owns <= 96 input columns of
+ * W1 (LDS) and their Adam moments (registers) for the whole pass, the leader owns the other layers; three
+ * hand-offs per step (partial pre-activations, dz1, squared-norm shares) through `xch`, which MUST come from
+ * osa_dp_exchange_alloc(osa_ppo_split_pass_xch_floats(...)) (uncached device memory; OSA_EINVAL otherwise).
+ * Same arguments, statistics and per-step arithmetic as osa_ppo_wide_pass (float32 re-association of the
+ * layer-1 sum only).  OSA_EUNSUPPORTED when the shape is not supported or the device cannot hold the
+ * workgroups together: use osa_ppo_wide_pass.  A peer that never arrives raises a sticky flag instead of
+ * hanging the device: osa_ppo_split_pass_timed_out(xch, &flag) reads it (synchronous copy). */
+int osa_ppo_split_pass_supported(int obs_dim, int act_dim, int hidden);
+size_t osa_ppo_split_pass_xch_floats(int obs_dim, int act_dim, int hidden);
+int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                       int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                       const float* logp, const float* target_value_r, const float* target_value_c,
+                       const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                       const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                       float* xch, float* step_stats, void* stream);
+int osa_ppo_split_pass_timed_out(const float* xch, int* out);
 /* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
  * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);
  * OSA_EUNSUPPORTED otherwise -- use osa_ppo_minibatch_ext.  ext == NULL: osa_ppo_pass.  With cost_kappa > 0

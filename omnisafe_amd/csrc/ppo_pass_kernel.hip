@@ -1373,7 +1373,8 @@ static const int OSA_MAX_XCH = 16;
 static char* g_xch_base[OSA_MAX_XCH];
 static size_t g_xch_bytes[OSA_MAX_XCH];
 
-static bool osa_is_exchange_ptr(const void* p) {
+// (library-internal: also used by wide_split_kernel.hip; not declared in the public header)
+bool osa_is_exchange_ptr(const void* p) {
   const char* c = static_cast<const char*>(p);
   for (int k = 0; k < OSA_MAX_XCH; ++k)
     if (g_xch_base[k] && c >= g_xch_base[k] && c < g_xch_base[k] + g_xch_bytes[k]) return true;

@@ -1,0 +1,921 @@
+// Persistent PPO-Lag update pass for WIDE observations, first layer SPLIT OVER COOPERATING CUs
+// (BASELINE config 4: SafetyHumanoidVelocity, 376 / 17).  Same contract as osa_ppo_wide_pass
+// (wide_pass_kernel.hip): ONE launch = one whole pass of PolicyGradient._update's inner loop
+// (policy_gradient.py:366-382), `nmb` dependent minibatch optimiser steps of <= 64 rows, three networks.
+//
+// osa_wide_pass_kernel runs a network on ONE CU and is bound by what that CU can move per step: W1 (96 KB at
+// 376 inputs), its two Adam moments and the gradient of the step in flight stream through one vector L1 --
+// 45 k of the 89 k cycles of a step, with 14 us of MFMA issue in a 37 us step.  Here a network is C + 1
+// workgroups on C + 1 CUs (cooperative launch):
+//   * helper c (C = ceil(KB / 6) of them) OWNS a slice of <= 6 K blocks (<= 96 input features) of W1 for the
+//     whole pass: the slice in LDS (25 KB), its Adam moments in registers (24 elements per lane) -- the
+//     layer-1 half of osa_ppo_pass_kernel.  Per step it gathers its 96 columns of the minibatch rows,
+//     computes the PARTIAL pre-activation W1[:, slice] x[slice] (96 MFMAs per wave) and publishes it; after
+//     the leader's dz1 arrives: dW1[:, slice] = dz1 x[slice]^T (96 MFMAs per wave, operands swapped so that a
+//     lane's accumulators are exactly the elements it owns), + 2 c w (critics), its share of |g|^2;
+//   * the leader owns W2, W3, the biases and log_std (LDS master copy, as the one-CU kernel): sums the C
+//     partial pre-activations in slice order, runs the rest of the forward pass, the loss and the backward
+//     pass, publishes dz1, computes dW2 / dW3 / bias gradients and its share of |g|^2;
+//   * the C + 1 squared-norm shares meet in an all-gather (every workgroup sums the slots in the same order:
+//     one clip factor, bit-identical everywhere); then everybody applies Adam to what it owns.
+// Three hand-offs per step (partials -> leader, dz1 -> helpers, norm shares -> all) through an UNCACHED
+// device buffer (osa_dp_exchange_alloc: stores are performed at the device-coherent level, so a hand-off is
+// "wait for my stores, barrier, relaxed flag store" / "poll, barrier" with no L2 write-back or invalidate;
+// measured 0.55-0.7 us each).  Flags are step counters (monotonic within a launch); a
+// peer that never arrives raises a sticky flag instead of hanging the device.
+//
+// Arithmetic: the fragment algebra and loss code of osa_wide_pass_kernel; the layer-1 pre-activation is
+// the sum of C partial sums instead of one chain over K (float32 re-association, ~1e-7 relative), and the
+// critics' L2 term is added element-wise (the helpers hold their weights) instead of through the algebraic
+// identity.  Parity: tests/test_mlp_gpu.py (vs the per-step kernels), tests/test_config_shapes_gpu.py::config4.
+#include "mlp_device.h"
+
+#define SSLD 68    // leading dimension (floats) of every [row][64 + pad] LDS tile
+#define SXLD 100   // leading dimension of the helper's W1 slice [64][96 + pad]
+#define SNSTAT 16
+#define SCMAX 6    // helpers per network (6 x 96 = 576 >= 512 inputs)
+#define SKQ 6      // K blocks per helper
+// exchange buffer (floats): [128] flag words, then per network SXNET floats
+#define SX_PART 0                          // [SCMAX][4096] partial pre-activations (fragment order)
+#define SX_DZ (SCMAX * 4096)               // [64][64] dz1, row = feature
+#define SX_NORM (SX_DZ + 4096)             // [SCMAX + 1][4]: gsq, psq, (leader:) step_size, inv_bc2_sqrt
+#define SXNET (SX_NORM + 32)
+#define SF_PART 0                          // flag words of a network: [32 net + ..]
+#define SF_DZ 8
+#define SF_NORM 16
+#define SF_ERR 96                          // sticky: a peer never arrived
+
+struct OsaSplitHp {
+  float clip, entropy_coef, critic_norm_coef, max_grad_norm;
+  float lr_actor, lr_critic, beta1, beta2, adam_eps;
+  int use_critic_norm, use_max_grad_norm, use_cost;
+};
+
+struct OsaSplitArgs {
+  OsaNet nd;
+  float* params;   // [3][P] padded global layout
+  float* adam_m;   // [3][P]
+  float* adam_v;   // [3][P]
+  int* adam_step;  // [3]
+  const float* obs;
+  int ld_obs;
+  const float* act;
+  int ld_act;
+  const float* logp;
+  const float* tgt_r;
+  const float* tgt_c;
+  const float* adv_r;
+  const float* adv_c;
+  const long* perm;  // [M] sample rows of the whole pass (nullptr = identity)
+  long M;
+  int B;    // minibatch size (<= 64); the last minibatch may be smaller
+  int nmb;  // minibatches in this launch
+  const float* lagrange;
+  OsaSplitHp hp;
+  int loss_kind;
+  int nets_mask;
+  float* stats;  // [nmb][SNSTAT]
+  float* xch;    // uncached exchange buffer (osa_ppo_split_pass_xch_floats)
+  int C;         // helpers per network
+  int kbper;     // K blocks per helper (balanced: ceil(KB / C) <= SKQ)
+};
+
+#ifdef OSA_SPLIT_CLOCKS
+#define STICK(k)                                   \
+  do {                                             \
+    if (tid == 0) {                                \
+      const long long now_ = clock64();            \
+      sdbg[k] += now_ - slast;                     \
+      slast = now_;                                \
+    }                                              \
+  } while (0)
+#else
+#define STICK(k) do { } while (0)
+#endif
+
+// my stores to the exchange buffer have been performed (uncached memory: at the device-coherent level)
+__device__ __forceinline__ void osa_xch_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
+// after a wait: drop what this CU's vector L1 still holds of the exchange buffer (it keeps lines of uncached
+// memory between two reads of the same address when little else is loaded in between: stale partials / dz1
+// were observed with small rollouts); an L1 invalidate, no L2 write-back
+__device__ __forceinline__ void osa_xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+// lane `tid < n` waits until flag[tid] >= target (bounded: raises the sticky flag and gives up for good)
+__device__ __forceinline__ void osa_xch_wait(int* flags, int n, int target, int tid, int* err, bool& dead) {
+  if (tid < n && !dead) {
+    int spins = 0;
+    while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 20)) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        break;
+      }
+    }
+  }
+}
+
+template <int OT>
+__global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int H = 64, HT = 4, OUTP = 16 * OT;
+  const OsaNet& nd = a.nd;
+  const int C = a.C;
+  const int net = blockIdx.x / (C + 1), role = blockIdx.x - net * (C + 1);  // role 0: leader, 1 + c: helper c
+  if (!((a.nets_mask >> net) & 1)) return;
+  const int KB = nd.KB, INP = nd.INP, P = nd.P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int i = j, cc = j;
+  float* __restrict__ gp = a.params + (long)net * P;
+  float* __restrict__ gm = a.adam_m + (long)net * P;
+  float* __restrict__ gv = a.adam_v + (long)net * P;
+  int* flags = reinterpret_cast<int*>(a.xch) + 32 * net;
+  int* err = reinterpret_cast<int*>(a.xch) + SF_ERR;
+  float* xn = a.xch + 128 + (long)net * SXNET;
+  const bool critic = net != 0;
+  const bool l2 = critic && a.hp.use_critic_norm;
+  const float c2 = 2.f * a.hp.critic_norm_coef;
+  const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
+  bool dead = false;
+#ifdef OSA_SPLIT_CLOCKS
+  long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long slast = clock64();
+#endif
+
+  if (role > 0) {
+    // =====================================================================================================
+    // helper: K blocks kb0 .. kb0 + nkb - 1 of W1
+    // =====================================================================================================
+    const int hc = role - 1;
+    const int kb0 = hc * a.kbper, nkb = min(a.kbper, KB - kb0);
+    float* sW = smem;                     // [H][SXLD]   W1 slice, element (feature f, local input k)
+    float* sX = sW + H * SXLD;            // [96][SSLD]  X^T of the step: element (local input k, sample c)
+    float* red = sX + 16 * SKQ * SSLD;    // [16]
+    const int ld_obs = a.ld_obs, obs_dim = nd.obs_dim;
+    auto load_chunk = [&](const float* __restrict__ xr, int col0) -> f32x4 {
+      const int cl = (col0 + 4 <= ld_obs) ? col0 : ld_obs - 4;
+      return *reinterpret_cast<const f32x4*>(xr + cl);
+    };
+    auto mask_chunk = [&](f32x4 v, int col0) -> f32x4 {
+      v.x = (col0 + 0 < obs_dim) ? v.x : 0.f;
+      v.y = (col0 + 1 < obs_dim) ? v.y : 0.f;
+      v.z = (col0 + 2 < obs_dim) ? v.z : 0.f;
+      v.w = (col0 + 3 < obs_dim) ? v.w : 0.f;
+      return v;
+    };
+    // the W1 elements this lane owns (D layout of the transposed weight-gradient tiles): feature row
+    // 16 wave + cc, local inputs 16 q + 4 g .. + 3 for q < SKQ
+    const int own_lds = (16 * wave + cc) * SXLD + 4 * g;
+    const int own_glb = nd.oW1 + (16 * wave + cc) * INP + 16 * kb0 + 4 * g;
+    f32x4 m1[SKQ], v1[SKQ];
+#pragma unroll
+    for (int q = 0; q < SKQ; ++q) {
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      m1[q] = w;
+      v1[q] = w;
+      if (q < nkb) {  // block-uniform
+        w = *reinterpret_cast<const f32x4*>(gp + own_glb + 16 * q);
+        m1[q] = *reinterpret_cast<const f32x4*>(gm + own_glb + 16 * q);
+        v1[q] = *reinterpret_cast<const f32x4*>(gv + own_glb + 16 * q);
+      }
+      *reinterpret_cast<f32x4*>(sW + own_lds + 16 * q) = w;
+    }
+    const int c = 16 * wave + j;  // this lane's sample column
+    long row_nxt;
+    {
+      const int B0 = (int)min((long)a.B, a.M);
+      const long p0 = (c < B0) ? c : 0;
+      row_nxt = a.perm ? a.perm[p0] : p0;
+    }
+    f32x4 xr[SKQ];
+    {
+      const float* __restrict__ xrow = a.obs + row_nxt * ld_obs;
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) xr[q] = load_chunk(xrow, 16 * (kb0 + q) + 4 * g);
+    }
+    __syncthreads();
+    for (int mb = 0; mb < a.nmb; ++mb) {
+      const long mb_lo = (long)mb * a.B;
+      const bool have_next = mb + 1 < a.nmb;
+      // the permutation entry of the NEXT step's sample: requested now, its row is gathered after this step's
+      // forward pass (two dependent memory round trips that would otherwise open every step)
+      long row_nn = row_nxt;
+      if (have_next) {
+        const long nlo = mb_lo + a.B;
+        const int nB = (int)(min(nlo + a.B, a.M) - nlo);
+        const long np = nlo + ((c < nB) ? c : 0);
+        row_nn = a.perm ? a.perm[np] : np;
+      }
+      // ---- this step's columns: B operand of the forward product, and (transposed) A operand of dW1
+      f32x4 x[SKQ];
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) {
+        x[q] = mask_chunk(xr[q], 16 * (kb0 + q) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sX[(16 * q + 4 * g + r) * SSLD + c] = x[q][r];
+      }
+      // ---- partial pre-activation: features 16 t + 4 g + r of sample c
+      f32x4 acc[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) {
+        if (q < nkb) {  // block-uniform
+          f32x4 w[HT];
+#pragma unroll
+          for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(sW + (16 * t + i) * SXLD + 16 * q + 4 * g);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) acc[t] = OSA_MFMA(w[t][s], x[q][s], acc[t]);
+        }
+      }
+      {
+        f32x4* dst = reinterpret_cast<f32x4*>(xn + SX_PART + hc * 4096);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) dst[t * 256 + tid] = acc[t];
+      }
+      osa_xch_release();
+      __syncthreads();  // partials performed; sX complete
+      if (tid == 0) __hip_atomic_store(flags + SF_PART + hc, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      STICK(0);
+      // ---- gather the next step's columns while the leader works
+      {
+        const float* __restrict__ xrow = a.obs + row_nn * ld_obs;
+#pragma unroll
+        for (int q = 0; q < SKQ; ++q) xr[q] = load_chunk(xrow, 16 * (kb0 + q) + 4 * g);
+      }
+      row_nxt = row_nn;
+      // the lane's own weights (norm share, Adam)
+      f32x4 wv[SKQ];
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) wv[q] = *reinterpret_cast<const f32x4*>(sW + own_lds + 16 * q);
+      // ---- dz1 of this step
+      osa_xch_wait(flags + SF_DZ, 1, mb + 1, tid, err, dead);
+      __syncthreads();
+      osa_xch_acquire();
+      STICK(1);
+      f32x4 a1[4];
+      {
+        const float* dz = xn + SX_DZ;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) a1[sb] = *reinterpret_cast<const f32x4*>(dz + (16 * wave + i) * 64 + 16 * sb + 4 * g);
+      }
+      // ---- dW1[f][k] = sum_s dz1[f][s] x[s][k], D[i = input 4g + r][j = feature cc]
+      f32x4 gq[SKQ];
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) gq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < SKQ; ++q) {
+          if (q < nkb) {  // block-uniform
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * q + i) * SSLD + 16 * sb + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) gq[q] = OSA_MFMA(b[s], a1[sb][s], gq[q]);
+          }
+        }
+      }
+      f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) {
+        if (l2) gq[q] = gq[q] + wv[q] * c2;
+        acc_g = acc_g + gq[q] * gq[q];
+        acc_p = acc_p + wv[q] * wv[q];
+      }
+      float gsq = (acc_g.x + acc_g.y) + (acc_g.z + acc_g.w);
+      float psq = (acc_p.x + acc_p.y) + (acc_p.z + acc_p.w);
+      gsq = osa_wave_sum_dpp(gsq);
+      psq = osa_wave_sum_dpp(psq);
+      if (lane == 0) {
+        red[2 * wave + 0] = gsq;
+        red[2 * wave + 1] = psq;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float* slot = xn + SX_NORM + 4 * hc;
+        slot[0] = (red[0] + red[2]) + (red[4] + red[6]);
+        slot[1] = (red[1] + red[3]) + (red[5] + red[7]);
+        osa_xch_release();
+        __hip_atomic_store(flags + SF_NORM + hc, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      STICK(2);
+      // ---- all norm shares
+      osa_xch_wait(flags + SF_NORM, C + 1, mb + 1, tid, err, dead);
+      __syncthreads();
+      osa_xch_acquire();
+      float t_gsq = 0.f;
+      for (int k = 0; k <= C; ++k) t_gsq += xn[SX_NORM + 4 * k];
+      const float step_size = xn[SX_NORM + 4 * C + 2], inv_bc2_sqrt = xn[SX_NORM + 4 * C + 3];
+      float gscale = 1.f;
+      if (a.hp.use_max_grad_norm) {
+        gscale = a.hp.max_grad_norm / (sqrtf(t_gsq) + 1e-6f);
+        gscale = gscale > 1.f ? 1.f : gscale;
+      }
+      STICK(3);
+#pragma unroll
+      for (int q = 0; q < SKQ; ++q) {
+        const f32x4 w = osa_adam_update4(gq[q] * gscale, m1[q], v1[q], wv[q], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+        *reinterpret_cast<f32x4*>(sW + own_lds + 16 * q) = w;
+      }
+      __syncthreads();  // the slice is consistent; sX and red are free
+      STICK(4);
+    }
+    // ---- write back the slice and its moments
+#pragma unroll
+    for (int q = 0; q < SKQ; ++q) {
+      if (q < nkb) {
+        *reinterpret_cast<f32x4*>(gp + own_glb + 16 * q) = *reinterpret_cast<const f32x4*>(sW + own_lds + 16 * q);
+        *reinterpret_cast<f32x4*>(gm + own_glb + 16 * q) = m1[q];
+        *reinterpret_cast<f32x4*>(gv + own_glb + 16 * q) = v1[q];
+      }
+    }
+#ifdef OSA_SPLIT_CLOCKS
+    if (tid == 0 && hc == 0 && a.nmb >= 8)  // helper 0 of network `net` -> row nmb-1-net, columns 8..12
+      for (int k = 0; k < 5; ++k) a.stats[(long)(a.nmb - 1 - net) * SNSTAT + 8 + k] = (float)sdbg[k] / (float)a.nmb;
+#endif
+    return;
+  }
+
+  // =======================================================================================================
+  // leader: layers 2 and 3, loss, backward pass, dW2 / dW3 / biases
+  // =======================================================================================================
+  float* sW2 = smem;                      // [H][SSLD]
+  float* sW3 = sW2 + H * SSLD;            // [OUTP][SSLD]
+  float* sB1 = sW3 + OUTP * SSLD;         // [H]
+  float* sB2 = sB1 + H;                   // [H]
+  float* sB3 = sB2 + H;                   // [OUTP]
+  float* sLS = sB3 + OUTP;                // [OUTP]
+  float* sH1 = sLS + OUTP;                // [H][SSLD]  element (feature f, sample c)
+  float* sH2 = sH1 + H * SSLD;
+  float* sZ1 = sH2 + H * SSLD;
+  float* sZ2 = sZ1 + H * SSLD;
+  float* sDO = sZ2 + H * SSLD;            // [OUTP][SSLD]
+  float* sDL = sDO + OUTP * SSLD;         // [OUTP][SSLD]
+  float* red = sDL + OUTP * SSLD;         // [16]
+  const bool leader = tid == 192;
+  for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * SSLD + (e & 63)] = gp[nd.oW2 + e];
+  for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * SSLD + (e & 63)] = gp[nd.oW3 + e];
+  if (tid < H) {
+    sB1[tid] = gp[nd.ob1 + tid];
+    sB2[tid] = gp[nd.ob2 + tid];
+  }
+  if (tid < OUTP) {
+    sB3[tid] = gp[nd.ob3 + tid];
+    sLS[tid] = gp[nd.oLS + tid];
+  }
+  // ownership (as osa_ppo_pass_kernel): W2[(16w+4g+r)][16ti+cc], W3[(16o+4g+r)][16w+cc], one bias-like
+  // scalar per thread; Adam moments in registers
+  float mb_ = 0.f, vb_ = 0.f;
+  int boff = -1;
+  float* sbias = sB1;
+  if (tid < H) { boff = nd.ob1 + tid; sbias = sB1 + tid; }
+  else if (tid < 2 * H) { boff = nd.ob2 + tid - H; sbias = sB2 + tid - H; }
+  else if (tid < 2 * H + OUTP) { boff = nd.ob3 + tid - 2 * H; sbias = sB3 + tid - 2 * H; }
+  else if (tid < 2 * H + 2 * OUTP) { boff = nd.oLS + tid - 2 * H - OUTP; sbias = sLS + tid - 2 * H - OUTP; }
+  if (critic && boff >= nd.oLS) boff = -1;  // critics have no log_std
+  if (boff >= 0) {
+    mb_ = gm[boff];
+    vb_ = gv[boff];
+  }
+  f32x4 m2[HT], v2[HT], m3[OT], v3[OT];
+#pragma unroll
+  for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+      m2[ti][r] = gm[off];
+      v2[ti][r] = gv[off];
+    }
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+      m3[o][r] = gm[off];
+      v3[o][r] = gv[off];
+    }
+  const int step0 = a.adam_step[net];
+  const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+  // Adam's bias corrections of every step of the launch, tabulated once (float64 like torch): columns
+  // 10 + 2 net, 11 + 2 net of the step's statistics row
+  for (int k = tid; k < a.nmb; k += 256) {
+    const double t = (double)(step0 + k + 1);
+    float* row = a.stats + (long)k * SNSTAT;
+    row[10 + 2 * net] = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    row[11 + 2 * net] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+  }
+  float lam = 0.f;
+  if (net == 0 && a.lagrange) lam = *a.lagrange;
+  const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
+  __syncthreads();  // LDS master copy + bias-correction table complete
+
+#define SPUT_TILE(S, V, T)                                                           \
+  _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (S)[(16 * (T) + 4 * g + r_) * SSLD + c] = (V)[r_]
+
+  const int c = 16 * wave + j;  // this lane's sample column
+  long row_nxt;
+  {
+    const int B0 = (int)min((long)a.B, a.M);
+    const long p0 = (c < B0) ? c : 0;
+    row_nxt = a.perm ? a.perm[p0] : p0;
+  }
+  // per-sample scalars of the step, gathered one step ahead
+  float n_act[4 * OT], n_logp = 0.f, n_advr = 0.f, n_advc = 0.f, n_tgt = 0.f;
+  auto gather = [&](long row) {
+    if (net == 0) {  // block-uniform
+      const float* __restrict__ arow = a.act + row * a.ld_act;
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n_act[4 * o + r] = arow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
+      n_logp = a.logp[row];
+      n_advr = a.adv_r[row];
+      n_advc = a.adv_c[row];
+    } else {
+      n_tgt = tgt[row];
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < 4 * OT; ++k) n_act[k] = 0.f;
+  gather(row_nxt);
+  for (int mb = 0; mb < a.nmb; ++mb) {
+    const long mb_lo = (long)mb * a.B;
+    const int Bcur = (int)(min(mb_lo + a.B, a.M) - mb_lo);
+    const float invB = 1.f / (float)Bcur;
+    const bool valid = c < Bcur;
+    const bool have_next = mb + 1 < a.nmb;
+    long row_nn = row_nxt;
+    if (have_next) {
+      const long nlo = mb_lo + a.B;
+      const int nB = (int)(min(nlo + a.B, a.M) - nlo);
+      const long np = nlo + ((c < nB) ? c : 0);
+      row_nn = a.perm ? a.perm[np] : np;
+    }
+    float s_act[4 * OT];
+#pragma unroll
+    for (int k = 0; k < 4 * OT; ++k) s_act[k] = n_act[k];
+    const float s_logp = n_logp, s_advr = n_advr, s_advc = n_advc, s_tgt = n_tgt;
+    const float* bc_row = a.stats + (long)mb * SNSTAT + 10 + 2 * net;
+    const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
+    float ent_pre = 0.f;
+    if (net == 0 && leader) {  // entropy of the pre-update policy
+      for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
+      ent_pre /= (float)nd.act_dim;
+    }
+    // ================= forward =================
+    f32x4 h1[HT], h2[HT], out[OT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
+    osa_xch_wait(flags + SF_PART, C, mb + 1, tid, err, dead);
+    __syncthreads();
+    osa_xch_acquire();
+    STICK(0);
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(xn + SX_PART);
+      for (int k = 0; k < C; ++k) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) h1[t] = h1[t] + src[k * 1024 + t * 256 + tid];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      h1[t] = osa_tanh4(h1[t]);
+      SPUT_TILE(sH1, h1[t], t);
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(sB2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int kb = 0; kb < HT; ++kb) {
+      f32x4 w[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * SSLD + 16 * kb + 4 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) h2[t] = OSA_MFMA(w[t][s], h1[kb][s], h2[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      h2[t] = osa_tanh4(h2[t]);
+      SPUT_TILE(sH2, h2[t], t);
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
+#pragma unroll
+    for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * SSLD + 16 * kb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
+      }
+    }
+    // ================= loss, dL/d(out) (osa_mb_grad_kernel's code path without extensions) =================
+    f32x4 dO[OT], dLS[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float loss_part = 0.f, ratio_part = 0.f;
+    if (net == 0) {
+      float lp = 0.f;
+      f32x4 zv[OT], ivar[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * o + 4 * g + r;
+          zv[o][r] = 0.f;
+          ivar[o][r] = 0.f;
+          if (d < nd.act_dim && valid) {
+            const float sd = expf(sLS[d]);
+            const float var = sd * sd;
+            const float z = s_act[4 * o + r] - out[o][r];
+            zv[o][r] = z;
+            ivar[o][r] = 1.f / var;
+            lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+          }
+        }
+      }
+      lp = osa_sum_over_groups(lp);
+      const float ratio = valid ? expf(lp - s_logp) : 0.f;
+      if (valid) {
+        const float adv = (s_advr - lam * s_advc) / (1.f + lam);  // ppo_lag.py:101-102
+        float dratio, li;
+        if (a.loss_kind == 0) {  // base/ppo.py:66-78
+          const float lo = 1.f - a.hp.clip, hi = 1.f + a.hp.clip;
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float s1 = ratio * adv, s2 = rc * adv;
+          const bool inrange = ratio >= lo && ratio <= hi;
+          li = -fminf(s1, s2);
+          dratio = (s1 < s2 || inrange) ? -adv : 0.f;
+        } else {  // policy_gradient.py:574-578
+          li = -(ratio * adv);
+          dratio = -adv;
+        }
+        const float dlogp = dratio * ratio * invB;
+        if (g == 0) {
+          loss_part = li;
+          ratio_part = ratio;
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = zv[o][r], iv = ivar[o][r];
+            dO[o][r] = dlogp * z * iv;
+            dLS[o][r] = (iv != 0.f) ? dlogp * (z * z * iv - 1.f) : 0.f;
+          }
+        }
+      }
+    } else if (valid) {
+      const float diff = out[0][0] - s_tgt;
+      if (g == 0) {
+        loss_part = diff * diff;
+        dO[0][0] = 2.f * diff * invB;
+      }
+    }
+    // ================= backward through the hidden layers (S layout) =================
+    f32x4 z2[HT], z1[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
+          const float w = sW3[(16 * o + 4 * g + s) * SSLD + 16 * t + i];
+          acc = OSA_MFMA(w, dO[o][s], acc);
+        }
+      }
+      z2[t] = acc * (1.f - h2[t] * h2[t]);
+      SPUT_TILE(sZ2, z2[t], t);
+    }
+    {
+      float* dz = xn + SX_DZ;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+            const float w = sW2[(16 * kb + 4 * g + s) * SSLD + 16 * t + i];
+            acc = OSA_MFMA(w, z2[kb][s], acc);
+          }
+        }
+        z1[t] = acc * (1.f - h1[t] * h1[t]);
+        // dz1 leaves for the helpers as soon as a tile is finished: row = feature, 16 consecutive samples per
+        // (g, r) = 64-byte segments
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz[(16 * t + 4 * g + r) * 64 + c] = z1[t][r];
+        SPUT_TILE(sZ1, z1[t], t);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      SPUT_TILE(sDO, dO[o], o);
+      SPUT_TILE(sDL, dLS[o], o);
+    }
+    osa_xch_release();
+    __syncthreads();  // (A) dz1 performed, tiles complete
+    if (tid == 0) __hip_atomic_store(flags + SF_DZ, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    STICK(1);
+    // ---- the next step's scalars (used after the next hand-off)
+    gather(row_nn);
+    row_nxt = row_nn;
+    // ================= weight gradients (registers) =================
+    f32x4 g2[HT], g3[OT];
+    {
+      f32x4 a2[4];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * wave + i) * SSLD + 16 * sb + 4 * g);
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) g2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        f32x4 b[HT];
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti)
+          b[ti] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SSLD + 16 * sb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ti = 0; ti < HT; ++ti) g2[ti] = OSA_MFMA(a2[sb][s], b[ti][s], g2[ti]);
+      }
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * SSLD + 16 * sb + 4 * g);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * SSLD + 16 * sb + 4 * g);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) g3[o] = OSA_MFMA(av[s], b[s], g3[o]);
+        }
+      }
+    }
+    // bias-like gradient owned by this thread: row sum over the 64 samples
+    float gb = 0.f;
+    {
+      const float* srow = (tid < H) ? sZ1 + tid * SSLD
+                          : (tid < 2 * H) ? sZ2 + (tid - H) * SSLD
+                          : (tid < 2 * H + OUTP) ? sDO + (tid - 2 * H) * SSLD
+                          : (tid < 2 * H + 2 * OUTP) ? sDL + (tid - 2 * H - OUTP) * SSLD
+                                                     : sZ1;
+      float rs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(srow + 4 * k);
+        rs += q.x;
+        rs += q.y;
+        rs += q.z;
+        rs += q.w;
+      }
+      gb = (boff >= 0) ? rs : 0.f;
+    }
+    if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
+      gb -= a.hp.entropy_coef / (float)nd.act_dim;
+    // ================= + 2 coef w (critics), squared norms =================
+    f32x4 w2r[HT], w3r[OT];
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w2r[ti][r] = sW2[(16 * wave + 4 * g + r) * SSLD + 16 * ti + cc];
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w3r[o][r] = sW3[(16 * o + 4 * g + r) * SSLD + 16 * wave + cc];
+    float wb = *sbias;
+    wb = (boff >= 0) ? wb : 0.f;
+    f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti) {
+      const f32x4 w = w2r[ti];
+      if (l2) g2[ti] = g2[ti] + w * c2;
+      acc_p = acc_p + w * w;
+      acc_g = acc_g + g2[ti] * g2[ti];
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const f32x4 w = w3r[o];
+      if (l2) g3[o] = g3[o] + w * c2;
+      acc_p = acc_p + w * w;
+      acc_g = acc_g + g3[o] * g3[o];
+    }
+    float gsq = (acc_g.x + acc_g.y) + (acc_g.z + acc_g.w);
+    float psq = (acc_p.x + acc_p.y) + (acc_p.z + acc_p.w);
+    if (boff >= 0) {
+      if (l2) gb += c2 * wb;
+      psq += wb * wb;
+      gsq += gb * gb;
+    }
+    gsq = osa_wave_sum_dpp(gsq);
+    psq = osa_wave_sum_dpp(psq);
+    loss_part = osa_wave_sum_dpp(loss_part);
+    ratio_part = osa_wave_sum_dpp(ratio_part);
+    if (lane == 0) {
+      red[4 * wave + 0] = gsq;
+      red[4 * wave + 1] = psq;
+      red[4 * wave + 2] = loss_part;
+      red[4 * wave + 3] = ratio_part;
+    }
+    __syncthreads();  // (B)
+    if (tid == 0) {
+      float* slot = xn + SX_NORM + 4 * C;
+      slot[0] = red[0] + red[4] + red[8] + red[12];
+      slot[1] = red[1] + red[5] + red[9] + red[13];
+      slot[2] = step_size;
+      slot[3] = inv_bc2_sqrt;
+      osa_xch_release();
+      __hip_atomic_store(flags + SF_NORM + C, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float t_loss = red[2] + red[6] + red[10] + red[14];
+    const float t_ratio = red[3] + red[7] + red[11] + red[15];
+    STICK(2);
+    osa_xch_wait(flags + SF_NORM, C + 1, mb + 1, tid, err, dead);
+    __syncthreads();
+    osa_xch_acquire();
+    float t_gsq = 0.f, t_psq = 0.f;
+    for (int k = 0; k <= C; ++k) {
+      t_gsq += xn[SX_NORM + 4 * k];
+      t_psq += xn[SX_NORM + 4 * k + 1];
+    }
+    const float total_norm = sqrtf(t_gsq);
+    float gscale = 1.f;
+    if (a.hp.use_max_grad_norm) {
+      gscale = a.hp.max_grad_norm / (total_norm + 1e-6f);
+      gscale = gscale > 1.f ? 1.f : gscale;
+    }
+    STICK(3);
+    // ================= Adam =================
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti) {
+      const f32x4 w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w2r[ti], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * SSLD + 16 * ti + cc] = w[r];
+    }
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const f32x4 w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w3r[o], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * SSLD + 16 * wave + cc] = w[r];
+    }
+    if (boff >= 0) {
+      float mv_ = mb_, vv_ = vb_;
+      *sbias = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+      mb_ = mv_;
+      vb_ = vv_;
+    }
+    if (leader) {
+      float* st = a.stats + (long)mb * SNSTAT;
+      if (net == 0) {
+        st[2] = t_loss * invB - a.hp.entropy_coef * ent_pre;
+        st[3] = t_ratio * invB;
+        st[4] = ent_pre;
+        st[7] = total_norm;
+      } else {
+        st[net - 1] = t_loss * invB;
+        st[4 + net] = t_psq;
+        st[7 + net] = total_norm;
+      }
+    }
+    __syncthreads();  // (C) frees tiles and `red`; the LDS master copy is consistent
+    STICK(4);
+  }
+#undef SPUT_TILE
+#ifdef OSA_SPLIT_CLOCKS
+  if (tid == 0 && a.nmb >= 8)  // leader of network `net` -> row nmb-1-net, columns 0..4: mean cycles per step
+    for (int k = 0; k < 5; ++k) a.stats[(long)(a.nmb - 1 - net) * SNSTAT + k] = (float)sdbg[k] / (float)a.nmb;
+#endif
+  // ---- write back: LDS master copy, Adam state
+  for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * SSLD + (e & 63)];
+  for (int e = tid; e < OUTP * H; e += 256) gp[nd.oW3 + e] = sW3[(e >> 6) * SSLD + (e & 63)];
+  if (tid < H) {
+    gp[nd.ob1 + tid] = sB1[tid];
+    gp[nd.ob2 + tid] = sB2[tid];
+  }
+  if (tid < OUTP) {
+    gp[nd.ob3 + tid] = sB3[tid];
+    if (!critic) gp[nd.oLS + tid] = sLS[tid];
+  }
+#pragma unroll
+  for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+      gm[off] = m2[ti][r];
+      gv[off] = v2[ti][r];
+    }
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+      gm[off] = m3[o][r];
+      gv[off] = v3[o][r];
+    }
+  if (boff >= 0) {
+    gm[boff] = mb_;
+    gv[boff] = vb_;
+  }
+  if (tid == 0) a.adam_step[net] = step0 + a.nmb;
+}
+
+static size_t osa_split_lds_bytes(int OT) {
+  const int H = 64, OUTP = 16 * OT;
+  const size_t lead = (size_t)H * SSLD + (size_t)OUTP * SSLD + 2 * H + 2 * OUTP + 4 * (size_t)H * SSLD +
+                      2 * (size_t)OUTP * SSLD + 64;
+  const size_t help = (size_t)H * SXLD + 16 * SKQ * (size_t)SSLD + 64;
+  return (lead > help ? lead : help) * sizeof(float);
+}
+
+extern "C" bool osa_is_exchange_ptr(const void* p);  // ppo_pass_kernel.hip
+
+template <int OT>
+static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds = osa_split_lds_bytes(OT);
+  if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return OSA_EHIP;
+    attr_set = true;
+  }
+  // the workgroups of a network wait for each other every step, so they MUST be co-resident: a cooperative
+  // launch makes the runtime verify that and refuses otherwise (the caller then takes the one-CU kernel)
+  OsaSplitArgs arg = a;
+  void* kargs[] = {&arg};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
+                                                  dim3(3 * (a.C + 1)), dim3(256), kargs, (unsigned)lds, stream);
+  if (e == hipSuccess) return OSA_OK;
+  (void)hipGetLastError();
+  return e == hipErrorCooperativeLaunchTooLarge ? OSA_EUNSUPPORTED : OSA_EHIP;
+}
+
+extern "C" {
+
+int osa_ppo_split_pass_supported(int obs_dim, int act_dim, int hidden) {
+  if (hidden != 64 || obs_dim < 65 || obs_dim > 16 * SKQ * SCMAX || obs_dim > 512 || act_dim < 1 || act_dim > 32)
+    return 0;
+  return 1;
+}
+
+size_t osa_ppo_split_pass_xch_floats(int obs_dim, int act_dim, int hidden) {
+  if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return 0;
+  return (size_t)128 + 3 * (size_t)SXNET;
+}
+
+int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                       int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                       const float* logp, const float* target_value_r, const float* target_value_c,
+                       const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                       const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                       float* xch, float* step_stats, void* stream) {
+  if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;  // larger batches: per-step kernels
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && xch);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
+  OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
+  if (!osa_is_exchange_ptr(xch)) return OSA_EINVAL;  // the hand-offs rely on uncached memory
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad the rows
+  if ((double)M * ld_obs >= 2147483647.0 * 4) return OSA_EUNSUPPORTED;
+  OsaSplitArgs a = {};
+  a.xch = xch;
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.C = (a.nd.KB + SKQ - 1) / SKQ;
+  a.kbper = (a.nd.KB + a.C - 1) / a.C;
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = perm; a.M = M; a.B = B; a.nmb = (int)((M + B - 1) / B); a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
+  hipStream_t st = osa_stream(stream);
+  // flag words are step counters of THIS launch (the sticky error word, SF_ERR, survives)
+  if (hipMemsetAsync(xch, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  const int OT = a.nd.OUTP / 16;
+  if (OT == 1) return osa_launch_split<1>(a, st);
+  if (OT == 2) return osa_launch_split<2>(a, st);
+  return OSA_EUNSUPPORTED;
+}
+
+// 1 when a workgroup of any split pass since the allocation of `xch` gave up waiting for a peer
+int osa_ppo_split_pass_timed_out(const float* xch, int* out) {
+  OSA_REQUIRE(xch && out);
+  return hipMemcpy(out, reinterpret_cast<const int*>(xch) + SF_ERR, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess
+             ? OSA_OK : OSA_EHIP;
+}
+
+}  // extern "C"

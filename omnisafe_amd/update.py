@@ -72,6 +72,37 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.profile_events: list | None = None
         self.last_path: str | None = None
         self._use_wide = False
+        self._split_xch: int | None = None  # uncached exchange buffer of the split wide pass (raw pointer)
+        self._split_tried = False
+
+    def _split_alloc(self) -> None:
+        """Exchange buffer of osa_ppo_split_pass (uncached device memory; OSA_WIDE_SPLIT=0 keeps the one-CU
+        kernel: A/B switch of tools/wide_pass_timing.py)."""
+        if self._split_tried:
+            return
+        self._split_tried = True
+        ac = self.ac
+        if os.environ.get('OSA_WIDE_SPLIT', '1') == '0' or not bool(
+                self.lib.osa_ppo_split_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)):
+            return
+        n = self.lib.osa_ppo_split_pass_xch_floats(ac.obs_dim, ac.act_dim, ac.hidden)
+        p = C.c_void_p()
+        if self.lib.osa_dp_exchange_alloc(max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
+            self._split_xch = p.value
+
+    def _split_free(self) -> None:
+        if self._split_xch:
+            self.lib.osa_dp_exchange_free(C.c_void_p(self._split_xch))
+        self._split_xch = None
+
+    def check_split_sync(self) -> None:
+        """Raises if a workgroup of a split wide pass ever gave up waiting for a peer (sticky device flag)."""
+        if self._split_xch:
+            flag = C.c_int(0)
+            _lib.check(self.lib.osa_ppo_split_pass_timed_out(C.c_void_p(self._split_xch), C.byref(flag)),
+                       'osa_ppo_split_pass_timed_out')
+            if flag.value:
+                raise _lib.OsaError('osa_ppo_split_pass: a cooperating workgroup never arrived (results invalid)')
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
@@ -121,6 +152,24 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         name = 'osa_ppo_pass_kernel'
+        if self._use_wide and self._split_xch:  # wide observations, first layer split over CUs (wide_split_kernel.hip)
+            rc = self.lib.osa_ppo_split_pass(
+                ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
+                _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+                _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+                _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
+                C.byref(self.hp), self.loss_kind, self._nets_mask(), C.c_void_p(self._split_xch),
+                _lib.ptr(stats_rows), _lib.stream_ptr())
+            if rc == _lib.OSA_EUNSUPPORTED:  # the device cannot hold the workgroups together: one CU per network
+                self._split_free()
+            else:
+                _lib.check(rc, 'osa_ppo_split_pass')
+                self.last_path = 'persistent-wide-split'
+                if ev is not None:
+                    ev[1].record()
+                    self.profile_events.append(('osa_wide_split_kernel', M, ev))
+                return
         if self._use_wide:  # wide observations: W1 and its Adam moments streamed from L2 (wide_pass_kernel.hip)
             _lib.check(self.lib.osa_ppo_wide_pass(
                 ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
@@ -206,6 +255,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                                            nmb, _lib.stream_ptr()), 'osa_ppo_dp_end_pass')
 
     def _dp_free(self) -> None:
+        self._split_free()
         st = self._dp
         if st.get('xch') is None and st.get('xch_ptr'):
             self.lib.osa_dp_exchange_free(st['xch_ptr'])
@@ -393,6 +443,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             if getattr(self, '_wide_ws', None) is None:
                 n = self.lib.osa_ppo_wide_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden)
                 self._wide_ws = torch.empty(n, dtype=torch.float32, device=ac.device)
+            self._split_alloc()
         use_pass = self._pass_fn is not None
         W = dist.world_size()
         data = self._aligned_rows(data)
@@ -444,6 +495,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
         if not use_repl and not use_pass and B > 64:
             self.check_reduce_sync()
+        if self._use_wide:
+            self.check_split_sync()
         used = stats[:step]
         out = {'stop_iter': update_counts, 'steps': step, 'stats': used}
         if self.update_actor:

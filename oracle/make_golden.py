@@ -489,6 +489,8 @@ def gen_sibling_updates(only=None):
 CONFIG_SHAPES = [
     ('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
     ('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', {'cost_limit': 0.71}, None),
+    # the infeasible-recovery branch (case 0: a pure step along -F^-1 b), half of CPO's updates early in training
+    ('config3_cpo_car_case0', 'CPO', 'SynthCarGoal1-v0', {'cost_limit': 0.5}, None),
     ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', {},
      {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
     ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),

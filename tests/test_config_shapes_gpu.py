@@ -29,6 +29,7 @@ LAG = {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}
 FIRST_ORDER = [('config2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', ({}, LAG)),
                ('config4_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', ({}, LAG))]
 TRUST_REGION = [('config3_cpo_car', 'CPO', 'SynthCarGoal1-v0', ({'cost_limit': 0.71}, None)),
+                ('config3_cpo_car_case0', 'CPO', 'SynthCarGoal1-v0', ({'cost_limit': 0.5}, None)),
                 ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', ({}, LAG))]
 
 
@@ -69,8 +70,10 @@ def test_trust_region_update_at_config_shape(golden, tmp_path, tag, name, env_id
         np.testing.assert_allclose(_log(algo, key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
     if name == 'CPO':
         info = algo._last_actor_update
-        assert info['case'] == int(g['log/Misc/OptimCase'][-1]) == 1  # constraint violated but recoverable: both
-        # projections (lambda_a, lambda_b) are evaluated and nu* > 0 (cpo.py:300-322)
+        want_case = 0 if tag.endswith('case0') else 1
+        assert info['case'] == int(g['log/Misc/OptimCase'][-1]) == want_case
+        # case 1: constraint violated but recoverable, both projections (lambda_a, lambda_b) are evaluated and
+        # nu* > 0 (cpo.py:300-322); case 0: infeasible, pure recovery step along -F^-1 b (cpo.py:289-299, 377-383)
         assert float(g['log/Misc/Nu_star'][-1]) > 1.0
         np.testing.assert_allclose(_log(algo, 'Misc/Nu_star')[-1], g['log/Misc/Nu_star'][-1], rtol=5e-2)
         for key, rtol in (('Misc/q', 1e-2), ('Misc/r', 5e-2), ('Misc/s', 1e-2), ('Misc/cost_gradient_norm', 1e-3),

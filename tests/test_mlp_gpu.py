@@ -247,11 +247,19 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
                                                 # wide observations: osa_ppo_wide_pass (W1 streamed from L2)
                                                 (376, 17, 1024, 64), (376, 17, 200, 64), (100, 3, 300, 64),
                                                 (200, 20, 256, 32), (512, 32, 192, 64), (97, 1, 130, 48)])
-def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
+def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, monkeypatch):
     """osa_ppo_pass (one persistent launch per pass, weights in LDS, Adam moments in registers) vs
     osa_ppo_minibatch (one launch per optimiser step): same parameters, moments and statistics after
-    two passes, including ragged last minibatches and every (KB, OT) template instance family."""
+    two passes, including ragged last minibatches and every (KB, OT) template instance family.  Wide
+    observations: both persistent kernels (first layer split over cooperating CUs = the default, and the
+    one-CU kernel behind OSA_WIDE_SPLIT=0) against the per-step launches."""
+    from omnisafe_amd import _lib
     from omnisafe_amd.update import PPOUpdater
+
+    narrow = bool(_lib.load().osa_ppo_pass_supported(obs_dim, act_dim, 64))
+    variants = [(True, '1', 'persistent' if narrow else 'persistent-wide-split'), (False, '1', 'per-step')]
+    if not narrow:
+        variants.insert(1, (True, '0', 'persistent-wide'))
 
     torch.manual_seed(obs_dim + act_dim)
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
@@ -259,7 +267,8 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
             'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
     acs, outs, paths = [], [], []
     perms = [torch.randperm(M), torch.randperm(M)]
-    for persistent in (True, False):
+    for persistent, split, _ in variants:
+        monkeypatch.setenv('OSA_WIDE_SPLIT', split)
         torch.manual_seed(99)
         ac = make_ac(obs_dim, act_dim)
         if 'logp' not in data:
@@ -271,13 +280,9 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
         outs.append(up.run(data, lam, perms=perms, actor_lr=3e-4, critic_lr=1e-3))
         paths.append(up.last_path)
         acs.append(ac)
-    assert outs[0]['steps'] == outs[1]['steps'] == 2 * ((M + B - 1) // B)
-    from omnisafe_amd import _lib
-
-    narrow = bool(_lib.load().osa_ppo_pass_supported(obs_dim, act_dim, 64))
-    assert paths == ['persistent' if narrow else 'persistent-wide', 'per-step']
+    assert all(o['steps'] == 2 * ((M + B - 1) // B) for o in outs)
+    assert paths == [v[2] for v in variants]
     assert narrow == (obs_dim <= 96 and not (obs_dim > 80 and act_dim > 16))
-    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()
     # B <= 64: the same operation order except for the 1-2-output layers, which the pass kernel evaluates
     # on the VALU (16-term partial dot products per lane group) and the per-step kernels on MFMA tiles:
     # float32 summation-order differences of ~1e-7.  B > 64: the pass kernel accumulates the 64-row chunks
@@ -286,12 +291,26 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B):
     # wide inputs: 376-term dot products; Adam's m / sqrt(v) turns ~1e-7 gradient differences into up to ~2e-6
     # in single parameters with small v (measured: 1 element of 1e5 at 1.6e-6)
     atol = (5e-7 if narrow else 5e-6) if B <= 64 else 5e-6
-    for name in ('params', 'adam_m', 'adam_v'):
-        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=name)
-    s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
-    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=2e-7)
-    np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
+    for k in range(len(variants) - 1):  # every persistent variant against the per-step launches
+        assert acs[k].adam_step.cpu().tolist() == acs[-1].adam_step.cpu().tolist()
+        for name in ('params', 'adam_m', 'adam_v'):
+            a, b = getattr(acs[k], name).cpu().numpy(), getattr(acs[-1], name).cpu().numpy()
+            if variants[k][2] != 'persistent-wide-split':
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=f'{variants[k][2]} {name}')
+                continue
+            # The split kernel sums the layer-1 pre-activation as C partial sums (the other persistent kernels keep
+            # the per-step kernels' order and agree to 1e-8): every gradient differs by ~1e-7 relative.  Adam's
+            # FIRST step is lr * g / (|g| + 1e-8): for the handful of elements whose first gradient is within
+            # ~1e-8 of zero (expected: ~1e-5 of all elements) that noise moves the update by a visible
+            # fraction of lr, and the moments follow at the 1e-4 relative level.  Everything else obeys the usual tolerance.
+            bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)
+            assert bad.sum() <= 4, (name, int(bad.sum()))
+            if bad.any():
+                lim = 2.5e-4 if name == 'params' else 2e-3 * np.abs(b[bad]).max()
+                assert np.abs(a - b)[bad].max() <= lim, (name, float(np.abs(a - b)[bad].max()))
+        s0, s1 = outs[k]['stats'].cpu().numpy(), outs[-1]['stats'].cpu().numpy()
+        np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=2e-7)
+        np.testing.assert_allclose(outs[k]['kl'], outs[-1]['kl'], rtol=1e-4, atol=1e-8)
 
 
 @pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),
