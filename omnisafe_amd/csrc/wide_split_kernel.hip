@@ -38,7 +38,7 @@
 // exchange buffer (floats): [128] flag words, then per network SXNET floats
 #define SX_PART 0                          // [SCMAX][4096] partial pre-activations (fragment order)
 #define SX_DZ (SCMAX * 4096)               // [64][64] dz1, row = feature
-#define SX_NORM (SX_DZ + 4096)             // [SCMAX + 1][4]: gsq, psq, (leader:) step_size, inv_bc2_sqrt
+#define SX_NORM (SX_DZ + 4096)             // [SCMAX + 1][2] 8-byte words {float share, int step}: |g|^2, |w|^2
 #define SXNET (SX_NORM + 32)
 #define SF_PART 0                          // flag words of a network: [32 net + ..]
 #define SF_DZ 8
@@ -77,7 +77,6 @@ struct OsaSplitArgs {
   float* stats;  // [nmb][SNSTAT]
   float* xch;    // uncached exchange buffer (osa_ppo_split_pass_xch_floats)
   int C;         // helpers per network
-  int kbper;     // K blocks per helper (balanced: ceil(KB / C) <= SKQ)
 };
 
 #ifdef OSA_SPLIT_CLOCKS
@@ -92,6 +91,13 @@ struct OsaSplitArgs {
 #else
 #define STICK(k) do { } while (0)
 #endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release, which on
+// gfx950 waits for EVERY outstanding vector-memory operation (one counter for loads and stores): it would
+// drain the next step's gathers, issued early on purpose, at each barrier of the step.
+__device__ __forceinline__ void osa_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // my stores to the exchange buffer have been performed (uncached memory: at the device-coherent level)
 __device__ __forceinline__ void osa_xch_release() {
@@ -119,6 +125,26 @@ __device__ __forceinline__ void osa_xch_wait(int* flags, int n, int target, int 
   }
 }
 
+// Squared-norm shares travel WITH their step counter in one 8-byte word (a relaxed agent-scope atomic): the
+// reader polls the data itself -- no flag -> invalidate -> data round trip in the all-gather.
+__device__ __forceinline__ void osa_slot_put(unsigned long long* slot, float v, int cnt) {
+  const unsigned long long w = ((unsigned long long)(unsigned)cnt << 32) | (unsigned long long)__float_as_uint(v);
+  __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float osa_slot_wait(unsigned long long* slot, int cnt, int* err, bool& dead) {
+  unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((int)(w >> 32) < cnt && !dead) {
+    __builtin_amdgcn_s_sleep(1);
+    w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > (1 << 20)) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dead = true;
+    }
+  }
+  return __uint_as_float((unsigned)w);
+}
+
 template <int OT>
 __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -136,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   int* flags = reinterpret_cast<int*>(a.xch) + 32 * net;
   int* err = reinterpret_cast<int*>(a.xch) + SF_ERR;
   float* xn = a.xch + 128 + (long)net * SXNET;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(xn + SX_NORM);  // [2 (C + 1)] {value, step}
   const bool critic = net != 0;
   const bool l2 = critic && a.hp.use_critic_norm;
   const float c2 = 2.f * a.hp.critic_norm_coef;
@@ -151,10 +178,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     // helper: K blocks kb0 .. kb0 + nkb - 1 of W1
     // =====================================================================================================
     const int hc = role - 1;
-    const int kb0 = hc * a.kbper, nkb = min(a.kbper, KB - kb0);
+    const int kb0 = hc * SKQ, nkb = min(SKQ, KB - kb0);  // the last slice may be short (zero blocks)
     float* sW = smem;                     // [H][SXLD]   W1 slice, element (feature f, local input k)
     float* sX = sW + H * SXLD;            // [96][SSLD]  X^T of the step: element (local input k, sample c)
     float* red = sX + 16 * SKQ * SSLD;    // [16]
+    float* sBC = red + 16;                // [nmb][2] Adam's bias corrections of every step (as the leader's table)
     const int ld_obs = a.ld_obs, obs_dim = nd.obs_dim;
     auto load_chunk = [&](const float* __restrict__ xr, int col0) -> f32x4 {
       const int cl = (col0 + 4 <= ld_obs) ? col0 : ld_obs - 4;
@@ -183,6 +211,15 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         v1[q] = *reinterpret_cast<const f32x4*>(gv + own_glb + 16 * q);
       }
       *reinterpret_cast<f32x4*>(sW + own_lds + 16 * q) = w;
+    }
+    {
+      const int step0 = a.adam_step[net];
+      const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+      for (int k = tid; k < a.nmb; k += 256) {
+        const double t = (double)(step0 + k + 1);
+        sBC[2 * k + 0] = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+        sBC[2 * k + 1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+      }
     }
     const int c = 16 * wave + j;  // this lane's sample column
     long row_nxt;
@@ -222,27 +259,29 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       f32x4 acc[HT];
 #pragma unroll
       for (int t = 0; t < HT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (all SKQ blocks unconditionally: blocks past the slice hold zero weights and meet zero-masked columns -- a
+      // block-uniform branch around each group is a scheduling barrier: measured 18 k instead of 5 k cycles in the
+      // dW1 loop below)
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) {
-        if (q < nkb) {  // block-uniform
-          f32x4 w[HT];
+        f32x4 w[HT];
 #pragma unroll
-          for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(sW + (16 * t + i) * SXLD + 16 * q + 4 * g);
+        for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(sW + (16 * t + i) * SXLD + 16 * q + 4 * g);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < HT; ++t) acc[t] = OSA_MFMA(w[t][s], x[q][s], acc[t]);
-        }
+          for (int t = 0; t < HT; ++t) acc[t] = OSA_MFMA(w[t][s], x[q][s], acc[t]);
       }
       {
         f32x4* dst = reinterpret_cast<f32x4*>(xn + SX_PART + hc * 4096);
 #pragma unroll
         for (int t = 0; t < HT; ++t) dst[t * 256 + tid] = acc[t];
       }
-      osa_xch_release();
-      __syncthreads();  // partials performed; sX complete
-      if (tid == 0) __hip_atomic_store(flags + SF_PART + hc, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       STICK(0);
+      osa_xch_release();
+      osa_lds_barrier();  // partials performed; sX complete
+      if (tid == 0) __hip_atomic_store(flags + SF_PART + hc, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      STICK(1);
       // ---- gather the next step's columns while the leader works
       {
         const float* __restrict__ xrow = a.obs + row_nn * ld_obs;
@@ -256,9 +295,9 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       for (int q = 0; q < SKQ; ++q) wv[q] = *reinterpret_cast<const f32x4*>(sW + own_lds + 16 * q);
       // ---- dz1 of this step
       osa_xch_wait(flags + SF_DZ, 1, mb + 1, tid, err, dead);
-      __syncthreads();
+      osa_lds_barrier();
       osa_xch_acquire();
-      STICK(1);
+      STICK(2);
       f32x4 a1[4];
       {
         const float* dz = xn + SX_DZ;
@@ -271,15 +310,15 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       for (int q = 0; q < SKQ; ++q) gq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int sb = 0; sb < 4; ++sb) {
+        f32x4 b[SKQ];
 #pragma unroll
-        for (int q = 0; q < SKQ; ++q) {
-          if (q < nkb) {  // block-uniform
-            const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * q + i) * SSLD + 16 * sb + 4 * g);
+        for (int q = 0; q < SKQ; ++q) b[q] = *reinterpret_cast<const f32x4*>(sX + (16 * q + i) * SSLD + 16 * sb + 4 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) gq[q] = OSA_MFMA(b[s], a1[sb][s], gq[q]);
-          }
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int q = 0; q < SKQ; ++q) gq[q] = OSA_MFMA(b[q][s], a1[sb][s], gq[q]);
       }
+      STICK(3);
       f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) {
@@ -295,35 +334,31 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         red[2 * wave + 0] = gsq;
         red[2 * wave + 1] = psq;
       }
-      __syncthreads();
+      osa_lds_barrier();
       if (tid == 0) {
-        float* slot = xn + SX_NORM + 4 * hc;
-        slot[0] = (red[0] + red[2]) + (red[4] + red[6]);
-        slot[1] = (red[1] + red[3]) + (red[5] + red[7]);
-        osa_xch_release();
-        __hip_atomic_store(flags + SF_NORM + hc, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        osa_slot_put(slots + 2 * hc, (red[0] + red[2]) + (red[4] + red[6]), mb + 1);
+        osa_slot_put(slots + 2 * hc + 1, (red[1] + red[3]) + (red[5] + red[7]), mb + 1);
       }
-      STICK(2);
-      // ---- all norm shares
-      osa_xch_wait(flags + SF_NORM, C + 1, mb + 1, tid, err, dead);
-      __syncthreads();
-      osa_xch_acquire();
+      STICK(4);
+      // ---- all norm shares (lane k <= C polls share k; summed in slot order by everybody)
+      if (tid <= C) red[8 + tid] = osa_slot_wait(slots + 2 * tid, mb + 1, err, dead);
+      osa_lds_barrier();
       float t_gsq = 0.f;
-      for (int k = 0; k <= C; ++k) t_gsq += xn[SX_NORM + 4 * k];
-      const float step_size = xn[SX_NORM + 4 * C + 2], inv_bc2_sqrt = xn[SX_NORM + 4 * C + 3];
+      for (int k = 0; k <= C; ++k) t_gsq += red[8 + k];
+      const float step_size = sBC[2 * mb], inv_bc2_sqrt = sBC[2 * mb + 1];
       float gscale = 1.f;
       if (a.hp.use_max_grad_norm) {
         gscale = a.hp.max_grad_norm / (sqrtf(t_gsq) + 1e-6f);
         gscale = gscale > 1.f ? 1.f : gscale;
       }
-      STICK(3);
+      STICK(5);
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) {
         const f32x4 w = osa_adam_update4(gq[q] * gscale, m1[q], v1[q], wv[q], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
         *reinterpret_cast<f32x4*>(sW + own_lds + 16 * q) = w;
       }
-      __syncthreads();  // the slice is consistent; sX and red are free
-      STICK(4);
+      osa_lds_barrier();  // the slice is consistent; sX and red are free
+      STICK(6);
     }
     // ---- write back the slice and its moments
 #pragma unroll
@@ -335,8 +370,8 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       }
     }
 #ifdef OSA_SPLIT_CLOCKS
-    if (tid == 0 && hc == 0 && a.nmb >= 8)  // helper 0 of network `net` -> row nmb-1-net, columns 8..12
-      for (int k = 0; k < 5; ++k) a.stats[(long)(a.nmb - 1 - net) * SNSTAT + 8 + k] = (float)sdbg[k] / (float)a.nmb;
+    if (tid == 0 && hc == 0 && a.nmb >= 8)  // helper 0 of network `net` -> row net (long since consumed), columns 8..15
+      for (int k = 0; k < 8; ++k) a.stats[(long)net * SNSTAT + 8 + k] = (float)sdbg[k] / (float)a.nmb;
 #endif
     return;
   }
@@ -356,17 +391,34 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   float* sZ2 = sZ1 + H * SSLD;
   float* sDO = sZ2 + H * SSLD;            // [OUTP][SSLD]
   float* sDL = sDO + OUTP * SSLD;         // [OUTP][SSLD]
-  float* red = sDL + OUTP * SSLD;         // [16]
+  float* red = sDL + OUTP * SSLD;         // [64]
+  // transposed copies for the backward pass (its A operands W^T[16t+i][k .. k+3] are then ONE 16-byte LDS read
+  // instead of four scalar ones): kept in step by the Adam writers
+  constexpr int S3LD = OUTP + 4;
+  float* sW2T = red + 64;                 // [H][SSLD]   element (input feature f, output feature o) = W2[o][f]
+  float* sW3T = sW2T + H * SSLD;          // [H][S3LD]   element (input feature f, output o) = W3[o][f]
+  // per-dimension constants of the Gaussian log-density, refreshed by the thread that owns the log_std element
+  // whenever Adam changes it (every lane would otherwise evaluate exp / log / a division per element and step)
+  float* sVAR = sW3T + H * S3LD;          // [OUTP]  sigma^2 = exp(log_std)^2
+  float* sIV = sVAR + OUTP;               // [OUTP]  1 / sigma^2
+  float* sLC = sIV + OUTP;                // [OUTP]  log(sigma) (the reference evaluates scale.log())
   const bool leader = tid == 192;
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * SSLD + (e & 63)] = gp[nd.oW2 + e];
   for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * SSLD + (e & 63)] = gp[nd.oW3 + e];
+  for (int e = tid; e < H * H; e += 256) sW2T[(e & 63) * SSLD + (e >> 6)] = gp[nd.oW2 + e];
+  for (int e = tid; e < OUTP * H; e += 256) sW3T[(e & 63) * S3LD + (e >> 6)] = gp[nd.oW3 + e];
   if (tid < H) {
     sB1[tid] = gp[nd.ob1 + tid];
     sB2[tid] = gp[nd.ob2 + tid];
   }
   if (tid < OUTP) {
     sB3[tid] = gp[nd.ob3 + tid];
-    sLS[tid] = gp[nd.oLS + tid];
+    const float ls = gp[nd.oLS + tid];
+    sLS[tid] = ls;
+    const float sd = expf(ls);
+    sVAR[tid] = sd * sd;
+    sIV[tid] = 1.f / (sd * sd);
+    sLC[tid] = logf(sd);
   }
   // ownership (as osa_ppo_pass_kernel): W2[(16w+4g+r)][16ti+cc], W3[(16o+4g+r)][16w+cc], one bias-like
   // scalar per thread; Adam moments in registers
@@ -472,14 +524,26 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(sB1 + 16 * t + 4 * g);
     osa_xch_wait(flags + SF_PART, C, mb + 1, tid, err, dead);
-    __syncthreads();
+    osa_lds_barrier();
     osa_xch_acquire();
     STICK(0);
     {
+      // all C x 4 loads in flight together (one round trip to the device-coherent level, not C)
       const f32x4* src = reinterpret_cast<const f32x4*>(xn + SX_PART);
-      for (int k = 0; k < C; ++k) {
+      f32x4 pt[SCMAX][HT];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) h1[t] = h1[t] + src[k * 1024 + t * 256 + tid];
+      for (int k = 0; k < SCMAX; ++k) {
+        if (k < C) {  // block-uniform
+#pragma unroll
+          for (int t = 0; t < HT; ++t) pt[k][t] = src[k * 1024 + t * 256 + tid];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SCMAX; ++k) {
+        if (k < C) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) h1[t] = h1[t] + pt[k][t];
+        }
       }
     }
 #pragma unroll
@@ -516,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       }
     }
     // ================= loss, dL/d(out) (osa_mb_grad_kernel's code path without extensions) =================
+    STICK(1);
     f32x4 dO[OT], dLS[OT];
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
@@ -534,12 +599,10 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
           zv[o][r] = 0.f;
           ivar[o][r] = 0.f;
           if (d < nd.act_dim && valid) {
-            const float sd = expf(sLS[d]);
-            const float var = sd * sd;
             const float z = s_act[4 * o + r] - out[o][r];
             zv[o][r] = z;
-            ivar[o][r] = 1.f / var;
-            lp += -(z * z) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+            ivar[o][r] = sIV[d];
+            lp += -(z * z) / (2.f * sVAR[d]) - sLC[d] - 0.91893853320467274178f;
           }
         }
       }
@@ -587,12 +650,10 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     for (int t = 0; t < HT; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
+      for (int o = 0; o < OT; ++o) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3T + (16 * t + i) * S3LD + 16 * o + 4 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
-          const float w = sW3[(16 * o + 4 * g + s) * SSLD + 16 * t + i];
-          acc = OSA_MFMA(w, dO[o][s], acc);
-        }
+        for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[s], dO[o][s], acc);
       }
       z2[t] = acc * (1.f - h2[t] * h2[t]);
       SPUT_TILE(sZ2, z2[t], t);
@@ -603,12 +664,10 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       for (int t = 0; t < HT; ++t) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {
+        for (int kb = 0; kb < HT; ++kb) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sW2T + (16 * t + i) * SSLD + 16 * kb + 4 * g);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
-            const float w = sW2[(16 * kb + 4 * g + s) * SSLD + 16 * t + i];
-            acc = OSA_MFMA(w, z2[kb][s], acc);
-          }
+          for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[s], z2[kb][s], acc);
         }
         z1[t] = acc * (1.f - h1[t] * h1[t]);
         // dz1 leaves for the helpers as soon as a tile is finished: row = feature, 16 consecutive samples per
@@ -623,10 +682,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       SPUT_TILE(sDO, dO[o], o);
       SPUT_TILE(sDL, dLS[o], o);
     }
+    STICK(2);
     osa_xch_release();
-    __syncthreads();  // (A) dz1 performed, tiles complete
+    osa_lds_barrier();  // (A) dz1 performed, tiles complete
     if (tid == 0) __hip_atomic_store(flags + SF_DZ, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    STICK(1);
+    STICK(3);
     // ---- the next step's scalars (used after the next hand-off)
     gather(row_nn);
     row_nxt = row_nn;
@@ -661,6 +721,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         }
       }
     }
+    STICK(4);
     // bias-like gradient owned by this thread: row sum over the 64 samples
     float gb = 0.f;
     {
@@ -726,26 +787,22 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       red[4 * wave + 2] = loss_part;
       red[4 * wave + 3] = ratio_part;
     }
-    __syncthreads();  // (B)
+    STICK(5);
+    osa_lds_barrier();  // (B)
     if (tid == 0) {
-      float* slot = xn + SX_NORM + 4 * C;
-      slot[0] = red[0] + red[4] + red[8] + red[12];
-      slot[1] = red[1] + red[5] + red[9] + red[13];
-      slot[2] = step_size;
-      slot[3] = inv_bc2_sqrt;
-      osa_xch_release();
-      __hip_atomic_store(flags + SF_NORM + C, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      osa_slot_put(slots + 2 * C, red[0] + red[4] + red[8] + red[12], mb + 1);
+      osa_slot_put(slots + 2 * C + 1, red[1] + red[5] + red[9] + red[13], mb + 1);
     }
     const float t_loss = red[2] + red[6] + red[10] + red[14];
     const float t_ratio = red[3] + red[7] + red[11] + red[15];
-    STICK(2);
-    osa_xch_wait(flags + SF_NORM, C + 1, mb + 1, tid, err, dead);
-    __syncthreads();
-    osa_xch_acquire();
+    STICK(6);
+    if (tid <= C) red[16 + tid] = osa_slot_wait(slots + 2 * tid, mb + 1, err, dead);
+    else if (tid >= 64 && tid - 64 <= C) red[24 + tid - 64] = osa_slot_wait(slots + 2 * (tid - 64) + 1, mb + 1, err, dead);
+    osa_lds_barrier();
     float t_gsq = 0.f, t_psq = 0.f;
     for (int k = 0; k <= C; ++k) {
-      t_gsq += xn[SX_NORM + 4 * k];
-      t_psq += xn[SX_NORM + 4 * k + 1];
+      t_gsq += red[16 + k];
+      t_psq += red[24 + k];
     }
     const float total_norm = sqrtf(t_gsq);
     float gscale = 1.f;
@@ -753,25 +810,34 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       gscale = a.hp.max_grad_norm / (total_norm + 1e-6f);
       gscale = gscale > 1.f ? 1.f : gscale;
     }
-    STICK(3);
+    STICK(7);
     // ================= Adam =================
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
       const f32x4 w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w2r[ti], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * SSLD + 16 * ti + cc] = w[r];
+      *reinterpret_cast<f32x4*>(sW2T + (16 * ti + cc) * SSLD + 16 * wave + 4 * g) = w;
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       const f32x4 w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w3r[o], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * SSLD + 16 * wave + cc] = w[r];
+      *reinterpret_cast<f32x4*>(sW3T + (16 * wave + cc) * S3LD + 16 * o + 4 * g) = w;
     }
     if (boff >= 0) {
       float mv_ = mb_, vv_ = vb_;
-      *sbias = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+      const float nw = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+      *sbias = nw;
       mb_ = mv_;
       vb_ = vv_;
+      if (boff >= nd.oLS) {  // (actor only) the log-density constants of the new log_std
+        const float sd = expf(nw);
+        sVAR[boff - nd.oLS] = sd * sd;
+        sIV[boff - nd.oLS] = 1.f / (sd * sd);
+        sLC[boff - nd.oLS] = logf(sd);
+      }
     }
     if (leader) {
       float* st = a.stats + (long)mb * SNSTAT;
@@ -786,13 +852,13 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         st[7 + net] = total_norm;
       }
     }
-    __syncthreads();  // (C) frees tiles and `red`; the LDS master copy is consistent
-    STICK(4);
+    osa_lds_barrier();  // (C) frees tiles and `red`; the LDS master copy is consistent
+    STICK(0);
   }
 #undef SPUT_TILE
 #ifdef OSA_SPLIT_CLOCKS
-  if (tid == 0 && a.nmb >= 8)  // leader of network `net` -> row nmb-1-net, columns 0..4: mean cycles per step
-    for (int k = 0; k < 5; ++k) a.stats[(long)(a.nmb - 1 - net) * SNSTAT + k] = (float)sdbg[k] / (float)a.nmb;
+  if (tid == 0 && a.nmb >= 8)  // leader of network `net` -> row net, columns 0..7: mean cycles per step
+    for (int k = 0; k < 8; ++k) a.stats[(long)net * SNSTAT + k] = (float)sdbg[k] / (float)a.nmb;
 #endif
   // ---- write back: LDS master copy, Adam state
   for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * SSLD + (e & 63)];
@@ -828,11 +894,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   if (tid == 0) a.adam_step[net] = step0 + a.nmb;
 }
 
-static size_t osa_split_lds_bytes(int OT) {
+static size_t osa_split_lds_bytes(int OT, int nmb) {
   const int H = 64, OUTP = 16 * OT;
   const size_t lead = (size_t)H * SSLD + (size_t)OUTP * SSLD + 2 * H + 2 * OUTP + 4 * (size_t)H * SSLD +
-                      2 * (size_t)OUTP * SSLD + 64;
-  const size_t help = (size_t)H * SXLD + 16 * SKQ * (size_t)SSLD + 64;
+                      2 * (size_t)OUTP * SSLD + 64 + (size_t)H * SSLD + (size_t)H * (OUTP + 4) + 3 * OUTP;
+  const size_t help = (size_t)H * SXLD + 16 * SKQ * (size_t)SSLD + 16 + 2 * (size_t)nmb;
   return (lead > help ? lead : help) * sizeof(float);
 }
 
@@ -841,7 +907,7 @@ extern "C" bool osa_is_exchange_ptr(const void* p);  // ppo_pass_kernel.hip
 template <int OT>
 static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds = osa_split_lds_bytes(OT);
+  const size_t lds = osa_split_lds_bytes(OT, a.nmb);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
@@ -881,6 +947,7 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
                        float* xch, float* step_stats, void* stream) {
   if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;  // larger batches: per-step kernels
+  if ((M + B - 1) / B > 8192) return OSA_EUNSUPPORTED;  // the helpers tabulate Adam's bias corrections in LDS
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && xch);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
@@ -891,7 +958,6 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   a.xch = xch;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.C = (a.nd.KB + SKQ - 1) / SKQ;
-  a.kbper = (a.nd.KB + a.C - 1) / a.C;
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
   a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
@@ -905,6 +971,8 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   hipStream_t st = osa_stream(stream);
   // flag words are step counters of THIS launch (the sticky error word, SF_ERR, survives)
   if (hipMemsetAsync(xch, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  for (int n = 0; n < 3; ++n)  // the squared-norm slots carry their own step counters
+    if (hipMemsetAsync(xch + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
   const int OT = a.nd.OUTP / 16;
   if (OT == 1) return osa_launch_split<1>(a, st);
   if (OT == 2) return osa_launch_split<2>(a, st);

@@ -43,12 +43,12 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32), (90, 17), (200, 8)):
         us = a.elapsed_time(b) * 1e3 / out['steps']
         if persistent and split == '1' and 'sclocks' in os.environ.get('OSA_LIB_PATH', ''):
             st = out['stats'].cpu().numpy()
-            ln = ['wait partials', 'sum..dz1 published', 'dW2/dW3/norm share', 'norm all-gather', 'Adam+barrier']
-            hn = ['stage x+fwd partial+publish', 'wait dz1', 'dW1+norm share', 'norm all-gather', 'Adam+barrier']
+            ln = ['wait partials', 'sum+forward', 'loss+backward+dz stores', 'publish dz1', 'dW2/dW3/norm share', 'norm all-gather', 'Adam+barrier']
+            hn = ['stage x+partial', 'publish', 'wait dz1', 'dW1', 'norm share', 'norm all-gather', 'Adam+barrier']
             for net in range(3):
-                row = st[out['steps'] - 1 - net]
-                print(f'   net {net} leader cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(ln, row[:5])) + f'  total={row[:5].sum():.0f}')
-                print(f'   net {net} helper0 cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(hn, row[8:13])) + f'  total={row[8:13].sum():.0f}')
+                row = st[net]
+                print(f'   net {net} leader cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(ln + ['x'], row[:8])) + f'  total={row[:8].sum():.0f}')
+                print(f'   net {net} helper0 cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(hn, row[8:15])) + f'  total={row[8:15].sum():.0f}')
         elif persistent and split == '0' and 'wclocks' in os.environ.get('OSA_LIB_PATH', ''):
             st = out['stats'].cpu().numpy()
             names = ['fwd L1', 'fwd rest+loss+bwd', 'dW2/dW3/bias', 'dW1', 'norm+barrier', 'Adam W1', 'Adam rest+barrier']
