@@ -264,12 +264,16 @@ int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float
 /* osa_ppo_wide_pass with the first layer SPLIT over cooperating compute units (csrc/wide_split_kernel.hip):
  * a network is 1 + ceil(KB / 6) workgroups of one cooperative launch -- every helper owns <= 96 input columns of
  * W1 (LDS) and their Adam moments (registers) for the whole pass, the leader owns the other layers; three
- * hand-offs per step (partial pre-activations, dz1, squared-norm shares) through `xch`, which MUST come from
- * osa_dp_exchange_alloc(osa_ppo_split_pass_xch_floats(...)) (uncached device memory; OSA_EINVAL otherwise).
+ * hand-offs per step (partial pre-activations, dz1, squared-norm shares) through `xch`
+ * (osa_ppo_split_pass_xch_floats floats, zero-initialised once).  local = 0: the workgroups are spread over the
+ * XCCs and xch MUST come from osa_dp_exchange_alloc (uncached device memory; OSA_EINVAL otherwise).  local = 1:
+ * the workgroups of a network are placed on ONE XCC (blocks net + 8 role of an 8 (C + 1) grid) and xch MUST be
+ * ordinary device memory: the hand-offs are then served by that XCC's L2; the kernel verifies the placement
+ * (XCC_ID of every workgroup) and raises the sticky flag with value 2 if it does not hold.
  * Same arguments, statistics and per-step arithmetic as osa_ppo_wide_pass (float32 re-association of the
  * layer-1 sum only).  OSA_EUNSUPPORTED when the shape is not supported or the device cannot hold the
  * workgroups together: use osa_ppo_wide_pass.  A peer that never arrives raises a sticky flag instead of
- * hanging the device: osa_ppo_split_pass_timed_out(xch, &flag) reads it (synchronous copy). */
+ * hanging the device: osa_ppo_split_pass_timed_out(xch, &flag) reads it (synchronous copy; 0 = fine). */
 int osa_ppo_split_pass_supported(int obs_dim, int act_dim, int hidden);
 size_t osa_ppo_split_pass_xch_floats(int obs_dim, int act_dim, int hidden);
 int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -277,7 +281,7 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
                        const float* logp, const float* target_value_r, const float* target_value_c,
                        const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                        const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                       float* xch, float* step_stats, void* stream);
+                       float* xch, int local, float* step_stats, void* stream);
 int osa_ppo_split_pass_timed_out(const float* xch, int* out);
 /* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
  * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);

@@ -43,6 +43,7 @@
 #define SF_PART 0                          // flag words of a network: [32 net + ..]
 #define SF_DZ 8
 #define SF_NORM 16
+#define SF_XCC 25                          // bit mask of the XCCs the network's workgroups ran on
 #define SF_ERR 96                          // sticky: a peer never arrived
 
 struct OsaSplitHp {
@@ -77,6 +78,7 @@ struct OsaSplitArgs {
   float* stats;  // [nmb][SNSTAT]
   float* xch;    // uncached exchange buffer (osa_ppo_split_pass_xch_floats)
   int C;         // helpers per network
+  int local;     // 1: one XCC per network, cached exchange buffer (see the kernel)
 };
 
 #ifdef OSA_SPLIT_CLOCKS
@@ -151,7 +153,19 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   constexpr int H = 64, HT = 4, OUTP = 16 * OT;
   const OsaNet& nd = a.nd;
   const int C = a.C;
-  const int net = blockIdx.x / (C + 1), role = blockIdx.x - net * (C + 1);  // role 0: leader, 1 + c: helper c
+  // placement: workgroup b of a grid runs on XCC b mod 8 (tools/xcd_probe.hip).  `local`: the C + 1 workgroups of
+  // a network are the blocks b = net + 8 role, i.e. they share ONE XCC and its L2, and the exchange buffer is
+  // ordinary cached memory (a hand-off then costs L2 round trips, not trips to the device-coherent level);
+  // otherwise consecutive blocks (spread over the XCCs) and an uncached buffer.  role 0: leader, 1 + c: helper c
+  int net, role;
+  if (a.local) {
+    net = blockIdx.x & 7;
+    role = blockIdx.x >> 3;
+    if (net >= 3) return;
+  } else {
+    net = blockIdx.x / (C + 1);
+    role = blockIdx.x - net * (C + 1);
+  }
   if (!((a.nets_mask >> net) & 1)) return;
   const int KB = nd.KB, INP = nd.INP, P = nd.P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -168,6 +182,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   const float c2 = 2.f * a.hp.critic_norm_coef;
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
   bool dead = false;
+  if (tid == 0) {  // which XCCs this network's workgroups run on (host-readable; `local` requires exactly one)
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
+    const int seen = __hip_atomic_fetch_or(flags + SF_XCC, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (1 << xcc);
+    if (a.local && (seen & (seen - 1)) != 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef OSA_SPLIT_CLOCKS
   long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long slast = clock64();
@@ -721,7 +740,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         }
       }
     }
-    STICK(4);
     // bias-like gradient owned by this thread: row sum over the 64 samples
     float gb = 0.f;
     {
@@ -787,7 +805,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       red[4 * wave + 2] = loss_part;
       red[4 * wave + 3] = ratio_part;
     }
-    STICK(5);
+    STICK(4);
     osa_lds_barrier();  // (B)
     if (tid == 0) {
       osa_slot_put(slots + 2 * C, red[0] + red[4] + red[8] + red[12], mb + 1);
@@ -795,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     }
     const float t_loss = red[2] + red[6] + red[10] + red[14];
     const float t_ratio = red[3] + red[7] + red[11] + red[15];
-    STICK(6);
+    STICK(5);
     if (tid <= C) red[16 + tid] = osa_slot_wait(slots + 2 * tid, mb + 1, err, dead);
     else if (tid >= 64 && tid - 64 <= C) red[24 + tid - 64] = osa_slot_wait(slots + 2 * (tid - 64) + 1, mb + 1, err, dead);
     osa_lds_barrier();
@@ -810,7 +828,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       gscale = a.hp.max_grad_norm / (total_norm + 1e-6f);
       gscale = gscale > 1.f ? 1.f : gscale;
     }
-    STICK(7);
+    STICK(6);
     // ================= Adam =================
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
@@ -853,7 +871,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       }
     }
     osa_lds_barrier();  // (C) frees tiles and `red`; the LDS master copy is consistent
-    STICK(0);
+    STICK(7);
   }
 #undef SPUT_TILE
 #ifdef OSA_SPLIT_CLOCKS
@@ -920,7 +938,8 @@ static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   OsaSplitArgs arg = a;
   void* kargs[] = {&arg};
   const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
-                                                  dim3(3 * (a.C + 1)), dim3(256), kargs, (unsigned)lds, stream);
+                                                  dim3(a.local ? 8 * (a.C + 1) : 3 * (a.C + 1)), dim3(256), kargs,
+                                                  (unsigned)lds, stream);
   if (e == hipSuccess) return OSA_OK;
   (void)hipGetLastError();
   return e == hipErrorCooperativeLaunchTooLarge ? OSA_EUNSUPPORTED : OSA_EHIP;
@@ -944,18 +963,20 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
                        const float* logp, const float* target_value_r, const float* target_value_c,
                        const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                        const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                       float* xch, float* step_stats, void* stream) {
+                       float* xch, int local, float* step_stats, void* stream) {
   if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;  // larger batches: per-step kernels
   if ((M + B - 1) / B > 8192) return OSA_EUNSUPPORTED;  // the helpers tabulate Adam's bias corrections in LDS
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && xch);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
-  if (!osa_is_exchange_ptr(xch)) return OSA_EINVAL;  // the hand-offs rely on uncached memory
+  if (!local && !osa_is_exchange_ptr(xch)) return OSA_EINVAL;  // hand-offs across XCCs rely on uncached memory
+  if (local && osa_is_exchange_ptr(xch)) return OSA_EINVAL;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad the rows
   if ((double)M * ld_obs >= 2147483647.0 * 4) return OSA_EUNSUPPORTED;
   OsaSplitArgs a = {};
   a.xch = xch;
+  a.local = local ? 1 : 0;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.C = (a.nd.KB + SKQ - 1) / SKQ;
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -979,7 +1000,8 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   return OSA_EUNSUPPORTED;
 }
 
-// 1 when a workgroup of any split pass since the allocation of `xch` gave up waiting for a peer
+// != 0 when a workgroup of any split pass since the allocation of `xch` gave up waiting for a peer (1) or the
+// workgroups of a network of a `local` pass were NOT placed on one XCC (2): results invalid
 int osa_ppo_split_pass_timed_out(const float* xch, int* out) {
   OSA_REQUIRE(xch && out);
   return hipMemcpy(out, reinterpret_cast<const int*>(xch) + SF_ERR, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess

@@ -74,6 +74,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._use_wide = False
         self._split_xch: int | None = None  # uncached exchange buffer of the split wide pass (raw pointer)
         self._split_tried = False
+        self._split_local = False
+        self._split_buf = None
 
     def _split_alloc(self) -> None:
         """Exchange buffer of osa_ppo_split_pass (uncached device memory; OSA_WIDE_SPLIT=0 keeps the one-CU
@@ -86,14 +88,22 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 self.lib.osa_ppo_split_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)):
             return
         n = self.lib.osa_ppo_split_pass_xch_floats(ac.obs_dim, ac.act_dim, ac.hidden)
+        # OSA_WIDE_SPLIT=local (default): one XCC per network, hand-offs through its L2 (ordinary memory);
+        # OSA_WIDE_SPLIT=spread: workgroups over all XCCs, uncached exchange buffer
+        self._split_local = os.environ.get('OSA_WIDE_SPLIT', 'local') != 'spread'
+        if self._split_local:
+            self._split_buf = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
+            self._split_xch = self._split_buf.data_ptr()
+            return
         p = C.c_void_p()
         if self.lib.osa_dp_exchange_alloc(max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
             self._split_xch = p.value
 
     def _split_free(self) -> None:
-        if self._split_xch:
+        if self._split_xch and not getattr(self, '_split_local', False):
             self.lib.osa_dp_exchange_free(C.c_void_p(self._split_xch))
         self._split_xch = None
+        self._split_buf = None
 
     def check_split_sync(self) -> None:
         """Raises if a workgroup of a split wide pass ever gave up waiting for a peer (sticky device flag)."""
@@ -102,7 +112,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.check(self.lib.osa_ppo_split_pass_timed_out(C.c_void_p(self._split_xch), C.byref(flag)),
                        'osa_ppo_split_pass_timed_out')
             if flag.value:
-                raise _lib.OsaError('osa_ppo_split_pass: a cooperating workgroup never arrived (results invalid)')
+                raise _lib.OsaError('osa_ppo_split_pass: ' + (
+                    'the workgroups of a network were not placed on one XCC; set OSA_WIDE_SPLIT=spread'
+                    if flag.value == 2 else 'a cooperating workgroup never arrived') + ' (results invalid)')
 
     # ------------------------------------------------------------------
     def _nets_mask(self) -> int:
@@ -160,7 +172,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
                 _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
                 C.byref(self.hp), self.loss_kind, self._nets_mask(), C.c_void_p(self._split_xch),
-                _lib.ptr(stats_rows), _lib.stream_ptr())
+                int(self._split_local), _lib.ptr(stats_rows), _lib.stream_ptr())
             if rc == _lib.OSA_EUNSUPPORTED:  # the device cannot hold the workgroups together: one CU per network
                 self._split_free()
             else:

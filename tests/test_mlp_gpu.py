@@ -258,8 +258,9 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
 
     narrow = bool(_lib.load().osa_ppo_pass_supported(obs_dim, act_dim, 64))
     variants = [(True, '1', 'persistent' if narrow else 'persistent-wide-split'), (False, '1', 'per-step')]
-    if not narrow:
-        variants.insert(1, (True, '0', 'persistent-wide'))
+    if not narrow:  # '1' = one XCC per network (L2 hand-offs); 'spread' = all XCCs, uncached exchange buffer
+        variants.insert(1, (True, 'spread', 'persistent-wide-split'))
+        variants.insert(2, (True, '0', 'persistent-wide'))
 
     torch.manual_seed(obs_dim + act_dim)
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),

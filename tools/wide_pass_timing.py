@@ -27,7 +27,7 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32), (90, 17), (200, 8)):
             'target_value_c': torch.randn(M, device=DEV), 'adv_r': torch.randn(M, device=DEV),
             'adv_c': torch.randn(M, device=DEV)}
     lam = torch.tensor([0.2], device=DEV)
-    for persistent, split in ((True, '1'), (True, '0'), (False, '1')):
+    for persistent, split in ((True, 'local'), (True, 'spread'), (True, '0'), (False, '1')):
         os.environ['OSA_WIDE_SPLIT'] = split
         ac = make_ac(obs_dim, act_dim)
         up = PPOUpdater(ac, batch_size=64, update_iters=1, target_kl=0.02, kl_early_stop=False,
@@ -41,13 +41,13 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32), (90, 17), (200, 8)):
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / out['steps']
-        if persistent and split == '1' and 'sclocks' in os.environ.get('OSA_LIB_PATH', ''):
+        if persistent and split in ('local', 'spread') and 'sclocks' in os.environ.get('OSA_LIB_PATH', ''):
             st = out['stats'].cpu().numpy()
-            ln = ['wait partials', 'sum+forward', 'loss+backward+dz stores', 'publish dz1', 'dW2/dW3/norm share', 'norm all-gather', 'Adam+barrier']
+            ln = ['wait partials', 'sum+forward', 'loss+backward+dz stores', 'publish dz1', 'dW2/dW3/bias/norm share', 'barrier+put', 'wait norm shares', 'Adam+barrier']
             hn = ['stage x+partial', 'publish', 'wait dz1', 'dW1', 'norm share', 'norm all-gather', 'Adam+barrier']
             for net in range(3):
                 row = st[net]
-                print(f'   net {net} leader cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(ln + ['x'], row[:8])) + f'  total={row[:8].sum():.0f}')
+                print(f'   net {net} leader cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(ln, row[:8])) + f'  total={row[:8].sum():.0f}')
                 print(f'   net {net} helper0 cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(hn, row[8:15])) + f'  total={row[8:15].sum():.0f}')
         elif persistent and split == '0' and 'wclocks' in os.environ.get('OSA_LIB_PATH', ''):
             st = out['stats'].cpu().numpy()
@@ -55,7 +55,8 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32), (90, 17), (200, 8)):
             for net in range(3):
                 row = st[out['steps'] - 1 - net, :7]
                 print(f'   net {net} cycles/step: ' + '  '.join(f'{n}={v:.0f}' for n, v in zip(names, row)) + f'  total={row.sum():.0f}')
-        res[f'{obs_dim}/{act_dim} {up.last_path}'] = round(us, 2)
-        print(f'{obs_dim}/{act_dim}: {up.last_path:16s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
+        tag = up.last_path + (f' ({split})' if up.last_path.endswith('split') else '')
+        res[f'{obs_dim}/{act_dim} {tag}'] = round(us, 2)
+        print(f'{obs_dim}/{act_dim}: {tag:32s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2_wide_pass_timing.json'), 'w'), indent=1)
