@@ -344,6 +344,19 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
                     const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                     const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                     float* exchange, int* sync, float* step_stats, void* stream);
+/* osa_ppo_dp_pass with an explicit placement.  local = 0: as osa_ppo_dp_pass (grid 3 x world, spread over the
+ * XCCs; `exchange` uncached or ordinary memory).  local = 1: the `world` workgroups of a network are the blocks
+ * net + 8 r of an 8 x world grid, i.e. they run on ONE XCC, and `exchange` MUST be ordinary device memory
+ * (OSA_EINVAL for an osa_dp_exchange_alloc buffer): the hand-offs are served by that XCC's L2.  sync: int[8]
+ * (zeroed once by the caller): sync[4..6] receive the bit masks of the XCCs each network's workgroups ran on;
+ * a network that finds more than one bit sets the sticky flag sync[3] to 2 (results invalid: use local = 0).
+ * world <= CUs / 8. */
+int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                    int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                    const float* logp, const float* target_value_r, const float* target_value_c,
+                    const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                    const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                    float* exchange, int* sync, int local, float* step_stats, void* stream);
 
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */

@@ -85,6 +85,9 @@ struct OsaPassArgs {
   // 1: dp_slabs lives in device memory allocated uncached (osa_dp_exchange_alloc): every access is served by
   // the device-coherent level, so the hand-off needs no L2 write-back / invalidate (~2.5k cycles per step)
   int dp_uncached;
+  // 1: the `world` workgroups of a network are blocks net + 8 rk of a 1-D grid, i.e. they run on ONE XCC
+  // (workgroup b of a grid lands on XCC b mod 8) and dp_slabs is ordinary memory served by that XCC's L2
+  int dp_local;
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -108,9 +111,16 @@ template <int KB, int OT, bool MULTI, bool COOP, bool EXT>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
-  const int net = blockIdx.x;
+  int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
+  if constexpr (COOP) {
+    if (a.dp_local) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
+      net_ = blockIdx.x & 7;
+      rk_ = blockIdx.x >> 3;
+      if (net_ >= 3) return;
+    }
+  }
+  const int net = net_, rk = rk_;
   if (!((a.nets_mask >> net) & 1)) return;
-  const int rk = blockIdx.y;  // virtual rank (0 outside the data-parallel mode)
   constexpr bool coop = COOP;
   const bool dp = a.dp_slabs != nullptr && !coop;
   const bool part = MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
@@ -337,6 +347,13 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   long long dbg_last = clock64();
 #endif
   bool coop_dead = false;
+  if constexpr (COOP) {
+    if (a.dp_local && threadIdx.x == 0) {  // verify the placement: all workgroups of the network on one XCC
+      const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
+      const int seen = __hip_atomic_fetch_or(a.dp_sync + 4 + net, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (1 << xcc);
+      if ((seen & (seen - 1)) != 0) __hip_atomic_store(a.dp_sync + 3, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   const float invB_full = 1.f / (float)a.B;
   for (int mb = a.mb0; mb < a.mb0 + a.nmb; ++mb) {
@@ -930,9 +947,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
         t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
       }
-      if (a.dp_uncached) {
+      if (a.dp_uncached || a.dp_local) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);  // the (uncached) slab stores have been performed at device scope
+        // the slab stores have been performed: at device scope (uncached memory) / in the XCC's L2 (local)
+        __builtin_amdgcn_s_waitcnt(0);
       } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       }
@@ -958,7 +976,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         }
       }
       __syncthreads();
-      if (!a.dp_uncached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // always an L1 invalidate: the vector L1 also keeps lines of UNCACHED memory between two reads of the
+      // same address (observed in wide_split_kernel.hip with small working sets; the double-buffered 38 KB
+      // slabs here never showed it, which is luck, not a guarantee)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       PTICK(10);
       // ---- sum the W gradients in rank order (same order on every peer), average
       f32x4 s2[HT], s1[KB], s3[OT];
@@ -1128,6 +1149,7 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
+  const dim3 grid = (COOP && a.dp_local) ? dim3(8 * grid_y) : dim3(3, grid_y);
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
@@ -1147,7 +1169,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), dim3(3, grid_y),
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1161,9 +1183,9 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
-    if ((long)per_cu * cus < 3L * grid_y) return OSA_EUNSUPPORTED;
+    if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), dim3(3, grid_y), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1425,7 +1447,19 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
                     const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                     const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                     float* exchange, int* sync, float* step_stats, void* stream) {
+  return osa_ppo_dp_pass_placed(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act,
+                                ld_act, logp, target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world,
+                                lagrange, hp, loss_kind, nets_mask, exchange, sync, 0, step_stats, stream);
+}
+
+int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                           int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                           const float* logp, const float* target_value_r, const float* target_value_c,
+                           const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                           const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                           float* exchange, int* sync, int local, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(exchange && sync && ld_obs >= obs_dim && ld_act >= act_dim);
@@ -1436,8 +1470,9 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return OSA_EHIP;
-  if (3 * world > cus) return OSA_EUNSUPPORTED;
+  if (3 * world > cus || (local && world > cus / 8)) return OSA_EUNSUPPORTED;
   OsaPassArgs a = {};
+  a.dp_local = local ? 1 : 0;
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -1456,6 +1491,7 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
   // it survives the per-pass reset so that a timeout in any pass of an update is still visible when the
   // host reads it (the caller zeroes all four words once, at allocation)
   if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if (local && hipMemsetAsync(sync + 4, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \

@@ -287,26 +287,31 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             n = lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
             # uncached device memory for the hand-off (no L2 write-back / invalidate per step); an ordinary
             # tensor if the runtime refuses (OSA_DP_XCH=cached forces that)
+            # OSA_DP_XCH=local (default while world <= CUs / 8): one XCC per network, ordinary memory served by
+            # that XCC's L2 (osa_ppo_dp_pass_placed(local = 1), placement verified on the device)
             p = C.c_void_p()
-            if os.environ.get('OSA_DP_XCH', 'uncached') == 'uncached' and lib.osa_dp_exchange_alloc(
+            mode = os.environ.get('OSA_DP_XCH', 'local')
+            cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
+            st['local'] = mode == 'local' and W <= cus // 8
+            if not st['local'] and mode in ('local', 'uncached') and lib.osa_dp_exchange_alloc(
                     max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
                 st['xch_ptr'], st['xch'] = p.value, None
             else:
                 st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
                 st['xch_ptr'] = st['xch'].data_ptr()
-            st['sync'] = torch.zeros(4, dtype=torch.int32, device=ac.device)
-        rc = lib.osa_ppo_dp_pass(
+            st['sync'] = torch.zeros(8, dtype=torch.int32, device=ac.device)
+        rc = lib.osa_ppo_dp_pass_placed(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),
             data_all['obs'].stride(0), _lib.ptr(data_all['act']), data_all['act'].stride(0),
             _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
             _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
             _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp),
-            self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']),
+            self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']), int(st['local']),
             _lib.ptr(st['pass_stats']), _lib.stream_ptr())
         if rc == _lib.OSA_EUNSUPPORTED:
             return False
-        _lib.check(rc, 'osa_ppo_dp_pass')
+        _lib.check(rc, 'osa_ppo_dp_pass_placed')
         st['coop_passes'] = st.get('coop_passes', 0) + 1
         return True
 
@@ -318,6 +323,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         not a silent fallback."""
         st = self._dp
         if 'sync' in st and int(st['sync'][3]) != 0:
+            if int(st['sync'][3]) == 2:
+                raise RuntimeError('osa_ppo_dp_pass_placed: the workgroups of a network were not placed on one XCC '
+                                   '(results invalid); set OSA_DP_XCH=uncached')
             raise RuntimeError('osa_ppo_dp_pass: a peer workgroup timed out (workgroups not co-resident?); '
                                'set OSA_DP_MODE=replicated-steps')
 

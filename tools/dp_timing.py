@@ -17,10 +17,13 @@ for W in (1, 2, 4, 8):
     data = {'obs': torch.randn(W * M, 60, device=dev), 'act': torch.randn(W * M, 2, device=dev), 'logp': torch.randn(W * M, device=dev) - 2,
             'target_value_r': torch.randn(W * M, device=dev), 'target_value_c': torch.randn(W * M, device=dev),
             'adv_r': torch.randn(W * M, device=dev), 'adv_c': torch.randn(W * M, device=dev)}
-    up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
-    up.hp.lr_actor = up.hp.lr_critic = 3e-4
     lam = torch.zeros(1, device=dev); st = torch.zeros(1024, 16, device=dev)
-    for coop, use_graph in ((True, False), (False, True)):
+    # cooperative pass with one XCC per network (L2 hand-offs) / spread over the XCCs with an uncached exchange
+    # buffer; then the two-launches-per-step graph
+    for coop, use_graph, xch in ((True, False, 'local'), (True, False, 'uncached'), (False, True, 'uncached')):
+        os.environ['OSA_DP_XCH'] = xch
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
+        up.hp.lr_actor = up.hp.lr_critic = 3e-4
         for _ in range(2):
             up.run_pass_replicated(data, M, W, lam, st, use_graph=use_graph, coop=coop)
         torch.cuda.synchronize()
@@ -35,4 +38,4 @@ for W in (1, 2, 4, 8):
             d = dbg.cpu().numpy().reshape(3, 16)[:, :13] / 1024.0
             names = ['prefetch', 'fwd', 'loss', 'bwd', 'transpose+barA', 'dW', 'bias+norms', 'barB', 'adam', 'stats+barC', 'wait+acquire', 'reduce', 'publish+release']
             print('   cycles/step (actor, V_r, V_c): ' + '  '.join(f'{n}={d[0, i]:.0f}/{d[1, i]:.0f}/{d[2, i]:.0f}' for i, n in enumerate(names)))
-        print(f'W={W} coop={coop} graph={use_graph}: {e0.elapsed_time(e1):8.2f} ms per pass = {e0.elapsed_time(e1)*1e3/1024:6.2f} us per optimiser step', flush=True)
+        print(f'W={W} coop={coop} graph={use_graph} xch={xch if coop else "-"}: {e0.elapsed_time(e1):8.2f} ms per pass = {e0.elapsed_time(e1)*1e3/1024:6.2f} us per optimiser step', flush=True)
