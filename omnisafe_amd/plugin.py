@@ -16,6 +16,26 @@ ACCELERATED = ('PolicyGradient', 'PPO', 'PPOLag', 'NaturalPG', 'TRPO', 'TRPOLag'
 
 
 _saved_entries: dict[str, type] = {}  # the reference's own classes, kept for uninstall()
+_installed: dict[str, type] = {}      # what install() registered: class NAME(omnisafe_amd NAME, reference NAME)
+
+
+def _as_subclass_of_reference(name: str, ours: type, ref_cls: type) -> type:
+    """The class that goes into the reference's registry: named like the reference's, a subclass of BOTH this
+    package's implementation (first in the MRO: every hook of the path -- `_init_env`, `_init_model`, `_init`,
+    `_init_log`, `learn`, `_update`, ... -- resolves to the HIP implementation) and of the reference's class, so
+    that `isinstance(agent.agent, omnisafe.algorithms.PPOLag)` and every `issubclass` test written against the
+    reference keep holding after the swap.  The reference's `__init__` is never reached: ours
+    does not chain to it."""
+    if name in _installed and _installed[name].__mro__[1] is ours and ref_cls in _installed[name].__mro__:
+        return _installed[name]
+    if issubclass(ours, ref_cls):
+        return ours
+    import types
+
+    cls = types.new_class(name, (ours, ref_cls), {}, lambda ns: ns.update(
+        {'__module__': ours.__module__, '__doc__': ours.__doc__, '__qualname__': name}))
+    _installed[name] = cls
+    return cls
 
 
 def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
@@ -31,9 +51,11 @@ def install(algorithms: tuple[str, ...] | None = None) -> list[str]:
     for name in (algorithms or ACCELERATED):
         if name in amd_registry.REGISTRY._module_dict and name in ref_registry.REGISTRY._module_dict:  # noqa: SLF001
             ours = amd_registry.get(name)
-            if ref_registry.REGISTRY._module_dict[name] is not ours:  # noqa: SLF001
-                _saved_entries.setdefault(name, ref_registry.REGISTRY._module_dict[name])  # noqa: SLF001
-            ref_registry.REGISTRY._module_dict[name] = ours  # noqa: SLF001
+            current = ref_registry.REGISTRY._module_dict[name]  # noqa: SLF001
+            if not issubclass(current, ours):  # (a second install() finds its own class there)
+                _saved_entries.setdefault(name, current)
+            ref_cls = _saved_entries.get(name, current)
+            ref_registry.REGISTRY._module_dict[name] = _as_subclass_of_reference(name, ours, ref_cls)  # noqa: SLF001
             swapped.append(name)
     # make the synthetic ids valid env ids for the reference's config checks (envs/core.py:362-386)
     reg = ref_env_core.ENV_REGISTRY

@@ -153,13 +153,22 @@ def test_plugin_installs_behind_reference_agent(tmp_path, monkeypatch):
     try:
         swapped = omnisafe_amd.install()
         assert 'PPOLag' in swapped
-        assert ref_registry.REGISTRY.get('PPOLag') is omnisafe_amd.algorithms.registry.get('PPOLag')
+        reg_cls = ref_registry.REGISTRY.get('PPOLag')
+        # "class named PPOLag, subclass of the reference PPOLag so isinstance and hook order hold" --
+        # and our implementation first in the MRO, so every hook of the path resolves to the HIP side
+        assert reg_cls.__name__ == 'PPOLag' and issubclass(reg_cls, keep['PPOLag'])
+        assert reg_cls.__mro__[1] is omnisafe_amd.algorithms.registry.get('PPOLag')
+        for hook in ('__init__', '_init_env', '_init_model', '_init', '_init_log', 'learn', '_update'):
+            owner = next(c for c in reg_cls.__mro__ if hook in vars(c))
+            assert owner.__module__.startswith('omnisafe_amd.'), (hook, owner)
         cfg = {'train_cfgs': {'device': 'cuda:0', 'total_steps': 2000, 'vector_env_nums': 4},
                'algo_cfgs': {'steps_per_epoch': 1000},
                'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': str(tmp_path)}}
         assert len(swapped) == 23  # every on-policy algorithm of the reference
         for name in swapped:  # every accelerated algorithm is reachable through the reference's own Agent
-            assert ref_registry.REGISTRY.get(name) is omnisafe_amd.algorithms.registry.get(name)
+            cls = ref_registry.REGISTRY.get(name)
+            assert cls.__mro__[1] is omnisafe_amd.algorithms.registry.get(name) and issubclass(cls, keep[name])
+            assert omnisafe_amd.install() == swapped and ref_registry.REGISTRY.get(name) is cls  # idempotent
             if name.endswith('EarlyTerminated'):  # utils/config.py:292-295: single env only
                 c1 = dict(cfg, train_cfgs=dict(cfg['train_cfgs'], vector_env_nums=1))
             else:

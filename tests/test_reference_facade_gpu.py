@@ -91,8 +91,12 @@ def test_reference_agent_runs_the_plugin(omnisafe_ref, tmp_path, algo):
         assert algo in swapped
         amd_dir = str(tmp_path / 'amd')
         agent = omnisafe.Agent(algo, 'SynthReach-v0', custom_cfgs=_cfg('cuda:0', amd_dir, defaults))
-        assert type(agent.agent) is omnisafe_amd.algorithms.registry.get(algo)
+        # what the registry hands out: a class named like the reference's, subclass of the reference's class
+        # (isinstance checks written against the reference hold) with the HIP implementation first in the MRO
+        assert type(agent.agent).__mro__[1] is omnisafe_amd.algorithms.registry.get(algo)
+        assert isinstance(agent.agent, ref_cls) and type(agent.agent).__name__ == algo
         assert type(agent.agent).__module__.startswith('omnisafe_amd.')
+        assert type(agent.agent).learn.__module__.startswith('omnisafe_amd.')
         ep_ret, ep_cost, ep_len = agent.learn()
         assert np.isfinite([ep_ret, ep_cost]).all() and ep_len == 50.0 == ref_ret[2]
         run_dir, header, rows = _progress(amd_dir)

@@ -17,3 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 1 --warmup 2 --update-iters 2 --no-cpu-baseline --no-variant > $R/gpurun_out/pmc_sq.log 2>&1
 ls $R/gpurun_out/prof_final/* $R/gpurun_out/pmc_FETCH_SIZE/* $R/gpurun_out/pmc_gae_FETCH_SIZE/* | head
+# wide-observation passes (config 4) and the BASELINE configs end to end next to the unmodified reference
+cd $R
+timeout 300 python tools/wide_pass_timing.py 65536 > gpurun_out/wide_pass_timing.log 2>&1; tail -25 gpurun_out/wide_pass_timing.log
+timeout 1500 python tools/baseline_configs.py > gpurun_out/baseline_configs.log 2>&1; tail -8 gpurun_out/baseline_configs.log
