@@ -182,10 +182,10 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
                   'Train/PolicyStd': self._actor_critic.actor.std})
         if a.use_cost:
             lg.store({'Loss/Loss_cost_critic': summ['Loss/Loss_cost_critic']})
-        # NB the reference logs the LAST minibatch's adv_r.mean() here (variable shadowing,
-        # policy_gradient.py:369-377,402); we log the full-batch mean of the standardised advantages.
-        lg.store({'Train/StopIter': out['stop_iter'], 'Value/Adv': float(data['adv_r'].mean()),
-                  'Train/KL': out['kl']})
+        # the reference logs the LAST minibatch's adv_r.mean() here (the dataloader's loop variables shadow the
+        # full batch: policy_gradient.py:369-377, 402) -- same here
+        lg.store({'Train/StopIter': out['stop_iter'],
+                  'Value/Adv': float(data['adv_r'][out['last_minibatch']].mean()), 'Train/KL': out['kl']})
 
 
 @register

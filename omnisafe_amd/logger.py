@@ -99,8 +99,11 @@ class Logger:  # pylint: disable=too-many-instance-attributes
 
     def get_stats(self, key: str, min_and_max: bool = False) -> tuple[float, ...]:
         """logger.py:344-374 via dist_statistics_scalar (distributed.py:361-393): global mean (and
-        population std / min / max) over all ranks' values.  Unlike the reference, min/max use scalar
-        reductions (the reference all-reduces a vector whose length may differ per rank)."""
+        population std / min / max) over all ranks' values.  `/Min` and `/Max` reproduce what the reference
+        WRITES, not what the names say: dist_min / dist_max reduce the vector of stored values element-wise
+        across ranks (distributed.py:388-390) and get_stats takes the MEAN of the result (logger.py:366) -- with
+        one rank both columns equal the mean.  (Round 1 logged the true extrema; the csv values of a drop-in
+        have to be the reference's.)"""
         if not dist.collectives_active():
             # float32 numpy reductions: torch CPU ops would open an OpenMP region per call, which costs
             # milliseconds on many-core hosts and sits on the epoch's critical path (the GPU idles meanwhile)
@@ -113,7 +116,8 @@ class Logger:  # pylint: disable=too-many-instance-attributes
             if not min_and_max:
                 return (float(mean),)
             std = np.sqrt(((vals - mean) ** 2).sum(dtype=np.float32) / np.float32(n))
-            return float(mean), float(vals.min()), float(vals.max()), float(std)
+            elem_mean = float(vals.mean(dtype=np.float32))  # min_val.mean() / max_val.mean() of the reference
+            return float(mean), elem_mean, elem_mean, float(std)
         vals = torch.tensor(list(self._data[key]), dtype=torch.float32)
         return _dist_stats(vals, min_and_max)
 
@@ -169,7 +173,10 @@ class Logger:  # pylint: disable=too-many-instance-attributes
 
 
 def _dist_stats(vals: torch.Tensor, min_and_max: bool):
-    """Cross-rank statistics through gloo/RCCL: [sum, n] -> mean; [sumsq] -> std; scalar min/max."""
+    """Cross-rank statistics through gloo/RCCL: [sum, n] -> mean; [sumsq] -> std; min / max as the reference
+    computes them: element-wise MIN / MAX of the ranks' vectors, then the mean (distributed.py:388-390,
+    logger.py:366).  The reference requires equally long vectors on all ranks (its all-reduce would fail
+    otherwise); with unequal lengths the common prefix is reduced."""
     dev = torch.device('cuda', torch.cuda.current_device()) if (
         torch.cuda.is_available() and torch.distributed.get_backend() == 'nccl') else torch.device('cpu')
     n = len(vals)
@@ -185,8 +192,13 @@ def _dist_stats(vals: torch.Tensor, min_and_max: bool):
                       device=dev)
     dist.all_reduce_sum_(sq)
     std = float(torch.sqrt(sq[0] / s[1]))
-    lo = torch.tensor([float(vals.min()) if n else float('inf')], dtype=torch.float64, device=dev)
-    hi = torch.tensor([float(vals.max()) if n else float('-inf')], dtype=torch.float64, device=dev)
+    nmin = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(nmin, op=torch.distributed.ReduceOp.MIN)
+    k = int(nmin.item())
+    if k == 0:
+        return mean, mean, mean, std
+    lo = vals[:k].to(device=dev, dtype=torch.float32).clone()
+    hi = lo.clone()
     torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
     torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-    return mean, lo.item(), hi.item(), std
+    return mean, lo.mean().item(), hi.mean().item(), std

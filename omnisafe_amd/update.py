@@ -501,6 +501,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
                     step += 1
             update_counts += 1
+            last_perm = self._dp['perm'][dist.rank()] if use_repl else perm
             # the KL pass feeds the early-stop test; without early stop only the last pass's value is
             # logged (policy_gradient.py:383-404), so the earlier full-batch passes are not computed
             if self.update_actor and (self.kl_early_stop or i == self.update_iters - 1):
@@ -518,7 +519,10 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if self._use_wide:
             self.check_split_sync()
         used = stats[:step]
-        out = {'stop_iter': update_counts, 'steps': step, 'stats': used}
+        # rows of the LAST minibatch of the last executed pass (the reference logs Value/Adv from the loop variable
+        # that shadows the full batch: policy_gradient.py:369-377, 402)
+        out = {'stop_iter': update_counts, 'steps': step, 'stats': used,
+               'last_minibatch': last_perm[(nmb - 1) * B:M]}
         if self.update_actor:
             out['kl'] = float(kl_dev) if kl_dev is not None else final_kl
         return out
@@ -534,7 +538,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         return {
             'Loss/Loss_reward_critic': float(loss_r.mean()), 'Loss/Loss_cost_critic': float(loss_c.mean()),
             'Loss/Loss_pi': float(s[:, 2].mean()), 'Train/PolicyRatio': float(s[:, 3].mean()),
-            'Train/PolicyRatio/Min': float(s[:, 3].min()), 'Train/PolicyRatio/Max': float(s[:, 3].max()),
             'Train/PolicyRatio/Std': float(s[:, 3].std()) if len(s) > 1 else 0.0,
             'Train/Entropy': float(s[:, 4].mean()),
             'per_step': {'loss_r': loss_r, 'loss_c': loss_c, 'loss_pi': s[:, 2], 'ratio_mean': s[:, 3],

@@ -56,6 +56,9 @@ def test_first_order_update_at_config_shape(golden, tmp_path, tag, name, env_id,
     for key in ('Loss/Loss_reward_critic', 'Loss/Loss_cost_critic'):
         np.testing.assert_allclose(_log(algo, key).mean(), g['log/' + key].mean(), rtol=2e-4)
     np.testing.assert_allclose(_log(algo, 'Train/Entropy').mean(), g['log/Train/Entropy'].mean(), rtol=1e-5)
+    # Value/Adv: the reference's loop variable shadows the full batch, so it logs the LAST minibatch's mean advantage
+    np.testing.assert_allclose(_log(algo, 'Value/Adv')[-1], g['log/Value/Adv'][-1], rtol=1e-5, atol=1e-7)
+    assert abs(float(g['log/Value/Adv'][-1]) - float(g['data/adv_r'].mean())) > 1e-3  # (not the full-batch mean)
 
 
 @pytest.mark.parametrize('tag,name,env_id,extra', TRUST_REGION)

@@ -1,6 +1,8 @@
 """Live cross-checks of the oracle (and of the product's pure-host classes) against the UNMODIFIED reference,
 imported from /root/reference through oracle/ref_harness.py.  Build container only: skipped where the
 reference is absent (e.g. the GPU box) -- there the committed golden vectors carry the same information."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -172,3 +174,42 @@ def test_learning_runs_get_the_same_custom_cfgs_on_both_sides(ref, tmp_path):
         assert theirs['train_cfgs'].pop('device') == 'cpu' and ours['train_cfgs'].pop('device') == tl.DEV
         assert theirs == ours, algo
     assert sorted(make_golden.LEARNING_ALGOS) == sorted(['PPOLag', 'TRPOLag', 'CPO'] + tl.SIBLINGS)
+
+
+def test_logger_rows_live(ref, tmp_path):
+    """The same sequence of register / store / dump calls through the reference's Logger and ours: identical
+    progress.csv (header and values, incl. the /Min /Max columns, which the reference fills with the mean,
+    window keys, /Delta and /Std)."""
+    import csv
+
+    from omnisafe.common.logger import Logger as RefLogger
+    from omnisafe.utils.config import Config
+
+    from omnisafe_amd.logger import Logger
+
+    def drive(lg):
+        lg.register_key('Metrics/EpRet', window_length=3)
+        lg.register_key('Train/PolicyRatio', min_and_max=True)
+        lg.register_key('Loss/Loss_pi', delta=True)
+        lg.register_key('Metrics/LagrangeMultiplier', min_and_max=True)
+        rng = np.random.default_rng(0)
+        for epoch in range(3):
+            for v in rng.normal(size=5):
+                lg.store({'Metrics/EpRet': float(v)})
+            for v in rng.normal(1.0, 0.1, size=7):
+                lg.store({'Train/PolicyRatio': float(v)})
+            lg.store({'Loss/Loss_pi': float(rng.normal())})
+            lg.store({'Metrics/LagrangeMultiplier': 0.1 * epoch})
+            lg.dump_tabular()
+        lg.close()
+        return list(csv.reader(open(os.path.join(lg.log_dir, 'progress.csv'))))
+
+    cfg = Config.dict2config({'exp_name': 'x', 'seed': 0, 'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False}})
+    ref_rows = drive(RefLogger(str(tmp_path / 'ref'), 'exp', seed=0, use_tensorboard=False, use_wandb=False,
+                               config=cfg))
+    our_rows = drive(Logger(str(tmp_path / 'ours'), 'exp', seed=0, verbose=False))
+    assert our_rows[0] == ref_rows[0]
+    np.testing.assert_allclose(np.array(our_rows[1:], dtype=float), np.array(ref_rows[1:], dtype=float), rtol=1e-6,
+                               atol=1e-7)
+    k = ref_rows[0].index('Train/PolicyRatio')
+    assert ref_rows[1][k + 1] == ref_rows[1][k + 2]  # the reference's Min == Max (== mean)
