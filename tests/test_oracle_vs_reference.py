@@ -176,12 +176,13 @@ def test_learning_runs_get_the_same_custom_cfgs_on_both_sides(ref, tmp_path):
     assert sorted(make_golden.LEARNING_ALGOS) == sorted(['PPOLag', 'TRPOLag', 'CPO'] + tl.SIBLINGS)
 
 
-def test_logger_rows_live(ref, tmp_path):
+def test_logger_rows_live(ref, tmp_path, monkeypatch):
     """The same sequence of register / store / dump calls through the reference's Logger and ours: identical
     progress.csv (header and values, incl. the /Min /Max columns, which the reference fills with the mean,
     window keys, /Delta and /Std)."""
     import csv
 
+    monkeypatch.setenv('OMNISAFE_DEVICE', 'cpu')  # (the reference's AlgoWrapper exports the device of the last Agent)
     from omnisafe.common.logger import Logger as RefLogger
     from omnisafe.utils.config import Config
 
