@@ -358,6 +358,22 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                     const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                     float* exchange, int* sync, int local, float* step_stats, void* stream);
 
+/* Single-process persistent pass for minibatches of 64 < B <= 2048 rows (the trust-region family's critic
+ * updates: batch_size 128, natural_pg.py:205-223) with the ceil(B / 64) 64-row CHUNKS of a minibatch on cooperating
+ * workgroups (one compute unit each, per network) instead of one workgroup walking through them: every workgroup
+ * keeps the network and its Adam state, computes the raw gradient of its chunk scaled by 1 / rows of the minibatch,
+ * the chunks' gradients are summed (exchange: osa_ppo_dp_pass_ws_floats(.., world = ceil(B / 64)) floats, zeroed
+ * once), the SUM is clipped by its norm and everybody applies the same Adam step: the arithmetic of
+ * osa_ppo_pass / osa_ppo_minibatch(mode 0) on the same rows (float32 re-association of the sum over chunks only).
+ * Arguments as osa_ppo_pass plus exchange / sync / local as in osa_ppo_dp_pass_placed (sync: int[8]; sticky
+ * sync[3]).  OSA_EUNSUPPORTED for B <= 64 (use osa_ppo_pass) or when the workgroups cannot be co-resident. */
+int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                         int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                         const float* logp, const float* target_value_r, const float* target_value_c,
+                         const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                         const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                         float* exchange, int* sync, int local, float* step_stats, void* stream);
+
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */
 int osa_debug_set_clock_buffer(long long* dev_ptr);

@@ -54,6 +54,8 @@ SIGNATURES: dict[str, tuple] = {
                         _P, _P, _I, _I, _P, _P, _P, _P]),
     'osa_ppo_dp_pass_placed': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                                _P, _P, _I, _I, _P, _P, _I, _P, _P]),
+    'osa_ppo_chunked_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
+                                  _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_dp_step': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,

@@ -88,6 +88,12 @@ struct OsaPassArgs {
   // 1: the `world` workgroups of a network are blocks net + 8 rk of a 1-D grid, i.e. they run on ONE XCC
   // (workgroup b of a grid lands on XCC b mod 8) and dp_slabs is ordinary memory served by that XCC's L2
   int dp_local;
+  // cooperative CHUNK mode (osa_ppo_chunked_pass): the dp_world workgroups of a network are the 64-row chunks
+  // of ONE minibatch of B <= 64 dp_world rows (same data, same permutation): every workgroup computes the raw
+  // gradient of its chunk (scaled by 1 / rows of the whole minibatch), the sum over the chunks is clipped by ITS
+  // norm and every workgroup applies the same Adam step -- the arithmetic of a single-process minibatch of B
+  // rows, not the clip-then-average of the data-parallel mode
+  int dp_chunk;
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -124,7 +130,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   constexpr bool coop = COOP;
   const bool dp = a.dp_slabs != nullptr && !coop;
   const bool part = MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
-  const long roff = part ? 0 : (long)rk * a.M;
+  const bool chunked = COOP && a.dp_chunk != 0;
+  const long roff = (part || chunked) ? 0 : (long)rk * a.M;
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
   const float* __restrict__ logp_p = a.logp + roff;
@@ -232,7 +239,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       row[11 + 2 * net] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
     }
   }
-  const bool l2 = critic && a.hp.use_critic_norm && !part;  // (partial sums get the L2 term once, later)
+  // terms that enter a minibatch's gradient ONCE (critics' L2 term, entropy bonus): partial sums get them later,
+  // the chunks of a chunked pass from chunk 0
+  const bool own_terms = !(chunked && rk != 0);
+  const bool l2 = critic && a.hp.use_critic_norm && !part && own_terms;
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
   // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
   const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
-  const int cstride = part ? a.part_stride : 1, cfirst = part ? rk : 0;
+  const int cstride = part ? a.part_stride : 1, cfirst = (part || chunked) ? rk : 0;
   const int nchunk = part ? (nchunk_all - cfirst + cstride - 1) / cstride : nchunk_all;
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
     const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
     }  // chunks
-    if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f)
+    if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f && own_terms)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
     // ================= + 2*coef*w (critics), squared norms (packed f32 math) =================
     // this lane's parameters: all LDS reads issued up front (one latency for the lot), kept in registers
@@ -936,13 +946,13 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     float st_loss = t_loss * invB, st_ratio = t_ratio * invB, st_psq = t_psq, st_norm = total_norm,
           st_ent = ent_pre;
-    if (net == 0) st_loss -= a.hp.entropy_coef * ent_pre;
+    if (net == 0 && own_terms) st_loss -= a.hp.entropy_coef * ent_pre;
     bool apply_clip = a.hp.use_max_grad_norm != 0;
     if constexpr (coop) {
       // ---- the gradient tiles are on their way (exchange layout: one f32x4 per thread per tile, 1 KB
       // contiguous per wave instruction); complete the slab with the clip factor and the statistics
       const int W = a.dp_world;
-      const float gs = apply_clip ? coef : 1.f;
+      const float gs = (apply_clip && !chunked) ? coef : 1.f;  // (chunk mode: the SUM is clipped, below)
       if (leader) {
         float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
         t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
@@ -1018,7 +1028,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           }
         }
       }
-      const float invW = 1.f / (float)W;
+      const float invW = chunked ? 1.f : 1.f / (float)W;
 #pragma unroll
       for (int ti = 0; ti < HT; ++ti) g2[ti] = s2[ti] * invW;
 #pragma unroll
@@ -1028,14 +1038,42 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       gb = sb_ * invW;
       PTICK(11);
       apply_clip = false;  // already clipped per rank (clip-then-average, policy_gradient.py:437-442)
+      float chunk_norm = 0.f;
+      if (chunked) {
+        // the minibatch's gradient is the SUM of its chunks' (every chunk scaled by 1 / rows of the minibatch): its
+        // norm decides the clip factor, as in a single-process step over all B rows
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) acc2 = acc2 + g2[ti] * g2[ti];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc2 = acc2 + g1[kb] * g1[kb];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc2 = acc2 + g3[o] * g3[o];
+        float q2 = (acc2.x + acc2.y) + (acc2.z + acc2.w);
+        if (boff >= 0) q2 += gb * gb;
+        q2 = osa_wave_sum_dpp(q2);
+        if (lane == 0) red[wave] = q2;
+        __syncthreads();
+        chunk_norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        if (a.hp.use_max_grad_norm) {
+          coef = a.hp.max_grad_norm / (chunk_norm + 1e-6f);
+          coef = coef > 1.f ? 1.f : coef;
+          apply_clip = true;
+        }
+      }
       if (leader && rk == 0) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < W; ++r) {
           const float* t = xbase + (long)r * XS + NT * 1024 + 256;
           for (int k = 0; k < 5; ++k) acc[k] += t[k];
         }
-        st_loss = acc[0] * invW; st_ratio = acc[1] * invW; st_psq = acc[2] * invW;
-        st_norm = acc[3] * invW; st_ent = acc[4] * invW;
+        if (chunked) {  // loss and ratio: sums of the chunks' shares; parameter norm and entropy: chunk 0's
+          const float* t0 = xbase + NT * 1024 + 256;
+          st_loss = acc[0]; st_ratio = acc[1]; st_psq = t0[2]; st_norm = chunk_norm; st_ent = t0[4];
+        } else {
+          st_loss = acc[0] * invW; st_ratio = acc[1] * invW; st_psq = acc[2] * invW;
+          st_norm = acc[3] * invW; st_ent = acc[4] * invW;
+        }
       }
     }
     // ================= Adam on the owned parameters; LDS master updated in place =================
@@ -1452,18 +1490,48 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
                                 lagrange, hp, loss_kind, nets_mask, exchange, sync, 0, step_stats, stream);
 }
 
+static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                         int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                         const float* logp, const float* target_value_r, const float* target_value_c,
+                         const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                         const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                         float* exchange, int* sync, int local, int chunk, float* step_stats, void* stream);
+
 int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
                            const float* logp, const float* target_value_r, const float* target_value_c,
                            const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                            const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                            float* exchange, int* sync, int local, float* step_stats, void* stream) {
+  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
+                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
+                       nets_mask, exchange, sync, local, 0, step_stats, stream);
+}
+
+int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                         int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                         const float* logp, const float* target_value_r, const float* target_value_c,
+                         const float* adv_r, const float* adv_c, const long* perm, long M, int B,
+                         const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                         float* exchange, int* sync, int local, float* step_stats, void* stream) {
+  if (B <= 64 || B > 64 * 32) return OSA_EUNSUPPORTED;  // one chunk: osa_ppo_pass
+  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
+                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, (B + 63) / 64, lagrange, hp,
+                       loss_kind, nets_mask, exchange, sync, local, 1, step_stats, stream);
+}
+
+static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                         int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                         const float* logp, const float* target_value_r, const float* target_value_c,
+                         const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                         const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                         float* exchange, int* sync, int local, int chunk, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(exchange && sync && ld_obs >= obs_dim && ld_act >= act_dim);
-  if ((double)M * world * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  if ((double)M * (chunk ? 1 : world) * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
   // all 3 * world workgroups must be co-resident (one per compute unit: ~150 KB of LDS each)
   int dev = 0, cus = 0;
@@ -1473,6 +1541,7 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
   if (3 * world > cus || (local && world > cus / 8)) return OSA_EUNSUPPORTED;
   OsaPassArgs a = {};
   a.dp_local = local ? 1 : 0;
+  a.dp_chunk = chunk ? 1 : 0;
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -1495,7 +1564,8 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return (B > 64) ? osa_launch_pass<K, O, true, true>(a, st, world) : osa_launch_pass<K, O, false, true>(a, st, world)
+    return (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                  \
+                              : osa_launch_pass<K, O, false, true>(a, st, world)
   OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);
   OSA_DPP_CASE(6, 1); OSA_DPP_CASE(1, 2); OSA_DPP_CASE(2, 2); OSA_DPP_CASE(3, 2); OSA_DPP_CASE(4, 2);
   OSA_DPP_CASE(5, 2); OSA_DPP_CASE(6, 2);

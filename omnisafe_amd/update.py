@@ -74,8 +74,36 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._use_wide = False
         self._split_xch: int | None = None  # uncached exchange buffer of the split wide pass (raw pointer)
         self._split_tried = False
+        self._chunk: dict = {}  # exchange buffer / sync words of osa_ppo_chunked_pass
         self._split_local = False
         self._split_buf = None
+
+    def _chunk_ok(self, data: dict) -> bool:
+        """osa_ppo_chunked_pass applies: plain surrogate, 64 < B <= 64 x (CUs / 8) rows, OSA_CHUNKED_PASS != 0.
+        Allocates its exchange buffer (ordinary memory: the workgroups of a network share one XCC) on first use."""
+        B = self.batch_size
+        ck = self._chunk
+        if ck.get('off') or self.ext is not None or B <= 64 or os.environ.get('OSA_CHUNKED_PASS', '1') == '0':
+            return False
+        W = (B + 63) // 64
+        if ck.get('W') != W:
+            ac = self.ac
+            cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
+            if W > cus // 8:
+                ck['off'] = True
+                return False
+            n = self.lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
+            ck.update(W=W, xch=torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device),
+                      sync=torch.zeros(8, dtype=torch.int32, device=ac.device))
+        return True
+
+    def check_chunk_sync(self) -> None:
+        """Sticky flag of the chunked pass (a workgroup never arrived: 1; a network's workgroups not on one XCC: 2)."""
+        ck = self._chunk
+        if 'sync' in ck and int(ck['sync'][3]) != 0:
+            raise _lib.OsaError('osa_ppo_chunked_pass: ' + (
+                'the workgroups of a network were not placed on one XCC' if int(ck['sync'][3]) == 2
+                else 'a cooperating workgroup never arrived') + ' (results invalid); set OSA_CHUNKED_PASS=0')
 
     def _split_alloc(self) -> None:
         """Exchange buffer of osa_ppo_split_pass (uncached device memory; OSA_WIDE_SPLIT=0 keeps the one-CU
@@ -195,6 +223,25 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 ev[1].record()
                 self.profile_events.append(('osa_wide_pass_kernel', M, ev))
             return
+        if self._chunk_ok(data):  # 64 < B: the minibatch's 64-row chunks on cooperating workgroups (one XCC per network)
+            ck = self._chunk
+            rc = self.lib.osa_ppo_chunked_pass(
+                ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
+                _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+                _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+                _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
+                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(ck['xch']), _lib.ptr(ck['sync']), 1,
+                _lib.ptr(stats_rows), _lib.stream_ptr())
+            if rc == _lib.OSA_EUNSUPPORTED:  # not co-resident: one workgroup walks through the chunks
+                ck['off'] = True
+            else:
+                _lib.check(rc, 'osa_ppo_chunked_pass')
+                self.last_path = 'persistent-chunked'
+                if ev is not None:
+                    ev[1].record()
+                    self.profile_events.append(('osa_ppo_pass_kernel', M, ev))
+                return
         ext = None
         if self.ext is not None:  # extended actor surrogate (FOCOPS / CUP / P3O) inside the persistent pass
             self.ext.old_mean = self._old_mean.data_ptr()
@@ -518,6 +565,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.check_reduce_sync()
         if self._use_wide:
             self.check_split_sync()
+        if self.last_path == 'persistent-chunked':
+            self.check_chunk_sync()
         used = stats[:step]
         # rows of the LAST minibatch of the last executed pass (the reference logs Value/Adv from the loop variable
         # that shadows the full batch: policy_gradient.py:369-377, 402)

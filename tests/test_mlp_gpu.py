@@ -243,7 +243,8 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
 
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
                                                 (90, 17, 512, 64), (5, 1, 130, 64), (60, 2, 1000, 128),
-                                                (72, 2, 700, 200),
+                                                (72, 2, 700, 200), (72, 2, 4096, 128), (27, 8, 2048, 128),
+                                                (60, 2, 1100, 512),
                                                 # wide observations: osa_ppo_wide_pass (W1 streamed from L2)
                                                 (376, 17, 1024, 64), (376, 17, 200, 64), (100, 3, 300, 64),
                                                 (200, 20, 256, 32), (512, 32, 192, 64), (97, 1, 130, 48)])
@@ -257,10 +258,13 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
     from omnisafe_amd.update import PPOUpdater
 
     narrow = bool(_lib.load().osa_ppo_pass_supported(obs_dim, act_dim, 64))
-    variants = [(True, '1', 'persistent' if narrow else 'persistent-wide-split'), (False, '1', 'per-step')]
+    first = ('persistent-chunked' if B > 64 else 'persistent') if narrow else 'persistent-wide-split'
+    variants = [(True, '1', first), (False, '1', 'per-step')]
     if not narrow:  # '1' = one XCC per network (L2 hand-offs); 'spread' = all XCCs, uncached exchange buffer
         variants.insert(1, (True, 'spread', 'persistent-wide-split'))
         variants.insert(2, (True, '0', 'persistent-wide'))
+    elif B > 64:  # the minibatch's 64-row chunks on cooperating workgroups (default) / walked by one workgroup
+        variants.insert(1, (True, 'nochunk', 'persistent'))
 
     torch.manual_seed(obs_dim + act_dim)
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
@@ -270,6 +274,7 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
     perms = [torch.randperm(M), torch.randperm(M)]
     for persistent, split, _ in variants:
         monkeypatch.setenv('OSA_WIDE_SPLIT', split)
+        monkeypatch.setenv('OSA_CHUNKED_PASS', '0' if split == 'nochunk' else '1')
         torch.manual_seed(99)
         ac = make_ac(obs_dim, act_dim)
         if 'logp' not in data:
@@ -296,11 +301,12 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
         assert acs[k].adam_step.cpu().tolist() == acs[-1].adam_step.cpu().tolist()
         for name in ('params', 'adam_m', 'adam_v'):
             a, b = getattr(acs[k], name).cpu().numpy(), getattr(acs[-1], name).cpu().numpy()
-            if variants[k][2] != 'persistent-wide-split':
+            if variants[k][2] not in ('persistent-wide-split', 'persistent-chunked'):
                 np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, err_msg=f'{variants[k][2]} {name}')
                 continue
             # The split kernel sums the layer-1 pre-activation as C partial sums (the other persistent kernels keep
-            # the per-step kernels' order and agree to 1e-8): every gradient differs by ~1e-7 relative.  Adam's
+            # the per-step kernels' order and agree to 1e-8): every gradient differs by ~1e-7 relative; the chunked
+            # pass sums per-chunk gradients where one workgroup accumulates all chunks in its MFMA accumulators.  Adam's
             # FIRST step is lr * g / (|g| + 1e-8): for the handful of elements whose first gradient is within
             # ~1e-8 of zero (expected: ~1e-5 of all elements) that noise moves the update by a visible
             # fraction of lr, and the moments follow at the 1e-4 relative level.  Everything else obeys the usual tolerance.
