@@ -18,11 +18,13 @@ import omnisafe_amd  # noqa: E402
 CONFIGS = {'2': ('PPOLag', 'SynthPointGoal1-v0'), '3': ('CPO', 'SynthCarGoal1-v0'),
            '4': ('PPOLag', 'SynthHumanoid-v0'), '5': ('TRPOLag', 'SynthAnt-v0')}
 algo, env_id = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else '3']
-N, T, EPOCHS = 4096, 16, int(sys.argv[2]) if len(sys.argv) > 2 else 4
+EPOCHS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096  # BASELINE config 1: 4 envs x 5000 steps (PPOLag.yaml defaults)
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 cfg = {'seed': 0, 'train_cfgs': {'device': 'cuda:0', 'vector_env_nums': N, 'total_steps': N * T * (EPOCHS + 1)},
        'algo_cfgs': {'steps_per_epoch': N * T},
        'logger_cfgs': {'log_dir': tempfile.mkdtemp(), 'save_model_freq': 10 ** 9, 'verbose': False},
-       'env_cfgs': {'horizon': T, 'cost_p': 0.05}}
+       'env_cfgs': {'horizon': min(T, 1000), 'cost_p': 0.05}}
 if algo == 'PPOLag':
     cfg['algo_cfgs']['kl_early_stop'] = False
 a = omnisafe_amd.Agent(algo, env_id, custom_cfgs=cfg).agent
@@ -36,4 +38,5 @@ for e in range(EPOCHS):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     a._logger.dump_tabular()
-    print(f'epoch {e}: rollout {1e3 * (t1 - t0):.2f} ms, update {1e3 * (t2 - t1):.2f} ms', flush=True)
+    print(f'epoch {e}: rollout {1e3 * (t1 - t0):.2f} ms, update {1e3 * (t2 - t1):.2f} ms -> {N * T / (t2 - t0):.0f} env-steps/s '
+          f'(rollout graphed: {getattr(a._env, "last_rollout_graphed", None)})', flush=True)
