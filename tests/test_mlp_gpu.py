@@ -244,7 +244,7 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
                                                 (90, 17, 512, 64), (5, 1, 130, 64), (60, 2, 1000, 128),
                                                 (72, 2, 700, 200), (72, 2, 4096, 128), (27, 8, 2048, 128),
-                                                (60, 2, 1100, 512),
+                                                (60, 2, 1100, 512), (60, 2, 2100, 1000),
                                                 # wide observations: osa_ppo_wide_pass (W1 streamed from L2)
                                                 (376, 17, 1024, 64), (376, 17, 200, 64), (100, 3, 300, 64),
                                                 (200, 20, 256, 32), (512, 32, 192, 64), (97, 1, 130, 48)])
@@ -264,7 +264,7 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
         variants.insert(1, (True, 'spread', 'persistent-wide-split'))
         variants.insert(2, (True, '0', 'persistent-wide'))
     elif B > 64:  # the minibatch's 64-row chunks on cooperating workgroups (default) / walked by one workgroup
-        variants.insert(1, (True, 'nochunk', 'persistent'))
+        variants.insert(1, (True, 'nochunk', 'persistent' if B <= 512 else 'per-step'))  # (one workgroup: up to 512)
 
     torch.manual_seed(obs_dim + act_dim)
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
