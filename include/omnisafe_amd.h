@@ -269,7 +269,8 @@ int osa_ppo_wide_pass(int obs_dim, int act_dim, int hidden, float* params, float
  * XCCs and xch MUST come from osa_dp_exchange_alloc (uncached device memory; OSA_EINVAL otherwise).  local = 1:
  * the workgroups of a network are placed on ONE XCC (blocks net + 8 role of an 8 (C + 1) grid) and xch MUST be
  * ordinary device memory: the hand-offs are then served by that XCC's L2; the kernel verifies the placement
- * (XCC_ID of every workgroup) and raises the sticky flag with value 2 if it does not hold.
+ * (XCC_ID of every workgroup) BEFORE anything is modified and, if it does not hold, every workgroup returns with
+ * parameters, Adam state and step counters untouched and the sticky flag set to 2 (repeat with local = 0).
  * Same arguments, statistics and per-step arithmetic as osa_ppo_wide_pass (float32 re-association of the
  * layer-1 sum only).  OSA_EUNSUPPORTED when the shape is not supported or the device cannot hold the
  * workgroups together: use osa_ppo_wide_pass.  A peer that never arrives raises a sticky flag instead of
@@ -348,9 +349,10 @@ int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* 
  * XCCs; `exchange` uncached or ordinary memory).  local = 1: the `world` workgroups of a network are the blocks
  * net + 8 r of an 8 x world grid, i.e. they run on ONE XCC, and `exchange` MUST be ordinary device memory
  * (OSA_EINVAL for an osa_dp_exchange_alloc buffer): the hand-offs are served by that XCC's L2.  sync: int[8]
- * (zeroed once by the caller): sync[4..6] receive the bit masks of the XCCs each network's workgroups ran on;
- * a network that finds more than one bit sets the sticky flag sync[3] to 2 (results invalid: use local = 0).
- * world <= CUs / 8. */
+ * (zeroed once by the caller): sync[4..6] receive the bit masks of the XCCs each network's workgroups ran on,
+ * sync[7] counts arrivals.  The placement is verified BEFORE anything is modified: if a network's mask holds
+ * more than one bit (or a workgroup never arrives) EVERY workgroup returns with parameters, Adam state and step
+ * counters untouched and the sticky flag sync[3] is 2 (1): repeat the call with local = 0.  world <= CUs / 8. */
 int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                     int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
                     const float* logp, const float* target_value_r, const float* target_value_c,

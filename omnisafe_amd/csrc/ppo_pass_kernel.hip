@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const OsaNet& nd = a.nd;
   int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
   if constexpr (COOP) {
-    if (a.dp_local) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
+    if (a.dp_local == 1) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
+      // (dp_local == 3: test hook -- the one-XCC protocol on the 3 x world grid, so that the placement check trips)
       net_ = blockIdx.x & 7;
       rk_ = blockIdx.x >> 3;
       if (net_ >= 3) return;
@@ -358,10 +359,35 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #endif
   bool coop_dead = false;
   if constexpr (COOP) {
-    if (a.dp_local && threadIdx.x == 0) {  // verify the placement: all workgroups of the network on one XCC
-      const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
-      const int seen = __hip_atomic_fetch_or(a.dp_sync + 4 + net, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (1 << xcc);
-      if ((seen & (seen - 1)) != 0) __hip_atomic_store(a.dp_sync + 3, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.dp_local) {
+      // Verify the placement BEFORE anything is modified: every workgroup ORs its XCC bit into sync[4 + net]
+      // and counts itself in at sync[7]; when all (active networks x dp_world) have arrived, every network's
+      // mask must hold ONE bit.  Otherwise EVERY workgroup returns with parameters, Adam state and step counters
+      // untouched and the sticky flag says why (2: a network on two XCCs; 1: somebody never arrived) -- the
+      // caller repeats the pass with another placement (update.py).
+      if (threadIdx.x == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
+        __hip_atomic_fetch_or(a.dp_sync + 4 + net, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int expect = a.dp_world * __builtin_popcount(a.nets_mask & 7);
+        // (release / acquire: the OR above is ordered before the arrival, the masks are read after the last one)
+        int v = __hip_atomic_fetch_add(a.dp_sync + 7, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        int spins = 0, why = 0;
+        while (v < expect) {
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(a.dp_sync + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1 << 21)) { why = 1; break; }
+        }
+        for (int n = 0; n < 3 && why == 0; ++n) {
+          const int mask = __hip_atomic_load(a.dp_sync + 4 + n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((mask & (mask - 1)) != 0) why = 2;
+        }
+        if (why) __hip_atomic_store(a.dp_sync + 3, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[0] = (float)why;
+      }
+      __syncthreads();
+      const bool bad_placement = red[0] != 0.f;
+      __syncthreads();
+      if (bad_placement) return;
     }
   }
 
@@ -1187,7 +1213,7 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
-  const dim3 grid = (COOP && a.dp_local) ? dim3(8 * grid_y) : dim3(3, grid_y);
+  const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : dim3(3, grid_y);
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
@@ -1540,7 +1566,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
     return OSA_EHIP;
   if (3 * world > cus || (local && world > cus / 8)) return OSA_EUNSUPPORTED;
   OsaPassArgs a = {};
-  a.dp_local = local ? 1 : 0;
+  a.dp_local = local;  // 0, 1, or 3 (see the kernel)
   a.dp_chunk = chunk ? 1 : 0;
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
@@ -1560,7 +1586,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   // it survives the per-pass reset so that a timeout in any pass of an update is still visible when the
   // host reads it (the caller zeroes all four words once, at allocation)
   if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
-  if (local && hipMemsetAsync(sync + 4, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks
+  if (local && hipMemsetAsync(sync + 4, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks, arrivals
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \

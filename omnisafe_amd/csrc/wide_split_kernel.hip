@@ -44,7 +44,8 @@
 #define SF_DZ 8
 #define SF_NORM 16
 #define SF_XCC 25                          // bit mask of the XCCs the network's workgroups ran on
-#define SF_ERR 96                          // sticky: a peer never arrived
+#define SF_ERR 96                          // sticky: a peer never arrived (1) / a network on two XCCs (2)
+#define SF_ARRIVE 97                       // arrivals of the placement check (zeroed per launch)
 
 struct OsaSplitHp {
   float clip, entropy_coef, critic_norm_coef, max_grad_norm;
@@ -158,11 +159,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   // ordinary cached memory (a hand-off then costs L2 round trips, not trips to the device-coherent level);
   // otherwise consecutive blocks (spread over the XCCs) and an uncached buffer.  role 0: leader, 1 + c: helper c
   int net, role;
-  if (a.local) {
+  if (a.local == 1) {
     net = blockIdx.x & 7;
     role = blockIdx.x >> 3;
     if (net >= 3) return;
-  } else {
+  } else {  // (local == 3: test hook -- the one-XCC protocol on the spread grid, so that the placement check trips)
     net = blockIdx.x / (C + 1);
     role = blockIdx.x - net * (C + 1);
   }
@@ -182,10 +183,37 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   const float c2 = 2.f * a.hp.critic_norm_coef;
   const float beta1 = a.hp.beta1, beta2 = a.hp.beta2, aeps = a.hp.adam_eps;
   bool dead = false;
-  if (tid == 0) {  // which XCCs this network's workgroups run on (host-readable; `local` requires exactly one)
-    const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
-    const int seen = __hip_atomic_fetch_or(flags + SF_XCC, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (1 << xcc);
-    if (a.local && (seen & (seen - 1)) != 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.local) {
+    // Verify the placement BEFORE anything is modified: every workgroup ORs its XCC bit into its network's
+    // SF_XCC word and counts itself in at SF_ARRIVE; when all (active networks x (C + 1)) have arrived every
+    // network's mask must hold ONE bit.  Otherwise EVERY workgroup returns with parameters, Adam state and step
+    // counters untouched and the sticky word says why (2: a network on two XCCs, 1: somebody never arrived) --
+    // the caller repeats the pass with local = 0 (update.py).
+    int* s_why = reinterpret_cast<int*>(smem);  // (the dynamic LDS is not in use yet; a static __shared__ variable
+    // on top of the 160 KB dynamic limit makes hipFuncSetAttribute refuse the kernel)
+    if (tid == 0) {
+      int* base = reinterpret_cast<int*>(a.xch);
+      const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
+      __hip_atomic_fetch_or(flags + SF_XCC, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int expect = (C + 1) * __builtin_popcount(a.nets_mask & 7);
+      int v = __hip_atomic_fetch_add(base + SF_ARRIVE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      int spins = 0, why = 0;
+      while (v < expect) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(base + SF_ARRIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1 << 21)) { why = 1; break; }
+      }
+      for (int n = 0; n < 3 && why == 0; ++n) {
+        const int mask = __hip_atomic_load(base + 32 * n + SF_XCC, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((mask & (mask - 1)) != 0) why = 2;
+      }
+      if (why) __hip_atomic_store(err, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_why = why;
+    }
+    __syncthreads();
+    const bool bad_placement = *s_why != 0;
+    __syncthreads();
+    if (bad_placement) return;
   }
 #ifdef OSA_SPLIT_CLOCKS
   long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -938,7 +966,7 @@ static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   OsaSplitArgs arg = a;
   void* kargs[] = {&arg};
   const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
-                                                  dim3(a.local ? 8 * (a.C + 1) : 3 * (a.C + 1)), dim3(256), kargs,
+                                                  dim3(a.local == 1 ? 8 * (a.C + 1) : 3 * (a.C + 1)), dim3(256), kargs,
                                                   (unsigned)lds, stream);
   if (e == hipSuccess) return OSA_OK;
   (void)hipGetLastError();
@@ -976,7 +1004,7 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   if ((double)M * ld_obs >= 2147483647.0 * 4) return OSA_EUNSUPPORTED;
   OsaSplitArgs a = {};
   a.xch = xch;
-  a.local = local ? 1 : 0;
+  a.local = local;  // 0, 1, or 3 (see the kernel)
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.C = (a.nd.KB + SKQ - 1) / SKQ;
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -992,6 +1020,7 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   hipStream_t st = osa_stream(stream);
   // flag words are step counters of THIS launch (the sticky error word, SF_ERR, survives)
   if (hipMemsetAsync(xch, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if (hipMemsetAsync(reinterpret_cast<int*>(xch) + SF_ARRIVE, 0, sizeof(int), st) != hipSuccess) return OSA_EHIP;
   for (int n = 0; n < 3; ++n)  // the squared-norm slots carry their own step counters
     if (hipMemsetAsync(xch + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
   const int OT = a.nd.OUTP / 16;

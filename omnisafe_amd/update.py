@@ -28,6 +28,18 @@ from .models import ConstraintActorCritic, HParams, SurrogateExt
 NSTAT = 16
 
 
+# What this process has learnt about the "workgroup b runs on XCC b mod 8" placement the one-XCC variants of the
+# cooperative kernels rely on: None = not tried yet, True = verified by a kernel, False = a kernel found a
+# network on two XCCs (every later launch takes the spread variant straight away).
+_PLACEMENT = {'local_ok': None}
+
+
+def _local_arg() -> int:
+    """`local` argument of the cooperative passes: 1, or 3 under OSA_DEBUG_PLACEMENT=wrong (test hook: the one-XCC
+    protocol on the spread grid, which the kernels' placement check must catch before anything is modified)."""
+    return 3 if os.environ.get('OSA_DEBUG_PLACEMENT') == 'wrong' else 1
+
+
 class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def __init__(self, ac: ConstraintActorCritic, *, batch_size: int, update_iters: int,
                  target_kl: float, kl_early_stop: bool, clip: float = 0.2, entropy_coef: float = 0.0,
@@ -76,6 +88,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._split_tried = False
         self._chunk: dict = {}  # exchange buffer / sync words of osa_ppo_chunked_pass
         self._split_local = False
+        self._split_verified = False
         self._split_buf = None
 
     def _chunk_ok(self, data: dict) -> bool:
@@ -94,7 +107,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 return False
             n = self.lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
             ck.update(W=W, xch=torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device),
-                      sync=torch.zeros(8, dtype=torch.int32, device=ac.device))
+                      sync=torch.zeros(8, dtype=torch.int32, device=ac.device),
+                      local=0 if _PLACEMENT['local_ok'] is False else 1, verified=False)
         return True
 
     def check_chunk_sync(self) -> None:
@@ -118,7 +132,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         n = self.lib.osa_ppo_split_pass_xch_floats(ac.obs_dim, ac.act_dim, ac.hidden)
         # OSA_WIDE_SPLIT=local (default): one XCC per network, hand-offs through its L2 (ordinary memory);
         # OSA_WIDE_SPLIT=spread: workgroups over all XCCs, uncached exchange buffer
-        self._split_local = os.environ.get('OSA_WIDE_SPLIT', 'local') != 'spread'
+        self._split_local = os.environ.get('OSA_WIDE_SPLIT', 'local') != 'spread' and _PLACEMENT['local_ok'] is not False
         if self._split_local:
             self._split_buf = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
             self._split_xch = self._split_buf.data_ptr()
@@ -200,11 +214,23 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
                 _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
                 C.byref(self.hp), self.loss_kind, self._nets_mask(), C.c_void_p(self._split_xch),
-                int(self._split_local), _lib.ptr(stats_rows), _lib.stream_ptr())
+                (1 if self._split_verified else _local_arg()) if self._split_local else 0, _lib.ptr(stats_rows),
+                _lib.stream_ptr())
             if rc == _lib.OSA_EUNSUPPORTED:  # the device cannot hold the workgroups together: one CU per network
                 self._split_free()
             else:
                 _lib.check(rc, 'osa_ppo_split_pass')
+                if self._split_local and not self._split_verified:
+                    # first pass with one XCC per network: the kernel checks its placement before it modifies
+                    # anything and returns untouched if it does not hold -> repeat spread over the XCCs
+                    torch.cuda.synchronize()
+                    if int(self._split_buf.view(torch.int32)[96]) != 0:
+                        _PLACEMENT['local_ok'] = False
+                        self._split_free()
+                        self._split_tried = False
+                        self._split_alloc()
+                        return self.run_pass(data, perm, lagrange, stats_rows)
+                    self._split_verified = _PLACEMENT['local_ok'] = True
                 self.last_path = 'persistent-wide-split'
                 if ev is not None:
                     ev[1].record()
@@ -231,12 +257,23 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
                 _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
                 _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, _lib.ptr(lagrange),
-                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(ck['xch']), _lib.ptr(ck['sync']), 1,
-                _lib.ptr(stats_rows), _lib.stream_ptr())
+                C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(ck['xch']), _lib.ptr(ck['sync']),
+                (1 if ck.get('verified') else _local_arg()) if ck.get('local', 1) else 0, _lib.ptr(stats_rows),
+                _lib.stream_ptr())
             if rc == _lib.OSA_EUNSUPPORTED:  # not co-resident: one workgroup walks through the chunks
                 ck['off'] = True
             else:
                 _lib.check(rc, 'osa_ppo_chunked_pass')
+                if ck.get('local', 1) and not ck.get('verified'):
+                    # (as above: an unverified placement leaves everything untouched; repeat with the workgroups
+                    # spread over the XCCs and agent-scope release / acquire fences around the hand-offs)
+                    torch.cuda.synchronize()
+                    if int(ck['sync'][3]) != 0:
+                        _PLACEMENT['local_ok'] = False
+                        ck['sync'].zero_()
+                        ck['local'] = 0
+                        return self.run_pass(data, perm, lagrange, stats_rows)
+                    ck['verified'] = _PLACEMENT['local_ok'] = True
                 self.last_path = 'persistent-chunked'
                 if ev is not None:
                     ev[1].record()
@@ -339,7 +376,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             p = C.c_void_p()
             mode = os.environ.get('OSA_DP_XCH', 'local')
             cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
-            st['local'] = mode == 'local' and W <= cus // 8
+            st['local'] = mode == 'local' and W <= cus // 8 and _PLACEMENT['local_ok'] is not False
             if not st['local'] and mode in ('local', 'uncached') and lib.osa_dp_exchange_alloc(
                     max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
                 st['xch_ptr'], st['xch'] = p.value, None
@@ -354,11 +391,22 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
             _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
             _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp),
-            self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']), int(st['local']),
+            self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']),
+            (1 if st.get('verified') else _local_arg()) if st['local'] else 0,
             _lib.ptr(st['pass_stats']), _lib.stream_ptr())
         if rc == _lib.OSA_EUNSUPPORTED:
             return False
         _lib.check(rc, 'osa_ppo_dp_pass_placed')
+        if st['local'] and not st.get('verified'):
+            # first pass with one XCC per network: an unverified placement returns with everything untouched
+            # -> repeat spread over the XCCs (same buffer, agent-scope release / acquire fences)
+            torch.cuda.synchronize()
+            if int(st['sync'][3]) != 0:
+                _PLACEMENT['local_ok'] = False
+                st['sync'].zero_()
+                st['local'] = False
+                return self._dp_coop_pass(data_all, M, W, lagrange, st)
+            st['verified'] = _PLACEMENT['local_ok'] = True
         st['coop_passes'] = st.get('coop_passes', 0) + 1
         return True
 

@@ -324,8 +324,9 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
                                                   (3, 256, 128, True, False), (2, 512, 64, False, True),
                                                   (4, 300, 64, False, True), (3, 256, 128, False, True),
                                                   (8, 1024, 64, False, True), (1, 200, 64, False, True),
-                                                  (6, 320, 64, False, True), (16, 128, 64, False, True)])
-def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop):
+                                                  (6, 320, 64, False, True), (16, 128, 64, False, True),
+                                                  (2, 384, 64, False, 'wrong-placement')])
+def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop, monkeypatch):
     """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
     workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
     data-parallel semantics emulated rank by rank with the per-step kernels (gradient + local clip per
@@ -333,8 +334,13 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
     import ctypes as C
 
     from omnisafe_amd import _lib
+    from omnisafe_amd import update as U
     from omnisafe_amd.update import PPOUpdater
 
+    if coop == 'wrong-placement':  # test hook: the one-XCC protocol on the spread grid -> the kernel's placement
+        # check trips before anything is modified, the updater repeats the pass spread over the XCCs
+        monkeypatch.setenv('OSA_DEBUG_PLACEMENT', 'wrong')
+        monkeypatch.setitem(U._PLACEMENT, 'local_ok', None)
     torch.manual_seed(W * 100 + M)
     obs_dim, act_dim = 60, 2
     data_all = {'obs': torch.randn(W * M, obs_dim, device=DEV), 'act': torch.randn(W * M, act_dim, device=DEV),
@@ -356,10 +362,12 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
         if mode == 'replicated':
             for i in range(3):
                 up.run_pass_replicated(data_all, M, W, lam, stats[i * nmb:(i + 1) * nmb], perms_all=perms[i],
-                                       use_graph=use_graph, coop=coop)
+                                       use_graph=use_graph, coop=bool(coop))
             if coop:  # the cooperative persistent launch ran (no silent fallback) and every peer arrived
                 assert up._dp.get('coop_passes') == 3
                 up.check_dp_sync()
+            if coop == 'wrong-placement':
+                assert U._PLACEMENT['local_ok'] is False and up._dp['local'] is False
             if use_graph:
                 assert up._dp.get('graph') is not None and not up._dp.get('graph_failed', False)
         else:
@@ -615,3 +623,46 @@ def test_constraint_actor_critic_like_the_reference_test(linear_lr_decay, lr):
     cac.annealing(5)
     act_det, _, _, logp_det = cac(obs, deterministic=True)
     assert float(logp_det) == pytest.approx(-act_dim * (np.log(want) + 0.5 * np.log(2 * np.pi)), rel=1e-5)
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,M,B,path', [(376, 17, 512, 64, 'persistent-wide-split'),
+                                                      (60, 2, 1024, 128, 'persistent-chunked')])
+def test_wrong_placement_is_caught_before_anything_changes(obs_dim, act_dim, M, B, path, monkeypatch):
+    """The one-XCC variants of the cooperative passes rely on "workgroup b runs on XCC b mod 8".  Test hook
+    OSA_DEBUG_PLACEMENT=wrong launches their protocol on the SPREAD grid: the kernels' placement check must trip
+    before any parameter, moment or step counter is modified, the updater must repeat the pass with the spread
+    variant, remember the verdict for the process, and the results must equal the per-step launches."""
+    from omnisafe_amd import update as U
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(3)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perms = [torch.randperm(M), torch.randperm(M)]
+    keep = U._PLACEMENT['local_ok']
+    acs, outs = [], []
+    try:
+        for persistent, debug in ((True, 'wrong'), (False, '')):
+            U._PLACEMENT['local_ok'] = None
+            monkeypatch.setenv('OSA_DEBUG_PLACEMENT', debug)
+            torch.manual_seed(99)
+            ac = make_ac(obs_dim, act_dim)
+            if 'logp' not in data:
+                data['logp'] = ac.step(data['obs'], eps=(data['act'] * 0))[3] + 0.2 * torch.randn(M, device=DEV)
+            up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False,
+                            entropy_coef=0.01, persistent=persistent)
+            outs.append(up.run(data, torch.tensor([0.3], device=DEV), perms=perms, actor_lr=3e-4, critic_lr=1e-3))
+            acs.append(ac)
+            if persistent:
+                assert up.last_path == path
+                assert U._PLACEMENT['local_ok'] is False  # the check tripped and the verdict was recorded
+    finally:
+        U._PLACEMENT['local_ok'] = keep
+    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist()  # no step was counted twice
+    for name in ('params', 'adam_m', 'adam_v'):
+        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
+        bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)
+        assert bad.sum() <= 4 and (not bad.any() or np.abs(a - b)[bad].max() <= 2.5e-4), name
+    np.testing.assert_allclose(outs[0]['stats'].cpu().numpy()[:, :10], outs[1]['stats'].cpu().numpy()[:, :10],
+                               rtol=1e-5, atol=2e-7)
