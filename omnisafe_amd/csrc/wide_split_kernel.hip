@@ -113,6 +113,14 @@ __device__ __forceinline__ void osa_xch_release() {
 // were observed with small rollouts); an L1 invalidate, no L2 write-back
 __device__ __forceinline__ void osa_xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
+// 16-byte load that bypasses the vector L1 and is served at the coherence point of the exchange buffer (sc0 sc1);
+// the caller waits for it (s_waitcnt vmcnt) before it uses the value
+__device__ __forceinline__ f32x4 osa_load_bypass4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // lane `tid < n` waits until flag[tid] >= target (bounded: raises the sticky flag and gives up for good)
 __device__ __forceinline__ void osa_xch_wait(int* flags, int n, int target, int tid, int* err, bool& dead) {
   if (tid < n && !dead) {
@@ -341,16 +349,27 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) wv[q] = *reinterpret_cast<const f32x4*>(sW + own_lds + 16 * q);
       // ---- dz1 of this step
-      osa_xch_wait(flags + SF_DZ, 1, mb + 1, tid, err, dead);
-      osa_lds_barrier();
-      osa_xch_acquire();
-      STICK(2);
+      // Every lane polls the flag itself and requests ITS four dz1 fragments right behind it (cache-bypassing loads,
+      // returned in issue order): when the flag it read says "published", the data it read after it is the
+      // published data -- one round trip for flag + data instead of flag, barrier, L1 invalidate, data.
       f32x4 a1[4];
       {
-        const float* dz = xn + SX_DZ;
+        const float* dz = xn + SX_DZ + (16 * wave + i) * 64 + 4 * g;
+        int spins = 0;
+        while (!dead) {
+          const int f = __hip_atomic_load(flags + SF_DZ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) a1[sb] = *reinterpret_cast<const f32x4*>(dz + (16 * wave + i) * 64 + 16 * sb + 4 * g);
+          for (int sb = 0; sb < 4; ++sb) a1[sb] = osa_load_bypass4(dz + 16 * sb);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (f >= mb + 1) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 20)) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = true;
+          }
+        }
       }
+      STICK(2);
       // ---- dW1[f][k] = sum_s dz1[f][s] x[s][k], D[i = input 4g + r][j = feature cc]
       f32x4 gq[SKQ];
 #pragma unroll
