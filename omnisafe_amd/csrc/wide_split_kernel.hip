@@ -753,9 +753,6 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     osa_lds_barrier();  // (A) dz1 performed, tiles complete
     if (tid == 0) __hip_atomic_store(flags + SF_DZ, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STICK(3);
-    // ---- the next step's scalars (used after the next hand-off)
-    gather(row_nn);
-    row_nxt = row_nn;
     // ================= weight gradients (registers) =================
     f32x4 g2[HT], g3[OT];
     {
@@ -917,6 +914,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         st[7 + net] = total_norm;
       }
     }
+    // ---- the next step's scalars: requested here, where the leader is about to wait for the helpers' partials
+    // anyway (between the dz1 hand-off and the norm shares it is on the critical path: the actor's 11 gathers with
+    // their address arithmetic cost 1.2 k cycles there)
+    gather(row_nn);
+    row_nxt = row_nn;
     osa_lds_barrier();  // (C) frees tiles and `red`; the LDS master copy is consistent
     STICK(7);
   }
