@@ -667,13 +667,16 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
           if (d < nd.act_dim && valid) {
             const float z = s_act[4 * o + r] - out[o][r];
             zv[o][r] = z;
-            ivar[o][r] = sIV[d];
-            lp += -(z * z) / (2.f * sVAR[d]) - sLC[d] - 0.91893853320467274178f;
+            const float iv = sIV[d];
+            ivar[o][r] = iv;
+            // (z^2 / (2 sigma^2) as a product with the tabulated 1 / sigma^2, as osa_ppo_pass_kernel does: a division per
+            // element and lane is ~12 VALU instructions on the leader's critical path)
+            lp += -(z * z) * (0.5f * iv) - sLC[d] - 0.91893853320467274178f;
           }
         }
       }
       lp = osa_sum_over_groups(lp);
-      const float ratio = valid ? expf(lp - s_logp) : 0.f;
+      const float ratio = valid ? __builtin_amdgcn_exp2f((lp - s_logp) * 1.44269504088896340736f) : 0.f;
       if (valid) {
         const float adv = (s_advr - lam * s_advc) / (1.f + lam);  // ppo_lag.py:101-102
         float dratio, li;
