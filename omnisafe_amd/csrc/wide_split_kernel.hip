@@ -18,11 +18,18 @@
 //     pass, publishes dz1, computes dW2 / dW3 / bias gradients and its share of |g|^2;
 //   * the C + 1 squared-norm shares meet in an all-gather (every workgroup sums the slots in the same order:
 //     one clip factor, bit-identical everywhere); then everybody applies Adam to what it owns.
-// Three hand-offs per step (partials -> leader, dz1 -> helpers, norm shares -> all) through an UNCACHED
-// device buffer (osa_dp_exchange_alloc: stores are performed at the device-coherent level, so a hand-off is
-// "wait for my stores, barrier, relaxed flag store" / "poll, barrier" with no L2 write-back or invalidate;
-// measured 0.55-0.7 us each).  Flags are step counters (monotonic within a launch); a
-// peer that never arrives raises a sticky flag instead of hanging the device.
+// Three hand-offs per step (partials -> leader, dz1 -> helpers, norm shares -> all) through the exchange buffer.
+// Placement (OsaSplitArgs::local): workgroup b of a grid runs on XCC b mod 8, so with local = 1 the launch is
+// 8 (C + 1) blocks of which block net + 8 role works: a network's workgroups share ONE XCC and the buffer is
+// ordinary memory served by that XCC's L2; with local = 0 consecutive blocks (all XCCs) and an UNCACHED buffer
+// (osa_dp_exchange_alloc: stores are performed at the device-coherent level).  Either way a hand-off is "my stores
+// are performed (s_waitcnt vmcnt(0)), LDS barrier, relaxed agent-scope flag store" on one side and on the other
+// "poll, LDS barrier, L1 invalidate (buffer_inv sc1: the vector L1 keeps lines even of uncached memory), loads"
+// (leader) or "every lane polls the flag and requests its own fragments right behind it with cache-bypassing
+// loads: one round trip" (helpers); the squared-norm shares travel with their step counter in one 8-byte word.
+// No L2 write-back anywhere.  Flags are step counters (monotonic within a launch); the one-XCC placement is
+// verified before anything is modified (all workgroups return untouched otherwise) and a peer that never
+// arrives raises a sticky flag instead of hanging the device.
 //
 // Arithmetic: the fragment algebra and loss code of osa_wide_pass_kernel; the layer-1 pre-activation is
 // the sum of C partial sums instead of one chain over K (float32 re-association, ~1e-7 relative), and the

@@ -21,7 +21,7 @@ DEV = 'cuda:0'
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 res = {}
 for obs_dim, act_dim, B, critics_only in ((72, 2, 128, True), (27, 8, 128, True), (60, 2, 128, False), (60, 2, 256, False),
-                                          (60, 2, 512, False), (60, 2, 1024, False), (60, 2, 2048, False)):
+                                          (60, 2, 512, False), (60, 2, 1024, False)):
     torch.manual_seed(0)
     data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
             'logp': torch.randn(M, device=DEV) * 0.1 - 3.0, 'target_value_r': torch.randn(M, device=DEV),

@@ -21,3 +21,5 @@ ls $R/gpurun_out/prof_final/* $R/gpurun_out/pmc_FETCH_SIZE/* $R/gpurun_out/pmc_g
 cd $R
 timeout 300 python tools/wide_pass_timing.py 65536 > gpurun_out/wide_pass_timing.log 2>&1; tail -25 gpurun_out/wide_pass_timing.log
 timeout 1500 python tools/baseline_configs.py > gpurun_out/baseline_configs.log 2>&1; tail -8 gpurun_out/baseline_configs.log
+timeout 300 python tools/chunked_pass_timing.py > gpurun_out/chunked_pass_timing.log 2>&1; tail -16 gpurun_out/chunked_pass_timing.log
+timeout 300 python tools/dp_timing.py 2>&1 | grep "^W=" > gpurun_out/dp_timing.log; cat gpurun_out/dp_timing.log
