@@ -626,15 +626,26 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(sB2 + 16 * t + 4 * g);
+    {
+      // (LDS fragment reads one K block ahead of the MFMAs that consume them: with one wave per SIMD nothing else
+      // hides an LDS round trip)
+      f32x4 wn[HT];
 #pragma unroll
-    for (int kb = 0; kb < HT; ++kb) {
-      f32x4 w[HT];
+      for (int t = 0; t < HT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * SSLD + 4 * g);
 #pragma unroll
-      for (int t = 0; t < HT; ++t) w[t] = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * SSLD + 16 * kb + 4 * g);
+      for (int kb = 0; kb < HT; ++kb) {
+        f32x4 w[HT];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int t = 0; t < HT; ++t) w[t] = wn[t];
+        if (kb + 1 < HT) {
 #pragma unroll
-        for (int t = 0; t < HT; ++t) h2[t] = OSA_MFMA(w[t][s], h1[kb][s], h2[t]);
+          for (int t = 0; t < HT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(sW2 + (16 * t + i) * SSLD + 16 * (kb + 1) + 4 * g);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) h2[t] = OSA_MFMA(w[t][s], h1[kb][s], h2[t]);
+      }
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
@@ -643,14 +654,18 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(sB3 + 16 * o + 4 * g);
+    {
+      f32x4 w3f[HT][OT];
 #pragma unroll
-    for (int kb = 0; kb < HT; ++kb) {
+      for (int kb = 0; kb < HT; ++kb)
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * SSLD + 16 * kb + 4 * g);
+        for (int o = 0; o < OT; ++o) w3f[kb][o] = *reinterpret_cast<const f32x4*>(sW3 + (16 * o + i) * SSLD + 16 * kb + 4 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) out[o] = OSA_MFMA(w[s], h2[kb][s], out[o]);
-      }
+      for (int kb = 0; kb < HT; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int o = 0; o < OT; ++o) out[o] = OSA_MFMA(w3f[kb][o][s], h2[kb][s], out[o]);
     }
     // ================= loss, dL/d(out) (osa_mb_grad_kernel's code path without extensions) =================
     STICK(1);
@@ -722,29 +737,47 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     }
     // ================= backward through the hidden layers (S layout) =================
     f32x4 z2[HT], z1[HT];
+    {
+      f32x4 wt[HT][OT], acc[HT];
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < HT; ++t) {
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sW3T + (16 * t + i) * S3LD + 16 * o + 4 * g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[s], dO[o][s], acc);
+        for (int o = 0; o < OT; ++o)  // A[i][k] = W3^T[16t+i][16o+4g+s]
+          wt[t][o] = *reinterpret_cast<const f32x4*>(sW3T + (16 * t + i) * S3LD + 16 * o + 4 * g);
       }
-      z2[t] = acc * (1.f - h2[t] * h2[t]);
-      SPUT_TILE(sZ2, z2[t], t);
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) acc[t] = OSA_MFMA(wt[t][o][s], dO[o][s], acc[t]);  // four independent chains
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        z2[t] = acc[t] * (1.f - h2[t] * h2[t]);
+        SPUT_TILE(sZ2, z2[t], t);
+      }
     }
     {
       float* dz = xn + SX_DZ;
+      f32x4 wn[HT];  // A[i][k] = W2^T[16t+i][16kb+4g+s]: the next tile's four fragments one tile ahead
+#pragma unroll
+      for (int kb = 0; kb < HT; ++kb) wn[kb] = *reinterpret_cast<const f32x4*>(sW2T + i * SSLD + 16 * kb + 4 * g);
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
+        f32x4 w[HT];
+#pragma unroll
+        for (int kb = 0; kb < HT; ++kb) w[kb] = wn[kb];
+        if (t + 1 < HT) {
+#pragma unroll
+          for (int kb = 0; kb < HT; ++kb)
+            wn[kb] = *reinterpret_cast<const f32x4*>(sW2T + (16 * (t + 1) + i) * SSLD + 16 * kb + 4 * g);
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
-          const f32x4 w = *reinterpret_cast<const f32x4*>(sW2T + (16 * t + i) * SSLD + 16 * kb + 4 * g);
+        for (int kb = 0; kb < HT; ++kb)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[s], z2[kb][s], acc);
-        }
+          for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[kb][s], z2[kb][s], acc);
         z1[t] = acc * (1.f - h1[t] * h1[t]);
         // dz1 leaves for the helpers as soon as a tile is finished: row = feature, 16 consecutive samples per
         // (g, r) = 64-byte segments
