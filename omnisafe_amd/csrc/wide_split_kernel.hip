@@ -804,28 +804,42 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       for (int sb = 0; sb < 4; ++sb) a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * wave + i) * SSLD + 16 * sb + 4 * g);
 #pragma unroll
       for (int ti = 0; ti < HT; ++ti) g2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (fragments one sample block ahead of their MFMAs; the output layer's fragments all up front and its OT
+      // accumulator chains interleaved)
+      f32x4 bn[HT];
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) bn[ti] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SSLD + 4 * g);
+      f32x4 av3[OT][4], b3[4];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        b3[sb] = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * SSLD + 16 * sb + 4 * g);
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+          av3[o][sb] = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * SSLD + 16 * sb + 4 * g);
+      }
 #pragma unroll
       for (int sb = 0; sb < 4; ++sb) {
         f32x4 b[HT];
 #pragma unroll
-        for (int ti = 0; ti < HT; ++ti)
-          b[ti] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SSLD + 16 * sb + 4 * g);
+        for (int ti = 0; ti < HT; ++ti) b[ti] = bn[ti];
+        if (sb + 1 < 4) {
+#pragma unroll
+          for (int ti = 0; ti < HT; ++ti)
+            bn[ti] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SSLD + 16 * (sb + 1) + 4 * g);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int ti = 0; ti < HT; ++ti) g2[ti] = OSA_MFMA(a2[sb][s], b[ti][s], g2[ti]);
       }
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int o = 0; o < OT; ++o) g3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * SSLD + 16 * sb + 4 * g);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * SSLD + 16 * sb + 4 * g);
+      for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) g3[o] = OSA_MFMA(av[s], b[s], g3[o]);
-        }
-      }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int o = 0; o < OT; ++o) g3[o] = OSA_MFMA(av3[o][sb][s], b3[sb][s], g3[o]);
     }
     // bias-like gradient owned by this thread: row sum over the 64 samples
     float gb = 0.f;
