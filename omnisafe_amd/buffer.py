@@ -180,7 +180,9 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         horizons -> tiled; v-trace (a float32 chain) always sequential."""
         if estimator == _EST['vtrace']:
             return 'sequential'
-        return 'tiled' if (T >= 128 and N < 32768) else 'sequential'
+        # (round 2, with 16 waves per workgroup for small grids: at T = 64 the tiled kernel takes 9-31 us where the
+        # lane-per-env kernel takes 23-38 us for N <= 32 768; at N = 65 536 the two are level from T = 128 on)
+        return 'tiled' if (T >= 64 and N <= 32768) else 'sequential'
 
     def compute_advantages(self) -> None:
         """K5: one backward scan over the (T, N) buffer (osa_gae_scan / osa_gae_scan_tiled)."""

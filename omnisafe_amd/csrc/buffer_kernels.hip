@@ -257,8 +257,12 @@ __device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long
   return x;
 }
 
-template <int EST, int NB>
-__global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
+// NWV waves per workgroup: 4 (one per SIMD) when the grid alone fills the chip; 16 (four per SIMD, ONE env per
+// wave) when N / NB workgroups are at most ~ 2 per compute unit -- the scan of a tile is a chain of dependent
+// float64 DPP rounds, and with one wave per SIMD nothing hides their latency (measured at T = 4096, N = 4096:
+// 6.5 us per 36 KB tile and workgroup, i.e. compute-latency-bound at 1.4 TB/s)
+template <int EST, int NB, int NWV>
+__global__ __launch_bounds__(64 * NWV) void osa_gae_tile_scan_kernel(
     const float* __restrict__ reward, const float* __restrict__ cost,
     const float* __restrict__ value_r, const float* __restrict__ value_c,
     const uint8_t* __restrict__ path_end, const float* __restrict__ boot_r,
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
     float pc, float* __restrict__ adv_r, float* __restrict__ adv_c, float* __restrict__ tgt_r,
     float* __restrict__ tgt_c, float* __restrict__ disc_ret) {
 #pragma clang fp contract(off)
-  constexpr int TT = 64, LD = NB + 1, EPW = NB / 4, PER = TT * NB / 256;  // envs per wave, elements per thread
+  constexpr int TT = 64, LD = NB + 1, NTH = 64 * NWV, EPW = NB / NWV, PER = TT * NB / NTH;  // envs per wave, elements per thread
   __shared__ float s_in[7][TT][LD];   // r, c, v_r, v_c, boot_r, boot_c, path_end (as 0/1)
   __shared__ float s_out[5][TT][LD];  // adv_r, adv_c, tgt_r, tgt_c, disc_ret
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
     const int t_hi = T - 1 - j * TT;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+      const int i = tid + NTH * k, tt = i / NB, e = i % NB;
       const int t = t_hi - tt, n = n0 + e;
       const bool ok = t >= 0 && n < N;
       const long g = ok ? (long)t * N + n : 0;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
   auto stage = [&]() {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+      const int i = tid + NTH * k, tt = i / NB, e = i % NB;
 #pragma unroll
       for (int a = 0; a < 7; ++a) s_in[a][tt][e] = pre[a][k];
     }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
     if (j + 1 < ntiles) fetch(j + 1);  // in flight while this tile is scanned
 #pragma unroll
     for (int q = 0; q < EPW; ++q) {
-      const int e = q * 4 + wave;  // envs interleaved over the waves: few envs still use all four
+      const int e = q * NWV + wave;  // envs interleaved over the waves: few envs still use all of them
       if (n0 + e >= N) continue;   // wave-uniform
       const float r = s_in[0][lane][e], c = s_in[1][lane][e];
       const float vr = s_in[2][lane][e], vc = s_in[3][lane][e];
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void osa_gae_tile_scan_kernel(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k, tt = i / NB, e = i % NB;
+      const int i = tid + NTH * k, tt = i / NB, e = i % NB;
       const int t = t_hi - tt, n = n0 + e;
       if (tt < nvalid && n < N) {
         const long g = (long)t * N + n;
@@ -599,10 +603,25 @@ int osa_gae_scan_tiled(const float* reward, const float* cost, const float* valu
   const double d_g = gamma, d_r = gamma * lam, d_c = gamma * lam_c;
   constexpr int NB = 16;
   const int blocks = (N + NB - 1) / NB;
-#define OSA_GAE_TILE_LAUNCH(E)                                                                     \
-  hipLaunchKernelGGL((osa_gae_tile_scan_kernel<E, NB>), dim3(blocks), dim3(256), 0, osa_stream(stream), \
-                     reward, cost, value_r, value_c, path_end, boot_r, boot_c, T, N, g32, d_g, d_r, d_c,  \
-                     penalty_coef, adv_r, adv_c, target_value_r, target_value_c, discounted_ret)
+  // 16 waves per workgroup (one env per wave, four waves per SIMD) while the grid is small enough to leave the
+  // compute units under-occupied; OSA_GAE_TILE_WAVES = 4 / 16 forces one (A/B switch of tools/gae_bandwidth.py)
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  bool wide_wg = blocks <= 2 * cus;
+  if (const char* e = getenv("OSA_GAE_TILE_WAVES")) wide_wg = e[0] == '1';
+#define OSA_GAE_TILE_LAUNCH(E)                                                                            \
+  do {                                                                                                    \
+    if (wide_wg)                                                                                          \
+      hipLaunchKernelGGL((osa_gae_tile_scan_kernel<E, NB, 16>), dim3(blocks), dim3(1024), 0,              \
+                         osa_stream(stream), reward, cost, value_r, value_c, path_end, boot_r, boot_c, T, \
+                         N, g32, d_g, d_r, d_c, penalty_coef, adv_r, adv_c, target_value_r,               \
+                         target_value_c, discounted_ret);                                                 \
+    else                                                                                                  \
+      hipLaunchKernelGGL((osa_gae_tile_scan_kernel<E, NB, 4>), dim3(blocks), dim3(256), 0,                \
+                         osa_stream(stream), reward, cost, value_r, value_c, path_end, boot_r, boot_c, T, \
+                         N, g32, d_g, d_r, d_c, penalty_coef, adv_r, adv_c, target_value_r,               \
+                         target_value_c, discounted_ret);                                                 \
+  } while (0)
   if (estimator == OSA_EST_GAE) OSA_GAE_TILE_LAUNCH(OSA_EST_GAE);
   else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_TILE_LAUNCH(OSA_EST_GAE_RTG);
   else OSA_GAE_TILE_LAUNCH(OSA_EST_PLAIN);

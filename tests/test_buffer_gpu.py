@@ -184,6 +184,8 @@ def test_gae_variant_auto_rule():
     assert B.gae_variant_for(5000, 4, 0) == 'tiled'           # BASELINE config 1: 4 envs, long horizon
     assert B.gae_variant_for(4096, 4096, 0) == 'tiled'
     assert B.gae_variant_for(16, 1 << 20, 0) == 'sequential'  # enough envs to fill the chip with lanes
+    assert B.gae_variant_for(64, 4096, 0) == 'tiled' and B.gae_variant_for(64, 32768, 0) == 'tiled'
+    assert B.gae_variant_for(32, 4096, 0) == 'sequential' and B.gae_variant_for(256, 65536, 0) == 'sequential'
     assert B.gae_variant_for(5000, 4, 3) == 'sequential'      # v-trace
     buf = _mk(5000, 4, 3, 2, variant='auto')
     buf.ptr = 5000
