@@ -522,6 +522,37 @@ __global__ __launch_bounds__(256) void osa_get_rows_kernel(const float* __restri
   dst[row * ld_dst + d] = src[((long)t * N + n) * ld_src + d];
 }
 
+// The same re-ordering with 16-byte accesses and 32-bit index arithmetic (rows 16-byte aligned, dim % 4 == 0,
+// fewer than 2^31 vectors): one thread moves one float4; consecutive threads walk the DESTINATION (contiguous
+// stores; the loads are row segments N * ld_src apart).  The scalar kernel above spends two 64-bit divisions per
+// 4 bytes and reached 2.3 TB/s at 16 M rows of 60 floats.
+__global__ __launch_bounds__(256) void osa_get_rows_vec4_kernel(const float* __restrict__ src, int ld_src,
+                                                                float* __restrict__ dst, int ld_dst,
+                                                                unsigned T, unsigned N, unsigned dim4,
+                                                                unsigned total4) {
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total4) return;
+  const unsigned row = gid / dim4, q = gid - row * dim4;  // env-major sample index i = n*T + t
+  const unsigned n = row / T, t = row - n * T;
+  const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)t * N + n) * ld_src + 4 * q);
+  *reinterpret_cast<float4*>(dst + (size_t)row * ld_dst + 4 * q) = v;
+}
+
+static void osa_launch_get_rows(const float* src, int ld_src, float* dst, int ld_dst, int T, int N, int dim,
+                                hipStream_t st) {
+  const long total = (long)T * N * dim;
+  const bool vec = dim % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && total / 4 < 2147483647L &&
+                   (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  if (vec) {
+    const unsigned total4 = (unsigned)(total / 4);
+    hipLaunchKernelGGL(osa_get_rows_vec4_kernel, dim3((total4 + 255) / 256), dim3(256), 0, st, src, ld_src, dst,
+                       ld_dst, (unsigned)T, (unsigned)N, (unsigned)(dim / 4), total4);
+  } else {
+    hipLaunchKernelGGL(osa_get_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src,
+                       dst, ld_dst, T, N, dim);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -684,15 +715,11 @@ int osa_buffer_get(int T, int N, int obs_dim, int act_dim, const float* obs, int
                      osa_stream(stream), p, T, N, stats);
   if (obs && out_obs) {
     OSA_REQUIRE(obs_dim > 0 && ld_obs >= obs_dim && ld_out_obs >= obs_dim);
-    const long total = (long)T * N * obs_dim;
-    hipLaunchKernelGGL(osa_get_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       osa_stream(stream), obs, ld_obs, out_obs, ld_out_obs, T, N, obs_dim);
+    osa_launch_get_rows(obs, ld_obs, out_obs, ld_out_obs, T, N, obs_dim, osa_stream(stream));
   }
   if (act && out_act) {
     OSA_REQUIRE(act_dim > 0 && ld_act >= act_dim && ld_out_act >= act_dim);
-    const long total = (long)T * N * act_dim;
-    hipLaunchKernelGGL(osa_get_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       osa_stream(stream), act, ld_act, out_act, ld_out_act, T, N, act_dim);
+    osa_launch_get_rows(act, ld_act, out_act, ld_out_act, T, N, act_dim, osa_stream(stream));
   }
   OSA_CHECK_LAUNCH();
   return OSA_OK;
