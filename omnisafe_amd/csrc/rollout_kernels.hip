@@ -15,6 +15,17 @@
 // ticket, and the LAST workgroup to arrive merges all partials into the running state (release fence ->
 // agent-scope atomic -> acquire fence; the ticket is left at 0 for the next call).  Round 1 used two
 // launches (partial, merge: 13 + 11.5 us per vector step for a 1 MB input).
+// partial sums of the single-launch reduction: relaxed agent-scope 8-byte accesses (performed at / served by the
+// device-coherent level, so that the last workgroup to arrive sees them whichever XCC wrote them)
+__device__ __forceinline__ void osa_ws_put(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double osa_ws_get(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 __global__ __launch_bounds__(256) void osa_norm_push_kernel(
     const float* __restrict__ x, int ld, int N, int D, const uint8_t* __restrict__ mask,
     float* __restrict__ mean, float* __restrict__ sumsq, float* __restrict__ var,
@@ -33,14 +44,27 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
     const double c = (col < D) ? (double)mean[col] : 0.0;
     double a1 = 0.0, a2 = 0.0;
     int cnt = 0;
-    for (int r = r0 + ry; r < r1; r += 4) {
-      const bool on = mask == nullptr || mask[r] != 0;
-      if (on) {
-        ++cnt;
-        if (col < D) {
-          const double d = (double)x[(long)r * ld + col] - c;
-          a1 += d;
-          a2 = __builtin_fma(d, d, a2);
+    // (loads of 8 rows in flight per trip, from clamped addresses, consumed afterwards in row order: the
+    // row-by-row loop was a chain of 32 dependent memory round trips per thread -- 25 us per call for 1 MB)
+    const int cl = (col < D) ? col : 0;
+    for (int rb = r0 + ry; rb < r1; rb += 32) {
+      float xv[8];
+      uint8_t mv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = min(rb + 4 * u, r1 - 1);
+        xv[u] = x[(long)r * ld + cl];
+        mv[u] = mask ? mask[r] : (uint8_t)1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (rb + 4 * u < r1 && mv[u] != 0) {
+          ++cnt;
+          if (col < D) {
+            const double d = (double)xv[u] - c;
+            a1 += d;
+            a2 = __builtin_fma(d, d, a2);
+          }
         }
       }
     }
@@ -52,14 +76,16 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
   if (ry == 0) {
     if (col < D) {
       double* o = ws + ((long)blockIdx.x * D + col) * 2;
-      o[0] = s1[0][cx] + s1[1][cx] + s1[2][cx] + s1[3][cx];
-      o[1] = s2[0][cx] + s2[1][cx] + s2[2][cx] + s2[3][cx];
+      osa_ws_put(o, s1[0][cx] + s1[1][cx] + s1[2][cx] + s1[3][cx]);
+      osa_ws_put(o + 1, s2[0][cx] + s2[1][cx] + s2[2][cx] + s2[3][cx]);
     }
     if (cx == 0 && blockIdx.y == 0)
-      ws[(long)nrb * D * 2 + blockIdx.x] = (double)(scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+      osa_ws_put(ws + (long)nrb * D * 2 + blockIdx.x, (double)(scnt[0] + scnt[1] + scnt[2] + scnt[3]));
   }
-  // ---- last-arriver ticket
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // ---- last-arriver ticket.  The partials travel as agent-scope (write-through / cache-bypassing) 8-byte
+  // accesses: "my stores are performed" is an s_waitcnt, and nobody needs an agent-scope RELEASE FENCE -- which
+  // writes back every dirty line of the XCC's L2 and made this kernel cost 21 us even for 16 rows
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const int total = gridDim.x * gridDim.y;
@@ -68,11 +94,11 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
   }
   __syncthreads();
   if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // ---- merge (Normalizer._push, normalizer.py:109-139): every other workgroup has finished reading `mean`
   if (threadIdx.x == 0) {
     double n = 0.0;
-    for (int b = 0; b < nrb; ++b) n += ws[(long)nrb * D * 2 + b];
+#pragma unroll 8
+    for (int b = 0; b < nrb; ++b) n += osa_ws_get(ws + (long)nrb * D * 2 + b);
     s_n = (long)n;
     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
   }
@@ -83,9 +109,21 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
   const long cnt_new = cnt_old + n_raw;
   for (int c0 = threadIdx.x; c0 < D; c0 += blockDim.x) {
     double S1 = 0.0, S2 = 0.0;
-    for (int b = 0; b < nrb; ++b) {
-      S1 += ws[((long)b * D + c0) * 2];
-      S2 += ws[((long)b * D + c0) * 2 + 1];
+    for (int b0 = 0; b0 < nrb; b0 += 8) {  // 8 partials' loads in flight, summed in order
+      double p1[8], p2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = min(b0 + u, nrb - 1);
+        p1[u] = osa_ws_get(ws + ((long)b * D + c0) * 2);
+        p2[u] = osa_ws_get(ws + ((long)b * D + c0) * 2 + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (b0 + u < nrb) {
+          S1 += p1[u];
+          S2 += p2[u];
+        }
+      }
     }
     const double c = (double)mean[c0];
     const float mean_raw = (float)(c + S1 / (double)n_raw);
