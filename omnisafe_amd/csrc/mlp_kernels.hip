@@ -751,6 +751,15 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     const float* s = a.slabs + (long)net * a.nblk * W + e;
     float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
     int b = 0;
+    for (; b + 16 <= a.nblk; b += 16) {  // 16 slabs' loads in flight; q[u] receives b + u, b + 8 + u in this order
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = s[(long)(b + u) * W];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] += t[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] += t[8 + u];
+    }
     for (; b + 8 <= a.nblk; b += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) q[u] += s[(long)(b + u) * W];
@@ -791,11 +800,13 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
   psq = osa_block_sum_f(psq, red);
   float* part = partials + ((long)net * nblk + blockIdx.x) * 2;
   if (threadIdx.x == 0) {
-    part[0] = gsq;
-    part[1] = psq;
+    // (agent-scope accesses for the two partial sums instead of an agent-scope release / acquire fence pair around
+    // the barrier: the release fence writes back every dirty line of the XCC's L2)
+    __hip_atomic_store(part, gsq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 1, psq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // ---- grid barrier of this network's workgroups
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) {
     int seen = __hip_atomic_fetch_add(sync + net, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
@@ -810,16 +821,25 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (threadIdx.x == 0) {
-    float tg = 0.f, tp = 0.f;
-    const float* pp = partials + (long)net * nblk * 2;
-    for (int k = 0; k < nblk; ++k) {  // block order: identical totals in every workgroup
-      tg += pp[2 * k];
-      tp += pp[2 * k + 1];
+  {
+    // every partial is fetched by its own thread (one round trip for all), then added in block order: identical
+    // totals in every workgroup
+    __shared__ float s_part[2][256];
+    float* pp = partials + (long)net * nblk * 2;
+    for (int k = threadIdx.x; k < nblk; k += blockDim.x) {  // (nblk <= 256 for every supported network)
+      s_part[0][k] = __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_part[1][k] = __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_tot[0] = tg;
-    s_tot[1] = tp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tg = 0.f, tp = 0.f;
+      for (int k = 0; k < nblk; ++k) {
+        tg += s_part[0][k];
+        tp += s_part[1][k];
+      }
+      s_tot[0] = tg;
+      s_tot[1] = tp;
+    }
   }
   __syncthreads();
   const float total_norm = sqrtf(s_tot[0]);
