@@ -23,3 +23,13 @@ timeout 300 python tools/wide_pass_timing.py 65536 > gpurun_out/wide_pass_timing
 timeout 1500 python tools/baseline_configs.py > gpurun_out/baseline_configs.log 2>&1; tail -8 gpurun_out/baseline_configs.log
 timeout 300 python tools/chunked_pass_timing.py > gpurun_out/chunked_pass_timing.log 2>&1; tail -16 gpurun_out/chunked_pass_timing.log
 timeout 300 python tools/dp_timing.py 2>&1 | grep "^W=" > gpurun_out/dp_timing.log; cat gpurun_out/dp_timing.log
+# per-kernel time of the BASELINE configs 3 and 4 (trust-region family with chunked critic passes; wide observations)
+cd /tmp
+for c in 3 4; do
+  rm -rf $R/gpurun_out/prof_cfg$c
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg$c -- python $R/tools/config_epoch_profile.py $c 4 > $R/gpurun_out/prof_cfg$c.log 2>&1
+  grep epoch $R/gpurun_out/prof_cfg$c.log | tail -2
+done
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq_cfg4 -- python $R/tools/config_epoch_profile.py 4 2 > $R/gpurun_out/pmc_sq_cfg4.log 2>&1
+cd $R
+timeout 600 python tools/gae_bandwidth.py > gpurun_out/gae_bandwidth.log 2>&1; tail -2 gpurun_out/gae_bandwidth.log
