@@ -120,8 +120,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 else 'a cooperating workgroup never arrived') + ' (results invalid); set OSA_CHUNKED_PASS=0')
 
     def _split_alloc(self) -> None:
-        """Exchange buffer of osa_ppo_split_pass (uncached device memory; OSA_WIDE_SPLIT=0 keeps the one-CU
-        kernel: A/B switch of tools/wide_pass_timing.py)."""
+        """Exchange buffer of osa_ppo_split_pass: ordinary memory with one XCC per network (default), uncached
+        device memory with the workgroups spread over the XCCs (OSA_WIDE_SPLIT=spread, or after a tripped
+        placement check); OSA_WIDE_SPLIT=0 keeps the one-CU kernel (A/B switch of tools/wide_pass_timing.py)."""
         if self._split_tried:
             return
         self._split_tried = True
