@@ -340,6 +340,7 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
     if coop == 'wrong-placement':  # test hook: the one-XCC protocol on the spread grid -> the kernel's placement
         # check trips before anything is modified, the updater repeats the pass spread over the XCCs
         monkeypatch.setenv('OSA_DEBUG_PLACEMENT', 'wrong')
+        monkeypatch.setenv('OSA_DP_XCH', 'local')
         monkeypatch.setitem(U._PLACEMENT, 'local_ok', None)
     torch.manual_seed(W * 100 + M)
     obs_dim, act_dim = 60, 2
@@ -646,6 +647,8 @@ def test_wrong_placement_is_caught_before_anything_changes(obs_dim, act_dim, M, 
         for persistent, debug in ((True, 'wrong'), (False, '')):
             U._PLACEMENT['local_ok'] = None
             monkeypatch.setenv('OSA_DEBUG_PLACEMENT', debug)
+            monkeypatch.setenv('OSA_WIDE_SPLIT', 'local')
+            monkeypatch.setenv('OSA_CHUNKED_PASS', '1')
             torch.manual_seed(99)
             ac = make_ac(obs_dim, act_dim)
             if 'logp' not in data:
