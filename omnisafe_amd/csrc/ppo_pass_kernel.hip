@@ -1026,6 +1026,23 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (chunked && W == 2) {
+        // two chunks (the trust-region family's batch of 128): own gradient from the registers + the peer's slab.
+        // A two-operand float sum is commutative, so both workgroups get the same bits without the rank order.
+        const float* __restrict__ xr = xbase + (long)(rk ^ 1) * XS;
+        const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
+        f32x4 t[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) t[q] = x4[q * 256 + tid];
+        const float tb = xr[NT * 1024 + tid];
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) s2[ti] = g2[ti] + t[ti];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) s1[kb] = g1[kb] + t[HT + kb];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) s3[o] = g3[o] + t[HT + KB + o];
+        sb_ = ((boff >= 0) ? gb : 0.f) + tb;
+      } else {
       // RU ranks per trip: their loads are all in flight together (one memory round trip per trip,
       // not per rank); the clamped duplicate loads of a ragged last trip are simply not added
       constexpr int RU = 4;
@@ -1053,6 +1070,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
             sb_ += tb[u] * tg[u];
           }
         }
+      }
       }
       const float invW = chunked ? 1.f : 1.f / (float)W;
 #pragma unroll
