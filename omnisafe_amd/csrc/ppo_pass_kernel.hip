@@ -113,6 +113,22 @@ struct OsaPassArgs {
 #define PTICK(k) do { } while (0)
 #endif
 
+// a * sa + b * sb with BOTH products rounded before the addition (no contraction into a fused multiply-add):
+// the value is then symmetric in (a, sa) <-> (b, sb), which is what lets two peers that see each other's operand
+// as "b" arrive at the same bits
+__device__ __forceinline__ f32x4 osa_sym_sum(f32x4 a, float sa, f32x4 b, float sb) {
+#pragma clang fp contract(off)
+  const f32x4 pa = a * sa;
+  const f32x4 pb = b * sb;
+  return pa + pb;
+}
+__device__ __forceinline__ float osa_sym_sum1(float a, float sa, float b, float sb) {
+#pragma clang fp contract(off)
+  const float pa = a * sa;
+  const float pb = b * sb;
+  return pa + pb;
+}
+
 template <int KB, int OT, bool MULTI, bool COOP, bool EXT>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1026,22 +1042,25 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (chunked && W == 2) {
-        // two chunks (the trust-region family's batch of 128): own gradient from the registers + the peer's slab.
-        // A two-operand float sum is commutative, so both workgroups get the same bits without the rank order.
+      if (W == 2) {
+        // two peers (two chunks of a 128-row minibatch, or two ranks): own gradient from the registers + the
+        // peer's slab.  Both sides form the same two products (g * clip factor; 1 in chunk mode) and a two-operand
+        // float sum is commutative, so they get the same bits without walking the slabs in rank order.
         const float* __restrict__ xr = xbase + (long)(rk ^ 1) * XS;
         const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
         f32x4 t[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) t[q] = x4[q * 256 + tid];
-        const float tb = xr[NT * 1024 + tid];
+        const float tb = xr[NT * 1024 + tid], tg = xr[NT * 1024 + 256 + 5];
+        // (both products ROUNDED, then added: a fused multiply-add would round g_own * gs differently from the
+        // peer's view of the same product, and the two replicas would drift apart by an ulp)
 #pragma unroll
-        for (int ti = 0; ti < HT; ++ti) s2[ti] = g2[ti] + t[ti];
+        for (int ti = 0; ti < HT; ++ti) s2[ti] = osa_sym_sum(g2[ti], gs, t[ti], tg);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) s1[kb] = g1[kb] + t[HT + kb];
+        for (int kb = 0; kb < KB; ++kb) s1[kb] = osa_sym_sum(g1[kb], gs, t[HT + kb], tg);
 #pragma unroll
-        for (int o = 0; o < OT; ++o) s3[o] = g3[o] + t[HT + KB + o];
-        sb_ = ((boff >= 0) ? gb : 0.f) + tb;
+        for (int o = 0; o < OT; ++o) s3[o] = osa_sym_sum(g3[o], gs, t[HT + KB + o], tg);
+        sb_ = osa_sym_sum1((boff >= 0) ? gb : 0.f, gs, tb, tg);
       } else {
       // RU ranks per trip: their loads are all in flight together (one memory round trip per trip,
       // not per rank); the clamped duplicate loads of a ragged last trip are simply not added
