@@ -1253,6 +1253,13 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 3) {
       int pb = cus / 3;
       if (pb > nblk) pb = nblk;
+      // the slowest workgroup walks through ceil(nchunk / pb) chunks whatever happens: take the FEWEST workgroups
+      // with that maximum (16 384 rows = 256 chunks: 64 workgroups x 4 chunks instead of 85 of which one has 4) --
+      // fewer slabs for the reduction that follows, the same critical path
+      {
+        const int per = (nchunk + pb - 1) / pb;
+        pb = (nchunk + per - 1) / per;
+      }
       const int prc = osa_pass_partial_grad(obs_dim, act_dim, hidden, params, obs, ld_obs, act, ld_act, logp,
                                             target_value_r, target_value_c, adv_r, adv_c, idx, B, lagrange,
                                             hp, loss_kind, a.nets_mask, pb, ws, stream);
