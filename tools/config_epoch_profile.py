@@ -40,3 +40,12 @@ for e in range(EPOCHS):
     a._logger.dump_tabular()
     print(f'epoch {e}: rollout {1e3 * (t1 - t0):.2f} ms, update {1e3 * (t2 - t1):.2f} ms -> {N * T / (t2 - t0):.0f} env-steps/s '
           f'(rollout graphed: {getattr(a._env, "last_rollout_graphed", None)})', flush=True)
+# explicit teardown while the runtime (and a profiler wrapped around it) is still up: the rollout's hipGraph and
+# the device buffers are released here, not by finalisers at interpreter exit
+a._logger.close()
+a._env.close()
+del a
+import gc  # noqa: E402
+
+gc.collect()
+torch.cuda.synchronize()
