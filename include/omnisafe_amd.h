@@ -406,8 +406,9 @@ int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params
  * mask (NULL = all N rows; zero selected rows = no-op): Chan/Golub/LeVeque merge of the batch mean and
  * centred sum of squares into the running state, var = sumsq/(count-1), std = max(sqrt(var), 1e-2).
  * State: mean/sumsq/var/std float32[D], count int64[1] (all device).  ws: osa_normalizer_ws_doubles(N, D)
- * doubles, ZERO-INITIALISED ONCE by the caller (its last word is the arrival ticket of the single-launch
- * reduction; every call leaves it at zero again). */
+ * doubles, ZERO-INITIALISED ONCE by the caller (its FIRST word is the arrival ticket of the single-launch
+ * reduction; every call leaves it at zero again, so one workspace sized for the largest N serves any
+ * smaller batch afterwards). */
 size_t osa_normalizer_ws_doubles(int N, int D);
 int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mask, float* mean,
                         float* sumsq, float* var, float* std_, long* count, double* ws,

@@ -244,7 +244,10 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             self._flush_logs(logger, buffer)
             return
         st = self.__dict__.setdefault('_rollout_graph', {})
-        key = (T, buffer.data['obs'].data_ptr(), agent.params.data_ptr(), self._num_envs)
+        # every by-value launch argument that can change between epochs is part of the key (a changed seed
+        # re-captures instead of silently replaying the old stream)
+        key = (T, buffer.data['obs'].data_ptr(), agent.params.data_ptr(), self._num_envs,
+               getattr(self._env, '_seed', None), getattr(agent, 'seed', None))
         if st.get('key') != key:  # first epoch (also sets kernel attributes, which must not happen under capture)
             st.clear()
             st.update(key=key, graph=None, failed=False)
@@ -258,7 +261,11 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                 buffer.ptr = 0
                 g.replay()
                 buffer.ptr = T
-            except Exception:  # pragma: no cover - capture refused: stay on eager launches
+            except Exception as exc:  # pragma: no cover - capture refused: stay on eager launches
+                import warnings
+
+                warnings.warn(f'omnisafe_amd: hipGraph capture of the rollout was refused ({exc!r}); the rollout '
+                              'stays on eager launches (set OSA_ROLLOUT_GRAPH=0 to silence)', RuntimeWarning)
                 st['failed'], st['graph'] = True, None
                 buffer.ptr = 0
                 self._rollout_device(T, agent, buffer)

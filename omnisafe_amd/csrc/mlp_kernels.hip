@@ -826,17 +826,26 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     // totals in every workgroup
     __shared__ float s_part[2][256];
     float* pp = partials + (long)net * nblk * 2;
-    for (int k = threadIdx.x; k < nblk; k += blockDim.x) {  // (nblk <= 256 for every supported network)
-      s_part[0][k] = __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_part[1][k] = __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float tg = 0.f, tp = 0.f;
-      for (int k = 0; k < nblk; ++k) {
-        tg += s_part[0][k];
-        tp += s_part[1][k];
+    float tg = 0.f, tp = 0.f;  // (thread 0's running totals)
+    // tiles of 256 partials (one tile for every network up to ~940 inputs; wider ones take more trips instead of
+    // writing past the staging array), added in block order across the tiles
+    for (int k0 = 0; k0 < nblk; k0 += 256) {
+      const int k = k0 + threadIdx.x;
+      if (k < nblk) {
+        s_part[0][threadIdx.x] = __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part[1][threadIdx.x] = __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int n = min(256, nblk - k0);
+        for (int q = 0; q < n; ++q) {
+          tg += s_part[0][q];
+          tp += s_part[1][q];
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
       s_tot[0] = tg;
       s_tot[1] = tp;
     }

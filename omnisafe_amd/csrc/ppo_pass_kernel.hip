@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           if ((mask & (mask - 1)) != 0) why = 2;
         }
         if (why) __hip_atomic_store(a.dp_sync + 3, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a late arriver sees a full count although an earlier one has already given up (and returned): the
+        // sticky word decides for everybody, so nobody goes on to modify anything after a time-out
+        if (!why) why = __hip_atomic_load(a.dp_sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         red[0] = (float)why;
       }
       __syncthreads();

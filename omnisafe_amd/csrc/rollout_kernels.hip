@@ -422,7 +422,7 @@ extern "C" {
 size_t osa_normalizer_ws_doubles(int N, int D) {
   if (N < 1 || D < 1) return 0;
   const size_t nrb = (size_t)(N + OSA_NORM_ROWS - 1) / OSA_NORM_ROWS;
-  return nrb * D * 2 + nrb + 1;  // partial sums, row counts, ticket word
+  return 1 + nrb * D * 2 + nrb;  // ticket word (first, zero-initialised by the caller), partial sums, row counts
 }
 
 int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mask, float* mean,
@@ -430,9 +430,12 @@ int osa_normalizer_push(const float* x, int ld, int N, int D, const uint8_t* mas
                         void* stream) {
   OSA_REQUIRE(x && mean && sumsq && var && std_ && count && ws && N > 0 && D > 0 && ld >= D);
   const int nrb = (N + OSA_NORM_ROWS - 1) / OSA_NORM_ROWS;
-  int* ticket = reinterpret_cast<int*>(ws + (size_t)nrb * D * 2 + nrb);
+  // the ticket word is ws[0], the partials follow: its position must NOT depend on N -- a workspace that served
+  // a large batch is reused for smaller ones (Normalizer._workspace), and a ticket behind the partials would
+  // then land on a leftover partial sum
+  int* ticket = reinterpret_cast<int*>(ws);
   hipLaunchKernelGGL(osa_norm_push_kernel, dim3(nrb, (D + 63) / 64), dim3(256), 0, osa_stream(stream), x, ld,
-                     N, D, mask, mean, sumsq, var, std_, count, ws, ticket);
+                     N, D, mask, mean, sumsq, var, std_, count, ws + 1, ticket);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

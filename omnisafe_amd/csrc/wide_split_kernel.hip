@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         if ((mask & (mask - 1)) != 0) why = 2;
       }
       if (why) __hip_atomic_store(err, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a late arriver sees a full count although an earlier one has already given up: the sticky word decides)
+      if (!why) why = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *s_why = why;
     }
     __syncthreads();

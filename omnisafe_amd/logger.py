@@ -36,6 +36,35 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         self._headers_delta: dict[str, bool] = {}
         self._current_row: dict[str, float] = {}
         self._csv = None
+        # Optional sinks of the reference (logger.py:130-150, 312-318): the epoch row goes to TensorBoard
+        # (`<log_dir>/tb`) and / or Weights & Biases when their packages are importable; when one is asked for and
+        # missing, the run continues on csv alone and SAYS so (a drop-in must not silently ignore a config key).
+        self._tb_writer = None
+        self._wandb = None
+        if self._maste_proc and use_tensorboard:
+            try:
+                from torch.utils.tensorboard.writer import SummaryWriter
+
+                self._tb_writer = SummaryWriter(log_dir=os.path.join(self._log_dir, 'tb'))
+            except Exception as exc:  # noqa: BLE001 - the tensorboard package is optional
+                import warnings
+
+                warnings.warn(f'omnisafe_amd.Logger: use_tensorboard=True but TensorBoard is unavailable ({exc!r}); '
+                              'logging to progress.csv only', RuntimeWarning)
+        if self._maste_proc and use_wandb:
+            try:
+                import wandb
+
+                cfgd = config.todict() if hasattr(config, 'todict') else (dict(config) if config is not None else {})
+                lc = cfgd.get('logger_cfgs', {}) if isinstance(cfgd, dict) else {}
+                wandb.init(project=lc.get('wandb_project', 'omnisafe'), name=f'{exp_name}-{rel}',
+                           dir=self._log_dir, config=cfgd)
+                self._wandb = wandb
+            except Exception as exc:  # noqa: BLE001 - the wandb package is optional
+                import warnings
+
+                warnings.warn(f'omnisafe_amd.Logger: use_wandb=True but wandb is unavailable ({exc!r}); '
+                              'logging to progress.csv only', RuntimeWarning)
         if self._maste_proc:
             os.makedirs(self._log_dir, exist_ok=True)
             self._output_file = open(os.path.join(self._log_dir, 'progress.csv'), 'w', encoding='utf-8',
@@ -130,6 +159,12 @@ class Logger:  # pylint: disable=too-many-instance-attributes
                 self._first_row = False
             self._csv_writer.writerow(self._current_row.values())
             self._output_file.flush()
+            if self._tb_writer is not None:
+                for key, val in self._current_row.items():
+                    self._tb_writer.add_scalar(key, val, global_step=self._epoch)
+                self._tb_writer.flush()
+            if self._wandb is not None:
+                self._wandb.log(self._current_row, step=self._epoch)
             if self._verbose:
                 width = max(len(k) for k in self._current_row)
                 print('\n'.join(f'  {k:<{width}}  {v}' for k, v in self._current_row.items()), flush=True)
@@ -170,6 +205,10 @@ class Logger:  # pylint: disable=too-many-instance-attributes
     def close(self) -> None:
         if self._maste_proc:
             self._output_file.close()
+            if self._tb_writer is not None:
+                self._tb_writer.close()
+            if self._wandb is not None:
+                self._wandb.finish()
 
 
 def _dist_stats(vals: torch.Tensor, min_and_max: bool):

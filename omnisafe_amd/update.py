@@ -225,7 +225,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     # first pass with one XCC per network: the kernel checks its placement before it modifies
                     # anything and returns untouched if it does not hold -> repeat spread over the XCCs
                     torch.cuda.synchronize()
-                    if int(self._split_buf.view(torch.int32)[96]) != 0:
+                    flag = int(self._split_buf.view(torch.int32)[96])
+                    if flag == 1:  # a workgroup never arrived at the placement check: not a placement question
+                        raise _lib.OsaError('osa_ppo_split_pass: a cooperating workgroup never arrived at the '
+                                            'placement check (device shared with another long-running kernel?)')
+                    if flag != 0:
                         _PLACEMENT['local_ok'] = False
                         self._split_free()
                         self._split_tried = False
@@ -269,7 +273,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     # (as above: an unverified placement leaves everything untouched; repeat with the workgroups
                     # spread over the XCCs and agent-scope release / acquire fences around the hand-offs)
                     torch.cuda.synchronize()
-                    if int(ck['sync'][3]) != 0:
+                    flag = int(ck['sync'][3])
+                    if flag == 1:  # time-out, not placement: never re-run on possibly modified parameters
+                        raise _lib.OsaError('osa_ppo_chunked_pass: a cooperating workgroup never arrived at the '
+                                            'placement check (device shared with another long-running kernel?)')
+                    if flag != 0:
                         _PLACEMENT['local_ok'] = False
                         ck['sync'].zero_()
                         ck['local'] = 0
@@ -402,7 +410,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             # first pass with one XCC per network: an unverified placement returns with everything untouched
             # -> repeat spread over the XCCs (same buffer, agent-scope release / acquire fences)
             torch.cuda.synchronize()
-            if int(st['sync'][3]) != 0:
+            flag = int(st['sync'][3])
+            if flag == 1:  # time-out, not placement: never re-run on possibly modified parameters
+                raise _lib.OsaError('osa_ppo_dp_pass_placed: a peer workgroup never arrived at the placement check '
+                                    '(workgroups not co-resident?); set OSA_DP_MODE=replicated-steps')
+            if flag != 0:
                 _PLACEMENT['local_ok'] = False
                 st['sync'].zero_()
                 st['local'] = False

@@ -98,6 +98,59 @@ def test_lagrange_vs_reference_golden(golden):
     assert np.float32(lag.lagrangian_multiplier) == g['update/lambda_after']
 
 
+def test_logger_optional_sinks(tmp_path, monkeypatch):
+    """use_tensorboard / use_wandb (reference logger.py:130-150, 312-318): the row reaches the sink when its package
+    is importable; when it is not, the logger WARNS and carries on with progress.csv (never a silent no-op)."""
+    import sys
+    import types
+    import warnings
+
+    from omnisafe_amd.logger import Logger
+
+    calls = []
+
+    class _Writer:
+        def __init__(self, log_dir):
+            calls.append(('init', log_dir))
+
+        def add_scalar(self, key, val, global_step):
+            calls.append(('scalar', key, val, global_step))
+
+        def flush(self):
+            pass
+
+        def close(self):
+            calls.append(('close',))
+
+    mod = types.ModuleType('torch.utils.tensorboard.writer')
+    mod.SummaryWriter = _Writer
+    pkg = types.ModuleType('torch.utils.tensorboard')
+    pkg.writer = mod
+    monkeypatch.setitem(sys.modules, 'torch.utils.tensorboard', pkg)
+    monkeypatch.setitem(sys.modules, 'torch.utils.tensorboard.writer', mod)
+    lg = Logger(str(tmp_path / 'a'), 'exp', seed=0, use_tensorboard=True, verbose=False)
+    lg.register_key('Loss/Loss_pi')
+    lg.store({'Loss/Loss_pi': 2.0})
+    lg.dump_tabular()
+    lg.close()
+    assert calls[0] == ('init', os.path.join(lg.log_dir, 'tb'))
+    assert ('scalar', 'Loss/Loss_pi', 2.0, 0) in calls and calls[-1] == ('close',)
+    # missing packages: a warning per requested sink, csv still written
+    monkeypatch.setitem(sys.modules, 'torch.utils.tensorboard', None)
+    monkeypatch.setitem(sys.modules, 'torch.utils.tensorboard.writer', None)
+    monkeypatch.setitem(sys.modules, 'wandb', None)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        lg = Logger(str(tmp_path / 'b'), 'exp', seed=0, use_tensorboard=True, use_wandb=True, verbose=False)
+    msgs = [str(w.message) for w in rec]
+    assert any('use_tensorboard=True' in m for m in msgs) and any('use_wandb=True' in m for m in msgs)
+    lg.register_key('Loss/Loss_pi')
+    lg.store({'Loss/Loss_pi': 1.0})
+    lg.dump_tabular()
+    lg.close()
+    assert len(list(csv.reader(open(os.path.join(lg.log_dir, 'progress.csv'))))) == 2
+
+
 def test_logger_columns(tmp_path):
     from omnisafe_amd.logger import Logger
 

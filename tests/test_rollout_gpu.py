@@ -63,6 +63,26 @@ def test_normalizer_masked_push_matches_oracle():
     assert torch.equal(before, norm.mean)
 
 
+def test_normalizer_batch_sizes_share_one_workspace():
+    """One Normalizer, batches of very different sizes (the reference accepts a (4096, D) batch followed by a
+    single (D,) observation): the arrival ticket of the single-launch reduction must not move with N -- round 2
+    kept it BEHIND the partial sums, where a later small batch found a leftover partial and never merged."""
+    from omnisafe_amd.normalizer import Normalizer
+
+    rng = np.random.default_rng(11)
+    ref = O.Normalizer((60,), clip=5)
+    norm = Normalizer((60,), clip=5, device=DEV)
+    for n in (4096, 1, 300, 4096, 7, 1):
+        x = (rng.standard_normal((n, 60)) * 2 - 0.5).astype(np.float32)
+        xin = x[0] if n == 1 else x  # a single (D,) observation, as Evaluator / single-env adapters pass it
+        y = norm.normalize(torch.from_numpy(xin).to(DEV))
+        yr = ref.normalize(torch.from_numpy(xin))
+        assert tuple(y.shape) == tuple(yr.shape)
+        np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=2e-5)
+        assert int(norm._count) == ref.count
+    np.testing.assert_allclose(norm.mean.cpu().numpy(), ref.mean.numpy(), rtol=1e-5, atol=1e-6)
+
+
 class TraceEnv:
     """Replays the raw env outputs recorded from the reference run (tests/golden/ppolag_epoch.npz)."""
     need_auto_reset_wrapper = False
