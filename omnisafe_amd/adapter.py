@@ -28,67 +28,9 @@ from .models import ConstraintActorCritic
 from .normalizer import Normalizer
 
 
-class _EnvWrapper:
-    """omnisafe/envs/core.py:185-297 (Wrapper): forwards everything it does not override."""
-
-    graph_safe = False  # host-side decisions per step
-
-    def __init__(self, env, device) -> None:
-        self._env, self._device = env, torch.device(device)
-
-    def __getattr__(self, name):
-        return getattr(self._env, name)
-
-    def reset(self, seed=None, options=None):
-        return self._env.reset(seed=seed, options=options)
-
-    def step(self, action):
-        return self._env.step(action)
-
-
-class TimeLimit(_EnvWrapper):
-    """omnisafe/envs/wrapper.py:31-107: truncated = (steps since reset >= time_limit); single env."""
-
-    need_time_limit_wrapper = False
-
-    def __init__(self, env, time_limit: int, device) -> None:
-        super().__init__(env, device)
-        assert int(env.num_envs) == 1, 'TimeLimit only supports single environment'
-        self._time, self._time_limit = 0, int(time_limit)
-
-    def reset(self, seed=None, options=None):
-        self._time = 0
-        return self._env.reset(seed=seed, options=options)
-
-    def step(self, action):
-        obs, reward, cost, terminated, truncated, info = self._env.step(action)
-        self._time += 1
-        truncated = torch.tensor(self._time >= self._time_limit, dtype=torch.bool, device=self._device)
-        return obs, reward, cost, terminated, truncated, info
-
-
-class AutoReset(_EnvWrapper):
-    """omnisafe/envs/wrapper.py:110-176: on terminated / truncated the env is reset, the returned observation is
-    the first of the new episode and the true last one goes to info['final_observation']; single env (one host
-    read of the two flags per step, as in the reference)."""
-
-    need_auto_reset_wrapper = False
-
-    def __init__(self, env, device) -> None:
-        super().__init__(env, device)
-        assert int(env.num_envs) == 1, 'AutoReset only supports single environment'
-
-    def step(self, action):
-        obs, reward, cost, terminated, truncated, info = self._env.step(action)
-        if bool(torch.as_tensor(terminated).any()) or bool(torch.as_tensor(truncated).any()):
-            new_obs, new_info = self._env.reset()
-            assert 'final_observation' not in new_info, 'info dict cannot contain key "final_observation" '
-            assert 'final_info' not in new_info, 'info dict cannot contain key "final_info" '
-            new_info = dict(new_info)
-            new_info['final_observation'] = obs
-            new_info['final_info'] = info
-            obs, info = new_obs, new_info
-        return obs, reward, cost, terminated, truncated, info
+# host-side wrappers (TimeLimit / AutoReset) and the host-env bridge live in host_env.py; re-exported here because
+# this is where the reference keeps its wrapper chain (adapter/online_adapter.py:120-140)
+from .host_env import AutoReset, HostEnvBridge, TimeLimit, _EnvWrapper  # noqa: E402,F401
 
 
 class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes

@@ -46,10 +46,18 @@ def support_envs() -> list[str]:
 
 
 def make(env_id: str, num_envs: int = 1, device='cuda:0', **env_cfgs):
-    """envs/core.py:389-421."""
-    if env_id not in ENV_REGISTRY:
-        raise KeyError(f'{env_id} is not registered with omnisafe_amd (known: {support_envs()})')
-    return ENV_REGISTRY[env_id](env_id, num_envs=num_envs, device=device, **env_cfgs)
+    """envs/core.py:389-421.  Ids of this package are device-resident envs; any other id is looked up in the
+    caller's ``omnisafe`` env registry (Safety-Gymnasium, user classes under ``@env_register``), built on the
+    host and driven through :class:`omnisafe_amd.host_env.HostEnvBridge` (one D2H / H2D pair per vector step)."""
+    if env_id in ENV_REGISTRY:
+        return ENV_REGISTRY[env_id](env_id, num_envs=num_envs, device=device, **env_cfgs)
+    from .host_env import make_reference_env
+
+    env = make_reference_env(env_id, num_envs=num_envs, device=device, **env_cfgs)
+    if env is None:
+        raise KeyError(f'{env_id} is registered neither with omnisafe_amd (known: {support_envs()}) nor with an '
+                       'importable omnisafe (omnisafe.envs.core.support_envs())')
+    return env
 
 
 @env_register

@@ -188,6 +188,22 @@ def import_reference():
     return omnisafe
 
 
+def import_simple_env():
+    """The reference's own test env (tests/simple_env.py:30-90, id 'Test-v0': single env that asks for the
+    TimeLimit and AutoReset wrappers), registered with the reference's env registry by its `@env_register`."""
+    import importlib.util
+
+    import_reference()
+    if 'ref_simple_env' in sys.modules:
+        return sys.modules['ref_simple_env']
+    path = os.path.join(reference_root(), 'tests', 'simple_env.py')
+    spec = importlib.util.spec_from_file_location('ref_simple_env', path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['ref_simple_env'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 _SYNTH_REGISTERED = False
 DEFAULT_HORIZON = 1000  # used when env_cfgs carries no 'horizon' (TRPOLag/CPO YAMLs have no env_cfgs key)
 

@@ -33,6 +33,11 @@ def _files():
             if f.endswith(_KEEP):
                 full = os.path.join(root, f)
                 yield full, os.path.relpath(full, REF_SRC)
+    # the reference's own test double of a user-registered single env (tests/simple_env.py: 'Test-v0'), driven
+    # through the installed plugin by tests/test_host_env_gpu.py
+    extra = os.path.join(REF_SRC, 'tests', 'simple_env.py')
+    if os.path.exists(extra):
+        yield extra, os.path.relpath(extra, REF_SRC)
 
 
 def stage(verbose: bool = True) -> str | None:

@@ -285,3 +285,148 @@ def test_default_configs_match_reference_yaml(golden_dir):
     assert len(config.DEFAULTS) >= 14
     for algo in config.DEFAULTS:
         cmp(algo, ref_all[algo], config.get_default_kwargs(algo))
+
+
+class _HostVecEnv:
+    """Deterministic host vector env with the reference's CMDP surface (envs/core.py:37-182): CPU tensors out,
+    gymnasium's vector auto-reset convention (final_observation + boolean numpy mask) every `horizon` steps for
+    the even envs and every 2 * horizon for the odd ones."""
+    need_auto_reset_wrapper = False
+    need_time_limit_wrapper = False
+    need_evaluation = False
+    env_spec_log = {}
+
+    def __init__(self, n=6, d_o=5, d_a=2, horizon=3):
+        from omnisafe_amd.spaces import Box
+
+        self.num_envs, self.d_o, self.d_a, self.h = n, d_o, d_a, horizon
+        self.observation_space = Box(-np.inf, np.inf, (d_o,))
+        self.action_space = Box(-2.0, 2.0, (d_a,))
+        self.k = np.zeros(n, np.int64)
+        self.t = 0
+        self.actions = []
+
+    def set_seed(self, seed):
+        self.seed = seed
+
+    def _obs(self):
+        return torch.from_numpy((self.k[:, None] + 0.1 * np.arange(self.d_o)[None] + 100.0 * self.t).astype(np.float32))
+
+    def reset(self, seed=None, options=None):
+        self.k[:] = 0
+        return self._obs(), {'why': 'reset'}
+
+    def step(self, action):
+        assert action.device.type == 'cpu' and tuple(action.shape) == (self.num_envs, self.d_a)
+        self.actions.append(action.clone())
+        self.t += 1
+        self.k += 1
+        lim = np.where(np.arange(self.num_envs) % 2 == 0, self.h, 2 * self.h)
+        trunc = self.k >= lim
+        obs = self._obs()
+        info = {'goal_met': False}
+        if trunc.any():
+            info['final_observation'] = obs.clone()
+            info['_final_observation'] = trunc.copy()  # numpy bool array, as gymnasium's vector envs
+            self.k[trunc] = 0
+            obs = self._obs()
+        reward = torch.from_numpy(action.numpy().sum(1).astype(np.float32))
+        cost = torch.from_numpy((self.k % 2).astype(np.float32))
+        return obs, reward, cost, torch.zeros(self.num_envs, dtype=torch.bool), torch.from_numpy(trunc), info
+
+    def close(self):
+        self.closed = True
+
+
+def test_host_env_bridge_staging_cpu():
+    """HostEnvBridge (omnisafe_amd/host_env.py) on CPU tensors: what comes out of step() is what the host env
+    returned, final rows travel only on steps where an env finished, byte counts are the documented
+    4 D_a down and 4 (D_o + 5) (+ 4 D_o) up per env-step."""
+    from omnisafe_amd.host_env import HostEnvBridge
+
+    host = _HostVecEnv()
+    twin = _HostVecEnv()
+    br = HostEnvBridge(host, 'cpu')
+    assert br.num_envs == 6 and br.observation_space.shape == (5,) and br.host_resident
+    assert not br.need_auto_reset_wrapper and not br.need_time_limit_wrapper and not br.graph_safe
+    o, info = br.reset()
+    o2, _ = twin.reset()
+    assert torch.equal(o, o2) and info == {'why': 'reset'}
+    finals = 0
+    for t in range(7):
+        act = torch.full((6, 2), 0.25 * t)
+        obs, r, c, term, trunc, info = br.step(act)
+        eo, er, ec, eterm, etrunc, einfo = twin.step(act)
+        assert torch.equal(obs, eo) and torch.equal(r, er) and torch.equal(c, ec)
+        assert torch.equal(term, eterm.float()) and torch.equal(trunc, etrunc.float())
+        assert ('final_observation' in info) == ('final_observation' in einfo)
+        assert info['goal_met'] is False
+        if 'final_observation' in einfo:
+            finals += 1
+            m = torch.from_numpy(einfo['_final_observation'])
+            assert torch.equal(info['_final_observation'], m.float())
+            assert torch.equal(info['final_observation'][m], einfo['final_observation'][m])
+    assert finals == 2  # step 3 (even envs) and step 6 (all envs)
+    down, up = br.pcie_bytes_per_env_step()
+    assert down == 4 * 2
+    n = 6
+    want_up = (7 * 4 * (5 + 5) * n + finals * 4 * 5 * n) / (7 * n)
+    assert up == pytest.approx(want_up + 4 * 5 * n / (7 * n))  # + the reset's observation upload
+    br.set_seed(5)
+    br.close()
+    assert host.seed == 5 and host.closed
+
+
+class _HostSingleEnv:
+    """Single host env that asks for both wrappers (the shape of SafetyGymnasiumEnv with num_envs = 1,
+    safety_gymnasium_env.py:147-158): scalar reward / cost / flags, terminates itself at step 4 of odd episodes."""
+    need_auto_reset_wrapper = True
+    need_time_limit_wrapper = True
+    need_evaluation = False
+    num_envs = 1
+    max_episode_steps = 6
+
+    def __init__(self):
+        from omnisafe_amd.spaces import Box
+
+        self.observation_space = Box(-np.inf, np.inf, (3,))
+        self.action_space = Box(-1.0, 1.0, (2,))
+        self.k, self.ep = 0, -1
+
+    def set_seed(self, seed):
+        pass
+
+    def reset(self, seed=None, options=None):
+        self.k, self.ep = 0, self.ep + 1
+        return torch.tensor([float(self.k), float(self.ep), 0.5]), {}
+
+    def step(self, action):
+        assert tuple(action.shape) == (2,)  # squeezed, as behind the reference's Unsqueeze wrapper
+        self.k += 1
+        term = self.ep % 2 == 1 and self.k >= 4
+        return (torch.tensor([float(self.k), float(self.ep), 0.5]), torch.tensor(1.0), torch.tensor(0.25),
+                torch.tensor(term), torch.tensor(False), {})
+
+    def close(self):
+        pass
+
+
+def test_host_env_bridge_single_env_wrappers_cpu():
+    """A single host env behind the bridge: TimeLimit + AutoReset run on the host side (online_adapter.py:120-132),
+    outputs are unsqueezed to N = 1 rows, the episode's true last observation arrives as final_observation."""
+    from omnisafe_amd.host_env import AutoReset, HostEnvBridge, TimeLimit
+
+    br = HostEnvBridge(_HostSingleEnv(), 'cpu')
+    assert isinstance(br.host_env, AutoReset) and isinstance(br.host_env._env, TimeLimit)
+    obs, _ = br.reset()
+    assert obs.tolist() == [[0.0, 0.0, 0.5]]
+    log = []
+    for _ in range(11):
+        obs, r, c, term, trunc, info = br.step(torch.zeros(1, 2))
+        assert tuple(obs.shape) == (1, 3) and tuple(r.shape) == (1,) and float(r[0]) == 1.0 and float(c[0]) == 0.25
+        log.append((obs[0, 0].item(), obs[0, 1].item(), bool(term[0]), bool(trunc[0]),
+                    info['final_observation'][0, 0].item() if 'final_observation' in info else None))
+    # episode 0: 6 steps, truncated by the time limit; episode 1: terminates itself at its 4th step
+    assert log[5] == (0.0, 1.0, False, True, 6.0)
+    assert log[9] == (0.0, 2.0, True, False, 4.0)
+    assert [x[4] for x in log[:5]] == [None] * 5 and log[10][:2] == (1.0, 2.0)

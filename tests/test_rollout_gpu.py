@@ -88,9 +88,10 @@ class TraceEnv:
     need_auto_reset_wrapper = False
     need_time_limit_wrapper = False
 
-    def __init__(self, g):
+    def __init__(self, g, dev=None):
         from omnisafe_amd.spaces import Box
 
+        self.dev = dev or DEV  # 'cpu': a HOST env (driven through omnisafe_amd.host_env.HostEnvBridge)
         self.g, self.t = g, 0
         self.num_envs = int(g['N'])
         self.observation_space = Box(-np.inf, np.inf, (60,))
@@ -102,12 +103,13 @@ class TraceEnv:
 
     def reset(self, seed=None, options=None):
         self.t = 0
-        return torch.from_numpy(self.g['rollout/reset_obs']).to(DEV), {}
+        return torch.from_numpy(self.g['rollout/reset_obs']).to(self.dev), {}
 
     def step(self, action):
         g, t = self.g, self.t
+        assert action.device.type == torch.device(self.dev).type
         self.actions.append(action.cpu().numpy().copy())
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
         info = {}
         fin = g['rollout/truncated'][t] | g['rollout/terminated'][t]
         if fin.any():
@@ -145,15 +147,20 @@ def _cfgs(**algo):
     return ns(train_cfgs=ns(device=DEV), algo_cfgs=ns(**a), env_cfgs=None)
 
 
-def test_rollout_on_reference_trace(golden):
-    from omnisafe_amd.adapter import OnPolicyAdapter
+@pytest.mark.parametrize('host_env', [False, True], ids=['device-env', 'host-env-bridge'])
+def test_rollout_on_reference_trace(golden, host_env):
+    """The whole rollout on the env trace recorded from the unmodified reference, noise injected: buffer rows,
+    normaliser state and episode metrics equal the reference's.  `host-env-bridge`: the SAME trace served by a host
+    env (CPU tensors in and out, as Safety-Gymnasium behind envs/safety_gymnasium_env.py:190-210) through
+    HostEnvBridge -- one D2H / H2D pair per vector step, everything else on the device, identical rows."""
+    from omnisafe_amd.adapter import HostEnvBridge, OnPolicyAdapter
     from omnisafe_amd.buffer import VectorOnPolicyBuffer
     from test_mlp_gpu import make_ac
 
     g = golden('ppolag_epoch.npz')
     N, T = int(g['N']), int(g['T'])
-    env = TraceEnv(g)
-    adapter = OnPolicyAdapter('trace', N, 0, _cfgs(), env=env)
+    env = TraceEnv(g, dev='cpu' if host_env else DEV)
+    adapter = OnPolicyAdapter('trace', N, 0, _cfgs(), env=HostEnvBridge(env, DEV) if host_env else env)
     ac = make_ac(60, 2, g, 'init/')
     eps_iter = iter(g['rollout/eps'])
     plain_step = ac.step
@@ -192,6 +199,14 @@ def test_rollout_on_reference_trace(golden):
     assert np.array_equal(np.float32(logger.data['Metrics/EpLen']), g['rollout/ep_len_window'])
     np.testing.assert_allclose(logger.data['Value/reward'][0], g['rollout/value_r_log_mean'], rtol=1e-3,
                                atol=1e-5)
+    if host_env:
+        # PCIe bytes per env-step: 4 D_a down; 4 (D_o + 5) up, + 4 D_o on steps where an env finished
+        br = adapter._env
+        down, up = br.pcie_bytes_per_env_step()
+        n_final = int(((g['rollout/truncated'] | g['rollout/terminated']).any(axis=1)).sum())
+        assert down == 4 * 2
+        assert up == pytest.approx((T * 4 * 65 + n_final * 4 * 60 + 4 * 60) / T)  # (+ the reset's observation)
+        assert not adapter.last_rollout_graphed if hasattr(adapter, 'last_rollout_graphed') else True
 
 
 def test_synth_env_statistics_and_autoreset():
