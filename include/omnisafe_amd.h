@@ -284,6 +284,27 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
                        const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                        float* xch, int local, float* step_stats, void* stream);
 int osa_ppo_split_pass_timed_out(const float* xch, int* out);
+/* The DATA-PARALLEL form of osa_ppo_split_pass (world_size > 1 without a per-step cross-GPU collective, as
+ * osa_ppo_dp_pass does for narrow observations): the arrays hold the all-gathered rollouts of `world` ranks (rank r:
+ * rows r M .. r M + M - 1), perm is [world][M] (row r = rank r's shuffle of its OWN M rows, indices in [0, M)).
+ * One cooperative launch of world x 3 x (1 + ceil(KB / 6)) workgroups: every virtual rank is a full set of leader
+ * + helpers computing ITS minibatch's gradient and ITS clip factor (avg_grads order of the reference:
+ * clip_grad_norm_ locally, then average -- policy_gradient.py:437-442, 478-483, 519-524; utils/distributed.py:167-198);
+ * then the `world` owners of the same parameters (helper c of every rank; the leaders) exchange their clipped
+ * shares, sum them in rank order, divide by world and apply the SAME Adam step to their own replica: no parameter
+ * ever crosses between replicas, they stay bit-identical, rank 0's is written back.  step_stats receive the
+ * rank-averaged statistics (what Logger.get_stats averages).  xch: osa_ppo_split_dp_xch_floats(...) floats from
+ * osa_dp_exchange_alloc (uncached; OSA_EINVAL otherwise), zero-initialised once; its sticky time-out word is read
+ * with osa_ppo_split_pass_timed_out.  OSA_EUNSUPPORTED when the device cannot hold the workgroups together
+ * (world x 3 x (C + 1) > compute units) or the shape is outside osa_ppo_split_pass_supported: use the per-step
+ * path (osa_ppo_minibatch mode 1 + all-reduce + osa_adam_apply). */
+size_t osa_ppo_split_dp_xch_floats(int obs_dim, int act_dim, int hidden, int world);
+int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                          const float* logp, const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                          float* xch, float* step_stats, void* stream);
 /* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
  * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);
  * OSA_EUNSUPPORTED otherwise -- use osa_ppo_minibatch_ext.  ext == NULL: osa_ppo_pass.  With cost_kappa > 0

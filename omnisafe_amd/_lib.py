@@ -69,6 +69,9 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_split_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                                 _P, _P, _I, _I, _P, _I, _P, _P]),
     'osa_ppo_split_pass_timed_out': (_I, [_P, _P]),
+    'osa_ppo_split_dp_xch_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_ppo_split_dp_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
+                                   _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_pass_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                               _P, _P, _I, _I, _P, _P, _P]),
     'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),

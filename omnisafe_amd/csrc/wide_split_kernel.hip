@@ -87,7 +87,22 @@ struct OsaSplitArgs {
   float* xch;    // uncached exchange buffer (osa_ppo_split_pass_xch_floats)
   int C;         // helpers per network
   int local;     // 1: one XCC per network, cached exchange buffer (see the kernel)
+  // data-parallel form (DP instantiation, osa_ppo_split_dp_pass): `world` virtual ranks, each a full set of
+  // 3 (C + 1) workgroups working on ITS rows (rank r: rows r M .. r M + M - 1 of the all-gathered arrays,
+  // permutation perm[r M ..]) with its own intra-rank exchange region (xch + r rank_xch); after a rank's clip
+  // factor is known, the `world` owners of the same parameters (helper c of every rank / the leaders) average
+  // their locally clipped gradients through dpx (clip-then-average, policy_gradient.py:437-442 +
+  // distributed.py:167-198) and every replica applies the same Adam step: nothing but gradients crosses between
+  // the replicas and they stay bit-identical.
+  int world;
+  long rank_xch;  // floats between the intra-rank regions of consecutive ranks
+  float* dpx;     // uncached: [128] arrival counters (int), then [2 parity][3][SCMAX + 1][world][SDPW] slabs
 };
+
+#define SDPW (SKQ * 1024 + 256 + 16)  // one owner's gradient share: <= 6 tiles x 256 x 4, bias-likes, tail
+#ifndef OSA_SPLIT_DP_RU
+#define OSA_SPLIT_DP_RU 2  // (4: 129 spilled VGPRs in the 17-action instantiation; 2: see DESIGN.md)
+#endif
 
 #ifdef OSA_SPLIT_CLOCKS
 #define STICK(k)                                   \
@@ -163,7 +178,74 @@ __device__ __forceinline__ float osa_slot_wait(unsigned long long* slot, int cnt
   return __uint_as_float((unsigned)w);
 }
 
-template <int OT>
+// Average of the `W` ranks' locally clipped gradients of ONE owner's parameters (data-parallel form): publish the
+// own share (NT tiles of one f32x4 per thread, optionally one bias-like scalar per thread, then the clip factor
+// and -- leaders -- the step's statistics in the tail), arrive at the owners' counter, wait for the W arrivals of
+// this step, then sum g_r * clip_r in RANK ORDER (the same order on every replica: bit-identical results) / W.
+// slabs: [W][SDPW] of this (step parity, network, role); uncached memory, so "published" = stores performed.
+template <int NT>
+__device__ __forceinline__ void osa_split_dp_average(f32x4 (&g)[NT], float& gb, float coef, const float* tail5,
+                                                     float* slabs, int rk, int W, int* cnt, int target, int tid,
+                                                     int* err, bool& dead) {
+  {
+    float* own = slabs + (long)rk * SDPW;
+    f32x4* o4 = reinterpret_cast<f32x4*>(own);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) o4[q * 256 + tid] = g[q];
+    own[SKQ * 1024 + tid] = gb;
+    if (tid == 0) own[SKQ * 1024 + 256] = coef;
+    if (tail5 != nullptr && tid >= 1 && tid <= 5) own[SKQ * 1024 + 256 + tid] = tail5[tid - 1];
+  }
+  osa_xch_release();
+  osa_lds_barrier();  // every thread's stores are performed
+  if (tid == 0 && !dead) {
+    int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    int spins = 0;
+    while (seen < target) {
+      __builtin_amdgcn_s_sleep(1);
+      seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1 << 20)) {  // a peer never arrived: sticky flag, never hang the device
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        break;
+      }
+    }
+  }
+  osa_lds_barrier();
+  osa_xch_acquire();
+  f32x4 s[NT];
+  float sb = 0.f;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int RU = OSA_SPLIT_DP_RU;  // ranks per trip: their loads are all in flight together
+  for (int r0 = 0; r0 < W; r0 += RU) {
+    f32x4 t[RU][NT];
+    float tb[RU], tg[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* xr = slabs + (long)min(r0 + u, W - 1) * SDPW;
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) t[u][q] = x4[q * 256 + tid];
+      tb[u] = xr[SKQ * 1024 + tid];
+      tg[u] = xr[SKQ * 1024 + 256];
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (r0 + u < W) {  // workgroup-uniform
+#pragma unroll
+        for (int q = 0; q < NT; ++q) s[q] = s[q] + t[u][q] * tg[u];
+        sb += tb[u] * tg[u];
+      }
+    }
+  }
+  const float invW = 1.f / (float)W;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) g[q] = s[q] * invW;
+  gb = sb * invW;
+}
+
+template <int OT, bool DP>
 __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int H = 64, HT = 4, OUTP = 16 * OT;
@@ -173,8 +255,13 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   // a network are the blocks b = net + 8 role, i.e. they share ONE XCC and its L2, and the exchange buffer is
   // ordinary cached memory (a hand-off then costs L2 round trips, not trips to the device-coherent level);
   // otherwise consecutive blocks (spread over the XCCs) and an uncached buffer.  role 0: leader, 1 + c: helper c
-  int net, role;
-  if (a.local == 1) {
+  int net, role, rk = 0;
+  if constexpr (DP) {  // rank-major: the 3 (C + 1) workgroups of rank rk are consecutive blocks (local == 0)
+    const int per = 3 * (C + 1), b = blockIdx.x % per;
+    rk = blockIdx.x / per;
+    net = b / (C + 1);
+    role = b - net * (C + 1);
+  } else if (a.local == 1) {
     net = blockIdx.x & 7;
     role = blockIdx.x >> 3;
     if (net >= 3) return;
@@ -183,15 +270,30 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     role = blockIdx.x - net * (C + 1);
   }
   if (!((a.nets_mask >> net) & 1)) return;
+  // data-parallel form: this rank's rows, permutation and intra-rank exchange region
+  const long roff = DP ? (long)rk * a.M : 0;
+  const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
+  const float* __restrict__ act_p = a.act + roff * a.ld_act;
+  const float* __restrict__ logp_p = a.logp + roff;
+  const float* __restrict__ advr_p = a.adv_r + roff;
+  const float* __restrict__ advc_p = a.adv_c + roff;
+  const long* __restrict__ perm_p = a.perm ? a.perm + roff : nullptr;
+  float* const xch_r = a.xch + (DP ? (long)rk * a.rank_xch : 0);
+  const int W = DP ? a.world : 1;
+  // cross-rank exchange of this (network, role): arrival counter + [2 parity][world][SDPW] slabs
+  int* dp_cnt = DP ? reinterpret_cast<int*>(a.dpx) + 8 * net + role : nullptr;
+  auto dp_slabs = [&](int mb) -> float* {
+    return a.dpx + 128 + ((((long)(mb & 1) * 3 + net) * (SCMAX + 1) + role) * W) * SDPW;
+  };
   const int KB = nd.KB, INP = nd.INP, P = nd.P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int i = j, cc = j;
   float* __restrict__ gp = a.params + (long)net * P;
   float* __restrict__ gm = a.adam_m + (long)net * P;
   float* __restrict__ gv = a.adam_v + (long)net * P;
-  int* flags = reinterpret_cast<int*>(a.xch) + 32 * net;
-  int* err = reinterpret_cast<int*>(a.xch) + SF_ERR;
-  float* xn = a.xch + 128 + (long)net * SXNET;
+  int* flags = reinterpret_cast<int*>(xch_r) + 32 * net;
+  int* err = reinterpret_cast<int*>(a.xch) + SF_ERR;  // (one sticky word for the launch: rank 0's region)
+  float* xn = xch_r + 128 + (long)net * SXNET;
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(xn + SX_NORM);  // [2 (C + 1)] {value, step}
   const bool critic = net != 0;
   const bool l2 = critic && a.hp.use_critic_norm;
@@ -290,11 +392,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     {
       const int B0 = (int)min((long)a.B, a.M);
       const long p0 = (c < B0) ? c : 0;
-      row_nxt = a.perm ? a.perm[p0] : p0;
+      row_nxt = perm_p ? perm_p[p0] : p0;
     }
     f32x4 xr[SKQ];
     {
-      const float* __restrict__ xrow = a.obs + row_nxt * ld_obs;
+      const float* __restrict__ xrow = obs_p + row_nxt * ld_obs;
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) xr[q] = load_chunk(xrow, 16 * (kb0 + q) + 4 * g);
     }
@@ -309,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         const long nlo = mb_lo + a.B;
         const int nB = (int)(min(nlo + a.B, a.M) - nlo);
         const long np = nlo + ((c < nB) ? c : 0);
-        row_nn = a.perm ? a.perm[np] : np;
+        row_nn = perm_p ? perm_p[np] : np;
       }
       // ---- this step's columns: B operand of the forward product, and (transposed) A operand of dW1
       f32x4 x[SKQ];
@@ -348,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       STICK(1);
       // ---- gather the next step's columns while the leader works
       {
-        const float* __restrict__ xrow = a.obs + row_nn * ld_obs;
+        const float* __restrict__ xrow = obs_p + row_nn * ld_obs;
 #pragma unroll
         for (int q = 0; q < SKQ; ++q) xr[q] = load_chunk(xrow, 16 * (kb0 + q) + 4 * g);
       }
@@ -427,6 +529,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         gscale = gscale > 1.f ? 1.f : gscale;
       }
       STICK(5);
+      if constexpr (DP) {  // average of the ranks' locally clipped slices (clip-then-average)
+        float nob = 0.f;
+        osa_split_dp_average<SKQ>(gq, nob, gscale, nullptr, dp_slabs(mb), rk, W, dp_cnt, W * (mb + 1), tid, err, dead);
+        gscale = 1.f;
+      }
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) {
         const f32x4 w = osa_adam_update4(gq[q] * gscale, m1[q], v1[q], wv[q], beta1, beta2, step_size, inv_bc2_sqrt, aeps);
@@ -435,7 +542,8 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       osa_lds_barrier();  // the slice is consistent; sX and red are free
       STICK(6);
     }
-    // ---- write back the slice and its moments
+    // ---- write back the slice and its moments (data-parallel form: the replicas are identical, rank 0 writes)
+    if (DP && rk != 0) return;
 #pragma unroll
     for (int q = 0; q < SKQ; ++q) {
       if (q < nkb) {
@@ -538,7 +646,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   }
   float lam = 0.f;
   if (net == 0 && a.lagrange) lam = *a.lagrange;
-  const float* __restrict__ tgt = (net == 1) ? a.tgt_r : a.tgt_c;
+  const float* __restrict__ tgt = ((net == 1) ? a.tgt_r : a.tgt_c) + roff;
   __syncthreads();  // LDS master copy + bias-correction table complete
 
 #define SPUT_TILE(S, V, T)                                                           \
@@ -549,20 +657,20 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   {
     const int B0 = (int)min((long)a.B, a.M);
     const long p0 = (c < B0) ? c : 0;
-    row_nxt = a.perm ? a.perm[p0] : p0;
+    row_nxt = perm_p ? perm_p[p0] : p0;
   }
   // per-sample scalars of the step, gathered one step ahead
   float n_act[4 * OT], n_logp = 0.f, n_advr = 0.f, n_advc = 0.f, n_tgt = 0.f;
   auto gather = [&](long row) {
     if (net == 0) {  // block-uniform
-      const float* __restrict__ arow = a.act + row * a.ld_act;
+      const float* __restrict__ arow = act_p + row * a.ld_act;
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int r = 0; r < 4; ++r) n_act[4 * o + r] = arow[min(16 * o + 4 * g + r, nd.act_dim - 1)];
-      n_logp = a.logp[row];
-      n_advr = a.adv_r[row];
-      n_advc = a.adv_c[row];
+      n_logp = logp_p[row];
+      n_advr = advr_p[row];
+      n_advc = advc_p[row];
     } else {
       n_tgt = tgt[row];
     }
@@ -581,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       const long nlo = mb_lo + a.B;
       const int nB = (int)(min(nlo + a.B, a.M) - nlo);
       const long np = nlo + ((c < nB) ? c : 0);
-      row_nn = a.perm ? a.perm[np] : np;
+      row_nn = perm_p ? perm_p[np] : np;
     }
     float s_act[4 * OT];
 #pragma unroll
@@ -932,6 +1040,37 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       gscale = gscale > 1.f ? 1.f : gscale;
     }
     STICK(6);
+    float st_loss = t_loss * invB - ((net == 0) ? a.hp.entropy_coef * ent_pre : 0.f), st_ratio = t_ratio * invB,
+          st_psq = t_psq, st_norm = total_norm, st_ent = ent_pre;
+    if constexpr (DP) {
+      // average of the ranks' locally clipped (W2, W3, bias-like) gradients; the step's statistics travel in the
+      // slab's tail and are averaged by rank 0's leader (what Logger.get_stats averages across ranks)
+      f32x4 gg[HT + OT];
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) gg[ti] = g2[ti];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) gg[HT + o] = g3[o];
+      float* t5 = red + 40;  // (red: 64 floats; 16 .. 31 hold the norm shares until barrier C)
+      if (leader) { t5[0] = st_loss; t5[1] = st_ratio; t5[2] = st_psq; t5[3] = st_norm; t5[4] = st_ent; }
+      osa_lds_barrier();
+      float* slabs = dp_slabs(mb);
+      osa_split_dp_average<HT + OT>(gg, gb, gscale, t5, slabs, rk, W, dp_cnt, W * (mb + 1), tid, err, dead);
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) g2[ti] = gg[ti];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) g3[o] = gg[HT + o];
+      gscale = 1.f;
+      if (leader && rk == 0) {
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < W; ++r) {
+          const float* t = slabs + (long)r * SDPW + SKQ * 1024 + 256 + 1;
+          for (int k = 0; k < 5; ++k) acc[k] += t[k];
+        }
+        const float invW = 1.f / (float)W;
+        st_loss = acc[0] * invW; st_ratio = acc[1] * invW; st_psq = acc[2] * invW; st_norm = acc[3] * invW;
+        st_ent = acc[4] * invW;
+      }
+    }
     // ================= Adam =================
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
@@ -960,17 +1099,17 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
         sLC[boff - nd.oLS] = logf(sd);
       }
     }
-    if (leader) {
+    if (leader && rk == 0) {
       float* st = a.stats + (long)mb * SNSTAT;
       if (net == 0) {
-        st[2] = t_loss * invB - a.hp.entropy_coef * ent_pre;
-        st[3] = t_ratio * invB;
-        st[4] = ent_pre;
-        st[7] = total_norm;
+        st[2] = st_loss;
+        st[3] = st_ratio;
+        st[4] = st_ent;
+        st[7] = st_norm;
       } else {
-        st[net - 1] = t_loss * invB;
-        st[4 + net] = t_psq;
-        st[7 + net] = total_norm;
+        st[net - 1] = st_loss;
+        st[4 + net] = st_psq;
+        st[7 + net] = st_norm;
       }
     }
     // ---- the next step's scalars: requested here, where the leader is about to wait for the helpers' partials
@@ -986,7 +1125,8 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   if (tid == 0 && a.nmb >= 8)  // leader of network `net` -> row net, columns 0..7: mean cycles per step
     for (int k = 0; k < 8; ++k) a.stats[(long)net * SNSTAT + k] = (float)sdbg[k] / (float)a.nmb;
 #endif
-  // ---- write back: LDS master copy, Adam state
+  // ---- write back: LDS master copy, Adam state (data-parallel form: the replicas are identical, rank 0 writes)
+  if (DP && rk != 0) return;
   for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * SSLD + (e & 63)];
   for (int e = tid; e < OUTP * H; e += 256) gp[nd.oW3 + e] = sW3[(e >> 6) * SSLD + (e & 63)];
   if (tid < H) {
@@ -1030,13 +1170,13 @@ static size_t osa_split_lds_bytes(int OT, int nmb) {
 
 extern "C" bool osa_is_exchange_ptr(const void* p);  // ppo_pass_kernel.hip
 
-template <int OT>
+template <int OT, bool DP = false>
 static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = osa_split_lds_bytes(OT, a.nmb);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT, DP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1045,8 +1185,9 @@ static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   // launch makes the runtime verify that and refuses otherwise (the caller then takes the one-CU kernel)
   OsaSplitArgs arg = a;
   void* kargs[] = {&arg};
-  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT>),
-                                                  dim3(a.local == 1 ? 8 * (a.C + 1) : 3 * (a.C + 1)), dim3(256), kargs,
+  const int nblk = DP ? a.world * 3 * (a.C + 1) : (a.local == 1 ? 8 * (a.C + 1) : 3 * (a.C + 1));
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT, DP>),
+                                                  dim3(nblk), dim3(256), kargs,
                                                   (unsigned)lds, stream);
   if (e == hipSuccess) return OSA_OK;
   (void)hipGetLastError();
@@ -1106,6 +1247,66 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   const int OT = a.nd.OUTP / 16;
   if (OT == 1) return osa_launch_split<1>(a, st);
   if (OT == 2) return osa_launch_split<2>(a, st);
+  return OSA_EUNSUPPORTED;
+}
+
+size_t osa_ppo_split_dp_xch_floats(int obs_dim, int act_dim, int hidden, int world) {
+  if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
+  const size_t per_rank = (size_t)128 + 3 * (size_t)SXNET;
+  return (size_t)world * per_rank + 128 + (size_t)2 * 3 * (SCMAX + 1) * world * SDPW;
+}
+
+int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                          const float* logp, const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                          float* xch, float* step_stats, void* stream) {
+  if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;
+  if ((M + B - 1) / B > 8192) return OSA_EUNSUPPORTED;  // the helpers tabulate Adam's bias corrections in LDS
+  OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && xch);
+  OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
+  OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim);
+  if (!osa_is_exchange_ptr(xch)) return OSA_EINVAL;  // hand-offs across XCCs rely on uncached memory
+  if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad the rows
+  if ((double)M * world * ld_obs >= 2147483647.0 * 4) return OSA_EUNSUPPORTED;
+  OsaSplitArgs a = {};
+  a.nd = osa_make_net(obs_dim, act_dim, hidden);
+  a.C = (a.nd.KB + SKQ - 1) / SKQ;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return OSA_EHIP;
+  if (world * 3 * (a.C + 1) > cus) return OSA_EUNSUPPORTED;  // one workgroup per CU, all co-resident
+  const size_t per_rank = (size_t)128 + 3 * (size_t)SXNET;
+  a.xch = xch;
+  a.local = 0;
+  a.world = world;
+  a.rank_xch = (long)per_rank;
+  a.dpx = xch + (size_t)world * per_rank;
+  a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
+  a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
+  a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
+  a.perm = perm; a.M = M; a.B = B; a.nmb = (int)((M + B - 1) / B); a.lagrange = lagrange;
+  a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
+  a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
+  a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
+  a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
+  hipStream_t st = osa_stream(stream);
+  // flag words and arrival counters are step counters of THIS launch (rank 0's sticky error word survives)
+  for (int r = 0; r < world; ++r) {
+    float* xr = xch + (size_t)r * per_rank;
+    if (hipMemsetAsync(xr, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+    for (int n = 0; n < 3; ++n)
+      if (hipMemsetAsync(xr + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
+  }
+  if (hipMemsetAsync(a.dpx, 0, 128 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  const int OT = a.nd.OUTP / 16;
+  if (OT == 1) return osa_launch_split<1, true>(a, st);
+  if (OT == 2) return osa_launch_split<2, true>(a, st);
   return OSA_EUNSUPPORTED;
 }
 

@@ -90,6 +90,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._split_local = False
         self._split_verified = False
         self._split_buf = None
+        self._repl_wide = False
 
     def _chunk_ok(self, data: dict) -> bool:
         """osa_ppo_chunked_pass applies: plain surrogate, 64 < B <= 64 x (CUs / 8) rows, OSA_CHUNKED_PASS != 0.
@@ -365,6 +366,39 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if st.get('xch') is None and st.get('xch_ptr'):
             self.lib.osa_dp_exchange_free(st['xch_ptr'])
         st.pop('xch_ptr', None)
+        if st.get('wide_xch'):
+            self.lib.osa_dp_exchange_free(C.c_void_p(st['wide_xch']))
+        st.pop('wide_xch', None)
+
+    def _wide_dp_fits(self, W: int) -> bool:
+        """The data-parallel split pass (osa_ppo_split_dp_pass) applies: wide observations, B <= 64, plain surrogate,
+        and the device holds W x 3 x (1 + ceil(KB / 6)) workgroups (one per compute unit) together."""
+        ac = self.ac
+        if (self.ext is not None or self.batch_size > 64 or self.loss_kind not in (0, 1) or not self.persistent
+                or os.environ.get('OSA_WIDE_SPLIT', '1') == '0'
+                or not bool(self.lib.osa_ppo_split_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
+            return False
+        helpers = ((ac.obs_dim + 15) // 16 + 5) // 6
+        cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
+        return W * 3 * (helpers + 1) <= cus
+
+    def _wide_dp_pass(self, data_all: dict, M: int, W: int, lagrange: torch.Tensor, st: dict) -> None:
+        """osa_ppo_split_dp_pass: one cooperative launch = one pass of the global update for wide observations
+        (BASELINE config 4 under world_size > 1): W virtual ranks x 3 networks x (leader + helpers)."""
+        ac, lib = self.ac, self.lib
+        if not st.get('wide_xch'):
+            n = lib.osa_ppo_split_dp_xch_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
+            p = C.c_void_p()
+            _lib.check(lib.osa_dp_exchange_alloc(max(n, 1), C.byref(p)), 'osa_dp_exchange_alloc')
+            st['wide_xch'] = p.value
+        _lib.check(lib.osa_ppo_split_dp_pass(
+            ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+            _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']), data_all['obs'].stride(0), _lib.ptr(data_all['act']),
+            data_all['act'].stride(0), _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
+            _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
+            _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp), self.loss_kind,
+            self._nets_mask(), C.c_void_p(st['wide_xch']), _lib.ptr(st['pass_stats']), _lib.stream_ptr()),
+            'osa_ppo_split_dp_pass')
 
     def __del__(self):
         try:
@@ -423,6 +457,17 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         st['coop_passes'] = st.get('coop_passes', 0) + 1
         return True
 
+    def check_wide_dp_sync(self) -> None:
+        """Sticky time-out word of the data-parallel split pass (a cooperating workgroup never arrived)."""
+        st = self._dp
+        if st.get('wide_xch'):
+            flag = C.c_int(0)
+            _lib.check(self.lib.osa_ppo_split_pass_timed_out(C.c_void_p(st['wide_xch']), C.byref(flag)),
+                       'osa_ppo_split_pass_timed_out')
+            if flag.value:
+                raise _lib.OsaError('osa_ppo_split_dp_pass: a cooperating workgroup never arrived (results invalid); '
+                                    'set OSA_DP_MODE=allreduce')
+
     def check_dp_sync(self) -> None:
         """Raise if ANY cooperative pass since allocation flagged a peer workgroup that never arrived (host
         sync).  sync[3] is sticky: osa_ppo_dp_pass resets only the arrival counters sync[0..2], so a time-out
@@ -459,6 +504,17 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         else:  # W uniform shuffles in one batched sort of random 62-bit keys (3 launches instead of ~4 W)
             keys = torch.randint(0, 1 << 62, (W, M), generator=st['gen'], device=ac.device, dtype=torch.int64)
             st['perm'].copy_(keys.argsort(dim=1))
+        if self._repl_wide:  # wide observations: the data-parallel split pass (no stepwise variant)
+            ev = None
+            if self.profile_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            self._wide_dp_pass(data_all, M, W, lagrange, st)
+            if ev is not None:
+                ev[1].record()
+                self.profile_events.append(('osa_wide_split_kernel', W * M, ev))
+            stats_rows.copy_(st['pass_stats'][:stats_rows.shape[0]])
+            return
         if coop is None:
             coop = self.dp_mode != 'replicated-steps'
         if coop:
@@ -582,10 +638,14 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         use_repl = (dist.collectives_active() and self.ext is None and self.update_critics
                     and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
+        # wide observations (BASELINE config 4): the data-parallel form of the split pass
+        self._repl_wide = (not use_repl and dist.collectives_active() and self.update_critics
+                           and self.dp_mode in ('replicated', 'replicated-steps') and self._wide_dp_fits(W))
+        use_repl = use_repl or self._repl_wide
         if use_repl:
             gathered = self._aligned_rows(self.gather_for_replicated(data, W))
         # which machinery ran (tests assert the timed path, not a fallback)
-        self.last_path = 'replicated' if use_repl else (
+        self.last_path = ('replicated-wide-split' if self._repl_wide else 'replicated') if use_repl else (
             ('persistent-wide' if self._use_wide else 'persistent') if use_pass else 'per-step')
         # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
         # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
@@ -622,10 +682,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     final_kl = float(kl_dev)  # the one host sync per pass
                     if use_repl:  # the stream is drained anyway: see a lost peer before the KL decision
                         self.check_dp_sync()
+                        self.check_wide_dp_sync()
                     if final_kl > self.target_kl:
                         break
         if use_repl:
             self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
+            self.check_wide_dp_sync()
         if not use_repl and not use_pass and B > 64:
             self.check_reduce_sync()
         if self._use_wide:
