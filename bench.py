@@ -44,6 +44,12 @@ W_PI = OBS_DIM * HIDDEN + HIDDEN * HIDDEN + HIDDEN * ACT_DIM  # 8064 weights (no
 W_V = OBS_DIM * HIDDEN + HIDDEN * HIDDEN + HIDDEN * 1         # 8000
 FLOPS_PER_SAMPLE_STEP = 6 * (W_PI + 2 * W_V)                  # fwd 2W + bwd 4W, three nets
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md (f32-input MFMA)
+PEAK_HBM_GBPS = 8000.0                                         # MI355X_MICROARCH.md (HBM3E)
+# Serial matrix-pipe floor of ONE 64-row optimiser step of one network (osa_ppo_pass_kernel, 60/2): every wave
+# issues 320 dependent-chain v_mfma_f32_16x16x4_f32 per step (layer 1: 64, layer 2: 64, dz1: 64, dW2: 64,
+# dW1: 64; the 1-2-output layer runs on the VALU), 32 issue cycles each, at the 2.4 GHz engine clock; the three
+# networks run concurrently on three CUs.  The B = 64 chain cannot go below this however the rest is scheduled.
+MFMA_PER_STEP, MFMA_CYCLES, ENGINE_GHZ = 320, 32, 2.4
 
 
 def parse():
@@ -167,6 +173,10 @@ def roofline_from_events(events, batch_size):
     elif name == 'osa_ppo_pass_kernel':
         steps = rows // len(events) // batch_size
         out['us_per_optimiser_step'] = round(us / steps, 3)
+        if batch_size <= 64:
+            floor = MFMA_PER_STEP * MFMA_CYCLES / (ENGINE_GHZ * 1e3)
+            out['chain_floor_us'] = round(floor, 3)  # serial MFMA issue cycles of one step (see the constants)
+            out['chain_frac'] = round(floor / (us / steps), 4)  # the meaningful denominator of a B = 64 chain
         out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
                        'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
                        'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
@@ -175,6 +185,22 @@ def roofline_from_events(events, batch_size):
         out['note'] = ('large-batch step: <= CUs/3 workgroups per network keep the weights in LDS and their partial '
                        'gradient in registers over several 64-row chunks, one slab each; slab reduce + clip/Adam launches')
     return out
+
+
+def whole_path(args, value, world, update_iters, kl_passes):
+    """SURVEY.md 8(d) whole-path figures of the headline metric: algorithmic bytes and FLOPs per env-step
+    (rollout + GAE + standardise side: 4 D_o + 4 D_a + 72 B; update: K x (4 (D_o + D_a + 5) B gathered +
+    6 (W_pi + 2 W_V) FLOP) per env-step, + one full-batch KL pass (4 D_o B, 2 W_pi FLOP) per pass that runs one) and
+    what the measured env-steps/s turn them into, against the vendor peaks.  Per GPU."""
+    bytes_step = (4 * OBS_DIM + 4 * ACT_DIM + 72) + update_iters * 4 * (OBS_DIM + ACT_DIM + 5) + kl_passes * 4 * OBS_DIM
+    flops_step = update_iters * FLOPS_PER_SAMPLE_STEP + kl_passes * 2 * W_PI
+    per_gpu = value / world
+    gbps, tflops = bytes_step * per_gpu / 1e9, flops_step * per_gpu / 1e12
+    return {'bytes_per_env_step': bytes_step, 'flops_per_env_step': flops_step,
+            'achieved_GBps': round(gbps, 3), 'frac_hbm_peak': round(gbps / PEAK_HBM_GBPS, 6),
+            'achieved_TFLOPs': round(tflops, 4), 'frac_f32_mfma_peak': round(tflops / PEAK_F32_MFMA_TFLOPS, 5),
+            'kl_passes_per_epoch': kl_passes,
+            'note': 'algorithmic (minimum) bytes / FLOPs of the whole epoch per env-step x measured env-steps/s per GPU'}
 
 
 def cpu_baseline(args):
@@ -304,6 +330,9 @@ def main():
                    'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None)},
     }
     out['roofline'] = roofline_from_events(events, args.batch_size)
+    # (without early stop only the last pass's KL is evaluated; with it, one per pass: update.py)
+    out['whole_path'] = whole_path(args, value, world, args.update_iters,
+                                   args.update_iters if args.kl_early_stop else 1)
     if world == 1 and not args.no_variant and rank == 0:
         del algo
         torch.cuda.empty_cache()
@@ -320,7 +349,8 @@ def main():
             'value': round(per_gpu_steps * v_steps / v_dt, 1), 'unit': 'env-steps/s',
             'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
             'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
-            'roofline': roofline_from_events(v_events, 16384)}
+            'roofline': roofline_from_events(v_events, 16384),
+            'whole_path': whole_path(args, per_gpu_steps * v_steps / v_dt, 1, 8, 1)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         port = cpu_baseline(args)
         ref = cpu_baseline_reference(args)

@@ -284,6 +284,9 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
                        const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                        float* xch, int local, float* step_stats, void* stream);
 int osa_ppo_split_pass_timed_out(const float* xch, int* out);
+/* Clears the sticky word after a tripped PLACEMENT check (flag 2: nothing was modified, the caller repeats the pass
+ * with another placement).  Never clear a time-out (flag 1). */
+int osa_ppo_split_pass_clear_flag(float* xch);
 /* The DATA-PARALLEL form of osa_ppo_split_pass (world_size > 1 without a per-step cross-GPU collective, as
  * osa_ppo_dp_pass does for narrow observations): the arrays hold the all-gathered rollouts of `world` ranks (rank r:
  * rows r M .. r M + M - 1), perm is [world][M] (row r = rank r's shuffle of its OWN M rows, indices in [0, M)).
@@ -294,17 +297,25 @@ int osa_ppo_split_pass_timed_out(const float* xch, int* out);
  * shares, sum them in rank order, divide by world and apply the SAME Adam step to their own replica: no parameter
  * ever crosses between replicas, they stay bit-identical, rank 0's is written back.  step_stats receive the
  * rank-averaged statistics (what Logger.get_stats averages).  xch: osa_ppo_split_dp_xch_floats(...) floats from
- * osa_dp_exchange_alloc (uncached; OSA_EINVAL otherwise), zero-initialised once; its sticky time-out word is read
- * with osa_ppo_split_pass_timed_out.  OSA_EUNSUPPORTED when the device cannot hold the workgroups together
- * (world x 3 x (C + 1) > compute units) or the shape is outside osa_ppo_split_pass_supported: use the per-step
- * path (osa_ppo_minibatch mode 1 + all-reduce + osa_adam_apply). */
+ * osa_dp_exchange_alloc (uncached; OSA_EINVAL otherwise), zero-initialised once; its sticky word (1: a workgroup
+ * never arrived, 2: placement) is read with osa_ppo_split_pass_timed_out.
+ * place = 0, dpx = NULL: rank-major workgroups spread over the XCCs, every hand-off through xch.
+ * place = 1: the `world` owners of the same parameters sit on ONE XCC (owner group g = (network, role) on XCC
+ * g mod 8) and average through dpx = osa_ppo_split_dp_dpx_floats(...) floats of ORDINARY device memory (zeroed
+ * once; OSA_EINVAL for an uncached buffer) served by that XCC's L2, the intra-rank hand-offs stay in xch; the
+ * kernel verifies the placement before it modifies anything and otherwise returns untouched with the sticky word
+ * at 2 (repeat with place = 0).  OSA_EUNSUPPORTED when the device cannot hold the workgroups together
+ * (world x 3 x (C + 1) > compute units; place = 1: ceil(3 (C + 1) / 8) x world > compute units / 8) or the shape
+ * is outside osa_ppo_split_pass_supported: use the per-step path (osa_ppo_minibatch mode 1 + all-reduce +
+ * osa_adam_apply). */
 size_t osa_ppo_split_dp_xch_floats(int obs_dim, int act_dim, int hidden, int world);
+size_t osa_ppo_split_dp_dpx_floats(int obs_dim, int act_dim, int hidden, int world);
 int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                           int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
                           const float* logp, const float* target_value_r, const float* target_value_c,
                           const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                           const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                          float* xch, float* step_stats, void* stream);
+                          float* xch, float* dpx, int place, float* step_stats, void* stream);
 /* osa_ppo_pass with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS, CUP's second stage,
  * P3O): B <= 64 (the trust-mask mean and the penalty are minibatch-level quantities of one 64-row block);
  * OSA_EUNSUPPORTED otherwise -- use osa_ppo_minibatch_ext.  ext == NULL: osa_ppo_pass.  With cost_kappa > 0
@@ -396,6 +407,22 @@ int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                          float* exchange, int* sync, int local, float* step_stats, void* stream);
+/* osa_ppo_chunked_pass UNDER DATA PARALLELISM (the critic passes of the trust-region family, batch 128, with
+ * world_size > 1 -- BASELINE configs 3 and 5; natural_pg.py:205-223 + distributed.py:167-198): arrays and perm as
+ * osa_ppo_dp_pass ([world][M] rows, rank r's shuffle of its own rows), world x ceil(B / 64) workgroups per network
+ * in one cooperative launch.  Two hand-offs per optimiser step: inside a rank's chunk group (sum of the chunks'
+ * gradients, ITS norm, the rank's clip factor -- the arithmetic of one B-row step of that rank), then across ranks
+ * (every chunk workgroup publishes its share of the tiles of the rank's sum; everybody adds the `world` clipped sums
+ * in rank order, / world) and the same Adam step in every replica.  exchange: osa_ppo_dp_chunked_pass_ws_floats
+ * floats (placement rules as osa_ppo_dp_pass_placed); sync: int[64], zero before the first call ([3] sticky
+ * time-out / placement flag as there). */
+size_t osa_ppo_dp_chunked_pass_ws_floats(int obs_dim, int act_dim, int hidden, int B, int world);
+int osa_ppo_dp_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                            const float* logp, const float* target_value_r, const float* target_value_c,
+                            const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                            const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                            float* exchange, int* sync, int local, float* step_stats, void* stream);
 
 /* Debugging aid: when set to a device buffer of 48 int64, every osa_ppo_minibatch launch records
  * s_memtime phase timestamps [3 networks][16] (used by tools/phase_clocks.py); NULL disables it. */

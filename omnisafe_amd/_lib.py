@@ -56,6 +56,9 @@ SIGNATURES: dict[str, tuple] = {
                                _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_chunked_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                                   _P, _P, _I, _I, _P, _P, _I, _P, _P]),
+    'osa_ppo_dp_chunked_pass_ws_floats': (C.c_size_t, [_I, _I, _I, _I, _I]),
+    'osa_ppo_dp_chunked_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
+                                     _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_dp_step': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
@@ -69,9 +72,11 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_split_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                                 _P, _P, _I, _I, _P, _I, _P, _P]),
     'osa_ppo_split_pass_timed_out': (_I, [_P, _P]),
+    'osa_ppo_split_pass_clear_flag': (_I, [_P]),
     'osa_ppo_split_dp_xch_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_ppo_split_dp_dpx_floats': (C.c_size_t, [_I, _I, _I, _I]),
     'osa_ppo_split_dp_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
-                                   _P, _P, _I, _I, _P, _P, _P]),
+                                   _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_pass_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                               _P, _P, _I, _I, _P, _P, _P]),
     'osa_adam_apply': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),

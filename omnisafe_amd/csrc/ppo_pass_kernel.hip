@@ -94,6 +94,14 @@ struct OsaPassArgs {
   // norm and every workgroup applies the same Adam step -- the arithmetic of a single-process minibatch of B
   // rows, not the clip-then-average of the data-parallel mode
   int dp_chunk;
+  // chunk mode UNDER data parallelism (osa_ppo_dp_chunked_pass): dp_ranks > 1 virtual ranks, each a group of
+  // dp_world / dp_ranks chunk workgroups (peer p = rank * chunks + chunk) working on ITS rows (rank r: rows
+  // r M .. of the all-gathered arrays, permutation perm[r M ..]).  Two hand-offs per step: (1) inside the rank group
+  // as in chunk mode -- sum of the chunks, ITS norm, the rank's clip factor; (2) across ranks -- every chunk
+  // workgroup publishes its share of the tiles of the rank's sum, all dp_world peers arrive, everybody adds the
+  // dp_ranks rank sums x clip factor in rank order, / dp_ranks (clip-then-average), same Adam step everywhere.
+  // dp_sync then is int[64]: [net] stage-2 arrivals, [3] sticky flag, [4..7] placement, [8 + 16 net + rank] stage 1.
+  int dp_ranks;
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -129,7 +137,7 @@ __device__ __forceinline__ float osa_sym_sum1(float a, float sa, float b, float 
   return pa + pb;
 }
 
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -148,7 +156,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const bool dp = a.dp_slabs != nullptr && !coop;
   const bool part = MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
   const bool chunked = COOP && a.dp_chunk != 0;
-  const long roff = (part || chunked) ? 0 : (long)rk * a.M;
+  // chunk mode under data parallelism: peer rk = rank * cw + chunk (cw chunk workgroups per rank)
+  // (HIER: its own instantiation, so that the plain chunk / data-parallel kernels keep their register allocation)
+  const int nranks = (HIER && chunked && a.dp_ranks > 1) ? a.dp_ranks : 1;
+  const int cw = chunked ? a.dp_world / nranks : 1;
+  const int crank = chunked ? rk / cw : 0, cchunk = chunked ? rk - crank * cw : 0;
+  const long roff = part ? 0 : (chunked ? (long)crank * a.M : (long)rk * a.M);
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
   const float* __restrict__ logp_p = a.logp + roff;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   }
   // terms that enter a minibatch's gradient ONCE (critics' L2 term, entropy bonus): partial sums get them later,
   // the chunks of a chunked pass from chunk 0
-  const bool own_terms = !(chunked && rk != 0);
+  const bool own_terms = !(chunked && cchunk != 0);
   const bool l2 = critic && a.hp.use_critic_norm && !part && own_terms;
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
   // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
   const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
-  const int cstride = part ? a.part_stride : 1, cfirst = (part || chunked) ? rk : 0;
+  const int cstride = part ? a.part_stride : 1, cfirst = part ? rk : (chunked ? cchunk : 0);
   const int nchunk = part ? (nchunk_all - cfirst + cstride - 1) / cstride : nchunk_all;
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
     const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
@@ -898,8 +911,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     float* __restrict__ xbase = nullptr;
     f32x4* __restrict__ xs4 = nullptr;
     if constexpr (coop) {
-      xbase = a.dp_slabs + ((long)((mb - a.mb0) & 1) * 3 + net) * a.dp_world * XS;
-      xs4 = reinterpret_cast<f32x4*>(xbase + (long)rk * XS);
+      // (chunk mode: the slabs of THIS rank's chunk group; own slab = chunk index)
+      xbase = a.dp_slabs + (((long)((mb - a.mb0) & 1) * 3 + net) * a.dp_world + (chunked ? crank * cw : 0)) * XS;
+      xs4 = reinterpret_cast<f32x4*>(xbase + (long)(chunked ? cchunk : rk) * XS);
     }
     f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -996,7 +1010,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     if constexpr (coop) {
       // ---- the gradient tiles are on their way (exchange layout: one f32x4 per thread per tile, 1 KB
       // contiguous per wave instruction); complete the slab with the clip factor and the statistics
-      const int W = a.dp_world;
+      const int W = chunked ? cw : a.dp_world;  // peers of this hand-off
       const float gs = (apply_clip && !chunked) ? coef : 1.f;  // (chunk mode: the SUM is clipped, below)
       if (leader) {
         float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
@@ -1012,7 +1026,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       __syncthreads();
       PTICK(12);
       if (tid == 0) {
-        int* cnt = a.dp_sync + net;
+        int* cnt = (nranks > 1) ? a.dp_sync + 8 + 16 * net + crank : a.dp_sync + net;
         const int target = W * (mb - a.mb0 + 1);
         // relaxed atomics: ordering comes from the agent-scope fences on either side of the barriers
         // (a release/acquire atomic would write back / invalidate the L2 a second time)
@@ -1049,7 +1063,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         // two peers (two chunks of a 128-row minibatch, or two ranks): own gradient from the registers + the
         // peer's slab.  Both sides form the same two products (g * clip factor; 1 in chunk mode) and a two-operand
         // float sum is commutative, so they get the same bits without walking the slabs in rank order.
-        const float* __restrict__ xr = xbase + (long)(rk ^ 1) * XS;
+        const float* __restrict__ xr = xbase + (long)((chunked ? cchunk : rk) ^ 1) * XS;
         const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
         f32x4 t[NT];
 #pragma unroll
@@ -1127,7 +1141,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
           apply_clip = true;
         }
       }
-      if (leader && rk == 0) {  // what Logger.get_stats averages across ranks
+      if (leader && (chunked ? cchunk == 0 : rk == 0)) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < W; ++r) {
           const float* t = xbase + (long)r * XS + NT * 1024 + 256;
@@ -1139,6 +1153,109 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         } else {
           st_loss = acc[0] * invW; st_ratio = acc[1] * invW; st_psq = acc[2] * invW;
           st_norm = acc[3] * invW; st_ent = acc[4] * invW;
+        }
+      }
+      if constexpr (HIER) {
+        // ---- second hand-off (chunk mode under data parallelism): the rank sums, across ranks.  Every chunk
+        // workgroup of a rank holds the same sum: chunk c publishes the tiles q = c, c + cw, ... (chunk 0 also
+        // the bias-like row, the rank's clip factor and its statistics); ALL peers arrive; everybody adds the
+        // nranks rank slabs x clip factor in rank order.
+        float* x2 = a.dp_slabs + (long)2 * 3 * a.dp_world * XS + (((long)((mb - a.mb0) & 1) * 3 + net) * nranks) * XS;
+        f32x4* o4 = reinterpret_cast<f32x4*>(x2 + (long)crank * XS);
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti)
+          if (ti % cw == cchunk) o4[ti * 256 + tid] = g2[ti];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          if ((HT + kb) % cw == cchunk) o4[(HT + kb) * 256 + tid] = g1[kb];
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+          if ((HT + KB + o) % cw == cchunk) o4[(HT + KB + o) * 256 + tid] = g3[o];
+        if (cchunk == 0) {
+          float* row = x2 + (long)crank * XS + NT * 1024;
+          row[tid] = (boff >= 0) ? gb : 0.f;
+          if (leader) {
+            float* t = row + 256;
+            t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent;
+            t[5] = apply_clip ? coef : 1.f;
+          }
+        }
+        if (a.dp_uncached || a.dp_local) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_waitcnt(0);
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int* cnt = a.dp_sync + net;
+          const int target = a.dp_world * (mb - a.mb0 + 1);
+          int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          if (!coop_dead) {
+            int spins = 0;
+            while (seen < target) {
+              __builtin_amdgcn_s_sleep(1);
+              seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (++spins > (1 << 21)) {
+                __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                coop_dead = true;
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) s2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sb_ = 0.f;
+        constexpr int RU2 = 4;
+        for (int r0 = 0; r0 < nranks; r0 += RU2) {
+          f32x4 t[RU2][NT];
+          float tb[RU2], tg[RU2];
+#pragma unroll
+          for (int u = 0; u < RU2; ++u) {
+            const float* __restrict__ xr = x2 + (long)min(r0 + u, nranks - 1) * XS;
+            const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) t[u][q] = x4[q * 256 + tid];
+            tb[u] = xr[NT * 1024 + tid];
+            tg[u] = xr[NT * 1024 + 256 + 5];
+          }
+#pragma unroll
+          for (int u = 0; u < RU2; ++u) {
+            if (r0 + u < nranks) {  // workgroup-uniform
+#pragma unroll
+              for (int ti = 0; ti < HT; ++ti) s2[ti] = s2[ti] + t[u][ti] * tg[u];
+#pragma unroll
+              for (int kb = 0; kb < KB; ++kb) s1[kb] = s1[kb] + t[u][HT + kb] * tg[u];
+#pragma unroll
+              for (int o = 0; o < OT; ++o) s3[o] = s3[o] + t[u][HT + KB + o] * tg[u];
+              sb_ += tb[u] * tg[u];
+            }
+          }
+        }
+        const float invR = 1.f / (float)nranks;
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) g2[ti] = s2[ti] * invR;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) g1[kb] = s1[kb] * invR;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) g3[o] = s3[o] * invR;
+        gb = sb_ * invR;
+        apply_clip = false;  // clipped per rank above (clip-then-average)
+        if (leader && rk == 0) {
+          float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int r = 0; r < nranks; ++r) {
+            const float* t = x2 + (long)r * XS + NT * 1024 + 256;
+            for (int k = 0; k < 5; ++k) acc[k] += t[k];
+          }
+          st_loss = acc[0] * invR; st_ratio = acc[1] * invR; st_psq = acc[2] * invR;
+          st_norm = acc[3] * invR; st_ent = acc[4] * invR;
         }
       }
     }
@@ -1251,14 +1368,14 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false>
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : dim3(3, grid_y);
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1273,7 +1390,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1282,14 +1399,14 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1561,7 +1678,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, float* step_stats, void* stream);
+                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream);
 
 int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
@@ -1571,7 +1688,7 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                            float* exchange, int* sync, int local, float* step_stats, void* stream) {
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
-                       nets_mask, exchange, sync, local, 0, step_stats, stream);
+                       nets_mask, exchange, sync, local, 0, 1, step_stats, stream);
 }
 
 int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1583,7 +1700,27 @@ int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   if (B <= 64 || B > 64 * 32) return OSA_EUNSUPPORTED;  // one chunk: osa_ppo_pass
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, (B + 63) / 64, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, local, 1, step_stats, stream);
+                       loss_kind, nets_mask, exchange, sync, local, 1, 1, step_stats, stream);
+}
+
+size_t osa_ppo_dp_chunked_pass_ws_floats(int obs_dim, int act_dim, int hidden, int B, int world) {
+  if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1 || B <= 64) return 0;
+  const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+  const size_t chunks = (size_t)(B + 63) / 64;
+  return (size_t)2 * 3 * (world * chunks) * osa_dp_pass_xs(nd) + (size_t)2 * 3 * world * osa_dp_pass_xs(nd);
+}
+
+int osa_ppo_dp_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                            const float* logp, const float* target_value_r, const float* target_value_c,
+                            const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                            const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                            float* exchange, int* sync, int local, float* step_stats, void* stream) {
+  if (B <= 64 || B > 64 * 32 || world < 1 || world > 16) return OSA_EUNSUPPORTED;
+  const int chunks = (B + 63) / 64;
+  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
+                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world * chunks, lagrange, hp,
+                       loss_kind, nets_mask, exchange, sync, local, 1, world, step_stats, stream);
 }
 
 static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1591,13 +1728,13 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, float* step_stats, void* stream) {
+                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(exchange && sync && ld_obs >= obs_dim && ld_act >= act_dim);
-  if ((double)M * (chunk ? 1 : world) * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
+  if ((double)M * (chunk ? ranks : world) * ld_obs >= 2147483647.0) return OSA_EUNSUPPORTED;
   if (ld_obs % 4 != 0 || (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return OSA_EUNSUPPORTED;  // pad rows
   // all 3 * world workgroups must be co-resident (one per compute unit: ~150 KB of LDS each)
   int dev = 0, cus = 0;
@@ -1608,6 +1745,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   OsaPassArgs a = {};
   a.dp_local = local;  // 0, 1, or 3 (see the kernel)
   a.dp_chunk = chunk ? 1 : 0;
+  a.dp_ranks = chunk ? ranks : 1;
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -1627,11 +1765,14 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   // host reads it (the caller zeroes all four words once, at allocation)
   if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   if (local && hipMemsetAsync(sync + 4, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks, arrivals
+  // (chunk mode under data parallelism: the per-rank arrival counters of the first hand-off; sync is int[64] there)
+  if (chunk && ranks > 1 && hipMemsetAsync(sync + 8, 0, 48 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                  \
-                              : osa_launch_pass<K, O, false, true>(a, st, world)
+    return (chunk && ranks > 1) ? osa_launch_pass<K, O, false, true, false, true>(a, st, world)  \
+           : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \
+                                : osa_launch_pass<K, O, false, true>(a, st, world)
   OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);
   OSA_DPP_CASE(6, 1); OSA_DPP_CASE(1, 2); OSA_DPP_CASE(2, 2); OSA_DPP_CASE(3, 2); OSA_DPP_CASE(4, 2);
   OSA_DPP_CASE(5, 2); OSA_DPP_CASE(6, 2);

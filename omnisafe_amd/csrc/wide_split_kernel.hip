@@ -96,10 +96,21 @@ struct OsaSplitArgs {
   // the replicas and they stay bit-identical.
   int world;
   long rank_xch;  // floats between the intra-rank regions of consecutive ranks
-  float* dpx;     // uncached: [128] arrival counters (int), then [2 parity][3][SCMAX + 1][world][SDPW] slabs
+  // cross-rank exchange: [SDPH] header ints (arrival counters [8 net + role], XCC masks [32 + group], placement
+  // arrivals [96]), then [2 parity][3][SCMAX + 1][world][SDPW] slabs
+  float* dpx;
+  // 0: rank-major blocks spread over the XCCs, dpx uncached like xch (every replica then reads the `world` slabs of
+  //    its owners from the device-coherent level: world^2 x 25 KB per owner group and step -- 24 MB per step at
+  //    376 / 17 and world 8, which is what bounds that variant);
+  // 1: the `world` owners of the same parameters (one "group" = (network, role)) are placed on ONE XCC (block
+  //    b -> XCC b mod 8: group g on XCC g mod 8) and dpx is ordinary memory served by that XCC's L2; the
+  //    intra-rank hand-offs (partials, dz1, norm shares) cross XCCs through the uncached xch.  Placement verified
+  //    before anything is modified (sticky flag 2 otherwise: repeat with 0).
+  int dp_place;
 };
 
 #define SDPW (SKQ * 1024 + 256 + 16)  // one owner's gradient share: <= 6 tiles x 256 x 4, bias-likes, tail
+#define SDPH 256                      // header words of the cross-rank exchange buffer
 #ifndef OSA_SPLIT_DP_RU
 #define OSA_SPLIT_DP_RU 2  // (4: 129 spilled VGPRs in the 17-action instantiation; 2: see DESIGN.md)
 #endif
@@ -186,7 +197,13 @@ __device__ __forceinline__ float osa_slot_wait(unsigned long long* slot, int cnt
 template <int NT>
 __device__ __forceinline__ void osa_split_dp_average(f32x4 (&g)[NT], float& gb, float coef, const float* tail5,
                                                      float* slabs, int rk, int W, int* cnt, int target, int tid,
-                                                     int* err, bool& dead) {
+                                                     int* err, bool& dead, long long* clk = nullptr) {
+#ifdef OSA_SPLIT_CLOCKS
+  long long c0 = clock64();
+#define DTICK(k) do { if (clk && tid == 0) { const long long n_ = clock64(); clk[k] += n_ - c0; c0 = n_; } } while (0)
+#else
+#define DTICK(k) do { } while (0)
+#endif
   {
     float* own = slabs + (long)rk * SDPW;
     f32x4* o4 = reinterpret_cast<f32x4*>(own);
@@ -198,6 +215,7 @@ __device__ __forceinline__ void osa_split_dp_average(f32x4 (&g)[NT], float& gb, 
   }
   osa_xch_release();
   osa_lds_barrier();  // every thread's stores are performed
+  DTICK(0);
   if (tid == 0 && !dead) {
     int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     int spins = 0;
@@ -213,6 +231,7 @@ __device__ __forceinline__ void osa_split_dp_average(f32x4 (&g)[NT], float& gb, 
   }
   osa_lds_barrier();
   osa_xch_acquire();
+  DTICK(1);
   f32x4 s[NT];
   float sb = 0.f;
 #pragma unroll
@@ -243,6 +262,8 @@ __device__ __forceinline__ void osa_split_dp_average(f32x4 (&g)[NT], float& gb, 
 #pragma unroll
   for (int q = 0; q < NT; ++q) g[q] = s[q] * invW;
   gb = sb * invW;
+  DTICK(2);
+#undef DTICK
 }
 
 template <int OT, bool DP>
@@ -256,11 +277,19 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   // ordinary cached memory (a hand-off then costs L2 round trips, not trips to the device-coherent level);
   // otherwise consecutive blocks (spread over the XCCs) and an uncached buffer.  role 0: leader, 1 + c: helper c
   int net, role, rk = 0;
-  if constexpr (DP) {  // rank-major: the 3 (C + 1) workgroups of rank rk are consecutive blocks (local == 0)
-    const int per = 3 * (C + 1), b = blockIdx.x % per;
-    rk = blockIdx.x / per;
-    net = b / (C + 1);
-    role = b - net * (C + 1);
+  if constexpr (DP) {
+    if (a.dp_place == 1) {  // owner group g = (network, role) on XCC g mod 8: blocks g mod 8 + 8 ((g / 8) world + rank)
+      const int slot = blockIdx.x >> 3, gid = (blockIdx.x & 7) + 8 * (slot / a.world);
+      if (gid >= 3 * (C + 1)) return;
+      rk = slot % a.world;
+      net = gid / (C + 1);
+      role = gid - net * (C + 1);
+    } else {  // rank-major: the 3 (C + 1) workgroups of rank rk are consecutive blocks
+      const int per = 3 * (C + 1), b = blockIdx.x % per;
+      rk = blockIdx.x / per;
+      net = b / (C + 1);
+      role = b - net * (C + 1);
+    }
   } else if (a.local == 1) {
     net = blockIdx.x & 7;
     role = blockIdx.x >> 3;
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   // cross-rank exchange of this (network, role): arrival counter + [2 parity][world][SDPW] slabs
   int* dp_cnt = DP ? reinterpret_cast<int*>(a.dpx) + 8 * net + role : nullptr;
   auto dp_slabs = [&](int mb) -> float* {
-    return a.dpx + 128 + ((((long)(mb & 1) * 3 + net) * (SCMAX + 1) + role) * W) * SDPW;
+    return a.dpx + SDPH + ((((long)(mb & 1) * 3 + net) * (SCMAX + 1) + role) * W) * SDPW;
   };
   const int KB = nd.KB, INP = nd.INP, P = nd.P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -334,8 +363,41 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     __syncthreads();
     if (bad_placement) return;
   }
+  if constexpr (DP) {
+    if (a.dp_place != 0) {  // (3: test hook -- verification on the rank-major grid, where it must trip)
+      // every owner group must sit on ONE XCC (its exchange slabs are ordinary memory in that XCC's L2): verified
+      // before anything is modified, as above; otherwise everybody returns untouched with the sticky word at 2
+      int* s_why = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        int* hdr = reinterpret_cast<int*>(a.dpx);
+        const int G = 3 * (C + 1), gid = net * (C + 1) + role;
+        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
+        __hip_atomic_fetch_or(hdr + 32 + gid, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int expect = a.world * (C + 1) * __builtin_popcount(a.nets_mask & 7);
+        int v = __hip_atomic_fetch_add(hdr + 96, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        int spins = 0, why = 0;
+        while (v < expect) {
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(hdr + 96, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1 << 21)) { why = 1; break; }
+        }
+        for (int q = 0; q < G && why == 0; ++q) {
+          const int mask = __hip_atomic_load(hdr + 32 + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((mask & (mask - 1)) != 0) why = 2;
+        }
+        if (why) __hip_atomic_store(err, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!why) why = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_why = why;
+      }
+      __syncthreads();
+      const bool bad_placement = *s_why != 0;
+      __syncthreads();
+      if (bad_placement) return;
+    }
+  }
 #ifdef OSA_SPLIT_CLOCKS
   long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dclk[3] = {0, 0, 0};  // data-parallel average: publish + release | arrive + wait + acquire | slab reads
   long long slast = clock64();
 #endif
 
@@ -531,7 +593,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       STICK(5);
       if constexpr (DP) {  // average of the ranks' locally clipped slices (clip-then-average)
         float nob = 0.f;
+#ifdef OSA_SPLIT_CLOCKS
+        osa_split_dp_average<SKQ>(gq, nob, gscale, nullptr, dp_slabs(mb), rk, W, dp_cnt, W * (mb + 1), tid, err, dead, dclk);
+#else
         osa_split_dp_average<SKQ>(gq, nob, gscale, nullptr, dp_slabs(mb), rk, W, dp_cnt, W * (mb + 1), tid, err, dead);
+#endif
         gscale = 1.f;
       }
 #pragma unroll
@@ -553,8 +619,10 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       }
     }
 #ifdef OSA_SPLIT_CLOCKS
-    if (tid == 0 && hc == 0 && a.nmb >= 8)  // helper 0 of network `net` -> row net (long since consumed), columns 8..15
+    if (tid == 0 && hc == 0 && rk == 0 && a.nmb >= 8) {  // helper 0 of network `net` -> row net (long since consumed), columns 8..15
       for (int k = 0; k < 8; ++k) a.stats[(long)net * SNSTAT + 8 + k] = (float)sdbg[k] / (float)a.nmb;
+      for (int k = 0; k < 3; ++k) a.stats[(long)(3 + net) * SNSTAT + 8 + k] = (float)dclk[k] / (float)a.nmb;
+    }
 #endif
     return;
   }
@@ -1054,7 +1122,11 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       if (leader) { t5[0] = st_loss; t5[1] = st_ratio; t5[2] = st_psq; t5[3] = st_norm; t5[4] = st_ent; }
       osa_lds_barrier();
       float* slabs = dp_slabs(mb);
+#ifdef OSA_SPLIT_CLOCKS
+      osa_split_dp_average<HT + OT>(gg, gb, gscale, t5, slabs, rk, W, dp_cnt, W * (mb + 1), tid, err, dead, dclk);
+#else
       osa_split_dp_average<HT + OT>(gg, gb, gscale, t5, slabs, rk, W, dp_cnt, W * (mb + 1), tid, err, dead);
+#endif
 #pragma unroll
       for (int ti = 0; ti < HT; ++ti) g2[ti] = gg[ti];
 #pragma unroll
@@ -1122,8 +1194,10 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   }
 #undef SPUT_TILE
 #ifdef OSA_SPLIT_CLOCKS
-  if (tid == 0 && a.nmb >= 8)  // leader of network `net` -> row net, columns 0..7: mean cycles per step
+  if (tid == 0 && rk == 0 && a.nmb >= 8) {  // leader of network `net` -> row net, columns 0..7: mean cycles per step
     for (int k = 0; k < 8; ++k) a.stats[(long)net * SNSTAT + k] = (float)sdbg[k] / (float)a.nmb;
+    for (int k = 0; k < 3; ++k) a.stats[(long)(3 + net) * SNSTAT + k] = (float)dclk[k] / (float)a.nmb;
+  }
 #endif
   // ---- write back: LDS master copy, Adam state (data-parallel form: the replicas are identical, rank 0 writes)
   if (DP && rk != 0) return;
@@ -1185,7 +1259,8 @@ static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
   // launch makes the runtime verify that and refuses otherwise (the caller then takes the one-CU kernel)
   OsaSplitArgs arg = a;
   void* kargs[] = {&arg};
-  const int nblk = DP ? a.world * 3 * (a.C + 1) : (a.local == 1 ? 8 * (a.C + 1) : 3 * (a.C + 1));
+  const int nblk = DP ? (a.dp_place == 1 ? 8 * ((3 * (a.C + 1) + 7) / 8) * a.world : a.world * 3 * (a.C + 1))
+                      : (a.local == 1 ? 8 * (a.C + 1) : 3 * (a.C + 1));
   const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT, DP>),
                                                   dim3(nblk), dim3(256), kargs,
                                                   (unsigned)lds, stream);
@@ -1250,10 +1325,15 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   return OSA_EUNSUPPORTED;
 }
 
+size_t osa_ppo_split_dp_dpx_floats(int obs_dim, int act_dim, int hidden, int world) {
+  if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
+  return (size_t)SDPH + (size_t)2 * 3 * (SCMAX + 1) * world * SDPW;
+}
+
 size_t osa_ppo_split_dp_xch_floats(int obs_dim, int act_dim, int hidden, int world) {
   if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
   const size_t per_rank = (size_t)128 + 3 * (size_t)SXNET;
-  return (size_t)world * per_rank + 128 + (size_t)2 * 3 * (SCMAX + 1) * world * SDPW;
+  return (size_t)world * per_rank + osa_ppo_split_dp_dpx_floats(obs_dim, act_dim, hidden, world);
 }
 
 int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1261,9 +1341,11 @@ int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, f
                           const float* logp, const float* target_value_r, const float* target_value_c,
                           const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                           const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                          float* xch, float* step_stats, void* stream) {
+                          float* xch, float* dpx, int place, float* step_stats, void* stream) {
   if (!osa_ppo_split_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
   if (B > 64 || loss_kind < 0 || loss_kind > 1) return OSA_EUNSUPPORTED;
+  OSA_REQUIRE((place == 1 || place == 3) ? dpx != nullptr : dpx == nullptr);
+  if (dpx && osa_is_exchange_ptr(dpx)) return OSA_EINVAL;  // the owner group's L2 serves ordinary memory
   if ((M + B - 1) / B > 8192) return OSA_EUNSUPPORTED;  // the helpers tabulate Adam's bias corrections in LDS
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && xch);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
@@ -1279,12 +1361,15 @@ int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, f
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return OSA_EHIP;
   if (world * 3 * (a.C + 1) > cus) return OSA_EUNSUPPORTED;  // one workgroup per CU, all co-resident
+  // (place: ceil(groups / 8) x world workgroups per XCC; 3: test hook -- the placed protocol on the rank-major grid)
+  if (place == 1 && ((3 * (a.C + 1) + 7) / 8) * world > cus / 8) return OSA_EUNSUPPORTED;
   const size_t per_rank = (size_t)128 + 3 * (size_t)SXNET;
   a.xch = xch;
   a.local = 0;
   a.world = world;
   a.rank_xch = (long)per_rank;
-  a.dpx = xch + (size_t)world * per_rank;
+  a.dpx = dpx ? dpx : xch + (size_t)world * per_rank;
+  a.dp_place = place;
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
   a.tgt_r = target_value_r; a.tgt_c = target_value_c; a.adv_r = adv_r; a.adv_c = adv_c;
@@ -1303,7 +1388,7 @@ int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, f
     for (int n = 0; n < 3; ++n)
       if (hipMemsetAsync(xr + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
   }
-  if (hipMemsetAsync(a.dpx, 0, 128 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if (hipMemsetAsync(a.dpx, 0, SDPH * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int OT = a.nd.OUTP / 16;
   if (OT == 1) return osa_launch_split<1, true>(a, st);
   if (OT == 2) return osa_launch_split<2, true>(a, st);
@@ -1316,6 +1401,13 @@ int osa_ppo_split_pass_timed_out(const float* xch, int* out) {
   OSA_REQUIRE(xch && out);
   return hipMemcpy(out, reinterpret_cast<const int*>(xch) + SF_ERR, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess
              ? OSA_OK : OSA_EHIP;
+}
+
+// clears the sticky word (after a tripped PLACEMENT check -- flag 2 -- nothing was modified and the caller repeats the
+// pass with another placement; a time-out -- flag 1 -- must not be cleared: the replica is no longer trustworthy)
+int osa_ppo_split_pass_clear_flag(float* xch) {
+  OSA_REQUIRE(xch);
+  return hipMemset(reinterpret_cast<int*>(xch) + SF_ERR, 0, sizeof(int)) == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
 }  // extern "C"

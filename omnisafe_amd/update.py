@@ -391,14 +391,44 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             p = C.c_void_p()
             _lib.check(lib.osa_dp_exchange_alloc(max(n, 1), C.byref(p)), 'osa_dp_exchange_alloc')
             st['wide_xch'] = p.value
+            # OSA_WIDE_DP=place (default): the W owners of the same parameters on ONE XCC, their exchange slabs in
+            # ordinary memory served by that XCC's L2 (every replica otherwise reads the W slabs of its owners from
+            # the device-coherent level: W^2 x 25 KB per owner group and step); OSA_WIDE_DP=spread: everything uncached
+            helpers = ((ac.obs_dim + 15) // 16 + 5) // 6
+            cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
+            st['wide_place'] = (os.environ.get('OSA_WIDE_DP', 'place') == 'place' and _PLACEMENT['local_ok'] is not False
+                                and ((3 * (helpers + 1) + 7) // 8) * W <= cus // 8)
+            st['wide_verified'] = False
+            if st['wide_place']:
+                st['wide_dpx'] = torch.zeros(lib.osa_ppo_split_dp_dpx_floats(ac.obs_dim, ac.act_dim, ac.hidden, W),
+                                             dtype=torch.float32, device=ac.device)
+        place = st['wide_place']
         _lib.check(lib.osa_ppo_split_dp_pass(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
             _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']), data_all['obs'].stride(0), _lib.ptr(data_all['act']),
             data_all['act'].stride(0), _lib.ptr(data_all['logp']), _lib.ptr(data_all['target_value_r']),
             _lib.ptr(data_all['target_value_c']), _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']),
             _lib.ptr(st['perm']), M, self.batch_size, W, _lib.ptr(lagrange), C.byref(self.hp), self.loss_kind,
-            self._nets_mask(), C.c_void_p(st['wide_xch']), _lib.ptr(st['pass_stats']), _lib.stream_ptr()),
-            'osa_ppo_split_dp_pass')
+            self._nets_mask(), C.c_void_p(st['wide_xch']), _lib.ptr(st['wide_dpx']) if place else None,
+            ((1 if st['wide_verified'] else _local_arg()) if place else 0), _lib.ptr(st['pass_stats']),
+            _lib.stream_ptr()), 'osa_ppo_split_dp_pass')
+        if place and not st['wide_verified']:
+            # first pass with the owner groups on one XCC each: an unverified placement returns with everything
+            # untouched -> repeat rank-major with the uncached exchange
+            torch.cuda.synchronize()
+            flag = C.c_int(0)
+            _lib.check(lib.osa_ppo_split_pass_timed_out(C.c_void_p(st['wide_xch']), C.byref(flag)),
+                       'osa_ppo_split_pass_timed_out')
+            if flag.value == 1:
+                raise _lib.OsaError('osa_ppo_split_dp_pass: a cooperating workgroup never arrived at the placement '
+                                    'check (device shared with another long-running kernel?)')
+            if flag.value != 0:
+                _PLACEMENT['local_ok'] = False
+                st['wide_place'] = False
+                _lib.check(lib.osa_ppo_split_pass_clear_flag(C.c_void_p(st['wide_xch'])),
+                           'osa_ppo_split_pass_clear_flag')
+                return self._wide_dp_pass(data_all, M, W, lagrange, st)
+            st['wide_verified'] = True
 
     def __del__(self):
         try:
@@ -410,24 +440,40 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         """osa_ppo_dp_pass: the whole pass as ONE cooperative launch of 3 x W persistent workgroups.
         Returns False when the device cannot hold them (caller falls back to the stepwise path)."""
         ac, lib = self.ac, self.lib
+        # batch > 64: the minibatch's 64-row chunks of every rank on their own workgroups (osa_ppo_dp_chunked_pass:
+        # W x ceil(B / 64) peers per network, two hand-offs per step) instead of one workgroup per rank walking
+        # through the chunks; OSA_CHUNKED_PASS=0 or a device too small for the peers keeps the latter
+        cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
+        nch = (self.batch_size + 63) // 64
+        chunked = (nch > 1 and os.environ.get('OSA_CHUNKED_PASS', '1') != '0' and 3 * W * nch <= cus
+                   and W <= 16 and not st.get('chunk_off'))
+        peers = W * nch if chunked else W
+        if st.get('xch_peers') != (peers, chunked):
+            if st.get('xch') is None and st.get('xch_ptr'):
+                lib.osa_dp_exchange_free(st['xch_ptr'])
+            for k in ('xch', 'xch_ptr', 'sync', 'verified'):
+                st.pop(k, None)
+            st['xch_peers'] = (peers, chunked)
+        st['chunked'] = chunked
         if 'xch' not in st:
-            n = lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
+            n = (lib.osa_ppo_dp_chunked_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, self.batch_size, W)
+                 if chunked else lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, W))
             # uncached device memory for the hand-off (no L2 write-back / invalidate per step); an ordinary
             # tensor if the runtime refuses (OSA_DP_XCH=cached forces that)
             # OSA_DP_XCH=local (default while world <= CUs / 8): one XCC per network, ordinary memory served by
             # that XCC's L2 (osa_ppo_dp_pass_placed(local = 1), placement verified on the device)
             p = C.c_void_p()
             mode = os.environ.get('OSA_DP_XCH', 'local')
-            cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
-            st['local'] = mode == 'local' and W <= cus // 8 and _PLACEMENT['local_ok'] is not False
+            st['local'] = mode == 'local' and peers <= cus // 8 and _PLACEMENT['local_ok'] is not False
             if not st['local'] and mode in ('local', 'uncached') and lib.osa_dp_exchange_alloc(
                     max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
                 st['xch_ptr'], st['xch'] = p.value, None
             else:
                 st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
                 st['xch_ptr'] = st['xch'].data_ptr()
-            st['sync'] = torch.zeros(8, dtype=torch.int32, device=ac.device)
-        rc = lib.osa_ppo_dp_pass_placed(
+            st['sync'] = torch.zeros(64, dtype=torch.int32, device=ac.device)
+        fn = lib.osa_ppo_dp_chunked_pass if chunked else lib.osa_ppo_dp_pass_placed
+        rc = fn(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),
             data_all['obs'].stride(0), _lib.ptr(data_all['act']), data_all['act'].stride(0),
@@ -437,9 +483,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.loss_kind, self._nets_mask(), st['xch_ptr'], _lib.ptr(st['sync']),
             (1 if st.get('verified') else _local_arg()) if st['local'] else 0,
             _lib.ptr(st['pass_stats']), _lib.stream_ptr())
+        if rc == _lib.OSA_EUNSUPPORTED and chunked:  # not co-resident: one workgroup per rank walks through the chunks
+            st['chunk_off'] = True
+            return self._dp_coop_pass(data_all, M, W, lagrange, st)
         if rc == _lib.OSA_EUNSUPPORTED:
             return False
-        _lib.check(rc, 'osa_ppo_dp_pass_placed')
+        _lib.check(rc, 'osa_ppo_dp_chunked_pass' if chunked else 'osa_ppo_dp_pass_placed')
         if st['local'] and not st.get('verified'):
             # first pass with one XCC per network: an unverified placement returns with everything untouched
             # -> repeat spread over the XCCs (same buffer, agent-scope release / acquire fences)

@@ -401,9 +401,11 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
     assert np.isfinite(results[0][1][:, :10]).all() and (results[0][1][:, 3] > 0).all()
 
 
-@pytest.mark.parametrize('W,M,obs_dim,act_dim', [(2, 384, 376, 17), (4, 256, 376, 17), (8, 192, 376, 17),
-                                                 (3, 200, 128, 6), (1, 128, 376, 17), (5, 150, 200, 1)])
-def test_wide_split_data_parallel_pass_equals_allreduce_semantics(W, M, obs_dim, act_dim):
+@pytest.mark.parametrize('W,M,obs_dim,act_dim,mode_dp', [
+    (2, 384, 376, 17, 'place'), (4, 256, 376, 17, 'place'), (8, 192, 376, 17, 'place'), (3, 200, 128, 6, 'place'),
+    (1, 128, 376, 17, 'place'), (5, 150, 200, 1, 'place'), (8, 192, 376, 17, 'spread'), (3, 200, 128, 6, 'spread'),
+    (2, 384, 376, 17, 'wrong-placement')])
+def test_wide_split_data_parallel_pass_equals_allreduce_semantics(W, M, obs_dim, act_dim, mode_dp, monkeypatch):
     """osa_ppo_split_dp_pass (BASELINE config 4 under world_size > 1: W virtual ranks x 3 networks x (leader +
     helpers) in ONE cooperative launch; the owners of the same parameters average their locally clipped shares)
     vs the reference's data-parallel semantics emulated rank by rank with the per-step kernels (gradient + local
@@ -412,8 +414,16 @@ def test_wide_split_data_parallel_pass_equals_allreduce_semantics(W, M, obs_dim,
     import ctypes as C
 
     from omnisafe_amd import _lib
+    from omnisafe_amd import update as U
     from omnisafe_amd.update import PPOUpdater
 
+    # 'place': the W owners of the same parameters on one XCC (default); 'spread': rank-major, uncached exchange;
+    # 'wrong-placement': test hook -- the placed protocol on the rank-major grid: the kernel's placement check trips
+    # before anything is modified and the updater repeats the pass spread
+    monkeypatch.setenv('OSA_WIDE_DP', 'spread' if mode_dp == 'spread' else 'place')
+    monkeypatch.setitem(U._PLACEMENT, 'local_ok', None)
+    if mode_dp == 'wrong-placement':
+        monkeypatch.setenv('OSA_DEBUG_PLACEMENT', 'wrong')
     torch.manual_seed(W * 1000 + M)
     B = 64
     data_all = {'obs': torch.randn(W * M, obs_dim, device=DEV), 'act': torch.randn(W * M, act_dim, device=DEV),
@@ -440,6 +450,9 @@ def test_wide_split_data_parallel_pass_equals_allreduce_semantics(W, M, obs_dim,
             for i in range(2):
                 up.run_pass_replicated(data_all, M, W, lam, stats[i * nmb:(i + 1) * nmb], perms_all=perms[i])
             up.check_wide_dp_sync()
+            assert up._dp['wide_place'] is (mode_dp == 'place')
+            if mode_dp == 'wrong-placement':
+                assert U._PLACEMENT['local_ok'] is False
         else:
             lib = _lib.load()
             row = torch.zeros(16, device=DEV)
@@ -474,6 +487,86 @@ def test_wide_split_data_parallel_pass_equals_allreduce_semantics(W, M, obs_dim,
         # the layer-1 pre-activation is a sum of partial sums, every gradient differs by ~1e-7 relative, and Adam's
         # first step amplifies that for the few elements whose first gradient is within ~1e-8 of zero)
         bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)
+        assert bad.sum() <= 6, (name, int(bad.sum()))
+        if bad.any():
+            lim = 2.5e-4 if name == 'params' else 2e-3 * np.abs(b[bad]).max()
+            assert np.abs(a - b)[bad].max() <= lim, (name, float(np.abs(a - b)[bad].max()))
+    st = results[0][1]
+    assert np.isfinite(st[:, :10]).all() and (st[:, 3] > 0).all() and (st[:, 7:10] > 0).all()
+
+
+@pytest.mark.parametrize('W,M,B,obs_dim,act_dim,chunked', [
+    (2, 512, 128, 27, 8, True), (4, 384, 128, 27, 8, True), (8, 256, 128, 27, 8, True), (3, 300, 128, 72, 2, True),
+    (2, 640, 256, 60, 2, True), (1, 256, 128, 27, 8, True), (4, 384, 128, 27, 8, False)])
+def test_chunked_data_parallel_pass_equals_allreduce_semantics(W, M, B, obs_dim, act_dim, chunked, monkeypatch):
+    """osa_ppo_dp_chunked_pass (the batch-128 critic / actor passes of BASELINE configs 3 and 5 under world_size > 1:
+    W ranks x ceil(B / 64) chunk workgroups per network, rank sum -> rank clip -> average over ranks) vs the
+    reference's data-parallel semantics emulated rank by rank with the per-step kernels (B-row gradient + local
+    clip per rank, average, Adam): natural_pg.py:205-223, policy_gradient.py:437-442, distributed.py:167-198.
+    max_grad_norm is small enough that the clip is active on most steps of the reward critic.  `chunked = False`:
+    the same through one workgroup per rank walking the chunks (OSA_CHUNKED_PASS=0)."""
+    import ctypes as C
+
+    from omnisafe_amd import _lib
+    from omnisafe_amd.update import PPOUpdater
+
+    monkeypatch.setenv('OSA_CHUNKED_PASS', '1' if chunked else '0')
+    torch.manual_seed(W * 1000 + M + B)
+    ld = (obs_dim + 3) // 4 * 4  # 16-byte aligned rows (update.py pads once per update; here by construction)
+    obs = torch.randn(W * M, ld, device=DEV)[:, :obs_dim]
+    data_all = {'obs': obs, 'act': torch.randn(W * M, act_dim, device=DEV),
+                'target_value_r': torch.randn(W * M, device=DEV) * 3, 'target_value_c': torch.randn(W * M, device=DEV),
+                'adv_r': torch.randn(W * M, device=DEV), 'adv_c': torch.randn(W * M, device=DEV)}
+    perms = [torch.stack([torch.randperm(M) for _ in range(W)]).to(DEV) for _ in range(2)]
+    lam = torch.tensor([0.4], device=DEV)
+    nmb = (M + B - 1) // B
+    results = []
+    for mode in ('replicated', 'emulated'):
+        torch.manual_seed(5)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data_all:
+            _, _, _, lp = ac.step(data_all['obs'].contiguous(), eps=data_all['act'] * 0)
+            data_all['logp'] = lp + 0.2 * torch.randn(W * M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01,
+                        max_grad_norm=1.5)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        stats = torch.zeros(2 * nmb, 16, device=DEV)
+        if mode == 'replicated':
+            for i in range(2):
+                up.run_pass_replicated(data_all, M, W, lam, stats[i * nmb:(i + 1) * nmb], perms_all=perms[i],
+                                       use_graph=False, coop=True)
+            assert up._dp.get('coop_passes') == 2 and up._dp['chunked'] is chunked
+            up.check_dp_sync()
+        else:
+            lib = _lib.load()
+            row = torch.zeros(16, device=DEV)
+            clipped = 0
+            for i in range(2):
+                for k in range(nmb):
+                    acc = torch.zeros_like(ac.grads)
+                    for r in range(W):
+                        idx = (perms[i][r, k * B:(k + 1) * B] + r * M).contiguous()
+                        _lib.check(lib.osa_ppo_minibatch(
+                            obs_dim, act_dim, 64, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+                            _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data_all['obs']), ld,
+                            _lib.ptr(data_all['act']), act_dim, _lib.ptr(data_all['logp']),
+                            _lib.ptr(data_all['target_value_r']), _lib.ptr(data_all['target_value_c']),
+                            _lib.ptr(data_all['adv_r']), _lib.ptr(data_all['adv_c']), _lib.ptr(idx), idx.numel(),
+                            _lib.ptr(lam), C.byref(up.hp), 0, 1, 7, 8, _lib.ptr(up._ws), _lib.ptr(row),
+                            _lib.stream_ptr()))
+                        acc += ac.grads
+                        clipped += int(float(row[8]) > 1.5)
+                    ac.grads.copy_(acc / W)
+                    _lib.check(lib.osa_adam_apply(obs_dim, act_dim, 64, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                                                  _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads),
+                                                  C.byref(up.hp), 7, _lib.stream_ptr()))
+            assert clipped >= nmb * W  # the clip really is active (reward critic: at least half of its steps)
+        results.append((ac, stats.cpu().numpy()))
+    a0, a1 = results[0][0], results[1][0]
+    assert a0.adam_step.cpu().tolist() == a1.adam_step.cpu().tolist() == [2 * nmb] * 3
+    for name in ('params', 'adam_m', 'adam_v'):
+        a, b = getattr(a0, name).cpu().numpy(), getattr(a1, name).cpu().numpy()
+        bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)  # (as the single-rank chunked pass: summation order of the chunks)
         assert bad.sum() <= 6, (name, int(bad.sum()))
         if bad.any():
             lim = 2.5e-4 if name == 'params' else 2e-3 * np.abs(b[bad]).max()
