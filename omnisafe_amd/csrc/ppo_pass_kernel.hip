@@ -137,6 +137,18 @@ __device__ __forceinline__ float osa_sym_sum1(float a, float sa, float b, float 
   return pa + pb;
 }
 
+// floats of dynamic LDS without the transposed W2 copy, and whether that copy still fits the 160 KB of a CU
+__host__ __device__ constexpr int osa_pass_lds_floats(int KB, int OT) {
+  return 64 * (16 * KB + 4) + 64 * PSLD + 16 * OT * PSLD + 2 * 64 + 2 * 16 * OT + 4 * 64 * PSLD + 16 * KB * PSLD +
+         2 * 16 * OT * PSLD + 64;
+}
+#ifndef OSA_PASS_W2T
+#define OSA_PASS_W2T 1
+#endif
+__host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
+  return OSA_PASS_W2T != 0 && (osa_pass_lds_floats(KB, OT) + 64 * PSLD) * 4 <= 160 * 1024;
+}
+
 template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -185,6 +197,11 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   float* sDO = sX + INP * PSLD;         // [OUTP][PSLD]
   float* sDL = sDO + OUTP * PSLD;       // [OUTP][PSLD]
   float* red = sDL + OUTP * PSLD;       // [4 waves][4] + spare
+  // transposed copy of W2 (element (input feature, output feature) = W2[out][in]) for the backward pass: its A
+  // operands W2^T[16t+i][k .. k+3] are then ONE 16-byte LDS read instead of four scalar ones (64 -> 16 LDS reads
+  // per lane and step); kept in step by the Adam writers.  Only where the LDS budget allows (narrow observations).
+  constexpr bool W2T = osa_pass_has_w2t(KB, OT);
+  float* sW2T = red + 64;               // [H][PSLD]   (W2T only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int i = j, cc = j;
@@ -380,6 +397,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   long row_nxt = row_of(cidx + 1);
   // ... while the remaining weights stream into LDS (matters for the one-step-per-launch dp mode)
   for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
+  if constexpr (W2T)
+    for (int e = tid; e < H * H; e += 256) sW2T[(e & 63) * PSLD + (e >> 6)] = gp[nd.oW2 + e];
   for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   __syncthreads();  // LDS master copy complete
 #ifdef OSA_PASS_CLOCKS
@@ -727,13 +746,26 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
     for (int t = 0; t < HT; ++t) z2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float wt[2][4][HT];
+    // A fragments of the W2^T product, K block kb: wt[.][s][t] = W2[16 kb + 4 g + s][16 t + i]
+    auto load_w2t = [&](int kb, float (&dst)[4][HT]) {
+      if constexpr (W2T) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sW2T + (16 * t + i) * PSLD + 16 * kb + 4 * g);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dst[s][t] = v[s];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) dst[s][t] = sW2[(16 * kb + 4 * g + s) * PSLD + 16 * t + i];
+      }
+    };
     if (small_out) {
       // z2[f] = sum_d W3[d][f] dO[d] with dO of this lane's sample held by lane group 0 (d = r)
       const float d0 = __shfl(dO[0][0], j, 64), d1 = __shfl(dO[0][1], j, 64);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)  // first W2^T block, in flight meanwhile
-#pragma unroll
-        for (int t = 0; t < HT; ++t) wt[0][s][t] = sW2[(4 * g + s) * PSLD + 16 * t + i];
+      load_w2t(0, wt[0]);  // first W2^T block, in flight meanwhile
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW3 + 16 * t + 4 * g);
@@ -748,10 +780,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int t = 0; t < HT; ++t) w3t[o][s][t] = sW3[(16 * o + 4 * g + s) * PSLD + 16 * t + i];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)  // first W2^T block, in flight under the W3^T MFMAs
-#pragma unroll
-        for (int t = 0; t < HT; ++t) wt[0][s][t] = sW2[(4 * g + s) * PSLD + 16 * t + i];
+      load_w2t(0, wt[0]);  // first W2^T block, in flight under the W3^T MFMAs
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int o = 0; o < OT; ++o)
@@ -769,13 +798,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     for (int t = 0; t < HT; ++t) z1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < HT; ++kb) {
-      if (kb + 1 < HT) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-            wt[(kb + 1) & 1][s][t] = sW2[(16 * (kb + 1) + 4 * g + s) * PSLD + 16 * t + i];
-      }
+      if (kb + 1 < HT) load_w2t(kb + 1, wt[(kb + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -1267,6 +1290,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc] = w[r];
+      if constexpr (W2T) *reinterpret_cast<f32x4*>(sW2T + (16 * ti + cc) * PSLD + 16 * wave + 4 * g) = w;
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -1362,9 +1386,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 static long long* g_osa_pass_dbg = nullptr;
 
 static size_t osa_pass_lds_bytes(int KB, int OT) {
-  const int H = 64, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + 4;
-  const size_t fl = (size_t)H * W1LD + (size_t)H * PSLD + (size_t)OUTP * PSLD + 2 * H + 2 * OUTP +
-                    4 * (size_t)H * PSLD + (size_t)INP * PSLD + 2 * (size_t)OUTP * PSLD + 64;
+  const size_t fl = (size_t)osa_pass_lds_floats(KB, OT) + (osa_pass_has_w2t(KB, OT) ? 64 * PSLD : 0);
   return fl * sizeof(float);
 }
 
