@@ -92,6 +92,21 @@ int osa_gae_scan_tiled(const float* reward, const float* cost, const float* valu
                        double gamma, double lam, double lam_c, float penalty_coef, int estimator,
                        float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
                        float* discounted_ret, void* stream);
+/* The same scan SPLIT OVER TIME across workgroups (csrc/buffer_kernels.hip K5c, round 3): levels of 128 steps, a
+ * wave = 64 envs x 16 steps with its inputs in registers, per-env carries chained between levels by a decoupled
+ * look-back (8-byte agent-scope words in `ws`; a level that contains a path end publishes its carry at once, so
+ * chains end at episode boundaries).  (T / 16) x (N / 64) waves whatever the shape: the large-N / long-T buffers
+ * where osa_gae_scan has too few lanes in flight and osa_gae_scan_tiled pays its log-depth scan.  Arithmetic: the
+ * sequential kernel's step for step given the incoming carry; the carry is assembled by the affine identity
+ * (float64 re-association): same tolerance class as osa_gae_scan_tiled, deterministic (independent of timing).
+ * ws: osa_gae_chained_ws_doubles(T, N) doubles, contents irrelevant (initialised by every call).  v-trace:
+ * OSA_EUNSUPPORTED. */
+size_t osa_gae_chained_ws_doubles(int T, int N);
+int osa_gae_scan_chained(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                         const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
+                         double gamma, double lam, double lam_c, float penalty_coef, int estimator,
+                         float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
+                         float* discounted_ret, double* ws, void* stream);
 
 /* Advantage statistics of VectorOnPolicyBuffer.get (vector_onpolicy_buffer.py:131-136 ->
  * omnisafe/utils/distributed.py:382-392), split in two phases so the cross-rank all-reduce (RCCL) can

@@ -55,8 +55,9 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         import os
 
         self._gae_variant = gae_variant or os.environ.get('OSA_GAE_VARIANT', 'auto')
-        if self._gae_variant not in ('auto', 'sequential', 'tiled'):
-            raise ValueError(f'gae_variant must be auto, sequential or tiled, not {self._gae_variant!r}')
+        if self._gae_variant not in ('auto', 'sequential', 'tiled', 'chained'):
+            raise ValueError(f'gae_variant must be auto, sequential, tiled or chained, not {self._gae_variant!r}')
+        self._gae_ws: torch.Tensor | None = None  # carry workspace of the chained (time-split) scan
         self._penalty_coefficient = float(penalty_coefficient)
         self._standardized_adv_r = bool(standardized_adv_r)
         self._standardized_adv_c = bool(standardized_adv_c)
@@ -174,15 +175,20 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
     # ------------------------------------------------------------------ get
     @staticmethod
     def gae_variant_for(T: int, N: int, estimator: int) -> str:
-        """The (T, N) rule of 'auto' (measured on MI355X, profiles/r2_gae_bandwidth.md): the lane-per-env
-        kernel needs many envs to fill the chip and pays one dependent float64 chain of length T per lane; the
-        time-parallel tiled kernel has N/16 workgroups and scans 64 steps per wave pass.  Few envs or long
-        horizons -> tiled; v-trace (a float32 chain) always sequential."""
-        if estimator == _EST['vtrace']:
+        """The (T, N) rule of 'auto' (measured on MI355X, profiles/r3_gae_bandwidth.md):
+          * `sequential` (lane per env, bit-exact): T < 64 -- the rollout-shaped buffers (BASELINE config 2:
+            T = 16), where one lane walks a handful of steps and N alone fills the chip; v-trace always
+            (a float32 chain);
+          * `tiled` (time-parallel wavefront scan, 16 envs x 64 steps per tile): short horizons with few envs
+            (64 <= T <= 256 and N <= 8192), where the whole buffer is a few hundred tiles;
+          * `chained` (time split over workgroups, 64 envs x 16 steps per wave in registers, carries by decoupled
+            look-back): everything else -- long horizons (BASELINE config 1: T = 5000, N = 4: 18 us against 108 us
+            tiled) and large buffers (4096 x 4096: 3.7 TB/s against 2.5 TB/s tiled; 256 x 65 536: 3.4 against 2.3)."""
+        if estimator == _EST['vtrace'] or T < 64:
             return 'sequential'
-        # (round 2, with 16 waves per workgroup for small grids: at T = 64 the tiled kernel takes 9-31 us where the
-        # lane-per-env kernel takes 23-38 us for N <= 32 768; at N = 65 536 the two are level from T = 128 on)
-        return 'tiled' if (T >= 64 and N <= 32768) else 'sequential'
+        if T <= 256 and N <= 8192:
+            return 'tiled'
+        return 'chained'
 
     def compute_advantages(self) -> None:
         """K5: one backward scan over the (T, N) buffer (osa_gae_scan / osa_gae_scan_tiled)."""
@@ -190,9 +196,20 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         variant = self._gae_variant
         if variant == 'auto':
             variant = self.gae_variant_for(T, N, self._estimator)
-        elif variant == 'tiled' and self._estimator == _EST['vtrace']:
+        elif variant in ('tiled', 'chained') and self._estimator == _EST['vtrace']:
             variant = 'sequential'
         self.last_gae_variant = variant
+        if variant == 'chained':
+            need = self._lib.osa_gae_chained_ws_doubles(T, N)
+            if self._gae_ws is None or self._gae_ws.numel() < need:
+                self._gae_ws = torch.empty(need, dtype=torch.float64, device=self._device)
+            _lib.check(self._lib.osa_gae_scan_chained(
+                _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),
+                _lib.ptr(b['path_end']), _lib.ptr(b['boot_r']), _lib.ptr(b['boot_c']), T, N, self._gamma,
+                self._lam, self._lam_c, self._penalty_coefficient, self._estimator, _lib.ptr(b['adv_r']),
+                _lib.ptr(b['adv_c']), _lib.ptr(b['target_value_r']), _lib.ptr(b['target_value_c']),
+                _lib.ptr(b['discounted_ret']), _lib.ptr(self._gae_ws), _lib.stream_ptr()), 'osa_gae_scan_chained')
+            return
         fn = self._lib.osa_gae_scan_tiled if variant == 'tiled' else self._lib.osa_gae_scan
         _lib.check(fn(
             _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),

@@ -398,6 +398,302 @@ __global__ __launch_bounds__(64 * NWV) void osa_gae_tile_scan_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5c  the dual GAE scan SPLIT OVER TIME across workgroups (round 3): "chained" lane-per-env scan.
+//
+// The lane-per-env kernel (K5) does the minimum arithmetic per transition but walks T sequentially per lane: it
+// needs N >= ~0.5 M envs to keep the chip's memory system busy (4.8 TB/s at 16 x 1 M, 2.4 TB/s at 256 x 65 536,
+// profiles/r2_gae_bandwidth.md).  The time-parallel kernel (K5b) fills lanes with time steps but pays a log-depth
+// float64 DPP scan per tile (2.5 TB/s at 4096 x 4096).  Here the (T, N) buffer is cut into LEVELS of 128 steps:
+// a workgroup = 8 waves x 64 envs, wave w owns 16 consecutive steps of the level and keeps its INPUTS in
+// registers (112 loads in flight per lane: the whole chunk is requested before anything is consumed), so the chip
+// runs (T / 16) x (N / 64) waves regardless of the shape.  Every recurrence y_t = x_t + d y_{t+1} is affine in
+// its incoming carry (coefficient d^len, or 0 once a path ends inside the stretch), so
+//   1. pass 1: each wave runs the sequential float64 recurrences over its 16 steps with ZERO carries -> its
+//      aggregate (the carries it would hand on) and an "open" bit (no path end in the chunk);
+//   2. the waves' aggregates meet in LDS; the level's aggregate is published (agent-scope 8-byte words, NaN
+//      sentinel = not yet there; a level with a path end publishes its INCLUSIVE carry right away: it does not
+//      depend on what comes in, which cuts the chain at every episode boundary);
+//   3. decoupled look-back (lane-wise: every env has its own chain): walk to later levels until one has its
+//      inclusive carry, then fold the aggregates back in level order, incl_j = agg_j + d^128 incl_{j-1} -- a pure
+//      function of the aggregates, so the bits do not depend on timing; publish the own inclusive carry;
+//   4. pass 2: each wave folds the level's incoming carry through the waves before it and re-runs the sequential
+//      recurrences FROM REGISTERS with its true incoming carries, writing the outputs.
+// One read of the inputs, one write of the outputs, + ~0.4 B per transition of carries.  Levels are mapped to
+// block indices latest-first, so a workgroup only ever waits for blocks dispatched before it.  Arithmetic: the
+// sequential kernel's, step for step, given the incoming carry; the carry itself is assembled by the affine
+// identity instead of the chain (float64 re-association: outputs equal the bit-exact kernel's in all but
+// ~1e-8 of the elements after rounding to float32; tests require rtol 1e-5 like K5b).  v-trace: K5 only.
+// ------------------------------------------------------------------------------------------------
+#define OSA_GC_TC 16                       // steps per wave
+#ifndef OSA_GC_NW
+#define OSA_GC_NW 8                        // waves per workgroup
+#endif
+#define OSA_GC_LEV (OSA_GC_TC * OSA_GC_NW)  // steps per level
+
+struct OsaGaeCarry {
+  double v[5];  // a_r, a_c, ret, rtg_r, rtg_c
+};
+
+__device__ __forceinline__ bool osa_gc_ready(double x) { return x == x; }  // the sentinel is a NaN
+__device__ __forceinline__ void osa_gc_put(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double osa_gc_get(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double osa_gc_wait(const double* p) {  // bounded: NaN inputs must not hang the device
+  double v = osa_gc_get(p);
+  for (int spins = 0; !osa_gc_ready(v) && spins < (1 << 22); ++spins) {
+    __builtin_amdgcn_s_sleep(1);
+    v = osa_gc_get(p);
+  }
+  return v;
+}
+
+// the sequential kernel's step (K5, without v-trace) over one 16-step chunk held in registers
+template <int EST, bool STORE>
+__device__ __forceinline__ void osa_gc_chunk(const float (&r)[OSA_GC_TC], const float (&c)[OSA_GC_TC],
+                                             const float (&vr)[OSA_GC_TC], const float (&vc)[OSA_GC_TC],
+                                             const float (&br)[OSA_GC_TC], const float (&bc)[OSA_GC_TC],
+                                             const uint8_t (&e)[OSA_GC_TC], int nsteps, float nv_r, float nv_c,
+                                             OsaGaeCarry& cy, bool& open, float g32, double d_g, double d_r,
+                                             double d_c, float pc, long i_hi, int N, float* __restrict__ adv_r,
+                                             float* __restrict__ adv_c, float* __restrict__ tgt_r,
+                                             float* __restrict__ tgt_c, float* __restrict__ disc_ret) {
+#pragma clang fp contract(off)
+  double a_r = cy.v[0], a_c = cy.v[1], ret = cy.v[2], rtg_r = cy.v[3], rtg_c = cy.v[4];
+#pragma unroll
+  for (int u = 0; u < OSA_GC_TC; ++u) {
+    if (u >= nsteps) continue;  // wave-uniform (no `break`: the loop must unroll, the chunk lives in registers)
+    if (e[u]) {  // a path ends after this step: re-seed every carry with the bootstrap
+      nv_r = br[u];
+      nv_c = bc[u];
+      a_r = 0.0;
+      a_c = 0.0;
+      ret = (double)br[u];
+      const float pb = pc * bc[u];
+      rtg_r = (double)(br[u] - pb);
+      rtg_c = (double)bc[u];
+      open = false;
+    }
+    const float pcost = pc * c[u];
+    const float r_pen = r[u] - pcost;
+    const float gr = g32 * nv_r;
+    const float gc = g32 * nv_c;
+    const float sr = r_pen + gr;
+    const float sc = c[u] + gc;
+    const float delta_r = sr - vr[u];
+    const float delta_c = sc - vc[u];
+    const double m0 = d_g * ret;
+    ret = (double)r[u] + m0;
+    double out_ar, out_ac, out_tr, out_tc;
+    if (EST != OSA_EST_GAE) {
+      const double m1 = d_g * rtg_r;
+      rtg_r = (double)r_pen + m1;
+      const double m2 = d_g * rtg_c;
+      rtg_c = (double)c[u] + m2;
+    }
+    if (EST == OSA_EST_PLAIN) {
+      out_ar = (double)delta_r;
+      out_ac = (double)delta_c;
+    } else {
+      const double m3 = d_r * a_r;
+      a_r = (double)delta_r + m3;
+      const double m4 = d_c * a_c;
+      a_c = (double)delta_c + m4;
+      out_ar = a_r;
+      out_ac = a_c;
+    }
+    if (EST == OSA_EST_GAE) {
+      out_tr = out_ar + (double)vr[u];
+      out_tc = out_ac + (double)vc[u];
+    } else {
+      out_tr = rtg_r;
+      out_tc = rtg_c;
+    }
+    if (STORE) {
+      const long i = i_hi - (long)u * N;
+      adv_r[i] = (float)out_ar;
+      adv_c[i] = (float)out_ac;
+      tgt_r[i] = (float)out_tr;
+      tgt_c[i] = (float)out_tc;
+      disc_ret[i] = (float)ret;
+    }
+    nv_r = vr[u];
+    nv_c = vc[u];
+  }
+  cy.v[0] = a_r; cy.v[1] = a_c; cy.v[2] = ret; cy.v[3] = rtg_r; cy.v[4] = rtg_c;
+}
+
+template <int EST>
+__global__ __launch_bounds__(64 * OSA_GC_NW) void osa_gae_chain_scan_kernel(
+    const float* __restrict__ reward, const float* __restrict__ cost,
+    const float* __restrict__ value_r, const float* __restrict__ value_c,
+    const uint8_t* __restrict__ path_end, const float* __restrict__ boot_r,
+    const float* __restrict__ boot_c, int T, int N, float g32, double d_g, double d_r, double d_c,
+    float pc, float* __restrict__ adv_r, float* __restrict__ adv_c, float* __restrict__ tgt_r,
+    float* __restrict__ tgt_c, float* __restrict__ disc_ret, double* __restrict__ ws, int nenvb,
+    unsigned int* __restrict__ ticket) {
+#pragma clang fp contract(off)
+  constexpr int TC = OSA_GC_TC, NW = OSA_GC_NW;
+  // which carries exist: GAE a_r a_c ret | GAE-RTG all five | PLAIN ret rtg_r rtg_c; KMASK bit k = carry k is live
+  constexpr int KMASK = EST == OSA_EST_GAE ? 0b00111 : (EST == OSA_EST_GAE_RTG ? 0b11111 : 0b11100);
+  __shared__ double s_agg[NW][5][64];
+  __shared__ double s_cin[5][64];
+  __shared__ uint8_t s_open[NW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // logical block index = order of ARRIVAL (a ticket), not blockIdx: a workgroup then only ever waits for
+  // workgroups that are already running or done, whatever order the dispatcher picks (rocPRIM's look-back scan
+  // does the same)
+  __shared__ int s_bid;
+  if (threadIdx.x == 0)
+    s_bid = (int)__hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(ticket), 1u, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int bid = s_bid;
+  const int lev = bid / nenvb, eb = bid - lev * nenvb;  // level 0 = the LAST 128 steps of the buffer
+  const int n = eb * 64 + lane;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;  // dead lanes read a valid column and never publish or store
+  const int t_hi = T - 1 - lev * OSA_GC_LEV - wave * TC;
+  const int nsteps = t_hi < 0 ? 0 : (t_hi + 1 < TC ? t_hi + 1 : TC);  // wave-uniform
+  const double dk[5] = {d_r, d_c, d_g, d_g, d_g};
+  double p16[5], p128[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    p16[k] = osa_powi(dk[k], TC);
+    p128[k] = osa_powi(p16[k], NW);  // d^(steps per level)
+  }
+  // ---- the chunk's inputs: everything requested before anything is consumed
+  float r[TC], c[TC], vr[TC], vc[TC], br[TC], bc[TC];
+  uint8_t e[TC];
+  const long i_hi = (long)(t_hi < 0 ? 0 : t_hi) * N + nc;
+#pragma unroll
+  for (int u = 0; u < TC; ++u) e[u] = path_end[(u < nsteps) ? i_hi - (long)u * N : i_hi];  // (first: see below)
+#pragma unroll
+  for (int u = 0; u < TC; ++u) {
+    const long i = (u < nsteps) ? i_hi - (long)u * N : i_hi;
+    r[u] = reward[i];
+    c[u] = cost[i];
+    vr[u] = value_r[i];
+    vc[u] = value_c[i];
+  }
+  // the bootstraps only count where a path ends: cache lines without any path end (most of them) are never
+  // read -- up to 8 of the 45 bytes a transition would otherwise move.  The flags were requested first, so this
+  // wait leaves the 64 loads above in flight.
+#pragma unroll
+  for (int u = 0; u < TC; ++u) {  // (lane-predicated loads, as K5: lanes without a path end generate no traffic)
+    const long i = (u < nsteps) ? i_hi - (long)u * N : i_hi;
+    br[u] = e[u] ? boot_r[i] : 0.f;
+    bc[u] = e[u] ? boot_c[i] : 0.f;
+  }
+  // value of the step after the chunk (the sequential kernel's running nv; 0 past the end of the buffer)
+  float nv_r = 0.f, nv_c = 0.f;
+  if (nsteps > 0 && t_hi + 1 < T) {
+    nv_r = value_r[i_hi + N];
+    nv_c = value_c[i_hi + N];
+  }
+  // ---- pass 1: aggregate of the chunk (zero incoming carries)
+  OsaGaeCarry agg = {{0.0, 0.0, 0.0, 0.0, 0.0}};
+  bool open = true;
+  osa_gc_chunk<EST, false>(r, c, vr, vc, br, bc, e, nsteps, nv_r, nv_c, agg, open, g32, d_g, d_r, d_c, pc, i_hi, N,
+                           adv_r, adv_c, tgt_r, tgt_c, disc_ret);
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    if ((KMASK >> k) & 1) s_agg[wave][k][lane] = agg.v[k];
+  s_open[wave][lane] = open ? 1 : 0;
+  __syncthreads();
+  // ---- the level's aggregate, look-back, the level's incoming carry (wave 0; one chain per lane = env)
+  const int nlevslots = 10;  // per level: [agg 0..4 | incl 0..4][N] doubles
+  if (wave == 0) {
+    double lagg[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    bool lopen = true;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {  // wave 0 holds the latest steps: carries flow from wave 0 to wave NW - 1
+      const bool ow = s_open[w][lane] != 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if ((KMASK >> k) & 1) {
+          const double m = (ow ? p16[k] : 0.0) * lagg[k];
+          lagg[k] = s_agg[w][k][lane] + m;
+        }
+      lopen = lopen && ow;
+    }
+    double cin[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double* mine = ws + ((long)lev * nlevslots) * N + nc;
+    if (lev == 0 || !lopen) {  // the inclusive carry of this level does not depend on what comes in: publish now
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if ((KMASK >> k) & 1) osa_gc_put(mine + (long)(5 + k) * N, lagg[k]);
+      }
+    } else if (live) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if ((KMASK >> k) & 1) osa_gc_put(mine + (long)k * N, lagg[k]);
+    }
+    if (lev > 0 && live) {
+      constexpr int K0 = (KMASK & 1) ? 0 : 2;  // a carry every estimator has (polled first)
+      // walk to later levels until one has published its inclusive carry (a level with a path end always has)
+      int j = lev - 1;
+      for (;;) {
+        const double* lv = ws + ((long)j * nlevslots) * N + nc;
+        double vi = osa_gc_get(lv + (long)(5 + K0) * N);
+        if (osa_gc_ready(vi)) break;
+        const double va = osa_gc_get(lv + (long)K0 * N);
+        if (osa_gc_ready(va)) { --j; continue; }  // open level, aggregate there: look further (j >= 0: level 0 publishes incl)
+        __builtin_amdgcn_s_sleep(1);
+      }
+      {  // inclusive carry of level j, then fold the aggregates of levels j + 1 .. lev - 1 back in, in level order
+        const double* lv = ws + ((long)j * nlevslots) * N + nc;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if ((KMASK >> k) & 1) cin[k] = osa_gc_wait(lv + (long)(5 + k) * N);
+      }
+      for (int q = j + 1; q < lev; ++q) {
+        const double* lv = ws + ((long)q * nlevslots) * N + nc;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if ((KMASK >> k) & 1) {
+            const double m = p128[k] * cin[k];
+            cin[k] = osa_gc_wait(lv + (long)k * N) + m;
+          }
+      }
+      if (lopen) {  // this level's inclusive carry, by the same formula anybody else would use for it
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if ((KMASK >> k) & 1) {
+            const double m = p128[k] * cin[k];
+            osa_gc_put(mine + (long)(5 + k) * N, lagg[k] + m);
+          }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_cin[k][lane] = cin[k];
+  }
+  __syncthreads();
+  // ---- pass 2: this wave's incoming carries (the level's, folded through the waves before it), final outputs
+  OsaGaeCarry cy;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) cy.v[k] = s_cin[k][lane];
+  for (int w = 0; w < wave; ++w) {
+    const bool ow = s_open[w][lane] != 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if ((KMASK >> k) & 1) {
+        const double m = (ow ? p16[k] : 0.0) * cy.v[k];
+        cy.v[k] = s_agg[w][k][lane] + m;
+      }
+  }
+  if (!live || nsteps == 0) return;
+  bool dummy = true;
+  osa_gc_chunk<EST, true>(r, c, vr, vc, br, bc, e, nsteps, nv_r, nv_c, cy, dummy, g32, d_g, d_r, d_c, pc, i_hi, N,
+                          adv_r, adv_c, tgt_r, tgt_c, disc_ret);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6  statistics: deterministic two-stage float64 reductions
 // ------------------------------------------------------------------------------------------------
 #define OSA_RED_BLOCKS 512
@@ -657,6 +953,42 @@ int osa_gae_scan_tiled(const float* reward, const float* cost, const float* valu
   else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_TILE_LAUNCH(OSA_EST_GAE_RTG);
   else OSA_GAE_TILE_LAUNCH(OSA_EST_PLAIN);
 #undef OSA_GAE_TILE_LAUNCH
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+size_t osa_gae_chained_ws_doubles(int T, int N) {
+  if (T < 1 || N < 1) return 0;
+  return (size_t)((T + OSA_GC_LEV - 1) / OSA_GC_LEV) * 10 * (size_t)N + 1;  // carries + the arrival ticket
+}
+
+int osa_gae_scan_chained(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                         const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
+                         double gamma, double lam, double lam_c, float penalty_coef, int estimator,
+                         float* adv_r, float* adv_c, float* target_value_r, float* target_value_c,
+                         float* discounted_ret, double* ws, void* stream) {
+  OSA_REQUIRE(T > 0 && N > 0 && ws);
+  OSA_REQUIRE(reward && cost && value_r && value_c && path_end && boot_r && boot_c);
+  OSA_REQUIRE(adv_r && adv_c && target_value_r && target_value_c && discounted_ret);
+  if (estimator < OSA_EST_GAE || estimator > OSA_EST_PLAIN) return OSA_EUNSUPPORTED;  // v-trace: float32 chain
+  const float g32 = (float)gamma;
+  const double d_g = gamma, d_r = gamma * lam, d_c = gamma * lam_c;
+  const int nlev = (T + OSA_GC_LEV - 1) / OSA_GC_LEV, nenvb = (N + 63) / 64;
+  if ((long)nlev * nenvb > 2147483647L) return OSA_EUNSUPPORTED;
+  hipStream_t st = osa_stream(stream);
+  // every carry slot starts as the "not yet there" NaN sentinel
+  const size_t nws = osa_gae_chained_ws_doubles(T, N);
+  if (hipMemsetAsync(ws, 0xFF, (nws - 1) * sizeof(double), st) != hipSuccess) return OSA_EHIP;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + (nws - 1));
+  if (hipMemsetAsync(ticket, 0, sizeof(double), st) != hipSuccess) return OSA_EHIP;
+#define OSA_GAE_CHAIN_LAUNCH(E)                                                                             \
+  hipLaunchKernelGGL((osa_gae_chain_scan_kernel<E>), dim3(nlev * nenvb), dim3(64 * OSA_GC_NW), 0, st, reward, \
+                     cost, value_r, value_c, path_end, boot_r, boot_c, T, N, g32, d_g, d_r, d_c, penalty_coef, \
+                     adv_r, adv_c, target_value_r, target_value_c, discounted_ret, ws, nenvb, ticket)
+  if (estimator == OSA_EST_GAE) OSA_GAE_CHAIN_LAUNCH(OSA_EST_GAE);
+  else if (estimator == OSA_EST_GAE_RTG) OSA_GAE_CHAIN_LAUNCH(OSA_EST_GAE_RTG);
+  else OSA_GAE_CHAIN_LAUNCH(OSA_EST_PLAIN);
+#undef OSA_GAE_CHAIN_LAUNCH
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

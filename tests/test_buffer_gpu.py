@@ -160,6 +160,54 @@ def test_tiled_scan_equals_lane_per_env_kernel(est, T, N, pc):
     assert same / total > 0.999, same / total
 
 
+@pytest.mark.parametrize('est', ['gae', 'gae-rtg', 'plain'])
+@pytest.mark.parametrize('T,N,pc,p_end', [
+    (16, 4096, 0.0, 0.05), (1, 64, 0.0, 0.05), (7, 1, 0.3, 0.05), (128, 64, 0.0, 0.05), (129, 33, 0.3, 0.05),
+    (257, 300, 0.0, 0.05), (1000, 4, 0.3, 0.002), (5000, 70, 0.0, 0.0005), (256, 16384, 0.0, 0.01),
+    (4096, 256, 0.0, 0.0), (2048, 512, 0.3, 0.001)])
+def test_chained_scan_equals_lane_per_env_kernel(est, T, N, pc, p_end):
+    """osa_gae_scan_chained (time split over workgroups: levels of 128 steps, chunks of 16 steps in registers,
+    per-env carries chained by a decoupled look-back) vs osa_gae_scan (bit-exact to the reference).  Given its
+    incoming carry a chunk runs the sequential kernel's arithmetic step for step; the carry is assembled by the
+    affine identity -> rtol 1e-5 / atol 1e-6 required, bit-identical float32 outputs in practice
+    (> 99.99 %).  Shapes: level-ragged T (1, 7, 129, 257, 1000, 5000), env blocks not a multiple of 64 (1, 4, 33,
+    70, 300), chains over up to 40 levels with NO path end at all (4096 x 256, p_end 0: the longest look-back) and
+    with rare ones; run twice: the result must not depend on timing."""
+    rng = np.random.default_rng(T * 11 + N)
+    g_in, pe, br, bc = _random_case(rng, T, N, p_end=p_end)
+    outs = {}
+    for variant in ('sequential', 'chained', 'chained-again'):
+        buf = _mk(T, N, 3, 2, est, pc, lam_c=0.9, variant=variant.split('-')[0])
+        _load_case(buf, g_in, pe, br, bc)
+        buf.compute_advantages()
+        assert buf.last_gae_variant == variant.split('-')[0]
+        outs[variant] = {k: buf.data[k].cpu().numpy().copy() for k in OUT_KEYS}
+    same = total = 0
+    for k in OUT_KEYS:
+        a, b = outs['chained'][k], outs['sequential'][k]
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6, err_msg=k)
+        assert np.array_equal(a, outs['chained-again'][k]), k  # deterministic: a pure function of the inputs
+        same += int((a == b).sum())
+        total += a.size
+    assert same / total > 0.9999, same / total
+
+
+def test_chained_scan_vs_reference_golden(golden):
+    """The chained kernel against the reference's own outputs (tests/golden/buffer.npz) for the three estimators it
+    implements, with and without the cost penalty; v-trace falls back to the lane-per-env kernel."""
+    g = golden('buffer.npz')
+    T, N = g['reward'].shape
+    for est in ('gae', 'gae-rtg', 'plain', 'vtrace'):
+        for pc in (0.0, 0.3):
+            buf = _mk(T, N, g['obs'].shape[2], g['act'].shape[2], est, pc, variant='chained')
+            _fill(buf, {k: g[k] for k in IN_KEYS}, g['path_end'], g['boot_r'], g['boot_c'])
+            buf.compute_advantages()
+            assert buf.last_gae_variant == ('sequential' if est == 'vtrace' else 'chained')
+            for k in OUT_KEYS:
+                got = O.env_major(buf.data[k].cpu().numpy())
+                np.testing.assert_allclose(got, g[f'{est}_pc{pc}/raw/{k}'], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_tiled_scan_vs_reference_golden(golden):
     """The tiled kernel against the reference's own outputs (tests/golden/buffer.npz: ragged paths, length-1
     paths, one path spanning the epoch) for the three estimators it implements, with and without the cost
@@ -180,15 +228,22 @@ def test_tiled_scan_vs_reference_golden(golden):
 def test_gae_variant_auto_rule():
     from omnisafe_amd.buffer import VectorOnPolicyBuffer as B
 
-    assert B.gae_variant_for(16, 4096, 0) == 'sequential'     # BASELINE config 2: T below one tile
-    assert B.gae_variant_for(5000, 4, 0) == 'tiled'           # BASELINE config 1: 4 envs, long horizon
-    assert B.gae_variant_for(4096, 4096, 0) == 'tiled'
-    assert B.gae_variant_for(16, 1 << 20, 0) == 'sequential'  # enough envs to fill the chip with lanes
-    assert B.gae_variant_for(64, 4096, 0) == 'tiled' and B.gae_variant_for(64, 32768, 0) == 'tiled'
-    assert B.gae_variant_for(32, 4096, 0) == 'sequential' and B.gae_variant_for(256, 65536, 0) == 'sequential'
+    assert B.gae_variant_for(16, 4096, 0) == 'sequential'     # BASELINE config 2: a handful of steps per lane
+    assert B.gae_variant_for(16, 1 << 20, 0) == 'sequential'
+    assert B.gae_variant_for(32, 4096, 0) == 'sequential'
+    assert B.gae_variant_for(5000, 4, 0) == 'chained'         # BASELINE config 1: 4 envs, long horizon
+    assert B.gae_variant_for(4096, 4096, 0) == 'chained' and B.gae_variant_for(4096, 16, 0) == 'chained'
+    assert B.gae_variant_for(256, 65536, 0) == 'chained' and B.gae_variant_for(64, 32768, 0) == 'chained'
+    assert B.gae_variant_for(1024, 64, 0) == 'chained'
+    assert B.gae_variant_for(64, 4096, 0) == 'tiled' and B.gae_variant_for(256, 256, 0) == 'tiled'
+    assert B.gae_variant_for(256, 4096, 0) == 'tiled'
     assert B.gae_variant_for(5000, 4, 3) == 'sequential'      # v-trace
     buf = _mk(5000, 4, 3, 2, variant='auto')
     buf.ptr = 5000
+    buf.compute_advantages()
+    assert buf.last_gae_variant == 'chained'
+    buf = _mk(128, 64, 3, 2, variant='auto')
+    buf.ptr = 128
     buf.compute_advantages()
     assert buf.last_gae_variant == 'tiled'
 

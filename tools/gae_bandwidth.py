@@ -46,7 +46,7 @@ def timed(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r2_gae_bandwidth'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r3_gae_bandwidth'))
     ap.add_argument('--shapes', nargs='*')
     ap.add_argument('--only-gae', action='store_true')
     ap.add_argument('--pmc-run', action='store_true')
@@ -70,7 +70,7 @@ def main():
         M = T * N
         rng = np.random.default_rng(T + N)
         bufs = {}
-        for variant in ('sequential', 'tiled'):
+        for variant in ('sequential', 'tiled', 'chained'):
             buf = VectorOnPolicyBuffer(Box(-np.inf, np.inf, (D_O,)), Box(-1, 1, (D_A,)), size=T, gamma=0.99,
                                        lam=0.95, lam_c=0.95, advantage_estimator='gae', penalty_coefficient=0.0,
                                        standardized_adv_r=True, standardized_adv_c=True, num_envs=N, device=dev,
@@ -104,6 +104,10 @@ def main():
         b = bufs['tiled'].data['adv_r']
         row['tiled_vs_sequential_max_rel'] = float(((a - b).abs() / a.abs().clamp_min(1e-6)).max())
         row['tiled_bit_identical_frac'] = float((a == b).float().mean())
+        bufs['chained'].compute_advantages()
+        b = bufs['chained'].data['adv_r']
+        row['chained_vs_sequential_max_rel'] = float(((a - b).abs() / a.abs().clamp_min(1e-6)).max())
+        row['chained_bit_identical_frac'] = float((a == b).float().mean())
         row['auto_picks'] = VectorOnPolicyBuffer.gae_variant_for(T, N, 0)
         if not args.only_gae:
             buf = bufs['sequential']
@@ -143,13 +147,16 @@ def main():
                 '8000 GB/s.  GAE: 36 B / transition (SURVEY.md 8d); get() chain (2 statistics phases + fused '
                 f'standardise/transpose of 6 scalar arrays + obs/act rows, D_o = {D_O}, D_a = {D_A}): '
                 f'{12 + 48 + 8 * (D_O + D_A)} B / transition.\n\n')
-        f.write('| T | N | M | lane-per-env us | GB/s | % of 8 TB/s | tiled us | GB/s | % of 8 TB/s | auto picks | '
-                'tiled == sequential (frac bit-identical, max rel) | get() us | GB/s |\n|' + '---|' * 13 + '\n')
+        f.write('| T | N | M | lane-per-env us | GB/s | % of 8 TB/s | tiled us | GB/s | % of 8 TB/s | chained us | GB/s | '
+                '% of 8 TB/s | auto picks | tiled == sequential (frac bit-identical, max rel) | chained == sequential | '
+                'get() us | GB/s |\n|' + '---|' * 17 + '\n')
         for r in rows:
             f.write(f"| {r['T']} | {r['N']} | {r['M']} | {r['gae_sequential_us']} | {r['gae_sequential_GBps']} | "
                     f"{r['gae_sequential_GBps'] / 80:.1f} | {r['gae_tiled_us']} | {r['gae_tiled_GBps']} | "
-                    f"{r['gae_tiled_GBps'] / 80:.1f} | {r['auto_picks']} | {r['tiled_bit_identical_frac']:.6f}, "
-                    f"{r['tiled_vs_sequential_max_rel']:.1e} | {r.get('get_chain_us', '')} | "
+                    f"{r['gae_tiled_GBps'] / 80:.1f} | {r['gae_chained_us']} | {r['gae_chained_GBps']} | "
+                    f"{r['gae_chained_GBps'] / 80:.1f} | {r['auto_picks']} | {r['tiled_bit_identical_frac']:.6f}, "
+                    f"{r['tiled_vs_sequential_max_rel']:.1e} | {r['chained_bit_identical_frac']:.6f}, "
+                    f"{r['chained_vs_sequential_max_rel']:.1e} | {r.get('get_chain_us', '')} | "
                     f"{r.get('get_chain_GBps', '')} |\n")
     print('wrote', args.out + '.{json,md}')
 
