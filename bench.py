@@ -125,13 +125,24 @@ def timed(algo, steps, warmup, world, dev):
     return dt
 
 
-def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r2_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction);
-    PMC counters cannot be read from inside the process, so this is the offline measurement of the
-    same command.  None if no matching entry."""
-    for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):  # newest committed PMC passes first
-        path = os.path.join(ROOT, 'profiles', name)
+def pmc_traffic(kernel_name, variant=False):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r3_pmc_traffic*.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction --
+    tools/r3_gpu_batch8.sh + tools/pmc_summary.py); PMC counters cannot be read from inside the process, so this is
+    the offline measurement of the same command.  None if no matching entry.  The large-batch step (`variant`) is two
+    launches -- partial gradients on the pass kernel's machinery, then slab reduce + clip + Adam -- and reports their
+    sum."""
+    prof = os.path.join(ROOT, 'profiles')
+    if variant:
+        path = os.path.join(prof, 'r3_pmc_traffic_variant.json')
+        if not os.path.exists(path):
+            return None
+        d = json.load(open(path))
+        parts = [v['traffic_bytes_per_launch'] for k, v in d.items()
+                 if k.startswith('osa_ppo_pass_kernel') or k.startswith('osa_slab_reduce_finalize_kernel')]
+        return sum(parts) if len(parts) == 2 else None
+    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):  # newest PMC passes first
+        path = os.path.join(prof, name)
         if not os.path.exists(path):
             continue
         for k, v in json.load(open(path)).items():
@@ -155,7 +166,8 @@ def roofline_from_events(events, batch_size):
     achieved = flops / (ms * 1e-3) / 1e12
     us = ms * 1e3 / len(events)
     out = {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
-           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': pmc_traffic(name),
+           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
+           'traffic': pmc_traffic(name, variant=name == 'osa_mb_grad_kernel'),
            'kernel': name, 'launches_timed': len(events), 'us_per_launch': round(us, 2),
            'flops_per_launch': flops // len(events), 'rows_per_launch': rows // len(events)}
     if name == 'osa_ppo_dp_step':

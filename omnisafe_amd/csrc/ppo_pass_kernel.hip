@@ -102,6 +102,10 @@ struct OsaPassArgs {
   // dp_ranks rank sums x clip factor in rank order, / dp_ranks (clip-then-average), same Adam step everywhere.
   // dp_sync then is int[64]: [net] stage-2 arrivals, [3] sticky flag, [4..7] placement, [8 + 16 net + rank] stage 1.
   int dp_ranks;
+  // plain pass (grid 3): 1 = the three networks' workgroups are blocks 0, 8, 16 of a 17-block grid, i.e. (block b
+  // runs on XCC b mod 8) they share ONE XCC and its L2: the rows all three gather (observations: 240 of the 268
+  // bytes of a sample) are then fetched from HBM once instead of three times
+  int one_xcc;
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
 };
 
@@ -154,6 +158,12 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
   int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
+  if constexpr (!COOP) {
+    if (a.one_xcc) {
+      if (blockIdx.x & 7) return;
+      net_ = blockIdx.x >> 3;
+    }
+  }
   if constexpr (COOP) {
     if (a.dp_local == 1) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
       // (dp_local == 3: test hook -- the one-XCC protocol on the 3 x world grid, so that the placement check trips)
@@ -1392,7 +1402,7 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
-  const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : dim3(3, grid_y);
+  const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
@@ -1483,6 +1493,10 @@ int osa_ppo_pass_ext(int obs_dim, int act_dim, int hidden, float* params, float*
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
   a.dbg = g_osa_pass_dbg;
   a.dp_slabs = nullptr; a.dp_world = 1; a.mb0 = 0; a.dp_sync = nullptr; a.part_stride = 0; a.dp_uncached = 0;
+  {  // OSA_PASS_ONE_XCC=0: the three workgroups on three XCCs (A/B switch; traffic: profiles/r3_pmc_traffic*)
+    static const bool one = !(getenv("OSA_PASS_ONE_XCC") && getenv("OSA_PASS_ONE_XCC")[0] == '0');
+    a.one_xcc = one ? 1 : 0;
+  }
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
   if (ext) {  // extended actor surrogates: single-chunk minibatches only (mask mean / penalty are per minibatch)
