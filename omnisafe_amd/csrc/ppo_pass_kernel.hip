@@ -102,6 +102,13 @@ struct OsaPassArgs {
   // dp_ranks rank sums x clip factor in rank order, / dp_ranks (clip-then-average), same Adam step everywhere.
   // dp_sync then is int[64]: [net] stage-2 arrivals, [3] sticky flag, [4..7] placement, [8 + 16 net + rank] stage 1.
   int dp_ranks;
+  // SLICE instantiation of the cooperative data-parallel pass (osa_ppo_dp_slice_pass; world >= 3): after the
+  // gradients have been published, rank r REDUCES only the tiles q with q mod world == r (the bias-like row counts
+  // as tile NT), applies Adam to them with the moments it alone keeps for them, and publishes the new PARAMETERS;
+  // after a second hand-off everybody installs the tiles it does not own.  Per replica and step world x 1/world +
+  // 1 slabs are read instead of world, Adam runs on 1/world of the parameters; the price is the second hand-off.
+  // dp_sync is int[64] ([8 + net]: arrivals of the second hand-off); the parameter slabs follow the gradient
+  // slabs in dp_slabs.
   // plain pass (grid 3): 1 = the three networks' workgroups are blocks 0, 8, 16 of a 17-block grid, i.e. (block b
   // runs on XCC b mod 8) they share ONE XCC and its L2: the rows all three gather (observations: 240 of the 268
   // bytes of a sample) are then fetched from HBM once instead of three times
@@ -153,7 +160,7 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
   return OSA_PASS_W2T != 0 && (osa_pass_lds_floats(KB, OT) + 64 * PSLD) * 4 <= 160 * 1024;
 }
 
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -1111,6 +1118,41 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 #pragma unroll
         for (int o = 0; o < OT; ++o) s3[o] = osa_sym_sum(g3[o], gs, t[HT + KB + o], tg);
         sb_ = osa_sym_sum1((boff >= 0) ? gb : 0.f, gs, tb, tg);
+      } else if constexpr (SLICE) {
+        // only the tiles this rank owns: all `world` copies of one tile in flight together, summed in rank order
+        constexpr int RS = 8;
+        auto reduce_tile = [&](int q) -> f32x4 {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int r0 = 0; r0 < W; r0 += RS) {
+            f32x4 t[RS];
+            float tg[RS];
+#pragma unroll
+            for (int u = 0; u < RS; ++u) {
+              const float* __restrict__ xr = xbase + (long)min(r0 + u, W - 1) * XS;
+              t[u] = reinterpret_cast<const f32x4*>(xr)[q * 256 + tid];
+              tg[u] = xr[NT * 1024 + 256 + 5];
+            }
+#pragma unroll
+            for (int u = 0; u < RS; ++u)
+              if (r0 + u < W) acc = acc + t[u] * tg[u];
+          }
+          return acc;
+        };
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti)
+          if (ti % W == rk) s2[ti] = reduce_tile(ti);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          if ((HT + kb) % W == rk) s1[kb] = reduce_tile(HT + kb);
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+          if ((HT + KB + o) % W == rk) s3[o] = reduce_tile(HT + KB + o);
+        if (NT % W == rk) {
+          for (int r = 0; r < W; ++r) {
+            const float* __restrict__ xr = xbase + (long)r * XS;
+            sb_ += xr[NT * 1024 + tid] * xr[NT * 1024 + 256 + 5];
+          }
+        }
       } else {
       // RU ranks per trip: their loads are all in flight together (one memory round trip per trip,
       // not per rank); the clamped duplicate loads of a ragged last trip are simply not added
@@ -1294,33 +1336,108 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     // ================= Adam on the owned parameters; LDS master updated in place =================
     const float gscale = apply_clip ? coef : 1.f;
-#pragma unroll
-    for (int ti = 0; ti < HT; ++ti) {
-      f32x4 w = w2r[ti];
-      w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+    // SLICE: this replica applies Adam to the tiles q with q mod world == rank only and publishes their new values
+    // (pslab: [NT][256] f32x4 + the bias-like row, parity of the step); the rest arrives after the second hand-off
+    const int sW_ = SLICE ? a.dp_world : 1;
+    auto mine = [&](int q) -> bool { return !SLICE || (q % sW_) == rk; };
+    float* __restrict__ pslab = nullptr;
+    if constexpr (SLICE)
+      pslab = a.dp_slabs + (long)2 * 3 * a.dp_world * XS + ((long)((mb - a.mb0) & 1) * 3 + net) * XS;
+    f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(pslab);
+    auto put_w2 = [&](int ti, f32x4 w) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc] = w[r];
       if constexpr (W2T) *reinterpret_cast<f32x4*>(sW2T + (16 * ti + cc) * PSLD + 16 * wave + 4 * g) = w;
+    };
+    auto put_w1 = [&](int kb, f32x4 w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc] = w[r];
+    };
+    auto put_w3 = [&](int o, f32x4 w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc] = w[r];
+    };
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti) {
+      if (mine(ti)) {
+        f32x4 w = w2r[ti];
+        w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+        put_w2(ti, w);
+        if constexpr (SLICE) p4[ti * 256 + tid] = w;
+      }
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      f32x4 w = w1r[kb];
-      w = osa_adam_update4(g1[kb] * gscale, m1[kb], v1[kb], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sW1[(16 * wave + 4 * g + r) * W1LD + 16 * kb + cc] = w[r];
+      if (mine(HT + kb)) {
+        f32x4 w = w1r[kb];
+        w = osa_adam_update4(g1[kb] * gscale, m1[kb], v1[kb], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+        put_w1(kb, w);
+        if constexpr (SLICE) p4[(HT + kb) * 256 + tid] = w;
+      }
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-      f32x4 w = w3r[o];
-      w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sW3[(16 * o + 4 * g + r) * PSLD + 16 * wave + cc] = w[r];
+      if (mine(HT + KB + o)) {
+        f32x4 w = w3r[o];
+        w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+        put_w3(o, w);
+        if constexpr (SLICE) p4[(HT + KB + o) * 256 + tid] = w;
+      }
     }
-    if (boff >= 0) {
-      float mv_ = mb_, vv_ = vb_;
-      *sbias = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
-      mb_ = mv_;
-      vb_ = vv_;
+    if (mine(HT + KB + OT)) {
+      float nb = wb;
+      if (boff >= 0) {
+        float mv_ = mb_, vv_ = vb_;
+        nb = osa_adam_update(gb * gscale, mv_, vv_, wb, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
+        *sbias = nb;
+        mb_ = mv_;
+        vb_ = vv_;
+      }
+      if constexpr (SLICE) pslab[(HT + KB + OT) * 1024 + tid] = nb;
+    }
+    if constexpr (SLICE) {
+      // ---- second hand-off: the new parameters of every slice
+      if (a.dp_uncached || a.dp_local) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int* cnt = a.dp_sync + 8 + net;
+        const int target = a.dp_world * (mb - a.mb0 + 1);
+        int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (!coop_dead) {
+          int spins = 0;
+          while (seen < target) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1 << 21)) {
+              __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              coop_dead = true;
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // install the tiles of the other ranks (all loads in flight, then the LDS writes)
+      f32x4 nw[HT + KB + OT];
+#pragma unroll
+      for (int q = 0; q < HT + KB + OT; ++q) nw[q] = p4[q * 256 + tid];
+      const float nbias = pslab[(HT + KB + OT) * 1024 + tid];
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti)
+        if (!mine(ti)) put_w2(ti, nw[ti]);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        if (!mine(HT + kb)) put_w1(kb, nw[HT + kb]);
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+        if (!mine(HT + KB + o)) put_w3(o, nw[HT + KB + o]);
+      if (!mine(HT + KB + OT) && boff >= 0) *sbias = nbias;
     }
     PTICK(8);
     // ---- statistics of this optimiser step
@@ -1347,6 +1464,46 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   if (a.dbg && tid == 0 && rk == 0)
     for (int k = 0; k < 13; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
 #endif
+  if constexpr (SLICE) {
+    // every rank writes back the Adam moments of the tiles IT updated (nobody else has them); the parameters
+    // (identical in every replica) and the step counter are rank 0's job below
+    constexpr int NTW = HT + KB + OT;
+    const int sw = a.dp_world;
+    if (rk != 0) {
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti)
+        if (ti % sw == rk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+            gm[off] = m2[ti][r];
+            gv[off] = v2[ti][r];
+          }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        if ((HT + kb) % sw == rk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
+            gm[off] = m1[kb][r];
+            gv[off] = v1[kb][r];
+          }
+#pragma unroll
+      for (int o = 0; o < OT; ++o)
+        if ((HT + KB + o) % sw == rk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+            gm[off] = m3[o][r];
+            gv[off] = v3[o][r];
+          }
+      if (NTW % sw == rk && boff >= 0) {
+        gm[boff] = mb_;
+        gv[boff] = vb_;
+      }
+      return;
+    }
+  }
   if (rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
   // ---- write back parameters and Adam state
   for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
@@ -1360,31 +1517,36 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     gp[nd.ob3 + tid] = sB3[tid];
     if (!critic) gp[nd.oLS + tid] = sLS[tid];
   }
+  // (SLICE: rank 0 holds valid moments only for the tiles it updated: q mod world == 0)
+  const int swb = SLICE ? a.dp_world : 1;
 #pragma unroll
   for (int ti = 0; ti < HT; ++ti)
+    if (ti % swb == 0)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
-      gm[off] = m2[ti][r];
-      gv[off] = v2[ti][r];
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+        gm[off] = m2[ti][r];
+        gv[off] = v2[ti][r];
+      }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
+    if ((HT + kb) % swb == 0)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
-      gm[off] = m1[kb][r];
-      gv[off] = v1[kb][r];
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
+        gm[off] = m1[kb][r];
+        gv[off] = v1[kb][r];
+      }
 #pragma unroll
   for (int o = 0; o < OT; ++o)
+    if ((HT + KB + o) % swb == 0)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
-      gm[off] = m3[o][r];
-      gv[off] = v3[o][r];
-    }
-  if (boff >= 0) {
+      for (int r = 0; r < 4; ++r) {
+        const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+        gm[off] = m3[o][r];
+        gv[off] = v3[o][r];
+      }
+  if (boff >= 0 && (HT + KB + OT) % swb == 0) {
     gm[boff] = mb_;
     gv[boff] = vb_;
   }
@@ -1400,14 +1562,14 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1422,7 +1584,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1431,14 +1593,14 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1695,7 +1857,7 @@ static size_t osa_dp_pass_xs(const OsaNet& nd) {
 size_t osa_ppo_dp_pass_ws_floats(int obs_dim, int act_dim, int hidden, int world) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
-  return (size_t)2 * 3 * world * osa_dp_pass_xs(nd);
+  return (size_t)2 * 3 * world * osa_dp_pass_xs(nd) + (size_t)2 * 3 * osa_dp_pass_xs(nd);  // + parameter slabs (slice pass)
 }
 
 int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1714,7 +1876,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream);
+                         float* exchange, int* sync, int local, int chunk, int ranks, int slice, float* step_stats, void* stream);
 
 int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
@@ -1724,7 +1886,18 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                            float* exchange, int* sync, int local, float* step_stats, void* stream) {
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
-                       nets_mask, exchange, sync, local, 0, 1, step_stats, stream);
+                       nets_mask, exchange, sync, local, 0, 1, 0, step_stats, stream);
+}
+
+int osa_ppo_dp_slice_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                          const float* logp, const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                          float* exchange, int* sync, int local, float* step_stats, void* stream) {
+  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
+                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
+                       nets_mask, exchange, sync, local, 0, 1, 1, step_stats, stream);
 }
 
 int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1736,7 +1909,7 @@ int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   if (B <= 64 || B > 64 * 32) return OSA_EUNSUPPORTED;  // one chunk: osa_ppo_pass
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, (B + 63) / 64, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, local, 1, 1, step_stats, stream);
+                       loss_kind, nets_mask, exchange, sync, local, 1, 1, 0, step_stats, stream);
 }
 
 size_t osa_ppo_dp_chunked_pass_ws_floats(int obs_dim, int act_dim, int hidden, int B, int world) {
@@ -1756,7 +1929,7 @@ int osa_ppo_dp_chunked_pass(int obs_dim, int act_dim, int hidden, float* params,
   const int chunks = (B + 63) / 64;
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world * chunks, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, local, 1, world, step_stats, stream);
+                       loss_kind, nets_mask, exchange, sync, local, 1, world, 0, step_stats, stream);
 }
 
 static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -1764,8 +1937,9 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream) {
+                         float* exchange, int* sync, int local, int chunk, int ranks, int slice, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  if (slice && (chunk || B > 64 || world < 3)) return OSA_EUNSUPPORTED;
   if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
@@ -1802,11 +1976,12 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   if (local && hipMemsetAsync(sync + 4, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks, arrivals
   // (chunk mode under data parallelism: the per-rank arrival counters of the first hand-off; sync is int[64] there)
-  if (chunk && ranks > 1 && hipMemsetAsync(sync + 8, 0, 48 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if (((chunk && ranks > 1) || slice) && hipMemsetAsync(sync + 8, 0, 48 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return (chunk && ranks > 1) ? osa_launch_pass<K, O, false, true, false, true>(a, st, world)  \
+    return slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
+           : (chunk && ranks > 1) ? osa_launch_pass<K, O, false, true, false, true>(a, st, world) \
            : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \
                                 : osa_launch_pass<K, O, false, true>(a, st, world)
   OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);

@@ -472,7 +472,14 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
                 st['xch_ptr'] = st['xch'].data_ptr()
             st['sync'] = torch.zeros(64, dtype=torch.int32, device=ac.device)
-        fn = lib.osa_ppo_dp_chunked_pass if chunked else lib.osa_ppo_dp_pass_placed
+        # OSA_DP_SLICE=1: the reduction sliced over the ranks + Adam on the slice + parameters exchanged
+        # (osa_ppo_dp_slice_pass, world >= 3).  OFF by default: measured 17.9 us per step at 8 virtual ranks against
+        # 15.7 for the direct sum (15.9 v 13.2 at 4) -- the second hand-off costs more than the W - 2 slab reads and
+        # the 7/8 of Adam it saves (profiles/r3_dp_shapes_timing.md)
+        sliced = (not chunked and self.batch_size <= 64 and W >= 3 and os.environ.get('OSA_DP_SLICE', '0') == '1')
+        st['sliced'] = sliced
+        fn = lib.osa_ppo_dp_chunked_pass if chunked else (lib.osa_ppo_dp_slice_pass if sliced
+                                                          else lib.osa_ppo_dp_pass_placed)
         rc = fn(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),

@@ -325,7 +325,10 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
                                                   (4, 300, 64, False, True), (3, 256, 128, False, True),
                                                   (8, 1024, 64, False, True), (1, 200, 64, False, True),
                                                   (6, 320, 64, False, True), (16, 128, 64, False, True),
-                                                  (2, 384, 64, False, 'wrong-placement')])
+                                                  (2, 384, 64, False, 'wrong-placement'),
+                                                  (3, 256, 64, False, 'slice'), (4, 300, 64, False, 'slice'),
+                                                  (8, 1024, 64, False, 'slice'), (11, 128, 64, False, 'slice'),
+                                                  (8, 256, 64, False, 'noslice')])
 def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop, monkeypatch):
     """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
     workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
@@ -337,6 +340,9 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
     from omnisafe_amd import update as U
     from omnisafe_amd.update import PPOUpdater
 
+    # 'slice': osa_ppo_dp_slice_pass (each rank reduces + Adam-updates the tiles q = rank mod world, parameters are
+    # exchanged: second hand-off) switched on; it is off by default (measured slower than the direct sum)
+    monkeypatch.setenv('OSA_DP_SLICE', '1' if coop == 'slice' else '0')
     if coop == 'wrong-placement':  # test hook: the one-XCC protocol on the spread grid -> the kernel's placement
         # check trips before anything is modified, the updater repeats the pass spread over the XCCs
         monkeypatch.setenv('OSA_DEBUG_PLACEMENT', 'wrong')
@@ -367,6 +373,7 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
             if coop:  # the cooperative persistent launch ran (no silent fallback) and every peer arrived
                 assert up._dp.get('coop_passes') == 3
                 up.check_dp_sync()
+                assert up._dp['sliced'] is (coop == 'slice')  # (off by default: measured slower)
             if coop == 'wrong-placement':
                 assert U._PLACEMENT['local_ok'] is False and up._dp['local'] is False
             if use_graph:
