@@ -31,10 +31,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct OsaNet {
   int obs_dim, act_dim, H, INP, OUTP, KB;
   int oW1, ob1, oW2, ob2, oW3, ob3, oLS, P;
+  int act;  // hidden activation (OSA_ACT_*), decoded from the `hidden` word of the C ABI
 };
 
-__host__ __device__ inline OsaNet osa_make_net(int obs_dim, int act_dim, int H) {
+// The `hidden` argument of every entry point: low 16 bits = width of the two hidden layers, bits 16-19 = their
+// activation (reference model_cfgs.*.activation, utils/model.py:47-70): 0 tanh (default, every YAML), 1 relu,
+// 2 sigmoid, 3 softplus, 4 identity.  The persistent pass kernels implement tanh only (osa_ppo_*_supported return 0
+// otherwise: such networks run on the per-step kernels).
+#define OSA_ACT_TANH 0
+#define OSA_ACT_RELU 1
+#define OSA_ACT_SIGMOID 2
+#define OSA_ACT_SOFTPLUS 3
+#define OSA_ACT_IDENTITY 4
+
+__host__ __device__ inline OsaNet osa_make_net(int obs_dim, int act_dim, int hidden) {
   OsaNet n;
+  const int H = hidden & 0xFFFF;
+  n.act = (hidden >> 16) & 0xF;
   n.obs_dim = obs_dim;
   n.act_dim = act_dim;
   n.H = H;
@@ -80,6 +93,43 @@ __device__ __forceinline__ f32x4 osa_tanh4(f32x4 v) {
   r.z = __builtin_amdgcn_rcpf(e.z);
   r.w = __builtin_amdgcn_rcpf(e.w);
   return 1.f - 2.f * r;  // packed f32 math on the vector
+}
+
+// Hidden activation and its derivative EXPRESSED THROUGH THE OUTPUT h (what the backward pass has at hand):
+//   tanh 1 - h^2 | relu [h > 0] | sigmoid h (1 - h) | softplus 1 - e^{-h} (= sigmoid(x)) | identity 1
+// `act` is uniform over the launch: the switch is a scalar branch per tile, tanh stays the first (default) case.
+__device__ __forceinline__ f32x4 osa_act4(f32x4 v, int act) {
+  if (act == OSA_ACT_TANH) return osa_tanh4(v);
+  f32x4 r;
+  if (act == OSA_ACT_RELU) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = fmaxf(v[k], 0.f);
+  } else if (act == OSA_ACT_SIGMOID) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = 1.f / (1.f + expf(-v[k]));
+  } else if (act == OSA_ACT_SOFTPLUS) {  // torch.nn.Softplus(beta = 1, threshold = 20)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = v[k] > 20.f ? v[k] : log1pf(expf(v[k]));
+  } else {
+    r = v;
+  }
+  return r;
+}
+__device__ __forceinline__ f32x4 osa_dact4(f32x4 h, int act) {
+  if (act == OSA_ACT_TANH) return 1.f - h * h;
+  f32x4 r;
+  if (act == OSA_ACT_RELU) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = h[k] > 0.f ? 1.f : 0.f;
+  } else if (act == OSA_ACT_SIGMOID) {
+    r = h * (1.f - h);
+  } else if (act == OSA_ACT_SOFTPLUS) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = 1.f - expf(-h[k]);
+  } else {
+    r = (f32x4){1.f, 1.f, 1.f, 1.f};
+  }
+  return r;
 }
 
 // One Adam step of one parameter (torch.optim.Adam single-tensor form):
@@ -180,7 +230,7 @@ __device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* _
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int t = 0; t < HT; ++t) h1[t] = osa_tanh4(h1[t]);
+  for (int t = 0; t < HT; ++t) h1[t] = osa_act4(h1[t], nd.act);
 #pragma unroll
   for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(p + nd.ob2 + 16 * t + 4 * g);
 #pragma unroll
@@ -195,7 +245,7 @@ __device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* _
     }
   }
 #pragma unroll
-  for (int t = 0; t < HT; ++t) h2[t] = osa_tanh4(h2[t]);
+  for (int t = 0; t < HT; ++t) h2[t] = osa_act4(h2[t], nd.act);
 #pragma unroll
   for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(p + nd.ob3 + 16 * o + 4 * g);
 #pragma unroll

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < HT; ++t) t1[t] = t1[t] * (1.f - h1[t] * h1[t]);
+      for (int t = 0; t < HT; ++t) t1[t] = t1[t] * osa_dact4(h1[t], nd.act);
 #pragma unroll
       for (int t = 0; t < HT; ++t) t2[t] = *reinterpret_cast<const f32x4*>(v + nd.ob2 + 16 * t + 4 * g);
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < HT; ++t) t2[t] = t2[t] * (1.f - h2[t] * h2[t]);
+      for (int t = 0; t < HT; ++t) t2[t] = t2[t] * osa_dact4(h2[t], nd.act);
 #pragma unroll
       for (int o = 0; o < OT; ++o) tm[o] = *reinterpret_cast<const f32x4*>(v + nd.ob3 + 16 * o + 4 * g);
 #pragma unroll
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
           acc = OSA_MFMA(w, dO[o][s], acc);
         }
       }
-      z2[t] = acc * (1.f - h2[t] * h2[t]);  // tanh'
+      z2[t] = acc * osa_dact4(h2[t], nd.act);  // activation' through its output
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
           acc = OSA_MFMA(w, z2[kb][s], acc);
         }
       }
-      z1[t] = acc * (1.f - h1[t] * h1[t]);
+      z1[t] = acc * osa_dact4(h1[t], nd.act);
     }
     OSA_TICK(3);
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f*SLD + c]
@@ -1132,7 +1132,8 @@ static size_t osa_mb_lds_bytes(const OsaNet& nd) {
 
 static int osa_check_dims(int obs_dim, int act_dim, int hidden) {
   if (obs_dim < 1 || act_dim < 1) return OSA_EINVAL;
-  if (hidden != 64) return OSA_EUNSUPPORTED;   // hidden_sizes [64, 64] (all BASELINE configs)
+  if ((hidden & 0xFFFF) != 64) return OSA_EUNSUPPORTED;   // hidden_sizes [64, 64] (all BASELINE configs)
+  if ((hidden >> 16) > OSA_ACT_IDENTITY) return OSA_EUNSUPPORTED;  // activation code (mlp_device.h)
   if (act_dim > 32) return OSA_EUNSUPPORTED;
   return OSA_OK;
 }

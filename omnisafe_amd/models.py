@@ -22,6 +22,8 @@ import torch
 from . import _lib
 from .spaces import is_box
 
+# activation codes of the C ABI (csrc/mlp_device.h OSA_ACT_*)
+ACTIVATIONS = {'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}
 ACTOR, REWARD_CRITIC, COST_CRITIC = 0, 1, 2
 
 
@@ -184,17 +186,27 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
     def __init__(self, obs_space, act_space, model_cfgs, epochs: int, device='cuda:0') -> None:
         if not is_box(obs_space) or not is_box(act_space):
             raise NotImplementedError  # models/base.py:66-74
-        self._lib = _lib.load(require_gpu=True)
         self.device = torch.device(device)
         self.obs_dim, self.act_dim = int(obs_space.shape[0]), int(act_space.shape[0])
         a_h, c_h = list(model_cfgs.actor.hidden_sizes), list(model_cfgs.critic.hidden_sizes)
         if a_h != c_h or len(a_h) != 2 or a_h[0] != a_h[1]:
             raise NotImplementedError(f'hidden_sizes {a_h}/{c_h}: omnisafe_amd supports [H, H] for both')
-        if model_cfgs.actor.activation != 'tanh' or model_cfgs.critic.activation != 'tanh':
-            raise NotImplementedError('omnisafe_amd kernels implement tanh MLPs (every on-policy YAML default)')
+        # hidden activation (utils/model.py:47-70: identity / relu / sigmoid / softplus / tanh).  tanh -- every
+        # on-policy YAML default -- runs on the persistent pass kernels; the others on the per-step kernels, which
+        # take the activation code in bits 16-19 of the `hidden` word of the C ABI (csrc/mlp_device.h)
+        if model_cfgs.actor.activation != model_cfgs.critic.activation:
+            raise NotImplementedError('omnisafe_amd: actor and critics must share one activation')
+        if model_cfgs.actor.activation not in ACTIVATIONS:
+            raise NotImplementedError(f'activation {model_cfgs.actor.activation!r}: one of {list(ACTIVATIONS)}')
         if getattr(model_cfgs, 'actor_type', 'gaussian_learning') != 'gaussian_learning':
             raise NotImplementedError('only actor_type gaussian_learning is on the accelerated path')
-        self.hidden = int(a_h[0])
+        self.activation = model_cfgs.actor.activation
+        self.width = int(a_h[0])
+        if self.width != 64:
+            raise NotImplementedError(f'hidden_sizes {a_h}: the kernels implement 64 x 64 (every on-policy YAML '
+                                      'default); see DESIGN.md 7')
+        self.hidden = self.width | (ACTIVATIONS[self.activation] << 16)  # what the C ABI calls `hidden`
+        self._lib = _lib.load(require_gpu=True)  # (after the configuration checks: those need no GPU)
         self.layout = Layout(self.obs_dim, self.act_dim, self.hidden)
         P = self.layout.P
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -240,7 +252,7 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
                 sd[f'{prefix}.{2 * j}.bias'] = lin.bias.detach()
             return sd
 
-        H = self.hidden
+        H = self.width
         sd = mlp_state([self.obs_dim, H, H, self.act_dim], 'mean')
         sd['log_std'] = torch.zeros(self.act_dim)
         self.actor.load_state_dict(sd)

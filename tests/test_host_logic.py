@@ -430,3 +430,26 @@ def test_host_env_bridge_single_env_wrappers_cpu():
     assert log[5] == (0.0, 1.0, False, True, 6.0)
     assert log[9] == (0.0, 2.0, True, False, 4.0)
     assert [x[4] for x in log[:5]] == [None] * 5 and log[10][:2] == (1.0, 2.0)
+
+
+def test_model_cfgs_activation_and_width_checks():
+    """models.py: activation names of the reference (utils/model.py:47-70) map to the ABI's codes; anything else,
+    unequal actor / critic activations and widths other than 64 raise NotImplementedError BEFORE the library is
+    touched (as the reference raises for unknown names)."""
+    import types
+
+    from omnisafe_amd import models
+
+    assert models.ACTIVATIONS == {'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}
+    src = open(models.__file__).read()
+    assert "self.hidden = self.width | (ACTIVATIONS[self.activation] << 16)" in src
+    ns = types.SimpleNamespace
+    from omnisafe_amd.spaces import Box
+
+    for a_act, c_act, hid in (('gelu', 'gelu', [64, 64]), ('relu', 'tanh', [64, 64]), ('tanh', 'tanh', [256, 256]),
+                              ('tanh', 'tanh', [64, 32])):
+        cfg = ns(actor=ns(hidden_sizes=hid, activation=a_act, lr=3e-4), critic=ns(hidden_sizes=hid, activation=c_act,
+                 lr=3e-4), weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
+                 linear_lr_decay=True)
+        with pytest.raises(NotImplementedError):
+            models.ConstraintActorCritic(Box(-1, 1, (4,)), Box(-1, 1, (2,)), cfg, 2, device='cuda:0')

@@ -16,20 +16,20 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def model_cfgs(lr=3e-4):
+def model_cfgs(lr=3e-4, activation='tanh'):
     ns = types.SimpleNamespace
-    return ns(actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr),
-              critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=lr),
+    return ns(actor=ns(hidden_sizes=[64, 64], activation=activation, lr=lr),
+              critic=ns(hidden_sizes=[64, 64], activation=activation, lr=lr),
               weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
               linear_lr_decay=True)
 
 
-def make_ac(obs_dim, act_dim, g=None, prefix='', epochs=4):
+def make_ac(obs_dim, act_dim, g=None, prefix='', epochs=4, activation='tanh'):
     from omnisafe_amd.models import ConstraintActorCritic
     from omnisafe_amd.spaces import Box
 
-    ac = ConstraintActorCritic(Box(-np.inf, np.inf, (obs_dim,)), Box(-1, 1, (act_dim,)), model_cfgs(),
-                               epochs, device=DEV)
+    ac = ConstraintActorCritic(Box(-np.inf, np.inf, (obs_dim,)), Box(-1, 1, (act_dim,)),
+                               model_cfgs(activation=activation), epochs, device=DEV)
     if g is not None:
         for net in ('actor', 'reward_critic', 'cost_critic'):
             sd = {k[len(prefix) + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
@@ -580,6 +580,58 @@ def test_chunked_data_parallel_pass_equals_allreduce_semantics(W, M, B, obs_dim,
             assert np.abs(a - b)[bad].max() <= lim, (name, float(np.abs(a - b)[bad].max()))
     st = results[0][1]
     assert np.isfinite(st[:, :10]).all() and (st[:, 3] > 0).all() and (st[:, 7:10] > 0).all()
+
+
+@pytest.mark.parametrize('activation', ['relu', 'sigmoid', 'softplus', 'identity', 'tanh'])
+def test_hidden_activations_vs_oracle(activation):
+    """model_cfgs.*.activation (reference utils/model.py:47-70: identity / relu / sigmoid / softplus / tanh): the
+    per-step kernel family takes the activation code in bits 16-19 of the `hidden` ABI word; the persistent passes
+    are tanh only and decline.  Against the oracle's torch modules built with the same activation: policy step,
+    one whole PolicyGradient._update (2 passes x 4 minibatches incl. a ragged one, injected permutations), the
+    full-batch KL, and the Fisher-vector product (double backward in the oracle, JVP + VJP here)."""
+    from omnisafe_amd.trust_region import TrustRegionSolver
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(7)
+    obs_dim, act_dim, M, B = 24, 3, 230, 64
+    ref = O.ActorCritic(obs_dim, act_dim, activation=activation)
+    ac = make_ac(obs_dim, act_dim, activation=activation)
+    assert ac.hidden == 64 | ({'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}[activation] << 16)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        getattr(ac, net).load_state_dict(getattr(ref, net).state_dict())
+    cpu = {'obs': torch.randn(M, obs_dim) * 1.5, 'act': torch.randn(M, act_dim),
+           'target_value_r': torch.randn(M), 'target_value_c': torch.randn(M), 'adv_r': torch.randn(M),
+           'adv_c': torch.randn(M)}
+    # ---- policy step
+    eps = torch.randn(M, act_dim)
+    a_ref, vr_ref, vc_ref, lp_ref = ref.step(cpu['obs'], eps=eps)
+    a, vr, vc, lp = ac.step(cpu['obs'].to(DEV), eps=eps.to(DEV))
+    for got, want in ((a, a_ref), (vr, vr_ref), (vc, vc_ref), (lp, lp_ref)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+    with torch.no_grad():
+        d = ref.actor.dist(cpu['obs'])
+        cpu['logp'] = d.log_prob(cpu['act']).sum(-1) + 0.3 * torch.randn(M)
+    dev = {k: v.to(DEV) for k, v in cpu.items()}
+    # ---- Fisher-vector product at the initial parameters
+    s = TrustRegionSolver(ac, cg_iters=5, cg_damping=0.1)
+    s.begin(dev['obs'])
+    v = ac.actor.pad(torch.randn(ac.actor.num_params))
+    Fv = ac.actor.unpad(s.fvp(v)).cpu().numpy()
+    Fv_ref = O.fvp(ref.actor, cpu['obs'], ac.actor.unpad(v).cpu(), cg_damping=0.1).numpy()
+    assert np.linalg.norm(Fv - Fv_ref) / np.linalg.norm(Fv_ref) < 2e-3
+    # ---- one whole update
+    perms = [torch.randperm(M) for _ in range(2)]
+    lam = 0.4
+    ref_out = O.ppolag_update(ref, cpu, lam, perms, batch_size=B, update_iters=2, kl_early_stop=False)
+    up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False)
+    out = up.run(dev, torch.tensor([lam], device=DEV), perms=perms, actor_lr=3e-4, critic_lr=3e-4)
+    assert up.last_path == ('persistent' if activation == 'tanh' else 'per-step')
+    assert out['steps'] == 8
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        want = getattr(ref, net).state_dict()
+        for k, t in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=0, atol=6e-6, err_msg=f'{net}/{k}')
+    np.testing.assert_allclose(out['kl'], ref_out['kl'], rtol=5e-3, atol=1e-7)
 
 
 def test_full_size_pass_properties():

@@ -137,3 +137,23 @@ def test_agents_end_to_end(tmp_path, algo_name):
            'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
     ep_ret, ep_cost, ep_len = omnisafe_amd.Agent(algo_name, 'SynthCarGoal1-v0', custom_cfgs=cfg).learn()
     assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
+
+
+@pytest.mark.parametrize('algo_name', ['PPOLag', 'CPO'])
+def test_agents_with_relu_networks(tmp_path, algo_name):
+    """model_cfgs.{actor,critic}.activation = relu through the Agent facade: the update runs on the per-step kernels
+    (the persistent passes are tanh only and decline), rollout / GAE / logging unchanged."""
+    import omnisafe_amd
+
+    cfg = {'seed': 2, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 128 * 32, 'vector_env_nums': 128},
+           'algo_cfgs': {'steps_per_epoch': 128 * 32, 'update_iters': 2},
+           'model_cfgs': {'actor': {'activation': 'relu'}, 'critic': {'activation': 'relu'}},
+           'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo_name, 'SynthCarGoal1-v0', custom_cfgs=cfg)
+    ac = agent.agent._actor_critic
+    assert ac.activation == 'relu' and ac.hidden == 64 | (1 << 16)
+    p0 = ac.params.clone()
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
+    assert agent.agent._updater.last_path == 'per-step'
+    assert torch.isfinite(ac.params).all() and not torch.equal(ac.params, p0)
