@@ -228,8 +228,8 @@ __device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long
     const double up = osa_dpp_f64<CTRL, 0xf>(x);                                                    \
     /* window of this lane before the step: lanes [lane-O+1 .. lane], all inside its row if lr >= O */ \
     const bool open = lr >= (O) && ((resets >> ((lane - (O) + 1) & 63)) & ((1ull << (O)) - 1ull)) == 0ull; \
-    const double m = (open ? (PW) : 0.0) * up;                                                      \
-    x = x + m;                                                                                      \
+    const double m = (PW) * up;  /* (a select below, not a product with 0: NaNs stop at path ends) */ \
+    x = open ? x + m : x;                                                                           \
   }
   OSA_SCAN_ROW_STEP(1, 0x111, p.o1)
   OSA_SCAN_ROW_STEP(2, 0x112, p.o2)
@@ -240,19 +240,19 @@ __device__ __forceinline__ double osa_affine_scan64(double x, unsigned long long
     const double up = osa_dpp_f64<0x142, 0xa>(x);
     const int rs = lane & ~15;
     const bool open = ((lane >> 4) & 1) && ((resets >> rs) & ((2ull << lr) - 1ull)) == 0ull;
-    const double m = (open ? p.row : 0.0) * up;
-    x = x + m;
+    const double m = p.row * up;
+    x = open ? x + m : x;
   }
   {  // rows 2 and 3 take the total of lanes 0..31 (lane 31)
     const double up = osa_dpp_f64<0x143, 0xc>(x);
     const bool open = lane >= 32 && ((resets >> 32) & ((2ull << (lane - 32)) - 1ull)) == 0ull;
-    const double m = (open ? p.half : 0.0) * up;
-    x = x + m;
+    const double m = p.half * up;
+    x = open ? x + m : x;
   }
   {
     const unsigned long long all = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const double m = ((resets & all) == 0ull ? p.all : 0.0) * carry;
-    x = x + m;
+    const double m = p.all * carry;
+    x = (resets & all) == 0ull ? x + m : x;
   }
   return x;
 }
@@ -434,7 +434,9 @@ struct OsaGaeCarry {
   double v[5];  // a_r, a_c, ret, rtg_r, rtg_c
 };
 
-__device__ __forceinline__ bool osa_gc_ready(double x) { return x == x; }  // the sentinel is a NaN
+// "not there yet" = the all-ones pattern the workspace is pre-set to (a NaN no arithmetic produces: genuine NaNs
+// of a diverged run have other payloads, count as values and propagate exactly as in the sequential kernel)
+__device__ __forceinline__ bool osa_gc_ready(double x) { return __double_as_longlong(x) != -1ll; }
 __device__ __forceinline__ void osa_gc_put(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -616,8 +618,10 @@ __global__ __launch_bounds__(64 * OSA_GC_NW) void osa_gae_chain_scan_kernel(
 #pragma unroll
       for (int k = 0; k < 5; ++k)
         if ((KMASK >> k) & 1) {
-          const double m = (ow ? p16[k] : 0.0) * lagg[k];
-          lagg[k] = s_agg[w][k][lane] + m;
+          // (a select, not a product with 0: a NaN behind a path end must stop there, as in the sequential kernel)
+          const double m = p16[k] * lagg[k];
+          const double av = s_agg[w][k][lane];
+          lagg[k] = ow ? av + m : av;
         }
       lopen = lopen && ow;
     }
@@ -638,12 +642,12 @@ __global__ __launch_bounds__(64 * OSA_GC_NW) void osa_gae_chain_scan_kernel(
       constexpr int K0 = (KMASK & 1) ? 0 : 2;  // a carry every estimator has (polled first)
       // walk to later levels until one has published its inclusive carry (a level with a path end always has)
       int j = lev - 1;
-      for (;;) {
+      for (int spins = 0; spins < (1 << 22); ++spins) {  // (bounded: never hang the device; the waits below are too)
         const double* lv = ws + ((long)j * nlevslots) * N + nc;
         double vi = osa_gc_get(lv + (long)(5 + K0) * N);
         if (osa_gc_ready(vi)) break;
         const double va = osa_gc_get(lv + (long)K0 * N);
-        if (osa_gc_ready(va)) { --j; continue; }  // open level, aggregate there: look further (j >= 0: level 0 publishes incl)
+        if (osa_gc_ready(va) && j > 0) { --j; continue; }  // open level, aggregate there: look further (level 0 always publishes incl)
         __builtin_amdgcn_s_sleep(1);
       }
       {  // inclusive carry of level j, then fold the aggregates of levels j + 1 .. lev - 1 back in, in level order
@@ -683,8 +687,9 @@ __global__ __launch_bounds__(64 * OSA_GC_NW) void osa_gae_chain_scan_kernel(
 #pragma unroll
     for (int k = 0; k < 5; ++k)
       if ((KMASK >> k) & 1) {
-        const double m = (ow ? p16[k] : 0.0) * cy.v[k];
-        cy.v[k] = s_agg[w][k][lane] + m;
+        const double m = p16[k] * cy.v[k];
+        const double av = s_agg[w][k][lane];
+        cy.v[k] = ow ? av + m : av;
       }
   }
   if (!live || nsteps == 0) return;

@@ -192,6 +192,30 @@ def test_chained_scan_equals_lane_per_env_kernel(est, T, N, pc, p_end):
     assert same / total > 0.9999, same / total
 
 
+def test_parallel_scans_propagate_nan_like_the_sequential_kernel():
+    """A NaN reward (a diverged run) must neither hang the look-back -- carries are "not there yet" only while they hold
+    the all-ones sentinel, any other NaN is a value -- nor spread differently from the sequential kernel: the same
+    elements become NaN (the env's earlier steps up to its previous path end), everything else is unchanged."""
+    rng = np.random.default_rng(3)
+    T, N = 700, 70
+    g_in, pe, br, bc = _random_case(rng, T, N, p_end=0.002)
+    g_in['reward'][400, 5] = np.nan
+    g_in['cost'][650, 69] = np.nan
+    outs = {}
+    for variant in ('sequential', 'chained', 'tiled'):
+        buf = _mk(T, N, 3, 2, 'gae', 0.0, lam_c=0.9, variant=variant)
+        _load_case(buf, g_in, pe, br, bc)
+        buf.compute_advantages()
+        torch.cuda.synchronize()
+        outs[variant] = {k: buf.data[k].cpu().numpy().copy() for k in OUT_KEYS}
+    for variant in ('chained', 'tiled'):
+        for k in OUT_KEYS:
+            a, b = outs[variant][k], outs['sequential'][k]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (variant, k)
+            np.testing.assert_allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=1e-5, atol=1e-6, err_msg=k)
+    assert np.isnan(outs['sequential']['adv_r'][:401, 5]).any() and not np.isnan(outs['sequential']['adv_r'][401:, 5]).any()
+
+
 def test_chained_scan_vs_reference_golden(golden):
     """The chained kernel against the reference's own outputs (tests/golden/buffer.npz) for the three estimators it
     implements, with and without the cost penalty; v-trace falls back to the lane-per-env kernel."""
