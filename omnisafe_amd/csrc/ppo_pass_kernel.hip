@@ -1810,7 +1810,7 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
 }
 
 // Uncached exchange buffers handed out by osa_dp_exchange_alloc (base, bytes)
-static const int OSA_MAX_XCH = 16;
+static const int OSA_MAX_XCH = 1024;  // (uncached buffers alive at once: one or two per updater; Python frees them when the updater is collected)
 static char* g_xch_base[OSA_MAX_XCH];
 static size_t g_xch_bytes[OSA_MAX_XCH];
 

@@ -47,4 +47,4 @@ for obs_dim, act_dim, B, critics_only in ((72, 2, 128, True), (27, 8, 128, True)
         res[tag] = round(us, 2)
         print(f'{tag:60s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2_chunked_pass_timing.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r3_chunked_pass_timing.json'), 'w'), indent=1)

@@ -59,4 +59,4 @@ for obs_dim, act_dim in ((376, 17), (128, 6), (512, 32), (90, 17), (200, 8)):
         res[f'{obs_dim}/{act_dim} {tag}'] = round(us, 2)
         print(f'{obs_dim}/{act_dim}: {tag:32s} {us:8.2f} us per optimiser step ({out["steps"]} steps)', flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2_wide_pass_timing.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r3_wide_pass_timing.json'), 'w'), indent=1)
