@@ -5,7 +5,6 @@
 // independent networks of ConstraintActorCritic run concurrently in one launch.
 #include "mlp_device.h"
 
-#define OSA_SLD 68  // LDS leading dimension (floats) of the [feature][sample] transposed tiles
 #define OSA_NSTAT 16
 
 struct OsaHp {  // mirrors osa_ppo_hparams in include/omnisafe_amd.h
@@ -243,9 +242,14 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
   if (threadIdx.x == 0) a.adam_step[net] = step;
 }
 
-template <int HT, int OT>
+// HT = hidden width / 16 (2, 4, 8, 16: hidden_sizes [32, 32] ... [256, 256]); NSB = 16-sample blocks per chunk: 4 (64
+// samples, one per lane of the four waves' S layout) while the four [H][SPC + 4] tiles fit the LDS, 2 at width 256
+// (32 samples: waves 2, 3 idle through forward / backward, all four waves share the weight-gradient tiles).
+template <int HT, int OT, int NSB>
 __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int SPC = 16 * NSB;   // samples per chunk
+  constexpr int OSA_SLD = SPC + 4;  // LDS leading dimension (floats) of the [feature][sample] transposed tiles
   const OsaNet& nd = a.nd;
   const int net = blockIdx.y;
   if (!((a.nets_mask >> net) & 1)) return;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
   float* sDO = sZ2 + H * OSA_SLD;                     // [OUTP][SLD]  dL/d(output)
   float* sDL = sDO + OUTP * OSA_SLD;                  // [OUTP][SLD]  per-sample dL/d(log_std)
   float* red = sDL + OUTP * OSA_SLD;                  // [32]
-  long* sIdx = reinterpret_cast<long*>(red + 32);     // [64] sample row or -1
+  long* sIdx = reinterpret_cast<long*>(red + 32);     // [SPC] sample row or -1
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int i = j;  // the same lane bits index weight rows (A operand) and samples (B operand)
@@ -271,14 +275,15 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
 
   OSA_TICK(0);
   float loss_acc = 0.f, ratio_acc = 0.f;  // per-lane partial sums over this block's chunks
-  const int nchunk = (a.B + 63) / 64;
+  const int nchunk = (a.B + SPC - 1) / SPC;
+  const bool active = wave < NSB;  // this wave holds 16 samples of the chunk (S layout)
   bool first = true;
   for (int chunk = blockIdx.x; chunk < nchunk; chunk += a.nblk, first = false) {
-    const int pos = chunk * 64 + 16 * wave + j;
-    const bool valid = pos < a.B;
+    const int pos = chunk * SPC + 16 * wave + j;
+    const bool valid = active && pos < a.B;
     const long row = valid ? (a.idx ? a.idx[pos] : (long)pos) : -1;
     __syncthreads();  // previous chunk's LDS fully consumed
-    if (g == 0) sIdx[16 * wave + j] = row;
+    if (g == 0 && active) sIdx[16 * wave + j] = row;
 
     f32x4 h1[HT], h2[HT], out[OT];
     osa_mlp_forward<HT, OT>(nd, p, valid ? a.obs + row * a.ld_obs : nullptr, a.ld_obs, vec_ok, h1, h2,
@@ -513,44 +518,50 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
     OSA_TICK(3);
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f*SLD + c]
     const int c = 16 * wave + j;
+    if (active) {
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
+      for (int t = 0; t < HT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 16 * t + 4 * g + r;
-        sH1[f * OSA_SLD + c] = h1[t][r];
-        sH2[f * OSA_SLD + c] = h2[t][r];
-        sZ1[f * OSA_SLD + c] = z1[t][r];
-        sZ2[f * OSA_SLD + c] = z2[t][r];
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          sH1[f * OSA_SLD + c] = h1[t][r];
+          sH2[f * OSA_SLD + c] = h2[t][r];
+          sZ1[f * OSA_SLD + c] = z1[t][r];
+          sZ2[f * OSA_SLD + c] = z2[t][r];
+        }
       }
-    }
 #pragma unroll
-    for (int o = 0; o < OT; ++o) {
+      for (int o = 0; o < OT; ++o) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 16 * o + 4 * g + r;
-        sDO[f * OSA_SLD + c] = dO[o][r];
-        sDL[f * OSA_SLD + c] = dLS[o][r];
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * o + 4 * g + r;
+          sDO[f * OSA_SLD + c] = dO[o][r];
+          sDL[f * OSA_SLD + c] = dLS[o][r];
+        }
       }
     }
     __syncthreads();
     OSA_TICK(4);
-    // ---- weight gradients: contraction over the 64 samples of the chunk.
-    // D tile: lane (cc = l&15, g) holds dW[row 4g + r][col cc].
+    // ---- weight gradients: contraction over the SPC samples of the chunk.
+    // D tile: lane (cc = l&15, g) holds dW[row 4g + r][col cc].  Wave w takes the row tiles w, w + 4, ...
     const int cc = j;
-    {  // dW2 row-tile `wave`, all HT column tiles;  dW1 row-tile `wave`, all KB column tiles
-      f32x4 a2[4], a1[4];
+    {
+      // this lane's sample rows (constant over the row tiles and K blocks)
+      long rows[4 * NSB];
 #pragma unroll
-      for (int sb = 0; sb < 4; ++sb) {
-        a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
-        a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
-      }
-      if (wave < HT) {
+      for (int q = 0; q < 4 * NSB; ++q) rows[q] = sIdx[16 * (q >> 2) + 4 * g + (q & 3)];
+      for (int rt = wave; rt < HT; rt += 4) {  // dW2 row-tile rt, all HT column tiles;  dW1 row-tile rt, all KB column tiles
+        f32x4 a2[NSB], a1[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+          a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * rt + i) * OSA_SLD + 16 * sb + 4 * g);
+          a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * rt + i) * OSA_SLD + 16 * sb + 4 * g);
+        }
 #pragma unroll
         for (int ti = 0; ti < HT; ++ti) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int sb = 0; sb < 4; ++sb) {
+          for (int sb = 0; sb < NSB; ++sb) {
             const f32x4 b =
                 *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * OSA_SLD + 16 * sb + 4 * g);
             acc = OSA_MFMA(a2[sb].x, b.x, acc);
@@ -560,57 +571,53 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* dst = gout + nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
+            float* dst = gout + nd.oW2 + (16 * rt + 4 * g + r) * H + 16 * ti + cc;
             *dst = first ? acc[r] : *dst + acc[r];
           }
         }
-        // this lane's 16 sample rows (constant over the K blocks); the 16 gathered x values of block kb+1
-        // are requested before the MFMAs of block kb issue
-        long rows[16];
+        // the gathered x values of block kb+1 are requested before the MFMAs of block kb issue
+        float xq[4 * NSB], xnq[4 * NSB];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) rows[q] = sIdx[16 * (q >> 2) + 4 * g + (q & 3)];
-        float xq[16], xnq[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int q = 0; q < 4 * NSB; ++q)
           xnq[q] = (rows[q] >= 0 && cc < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + cc] : 0.f;
         for (int kb = 0; kb < nd.KB; ++kb) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const int col = 16 * kb + cc;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) xq[q] = xnq[q];
+          for (int q = 0; q < 4 * NSB; ++q) xq[q] = xnq[q];
           if (kb + 1 < nd.KB) {
             const int coln = col + 16;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < 4 * NSB; ++q)
               xnq[q] = (rows[q] >= 0 && coln < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + coln] : 0.f;
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int sb = 0; sb < 4; ++sb) {
+          for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)  // B[k = sample 16sb+4g+s][j = input feature col]
               acc = OSA_MFMA(a1[sb][s], xq[4 * sb + s], acc);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* dst = gout + nd.oW1 + (long)(16 * wave + 4 * g + r) * INP + col;
+            float* dst = gout + nd.oW1 + (long)(16 * rt + 4 * g + r) * INP + col;
             *dst = first ? acc[r] : *dst + acc[r];
           }
         }
       }
     }
     OSA_TICK(5);
-    // dW3: output tiles o x column tile `wave`
-    if (wave < HT) {
+    // dW3: output tiles o x column tiles wave, wave + 4, ...
+    for (int ct = wave; ct < HT; ct += 4) {
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
+        for (int sb = 0; sb < NSB; ++sb) {
           const f32x4 av =
               *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * OSA_SLD + 16 * sb + 4 * g);
           const f32x4 b =
-              *reinterpret_cast<const f32x4*>(sH2 + (16 * wave + i) * OSA_SLD + 16 * sb + 4 * g);
+              *reinterpret_cast<const f32x4*>(sH2 + (16 * ct + i) * OSA_SLD + 16 * sb + 4 * g);
           acc = OSA_MFMA(av.x, b.x, acc);
           acc = OSA_MFMA(av.y, b.y, acc);
           acc = OSA_MFMA(av.z, b.z, acc);
@@ -618,17 +625,16 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float* dst = gout + nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
+          float* dst = gout + nd.oW3 + (16 * o + 4 * g + r) * H + 16 * ct + cc;
           *dst = first ? acc[r] : *dst + acc[r];
         }
       }
     }
     OSA_TICK(6);
     // bias / log_std gradients: one thread per feature sums its LDS row over the 64 samples
-    {
-      const int tid = threadIdx.x;
-      const float* srow = nullptr;
-      float* dst = nullptr;
+    for (int tid = threadIdx.x; tid < 2 * H + 2 * OUTP; tid += blockDim.x) {
+      const float* srow;
+      float* dst;
       if (tid < H) {
         srow = sZ1 + tid * OSA_SLD;
         dst = gout + nd.ob1 + tid;
@@ -638,16 +644,14 @@ __global__ __launch_bounds__(256) void osa_mb_grad_kernel(OsaMbArgs a) {
       } else if (tid < 2 * H + OUTP) {
         srow = sDO + (tid - 2 * H) * OSA_SLD;
         dst = gout + nd.ob3 + (tid - 2 * H);
-      } else if (tid < 2 * H + 2 * OUTP) {
+      } else {
         srow = sDL + (tid - 2 * H - OUTP) * OSA_SLD;
         dst = gout + nd.oLS + (tid - 2 * H - OUTP);
       }
-      if (dst) {
-        float s = 0.f;
+      float s = 0.f;
 #pragma unroll 16
-        for (int k = 0; k < 64; ++k) s += srow[k];
-        *dst = first ? s : *dst + s;
-      }
+      for (int k = 0; k < SPC; ++k) s += srow[k];
+      *dst = first ? s : *dst + s;
     }
   }  // chunks
   // ---- block-level loss statistics (deterministic order)
