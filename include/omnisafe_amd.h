@@ -138,11 +138,12 @@ int osa_buffer_get(int T, int N, int obs_dim, int act_dim,
  * omnisafe/models/actor_critic/{actor_critic,constraint_actor_critic}.py on this path)
  *
  * Three MLPs obs_dim -> H -> H -> {act_dim | 1 | 1} (omnisafe/utils/model.py:73-111).  The `hidden` argument of
- * every entry point carries the width H in its low 16 bits (64 = hidden_sizes [64, 64], every on-policy YAML
- * default; other widths: OSA_EUNSUPPORTED) and the hidden activation in bits 16-19 (model_cfgs.*.activation,
+ * every entry point carries the width H in its low 16 bits (hidden_sizes [H, H]: 64 = every on-policy YAML
+ * default; 32, 128 and 256 on the per-step entry points; anything else: OSA_EUNSUPPORTED) and the hidden
+ * activation in bits 16-19 (model_cfgs.*.activation,
  * utils/model.py:47-70): 0 tanh (default: `hidden = 64`), 1 relu, 2 sigmoid, 3 softplus, 4 identity.  The per-step
  * entry points (policy step, minibatch, KL, evaluation, Fisher-vector product) implement all five; the persistent
- * passes (osa_ppo_pass / _wide_ / _split_ / _dp_ / _chunked_) are tanh only and report 0 from their *_supported
+ * passes (osa_ppo_pass / _wide_ / _split_ / _dp_ / _chunked_) are 64-wide tanh only and report 0 from their *_supported
  * probes for anything else, which routes the update to the per-step entry points.  Each network's parameters, Adam moments and
  * gradients live in one PADDED float32 block of P floats described by osa_mlp_layout:
  *   W1 [H][INP] | b1 [H] | W2 [H][H] | b2 [H] | W3 [OUTP][H] | b3 [OUTP] | log_std [OUTP]

@@ -1129,23 +1129,32 @@ __global__ __launch_bounds__(1024) void osa_vec_dot_kernel(int n, const float* _
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// samples per chunk of osa_mb_grad_kernel: 64 while its four [H][SPC + 4] tiles fit the LDS, 32 at width 256
+static int osa_mb_spc(const OsaNet& nd) { return nd.H > 128 ? 32 : 64; }
 static size_t osa_mb_lds_bytes(const OsaNet& nd) {
-  return (size_t)(4 * nd.H + 2 * nd.OUTP) * OSA_SLD * sizeof(float) + 32 * sizeof(float) +
-         64 * sizeof(long);
+  const int spc = osa_mb_spc(nd);
+  return (size_t)(4 * nd.H + 2 * nd.OUTP) * (spc + 4) * sizeof(float) + 32 * sizeof(float) + (size_t)spc * sizeof(long);
 }
 
 static int osa_check_dims(int obs_dim, int act_dim, int hidden) {
   if (obs_dim < 1 || act_dim < 1) return OSA_EINVAL;
-  if ((hidden & 0xFFFF) != 64) return OSA_EUNSUPPORTED;   // hidden_sizes [64, 64] (all BASELINE configs)
+  // hidden_sizes [H, H]: 64 (all BASELINE configs; the persistent passes), and 32 / 128 / 256 on this per-step family
+  const int H_ = hidden & 0xFFFF;
+  if (H_ != 32 && H_ != 64 && H_ != 128 && H_ != 256) return OSA_EUNSUPPORTED;
   if ((hidden >> 16) > OSA_ACT_IDENTITY) return OSA_EUNSUPPORTED;  // activation code (mlp_device.h)
   if (act_dim > 32) return OSA_EUNSUPPORTED;
   return OSA_OK;
 }
 
-#define OSA_DISPATCH_OT(nd, CALL)            \
-  do {                                       \
-    if ((nd).OUTP == 16) { CALL(4, 1); }     \
-    else { CALL(4, 2); }                     \
+// CALL(HT, OT, NSB): hidden tiles, output tiles, 16-sample blocks per chunk of osa_mb_grad_kernel (ignored by the
+// forward-only kernels)
+#define OSA_DISPATCH_OT(nd, CALL)                                   \
+  do {                                                              \
+    const int ot_ = (nd).OUTP == 16 ? 1 : 2;                        \
+    if ((nd).H == 64) { if (ot_ == 1) { CALL(4, 1, 4); } else { CALL(4, 2, 4); } }          \
+    else if ((nd).H == 128) { if (ot_ == 1) { CALL(8, 1, 4); } else { CALL(8, 2, 4); } }    \
+    else if ((nd).H == 256) { if (ot_ == 1) { CALL(16, 1, 2); } else { CALL(16, 2, 2); } }  \
+    else { if (ot_ == 1) { CALL(2, 1, 4); } else { CALL(2, 2, 4); } }                       \
   } while (0)
 
 static long long* g_osa_dbg_clocks = nullptr;
@@ -1178,7 +1187,7 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
   OSA_REQUIRE(!act || ld_act >= act_dim);
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
   const dim3 grid((N + 63) / 64, 3);
-#define OSA_CALL(HT, OT)                                                                          \
+#define OSA_CALL(HT, OT, NSB)                                                                          \
   hipLaunchKernelGGL((osa_policy_step_kernel<HT, OT>), grid, dim3(256), 0, osa_stream(stream), nd, \
                      params, obs, ld_obs, N, eps, seed, offset, offset_base, deterministic, nets_mask, act, \
                      ld_act, value_r, value_c, logp, mean_out, ld_mean)
@@ -1247,7 +1256,10 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3);
   a.dbg = g_osa_dbg_clocks;
   a.vec = nullptr; a.fvp_scale = 0.f;
-  const int nchunk = (B + 63) / 64;
+  const int spc = osa_mb_spc(a.nd);
+  // (the minibatch-level quantities of P3O / FOCOPS need the whole minibatch in ONE chunk: 32 rows at width 256)
+  if (ext && (ext->cost_kappa > 0.f || ext->kl_mask_eta >= 0.f) && B > spc) return OSA_EUNSUPPORTED;
+  const int nchunk = (B + spc - 1) / spc;
   int nblk = nchunk;
   if (max_blocks < 1) max_blocks = 1;
   if (nblk > max_blocks) nblk = max_blocks;
@@ -1289,17 +1301,17 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
     }
   }
   const size_t lds = osa_mb_lds_bytes(a.nd);
-#define OSA_CALL(HT, OT)                                                                          \
+#define OSA_CALL(HT, OT, NSB)                                                                          \
   do {                                                                                            \
     static bool attr_set = false;                                                                 \
     if (!attr_set) {                                                                              \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT>),         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT, NSB>),         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=    \
           hipSuccess)                                                                             \
         return OSA_EHIP;                                                                          \
       attr_set = true;                                                                            \
     }                                                                                             \
-    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT>), dim3(nblk, 3), dim3(256), lds,               \
+    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT, NSB>), dim3(nblk, 3), dim3(256), lds,               \
                        osa_stream(stream), a);                                                    \
   } while (0)
   OSA_DISPATCH_OT(a.nd, OSA_CALL);
@@ -1344,19 +1356,20 @@ int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float
   a.vec = vec; a.fvp_scale = (float)(1.0 / ((double)M * act_dim));
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.hp.use_cost = 1;
-  const int nchunk = (int)((M + 63) / 64);
+  const int spc = osa_mb_spc(a.nd);
+  const int nchunk = (int)((M + spc - 1) / spc);
   int nblk = nchunk;
   if (max_blocks < 1) max_blocks = 1;
   if (nblk > max_blocks) nblk = max_blocks;
   a.nblk = nblk; a.slabs = ws;
   const size_t lds = osa_mb_lds_bytes(a.nd);
-#define OSA_CALL(HT, OT)                                                                          \
+#define OSA_CALL(HT, OT, NSB)                                                                          \
   do {                                                                                            \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT>),           \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT, NSB>),           \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=      \
         hipSuccess)                                                                               \
       return OSA_EHIP;                                                                            \
-    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT>), dim3(nblk, 1), dim3(256), lds,               \
+    hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT, NSB>), dim3(nblk, 1), dim3(256), lds,               \
                        osa_stream(stream), a);                                                    \
   } while (0)
   OSA_DISPATCH_OT(a.nd, OSA_CALL);
@@ -1422,7 +1435,7 @@ int osa_actor_eval(int obs_dim, int act_dim, int hidden, const float* actor_para
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
   long nb = (M + 63) / 64;
   if (nb > 1024) nb = 1024;
-#define OSA_CALL(HT, OT)                                                                          \
+#define OSA_CALL(HT, OT, NSB)                                                                          \
   hipLaunchKernelGGL((osa_actor_eval_kernel<HT, OT>), dim3((unsigned)nb), dim3(256), 0,           \
                      osa_stream(stream), nd, actor_params, obs, ld_obs, M, act, ld_act, logp,     \
                      adv_r, adv_c, lagrange, old_mean, ld_old, old_log_std, ws)
@@ -1445,7 +1458,7 @@ int osa_actor_kl(int obs_dim, int act_dim, int hidden, const float* actor_params
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
   long nb = (M + 63) / 64;
   if (nb > 1024) nb = 1024;
-#define OSA_CALL(HT, OT)                                                                          \
+#define OSA_CALL(HT, OT, NSB)                                                                          \
   hipLaunchKernelGGL((osa_actor_kl_kernel<HT, OT>), dim3((unsigned)nb), dim3(256), 0,             \
                      osa_stream(stream), nd, actor_params, obs, ld_obs, M, old_mean, ld_old,      \
                      old_log_std, mean_out, ld_mean, ws)

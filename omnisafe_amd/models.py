@@ -202,9 +202,9 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
             raise NotImplementedError('only actor_type gaussian_learning is on the accelerated path')
         self.activation = model_cfgs.actor.activation
         self.width = int(a_h[0])
-        if self.width != 64:
-            raise NotImplementedError(f'hidden_sizes {a_h}: the kernels implement 64 x 64 (every on-policy YAML '
-                                      'default); see DESIGN.md 7')
+        if self.width not in (32, 64, 128, 256):
+            raise NotImplementedError(f'hidden_sizes {a_h}: the kernels implement [H, H] with H in 32, 64, 128, 256 '
+                                      '(64 = every on-policy YAML default, the only width of the persistent passes)')
         self.hidden = self.width | (ACTIVATIONS[self.activation] << 16)  # what the C ABI calls `hidden`
         self._lib = _lib.load(require_gpu=True)  # (after the configuration checks: those need no GPU)
         self.layout = Layout(self.obs_dim, self.act_dim, self.hidden)

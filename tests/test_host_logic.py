@@ -446,8 +446,8 @@ def test_model_cfgs_activation_and_width_checks():
     ns = types.SimpleNamespace
     from omnisafe_amd.spaces import Box
 
-    for a_act, c_act, hid in (('gelu', 'gelu', [64, 64]), ('relu', 'tanh', [64, 64]), ('tanh', 'tanh', [256, 256]),
-                              ('tanh', 'tanh', [64, 32])):
+    for a_act, c_act, hid in (('gelu', 'gelu', [64, 64]), ('relu', 'tanh', [64, 64]), ('tanh', 'tanh', [96, 96]),
+                              ('tanh', 'tanh', [64, 32]), ('tanh', 'tanh', [64, 64, 64])):
         cfg = ns(actor=ns(hidden_sizes=hid, activation=a_act, lr=3e-4), critic=ns(hidden_sizes=hid, activation=c_act,
                  lr=3e-4), weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
                  linear_lr_decay=True)

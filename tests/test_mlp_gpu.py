@@ -16,20 +16,20 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def model_cfgs(lr=3e-4, activation='tanh'):
+def model_cfgs(lr=3e-4, activation='tanh', width=64):
     ns = types.SimpleNamespace
-    return ns(actor=ns(hidden_sizes=[64, 64], activation=activation, lr=lr),
-              critic=ns(hidden_sizes=[64, 64], activation=activation, lr=lr),
+    return ns(actor=ns(hidden_sizes=[width, width], activation=activation, lr=lr),
+              critic=ns(hidden_sizes=[width, width], activation=activation, lr=lr),
               weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
               linear_lr_decay=True)
 
 
-def make_ac(obs_dim, act_dim, g=None, prefix='', epochs=4, activation='tanh'):
+def make_ac(obs_dim, act_dim, g=None, prefix='', epochs=4, activation='tanh', width=64):
     from omnisafe_amd.models import ConstraintActorCritic
     from omnisafe_amd.spaces import Box
 
     ac = ConstraintActorCritic(Box(-np.inf, np.inf, (obs_dim,)), Box(-1, 1, (act_dim,)),
-                               model_cfgs(activation=activation), epochs, device=DEV)
+                               model_cfgs(activation=activation, width=width), epochs, device=DEV)
     if g is not None:
         for net in ('actor', 'reward_critic', 'cost_critic'):
             sd = {k[len(prefix) + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
@@ -582,11 +582,14 @@ def test_chunked_data_parallel_pass_equals_allreduce_semantics(W, M, B, obs_dim,
     assert np.isfinite(st[:, :10]).all() and (st[:, 3] > 0).all() and (st[:, 7:10] > 0).all()
 
 
-@pytest.mark.parametrize('activation', ['relu', 'sigmoid', 'softplus', 'identity', 'tanh'])
-def test_hidden_activations_vs_oracle(activation):
+@pytest.mark.parametrize('activation,width', [('relu', 64), ('sigmoid', 64), ('softplus', 64), ('identity', 64),
+                                              ('tanh', 64), ('tanh', 128), ('relu', 256), ('tanh', 256),
+                                              ('relu', 32), ('softplus', 128)])
+def test_hidden_activations_and_widths_vs_oracle(activation, width):
     """model_cfgs.*.activation (reference utils/model.py:47-70: identity / relu / sigmoid / softplus / tanh): the
-    per-step kernel family takes the activation code in bits 16-19 of the `hidden` ABI word; the persistent passes
-    are tanh only and decline.  Against the oracle's torch modules built with the same activation: policy step,
+    per-step kernel family takes the activation code in bits 16-19 of the `hidden` ABI word and hidden_sizes [H, H]
+    with H in 32 / 64 / 128 / 256 (256: 32-sample chunks, the four [H][36] tiles fill the LDS); the persistent
+    passes are 64-wide tanh only and decline.  Against the oracle's torch modules built alike: policy step,
     one whole PolicyGradient._update (2 passes x 4 minibatches incl. a ragged one, injected permutations), the
     full-batch KL, and the Fisher-vector product (double backward in the oracle, JVP + VJP here)."""
     from omnisafe_amd.trust_region import TrustRegionSolver
@@ -594,9 +597,9 @@ def test_hidden_activations_vs_oracle(activation):
 
     torch.manual_seed(7)
     obs_dim, act_dim, M, B = 24, 3, 230, 64
-    ref = O.ActorCritic(obs_dim, act_dim, activation=activation)
-    ac = make_ac(obs_dim, act_dim, activation=activation)
-    assert ac.hidden == 64 | ({'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}[activation] << 16)
+    ref = O.ActorCritic(obs_dim, act_dim, hidden=(width, width), activation=activation)
+    ac = make_ac(obs_dim, act_dim, activation=activation, width=width)
+    assert ac.hidden == width | ({'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}[activation] << 16)
     for net in ('actor', 'reward_critic', 'cost_critic'):
         getattr(ac, net).load_state_dict(getattr(ref, net).state_dict())
     cpu = {'obs': torch.randn(M, obs_dim) * 1.5, 'act': torch.randn(M, act_dim),
@@ -625,7 +628,7 @@ def test_hidden_activations_vs_oracle(activation):
     ref_out = O.ppolag_update(ref, cpu, lam, perms, batch_size=B, update_iters=2, kl_early_stop=False)
     up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False)
     out = up.run(dev, torch.tensor([lam], device=DEV), perms=perms, actor_lr=3e-4, critic_lr=3e-4)
-    assert up.last_path == ('persistent' if activation == 'tanh' else 'per-step')
+    assert up.last_path == ('persistent' if (activation == 'tanh' and width == 64) else 'per-step')
     assert out['steps'] == 8
     for net in ('actor', 'reward_critic', 'cost_critic'):
         want = getattr(ref, net).state_dict()

@@ -139,19 +139,22 @@ def test_agents_end_to_end(tmp_path, algo_name):
     assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
 
 
-@pytest.mark.parametrize('algo_name', ['PPOLag', 'CPO'])
-def test_agents_with_relu_networks(tmp_path, algo_name):
-    """model_cfgs.{actor,critic}.activation = relu through the Agent facade: the update runs on the per-step kernels
-    (the persistent passes are tanh only and decline), rollout / GAE / logging unchanged."""
+@pytest.mark.parametrize('algo_name,width', [('PPOLag', 64), ('CPO', 64), ('PPOLag', 256), ('TRPOLag', 128)])
+def test_agents_with_relu_networks(tmp_path, algo_name, width):
+    """model_cfgs.{actor,critic}.{activation = relu, hidden_sizes = [H, H]} through the Agent facade (the reference's
+    efficiency table has a 1024 x 1024 row, docs/source/start/efficiency.rst:23; its YAMLs use 64 x 64 tanh): the
+    update runs on the per-step kernels (the persistent passes are 64-wide tanh only and decline), rollout / GAE /
+    trust-region machinery / logging unchanged."""
     import omnisafe_amd
 
     cfg = {'seed': 2, 'train_cfgs': {'device': DEV, 'total_steps': 2 * 128 * 32, 'vector_env_nums': 128},
            'algo_cfgs': {'steps_per_epoch': 128 * 32, 'update_iters': 2},
-           'model_cfgs': {'actor': {'activation': 'relu'}, 'critic': {'activation': 'relu'}},
+           'model_cfgs': {'actor': {'activation': 'relu', 'hidden_sizes': [width, width]},
+                          'critic': {'activation': 'relu', 'hidden_sizes': [width, width]}},
            'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}, 'env_cfgs': {'horizon': 16, 'cost_p': 0.3}}
     agent = omnisafe_amd.Agent(algo_name, 'SynthCarGoal1-v0', custom_cfgs=cfg)
     ac = agent.agent._actor_critic
-    assert ac.activation == 'relu' and ac.hidden == 64 | (1 << 16)
+    assert ac.activation == 'relu' and ac.hidden == width | (1 << 16)
     p0 = ac.params.clone()
     ep_ret, ep_cost, ep_len = agent.learn()
     assert ep_len == 16.0 and 2.0 < ep_cost < 8.0 and np.isfinite(ep_ret)
