@@ -76,6 +76,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     digest = source_digest()
     stamp = os.path.join(LIB_DIR, 'abi_digest.txt')
     digest_changed = not os.path.exists(stamp) or open(stamp).read().strip() != digest
+    cmds = []
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src) + '.o')
         is_info = os.path.basename(src) == ABI_INFO
@@ -83,14 +84,23 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 os.path.getmtime(src),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))),
                 *(os.path.getmtime(h) for h in glob.glob(os.path.join(os.path.dirname(PKG), 'include', '*.h')))):
-            cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
-                   '-Wall', '-Wno-unused-function'] + PER_FILE_FLAGS.get(os.path.basename(src), []) + \
-                ([f'-DOSA_ABI_DIGEST="{digest}"'] if is_info else []) + \
-                os.environ.get('OSA_EXTRA_CFLAGS', '').split()
+            cmds.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj,
+                         '-Wall', '-Wno-unused-function'] + PER_FILE_FLAGS.get(os.path.basename(src), []) +
+                        ([f'-DOSA_ABI_DIGEST="{digest}"'] if is_info else []) +
+                        os.environ.get('OSA_EXTRA_CFLAGS', '').split())
+        objs.append(obj)
+    if cmds:
+        # the sources are independent translation units (the two big ones instantiate ~90 persistent-pass and
+        # ~30 per-step kernels: 2-3 minutes each): compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+
+        with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, (os.cpu_count() or 2)))) as ex:
+            list(ex.map(run, cmds))
     cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB_PATH, *objs]
     if verbose:
         print(' '.join(cmd), flush=True)
