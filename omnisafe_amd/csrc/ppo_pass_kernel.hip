@@ -160,7 +160,10 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
   return OSA_PASS_W2T != 0 && (osa_pass_lds_floats(KB, OT) + 64 * PSLD) * 4 <= 160 * 1024;
 }
 
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false>
+// DPS: the gradient-only slab modes (osa_ppo_dp_step's data-parallel gradient step, the large-batch partial
+// gradients) are their own instantiations: carrying them as a runtime branch cost the plain pass 1.3 % (same-box
+// A/B: 9.22 -> 9.10 us per step; 72 slab-store addresses parked in AGPRs for the whole pass)
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -182,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const int net = net_, rk = rk_;
   if (!((a.nets_mask >> net) & 1)) return;
   constexpr bool coop = COOP;
-  const bool dp = a.dp_slabs != nullptr && !coop;
-  const bool part = MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
+  const bool dp = DPS && a.dp_slabs != nullptr && !coop;
+  const bool part = DPS && MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
   const bool chunked = COOP && a.dp_chunk != 0;
   // chunk mode under data parallelism: peer rk = rank * cw + chunk (cw chunk workgroups per rank)
   // (HIER: its own instantiation, so that the plain chunk / data-parallel kernels keep their register allocation)
@@ -1562,14 +1565,15 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false>
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false,
+          bool DPS = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1584,7 +1588,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1593,14 +1597,14 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1797,7 +1801,8 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   int rc = OSA_EUNSUPPORTED;
 #define OSA_DP_CASE(K, O)                                                                        \
   if (KB == K && OT == O)                                                                        \
-    rc = (B > 64) ? osa_launch_pass<K, O, true>(a, st, world) : osa_launch_pass<K, O, false>(a, st, world)
+    rc = (B > 64) ? osa_launch_pass<K, O, true, false, false, false, false, true>(a, st, world)  \
+                  : osa_launch_pass<K, O, false, false, false, false, false, true>(a, st, world)
   OSA_DP_CASE(1, 1); OSA_DP_CASE(2, 1); OSA_DP_CASE(3, 1); OSA_DP_CASE(4, 1); OSA_DP_CASE(5, 1);
   OSA_DP_CASE(6, 1); OSA_DP_CASE(1, 2); OSA_DP_CASE(2, 2); OSA_DP_CASE(3, 2); OSA_DP_CASE(4, 2);
   OSA_DP_CASE(5, 2); OSA_DP_CASE(6, 2);
@@ -2020,7 +2025,7 @@ int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, c
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PG_CASE(K, O) \
-  if (KB == K && OT == O) return osa_launch_pass<K, O, true>(a, st, nblk)
+  if (KB == K && OT == O) return osa_launch_pass<K, O, true, false, false, false, false, true>(a, st, nblk)
   OSA_PG_CASE(1, 1); OSA_PG_CASE(2, 1); OSA_PG_CASE(3, 1); OSA_PG_CASE(4, 1); OSA_PG_CASE(5, 1);
   OSA_PG_CASE(6, 1); OSA_PG_CASE(1, 2); OSA_PG_CASE(2, 2); OSA_PG_CASE(3, 2); OSA_PG_CASE(4, 2);
   OSA_PG_CASE(5, 2); OSA_PG_CASE(6, 2);
