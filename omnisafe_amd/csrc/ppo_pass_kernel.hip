@@ -163,7 +163,12 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // DPS: the gradient-only slab modes (osa_ppo_dp_step's data-parallel gradient step, the large-batch partial
 // gradients) are their own instantiations: carrying them as a runtime branch cost the plain pass 1.3 % (same-box
 // A/B: 9.22 -> 9.10 us per step; 72 slab-store addresses parked in AGPRs for the whole pass)
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false>
+// SO ("small outputs"): EVERY network of the launch has 1-2 outputs (act_dim <= 2: SafetyPointGoal / CarGoal), so
+// the VALU form of the output layer is taken at compile time: the run-time switch stood in front of every one of
+// the 8 output-layer groups of the unrolled forward loop and in the backward / weight-gradient phases -- 16 scheduling
+// barriers in the hottest code (same-box A/B: 9.11 -> 8.87 us per step)
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false,
+          bool SO = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   // its weight gradient run on the VALU -- on gfx950 a float32 MFMA costs the same issue cycles as the
   // equivalent packed VALU math and does not overlap with it, so 48 MFMAs on a 16-wide tile that is 7/8
   // padding are pure waste (block-uniform switch; wider outputs keep the MFMA tiles)
-  const bool small_out = (OT == 1) && out_dim <= 2;
+  const bool small_out = SO || ((OT == 1) && out_dim <= 2);  // (SO: a compile-time `true`)
 
   // ---- load parameters into the LDS master copy (coalesced)
   for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
@@ -1566,14 +1571,14 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 }
 
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false,
-          bool DPS = false>
+          bool DPS = false, bool SO = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1588,7 +1593,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1597,15 +1602,24 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+// the SO instantiation where it applies (one output tile and act_dim <= 2: every network then has 1-2 outputs)
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
+static int osa_launch_pass_so(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
+  if constexpr (OT == 1) {
+    if (a.nd.act_dim <= 2) return osa_launch_pass<KB, OT, MULTI, COOP, EXT, HIER, false, false, true>(a, stream, grid_y);
+  }
+  return osa_launch_pass<KB, OT, MULTI, COOP, EXT, HIER>(a, stream, grid_y);
 }
 
 extern "C" {
@@ -1677,7 +1691,7 @@ int osa_ppo_pass_ext(int obs_dim, int act_dim, int hidden, float* params, float*
       a.ext_kl_coef = ext->kl_coef; a.ext_mask_eta = ext->kl_mask_eta; a.ext_ratio_scale = ext->ratio_scale;
       a.ext_cost_kappa = ext->cost_kappa; a.ext_cost_excess = ext->cost_excess;
 #define OSA_PASS_EXT_CASE(K, O) \
-  if (KB == K && OT == O) return osa_launch_pass<K, O, false, false, true>(a, st)
+  if (KB == K && OT == O) return osa_launch_pass_so<K, O, false, false, true>(a, st)
       OSA_PASS_EXT_CASE(1, 1); OSA_PASS_EXT_CASE(2, 1); OSA_PASS_EXT_CASE(3, 1); OSA_PASS_EXT_CASE(4, 1);
       OSA_PASS_EXT_CASE(5, 1); OSA_PASS_EXT_CASE(6, 1);
       OSA_PASS_EXT_CASE(1, 2); OSA_PASS_EXT_CASE(2, 2); OSA_PASS_EXT_CASE(3, 2); OSA_PASS_EXT_CASE(4, 2);
@@ -1687,7 +1701,7 @@ int osa_ppo_pass_ext(int obs_dim, int act_dim, int hidden, float* params, float*
     }
   }
 #define OSA_PASS_CASE(K, O) \
-  if (KB == K && OT == O) return (B > 64) ? osa_launch_pass<K, O, true>(a, st) : osa_launch_pass<K, O, false>(a, st)
+  if (KB == K && OT == O) return (B > 64) ? osa_launch_pass_so<K, O, true>(a, st) : osa_launch_pass_so<K, O, false>(a, st)
   OSA_PASS_CASE(1, 1); OSA_PASS_CASE(2, 1); OSA_PASS_CASE(3, 1); OSA_PASS_CASE(4, 1);
   OSA_PASS_CASE(5, 1); OSA_PASS_CASE(6, 1);
   OSA_PASS_CASE(1, 2); OSA_PASS_CASE(2, 2); OSA_PASS_CASE(3, 2); OSA_PASS_CASE(4, 2);
@@ -1986,9 +2000,9 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
     return slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
-           : (chunk && ranks > 1) ? osa_launch_pass<K, O, false, true, false, true>(a, st, world) \
+           : (chunk && ranks > 1) ? osa_launch_pass_so<K, O, false, true, false, true>(a, st, world) \
            : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \
-                                : osa_launch_pass<K, O, false, true>(a, st, world)
+                                : osa_launch_pass_so<K, O, false, true>(a, st, world)
   OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);
   OSA_DPP_CASE(6, 1); OSA_DPP_CASE(1, 2); OSA_DPP_CASE(2, 2); OSA_DPP_CASE(3, 2); OSA_DPP_CASE(4, 2);
   OSA_DPP_CASE(5, 2); OSA_DPP_CASE(6, 2);
