@@ -167,28 +167,13 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // the VALU form of the output layer is taken at compile time: the run-time switch stood in front of every one of
 // the 8 output-layer groups of the unrolled forward loop and in the backward / weight-gradient phases -- 16 scheduling
 // barriers in the hottest code (same-box A/B: 9.11 -> 8.87 us per step)
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false,
-          bool SO = false>
-__global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
+// NETK: -1 = the network (actor / critic) is a run-time property of the workgroup; 0 / 1 = this body is the
+// actor's / a critic's (OSA_PASS_NET_SPLIT: the kernel then dispatches on its network once, and the loss code, the
+// gathers and the L2 / learning-rate selections lose their block-uniform branches)
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool SLICE, bool DPS, bool SO, int NETK>
+__device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const int net, const int rk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
-  int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
-  if constexpr (!COOP) {
-    if (a.one_xcc) {
-      if (blockIdx.x & 7) return;
-      net_ = blockIdx.x >> 3;
-    }
-  }
-  if constexpr (COOP) {
-    if (a.dp_local == 1) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
-      // (dp_local == 3: test hook -- the one-XCC protocol on the 3 x world grid, so that the placement check trips)
-      net_ = blockIdx.x & 7;
-      rk_ = blockIdx.x >> 3;
-      if (net_ >= 3) return;
-    }
-  }
-  const int net = net_, rk = rk_;
-  if (!((a.nets_mask >> net) & 1)) return;
   constexpr bool coop = COOP;
   const bool dp = DPS && a.dp_slabs != nullptr && !coop;
   const bool part = DPS && MULTI && a.part_stride > 0;  // (only the multi-chunk instantiations have this mode)
@@ -237,7 +222,8 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   float* __restrict__ gp = a.params + (long)net * P;
   float* __restrict__ gm = a.adam_m + (long)net * P;
   float* __restrict__ gv = a.adam_v + (long)net * P;
-  const bool critic = net != 0;
+  const bool critic = NETK < 0 ? net != 0 : NETK != 0;  // (compile-time when NETK >= 0)
+  const bool is_actor = !critic;
   const int out_dim = critic ? 1 : nd.act_dim;
   // 1-2 real outputs (every critic; the actor of the 2-D action spaces): the output layer, its backward and
   // its weight gradient run on the VALU -- on gfx950 a float32 MFMA costs the same issue cycles as the
@@ -317,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const bool l2 = critic && a.hp.use_critic_norm && !part && own_terms;
   const float c2 = 2.f * a.hp.critic_norm_coef;
   float lam = 0.f;
-  if (net == 0 && a.lagrange) lam = *a.lagrange;
+  if (is_actor && a.lagrange) lam = *a.lagrange;
   const float inv_1p_lam = 1.f / (1.f + lam);
   // observation rows are 16-byte aligned with ld % 4 == 0 (checked by the entry points; the host pads
   // other layouts once per update): one code path, no branch inside the forward scheduling region
@@ -376,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     // 32-bit index arithmetic (host guarantees M * ld < 2^31): 64-bit multiplies per load made the
     // prefetch issue itself cost ~1k cycles.  The actor-only loads sit behind a block-uniform branch.
     const int ri = (int)rr;
-    if (net == 0) {
+    if (is_actor) {
       const float* arow = act_p + ri * a.ld_act;
 #pragma unroll
       for (int o = 0; o < OT; ++o)
@@ -487,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     const float step_size = bc_row[0], inv_bc2_sqrt = bc_row[1];
     float gb = 0.f, loss_part = 0.f, ratio_part = 0.f, ent_pre = 0.f;
     float cost_pen = 0.f;  // P3O penalty value of this step (EXT)
-    if (net == 0 && leader) {  // entropy of the pre-update policy (read before any Adam write)
+    if (is_actor && leader) {  // entropy of the pre-update policy (read before any Adam write)
       for (int d = 0; d < nd.act_dim; ++d) ent_pre += 1.41893853320467274178f + sLS[d];
       ent_pre /= (float)nd.act_dim;
     }
@@ -635,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
       dO[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dLS[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (net == 0) {
+    if (is_actor) {
       // Branch-free over the action dimensions (dm = 1 for this lane's real dimensions, 0 for padding): the
       // divergent `if (d < act_dim && valid)` form cost exec-mask juggling on the critical (actor) block.
       float lp = 0.f;
@@ -931,7 +917,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
     }  // chunks
-    if (boff >= 0 && net == 0 && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f && own_terms)
+    if (boff >= 0 && is_actor && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f && own_terms)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
     // ================= + 2*coef*w (critics), squared norms (packed f32 math) =================
     // this lane's parameters: all LDS reads issued up front (one latency for the lot), kept in registers
@@ -1043,7 +1029,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
         slab[P + 0] = t_loss;
         slab[P + 1] = t_ratio;
       } else if (leader) {
-        slab[P + 0] = t_loss * invB - (net == 0 ? a.hp.entropy_coef * ent_pre : 0.f);
+        slab[P + 0] = t_loss * invB - (is_actor ? a.hp.entropy_coef * ent_pre : 0.f);
         slab[P + 1] = t_ratio * invB;
         slab[P + 2] = t_psq;
         slab[P + 3] = total_norm;
@@ -1053,7 +1039,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     }
     float st_loss = t_loss * invB, st_ratio = t_ratio * invB, st_psq = t_psq, st_norm = total_norm,
           st_ent = ent_pre;
-    if (net == 0 && own_terms) st_loss -= a.hp.entropy_coef * ent_pre;
+    if (is_actor && own_terms) st_loss -= a.hp.entropy_coef * ent_pre;
     bool apply_clip = a.hp.use_max_grad_norm != 0;
     if constexpr (coop) {
       // ---- the gradient tiles are on their way (exchange layout: one f32x4 per thread per tile, 1 KB
@@ -1451,7 +1437,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
     // ---- statistics of this optimiser step
     if (leader && rk == 0) {
       float* st = a.stats + (long)(mb - a.mb0) * PNSTAT;
-      if (net == 0) {
+      if (is_actor) {
         st[2] = st_loss;
         st[3] = st_ratio;
         st[4] = st_ent;
@@ -1560,6 +1546,37 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   }
   if (tid == 0) a.adam_step[net] = step0 + a.nmb;
   (void)out_dim;
+}
+
+#ifndef OSA_PASS_NET_SPLIT
+#define OSA_PASS_NET_SPLIT 0
+#endif
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false,
+          bool SO = false>
+__global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
+  int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
+  if constexpr (!COOP) {
+    if (a.one_xcc) {
+      if (blockIdx.x & 7) return;
+      net_ = blockIdx.x >> 3;
+    }
+  }
+  if constexpr (COOP) {
+    if (a.dp_local == 1) {  // one XCC per network: 8 x world blocks, blocks 3..7 (mod 8) have nothing to do
+      // (dp_local == 3: test hook -- the one-XCC protocol on the 3 x world grid, so that the placement check trips)
+      net_ = blockIdx.x & 7;
+      rk_ = blockIdx.x >> 3;
+      if (net_ >= 3) return;
+    }
+  }
+  const int net = net_, rk = rk_;
+  if (!((a.nets_mask >> net) & 1)) return;
+  if constexpr (OSA_PASS_NET_SPLIT != 0 && !MULTI && !COOP && !EXT && !DPS) {  // (the plain 64-row pass: the headline path)
+    if (net == 0) osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, 0>(a, net, rk);
+    else osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, 1>(a, net, rk);
+  } else {
+    osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, -1>(a, net, rk);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
