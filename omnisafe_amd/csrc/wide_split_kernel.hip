@@ -44,8 +44,9 @@
 #define SKQ 6      // K blocks per helper
 // exchange buffer (floats): [128] flag words, then per network SXNET floats
 #define SX_PART 0                          // [SCMAX][4096] partial pre-activations (fragment order)
-#define SX_DZ (SCMAX * 4096)               // [64][64] dz1, row = feature
-#define SX_NORM (SX_DZ + 4096)             // [SCMAX + 1][2] 8-byte words {float share, int step}: |g|^2, |w|^2
+#define SX_DZ (SCMAX * 4096)               // [2 step parity][64][64] dz1, row = feature; words not yet published hold SX_SENT
+#define SX_NORM (SX_DZ + 2 * 4096)         // [SCMAX + 1][2] 8-byte words {float share, int step}: |g|^2, |w|^2
+#define SX_SENT 0xFFFFFFFFu                // "not published": a NaN no arithmetic produces (host memset 0xFF per launch)
 #define SXNET (SX_NORM + 32)
 #define SF_PART 0                          // flag words of a network: [32 net + ..]
 #define SF_DZ 8
@@ -96,9 +97,12 @@ struct OsaSplitArgs {
   // the replicas and they stay bit-identical.
   int world;
   long rank_xch;  // floats between the intra-rank regions of consecutive ranks
-  // cross-rank exchange: [SDPH] header ints (arrival counters [8 net + role], XCC masks [32 + group], placement
-  // arrivals [96]), then [2 parity][3][SCMAX + 1][world][SDPW] slabs
+  // cross-rank exchange: [SDPH] header floats (unused here), then [2 parity][3][SCMAX + 1][world][SDPW] slabs
   float* dpx;
+  // its header: [SDPH] ints (arrival counters [8 net + role], XCC masks [32 + group], placement arrivals [96]) --
+  // ALWAYS in the uncached region, also when the slabs are ordinary memory (dp_place 1): words that are reset by a
+  // memset per launch and then counted up by workgroups on all XCCs have no business in a write-back cache
+  int* dp_hdr;
   // 0: rank-major blocks spread over the XCCs, dpx uncached like xch (every replica then reads the `world` slabs of
   //    its owners from the device-coherent level: world^2 x 25 KB per owner group and step -- 24 MB per step at
   //    376 / 17 and world 8, which is what bounds that variant);
@@ -146,6 +150,11 @@ __device__ __forceinline__ void osa_xch_release() {
 // were observed with small rollouts); an L1 invalidate, no L2 write-back
 __device__ __forceinline__ void osa_xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
+__device__ __forceinline__ unsigned osa_max3u(unsigned a, unsigned b, unsigned c) {
+  unsigned d;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 // 16-byte load that bypasses the vector L1 and is served at the coherence point of the exchange buffer (sc0 sc1);
 // the caller waits for it (s_waitcnt vmcnt) before it uses the value
 __device__ __forceinline__ f32x4 osa_load_bypass4(const float* p) {
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
   float* const xch_r = a.xch + (DP ? (long)rk * a.rank_xch : 0);
   const int W = DP ? a.world : 1;
   // cross-rank exchange of this (network, role): arrival counter + [2 parity][world][SDPW] slabs
-  int* dp_cnt = DP ? reinterpret_cast<int*>(a.dpx) + 8 * net + role : nullptr;
+  int* dp_cnt = DP ? a.dp_hdr + 8 * net + role : nullptr;
   auto dp_slabs = [&](int mb) -> float* {
     return a.dpx + SDPH + ((((long)(mb & 1) * 3 + net) * (SCMAX + 1) + role) * W) * SDPW;
   };
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       // before anything is modified, as above; otherwise everybody returns untouched with the sticky word at 2
       int* s_why = reinterpret_cast<int*>(smem);
       if (tid == 0) {
-        int* hdr = reinterpret_cast<int*>(a.dpx);
+        int* hdr = a.dp_hdr;
         const int G = 3 * (C + 1), gid = net * (C + 1) + role;
         const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_XCC_ID[3:0]
         __hip_atomic_fetch_or(hdr + 32 + gid, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -522,19 +531,28 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
 #pragma unroll
       for (int q = 0; q < SKQ; ++q) wv[q] = *reinterpret_cast<const f32x4*>(sW + own_lds + 16 * q);
       // ---- dz1 of this step
-      // Every lane polls the flag itself and requests ITS four dz1 fragments right behind it (cache-bypassing loads,
-      // returned in issue order): when the flag it read says "published", the data it read after it is the
-      // published data -- one round trip for flag + data instead of flag, barrier, L1 invalidate, data.
+      // The data carries its own readiness: the leader resets the buffer of the OTHER step parity to all-ones words
+      // one step ahead (and the host both buffers before the launch), so a lane polls ITS sixteen words with
+      // cache-bypassing loads until none of them is the sentinel -- one round trip for the hand-off, and nothing
+      // that relies on the order in which two loads are performed.  (Rounds 2-3 polled a flag and requested the
+      // data right behind it in the same trip: loads RETURN in issue order, but the flag and the data live in
+      // different memory channels and the data load can be PERFORMED first -- stale dz1 of an older step in about 1
+      // of 1000 passes at 8 virtual ranks, tools/dp_stress.py.)
       f32x4 a1[4];
       {
-        const float* dz = xn + SX_DZ + (16 * wave + i) * 64 + 4 * g;
+        const float* dz = xn + SX_DZ + (mb & 1) * 4096 + (16 * wave + i) * 64 + 4 * g;
         int spins = 0;
         while (!dead) {
-          const int f = __hip_atomic_load(flags + SF_DZ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
           for (int sb = 0; sb < 4; ++sb) a1[sb] = osa_load_bypass4(dz + 16 * sb);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (f >= mb + 1) break;
+          unsigned m = 0u;
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+            m = osa_max3u(m, __float_as_uint(a1[sb][0]), __float_as_uint(a1[sb][1]));
+            m = osa_max3u(m, __float_as_uint(a1[sb][2]), __float_as_uint(a1[sb][3]));
+          }
+          if (__builtin_amdgcn_ballot_w64(m == SX_SENT) == 0) break;
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 20)) {
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -779,6 +797,15 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     osa_xch_acquire();
     STICK(0);
     {
+      // every helper has sent its partials of this step, i.e. has consumed dz1 of the previous one: its buffer (the
+      // other step parity) goes back to "not published" for the step after this one.  Performed, with the dz1 of
+      // this step, before this workgroup's norm share -- which every helper reads before it polls that buffer.
+      const float sf = __uint_as_float(SX_SENT);
+      f32x4* nx = reinterpret_cast<f32x4*>(xn + SX_DZ + ((mb + 1) & 1) * 4096);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nx[k * 256 + tid] = (f32x4){sf, sf, sf, sf};
+    }
+    {
       // all C x 4 loads in flight together (one round trip to the device-coherent level, not C)
       const f32x4* src = reinterpret_cast<const f32x4*>(xn + SX_PART);
       f32x4 pt[SCMAX][HT];
@@ -937,7 +964,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
       }
     }
     {
-      float* dz = xn + SX_DZ;
+      float* dz = xn + SX_DZ + (mb & 1) * 4096;
       f32x4 wn[HT];  // A[i][k] = W2^T[16t+i][16kb+4g+s]: the next tile's four fragments one tile ahead
 #pragma unroll
       for (int kb = 0; kb < HT; ++kb) wn[kb] = *reinterpret_cast<const f32x4*>(sW2T + i * SSLD + 16 * kb + 4 * g);
@@ -971,8 +998,7 @@ __global__ __launch_bounds__(256, 1) void osa_wide_split_kernel(OsaSplitArgs a) 
     }
     STICK(2);
     osa_xch_release();
-    osa_lds_barrier();  // (A) dz1 performed, tiles complete
-    if (tid == 0) __hip_atomic_store(flags + SF_DZ, mb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    osa_lds_barrier();  // (A) dz1 (and the other buffer's reset) performed, tiles complete
     STICK(3);
     // ================= weight gradients (registers) =================
     f32x4 g2[HT], g3[OT];
@@ -1317,8 +1343,9 @@ int osa_ppo_split_pass(int obs_dim, int act_dim, int hidden, float* params, floa
   // flag words are step counters of THIS launch (the sticky error word, SF_ERR, survives)
   if (hipMemsetAsync(xch, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   if (hipMemsetAsync(reinterpret_cast<int*>(xch) + SF_ARRIVE, 0, sizeof(int), st) != hipSuccess) return OSA_EHIP;
-  for (int n = 0; n < 3; ++n)  // the squared-norm slots carry their own step counters
-    if (hipMemsetAsync(xch + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
+  // data regions: all-ones = "not published" for the dz1 buffers (SX_SENT) and step -1 for the squared-norm slots
+  // (which carry their own step counters)
+  if (hipMemsetAsync(xch + 128, 0xFF, 3 * (size_t)SXNET * sizeof(float), st) != hipSuccess) return OSA_EHIP;
   const int OT = a.nd.OUTP / 16;
   if (OT == 1) return osa_launch_split<1>(a, st);
   if (OT == 2) return osa_launch_split<2>(a, st);
@@ -1369,6 +1396,7 @@ int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, f
   a.world = world;
   a.rank_xch = (long)per_rank;
   a.dpx = dpx ? dpx : xch + (size_t)world * per_rank;
+  a.dp_hdr = reinterpret_cast<int*>(xch + (size_t)world * per_rank);
   a.dp_place = place;
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
   a.obs = obs; a.ld_obs = ld_obs; a.act = act; a.ld_act = ld_act; a.logp = logp;
@@ -1385,10 +1413,9 @@ int osa_ppo_split_dp_pass(int obs_dim, int act_dim, int hidden, float* params, f
   for (int r = 0; r < world; ++r) {
     float* xr = xch + (size_t)r * per_rank;
     if (hipMemsetAsync(xr, 0, SF_ERR * sizeof(int), st) != hipSuccess) return OSA_EHIP;
-    for (int n = 0; n < 3; ++n)
-      if (hipMemsetAsync(xr + 128 + (size_t)n * SXNET + SX_NORM, 0, 32 * sizeof(float), st) != hipSuccess) return OSA_EHIP;
+    if (hipMemsetAsync(xr + 128, 0xFF, 3 * (size_t)SXNET * sizeof(float), st) != hipSuccess) return OSA_EHIP;
   }
-  if (hipMemsetAsync(a.dpx, 0, SDPH * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if (hipMemsetAsync(a.dp_hdr, 0, SDPH * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int OT = a.nd.OUTP / 16;
   if (OT == 1) return osa_launch_split<1, true>(a, st);
   if (OT == 2) return osa_launch_split<2, true>(a, st);

@@ -326,10 +326,15 @@ def test_cabi_error_codes():
     assert lib.osa_vec_dot(0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None) == EINVAL
     assert lib.osa_saute_step(4, None, None, None, None, None, None, 0.999, -1.0, None, None, None, 8, None, 0, 7,
                               None, None, None) == EINVAL
-    # shapes the reference allows but the kernels do not cover: hidden != 64, act_dim > 32, obs too wide for
-    # the persistent kernel
+    # shapes the reference allows but the kernels do not cover: hidden widths other than 32 / 64 / 128 / 256, unknown
+    # activation codes (bits 16-19 of the hidden word), act_dim > 32, obs too wide for the persistent kernel (which
+    # also is 64-wide tanh only)
     out12 = (C.c_int * 12)()
-    assert lib.osa_mlp_layout(60, 2, 128, out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 2, 96, out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 2, 512, out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 2, 64 | (7 << 16), out12) == EUNSUPPORTED
+    assert lib.osa_mlp_layout(60, 2, 128 | (1 << 16), out12) == 0 and out12[10] == 128
+    assert lib.osa_ppo_pass_supported(60, 2, 128) == 0 and lib.osa_ppo_pass_supported(60, 2, 64 | (1 << 16)) == 0
     assert lib.osa_mlp_layout(60, 40, 64, out12) == EUNSUPPORTED
     assert lib.osa_mlp_layout(60, 2, 64, out12) == 0 and out12[0] == 64 and out12[1] == 16
     assert lib.osa_ppo_pass_supported(60, 2, 64) == 1 and lib.osa_ppo_pass_supported(376, 17, 64) == 0

@@ -5,7 +5,7 @@ set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee gpurun_out/r3_final_pytest.log
+timeout 1200 python -m pytest tests -q -m gpu --tb=short --show-capture=no 2>&1 | tail -120 > gpurun_out/r3_final_pytest.log; tail -4 gpurun_out/r3_final_pytest.log
 timeout 600 python bench.py > gpurun_out/r3_bench_final.json 2> gpurun_out/r3_bench_final.err; tail -c 800 gpurun_out/r3_bench_final.json
 OSA_DIST_BACKEND=gloo OSA_SINGLE_DEVICE_RANKS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 2 > gpurun_out/r3_bench_2ranks_on_1gpu.json 2> gpurun_out/r3_bench_2rank.err; tail -c 300 gpurun_out/r3_bench_2ranks_on_1gpu.json
 timeout 900 python tools/baseline_configs.py --no-reference > gpurun_out/r3_baseline_configs.log 2>&1; tail -8 gpurun_out/r3_baseline_configs.log
