@@ -167,6 +167,34 @@ def test_learning_curve_within_one_sigma_of_reference(algo, tmp_path):
         assert ok, rep
 
 
+@pytest.mark.parametrize('algo', ['PPOLag', 'CPO', 'TRPOLag', 'FOCOPS', 'PPOSaute'])
+def test_same_seed_same_parameters_bit_for_bit(algo, tmp_path):
+    """The whole path as a race detector: rollout (graph replays), normaliser, buffer, GAE, every update kernel of the
+    algorithm.  Two trainings with the same seed must end in bit-identical parameters, Adam moments and curves --
+    every reduction on the path has a fixed order (tickets / slabs, no floating-point atomics), so any difference is
+    a race (round 3 found one in the split pass this way: tools/dp_stress.py)."""
+    import omnisafe_amd
+
+    g = json.load(open(GOLDEN))
+    cfg = dict(g['config'], epochs=3)
+    runs = []
+    for rep in range(2):
+        d = tmp_path / f'rep{rep}'
+        agent = omnisafe_amd.Agent(algo, cfg['env_id'], custom_cfgs=reach_custom_cfgs(algo, 7, cfg, str(d)))
+        agent.learn()
+        ac = agent.agent._actor_critic  # noqa: SLF001
+        torch.cuda.synchronize()
+        path = glob.glob(os.path.join(str(d), '*', 'seed-007-*', 'progress.csv'))[0]
+        runs.append((ac.params.clone(), ac.adam_m.clone(), ac.adam_v.clone(), open(path).read().split('\n')))
+    for a, b, name in zip(runs[0][:3], runs[1][:3], ('params', 'adam_m', 'adam_v')):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    # the logged metrics (everything but the wall-clock columns)
+    hdr = runs[0][3][0].split(',')
+    keep = [i for i, h in enumerate(hdr) if not h.startswith('Time/')]
+    for la, lb in zip(runs[0][3][1:], runs[1][3][1:]):
+        assert [la.split(',')[i] for i in keep if la] == [lb.split(',')[i] for i in keep if lb]
+
+
 SIBLINGS = ['PolicyGradient', 'PPO', 'NaturalPG', 'TRPO', 'PDO', 'RCPO', 'CPPOPID', 'TRPOPID', 'PCPO', 'FOCOPS',
             'CUP', 'IPO', 'P3O', 'OnCRPO', 'PPOSaute', 'TRPOSaute', 'PPOSimmerPID', 'TRPOSimmerPID']
 
