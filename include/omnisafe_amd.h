@@ -611,6 +611,14 @@ int osa_actor_eval(int obs_dim, int act_dim, int hidden, const float* actor_para
                    const float* old_mean, int ld_old, const float* old_log_std, double* ws,
                    float* out4, void* stream);
 
+/* The minibatch shuffles of an update: perm[row][0 .. M) = a pseudo-random permutation of 0 .. M-1 per row, one row
+ * per pass (the DataLoader(shuffle=True) the reference iterates in every pass of _update:
+ * algorithms/on_policy/base/policy_gradient.py:357-377, natural_pg.py:196-223 -- torch's RandomSampler = randperm).
+ * No sort: a keyed bijection of [0, 2^k) (24 alternating Feistel steps over the two halves of k = ceil(log2 M) bits,
+ * cycle-walked into [0, M)), element i of row r depends on (row_seeds[r], i) only.  row_seeds: device int64[rows]
+ * (drawn by the host framework's seeded generator); perm: device int64 [rows][M].  M <= 2^40, rows <= 65535. */
+int osa_shuffle_rows(const long long* row_seeds, int rows, long M, long long* perm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_dp_end_pass': (_I, [_P, _I, _I, _P]),
     'osa_ppo_dp_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
     'osa_ppo_dp_pass_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_shuffle_rows': (_I, [_P, _I, _L, _P, _P]),
     'osa_dp_exchange_alloc': (_I, [C.c_size_t, C.POINTER(C.c_void_p)]),
     'osa_dp_exchange_free': (_I, [_P]),
     'osa_ppo_dp_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,

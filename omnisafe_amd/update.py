@@ -165,6 +165,28 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         m = (0b110 if self.hp.use_cost else 0b010) if self.update_critics else 0
         return m | (1 if self.update_actor else 0)
 
+    def shuffles(self, rows: int, M: int, out: torch.Tensor | None = None,
+                 generator: torch.Generator | None = None) -> torch.Tensor:
+        """`rows` random permutations of 0 .. M-1 (one per pass: the reference's DataLoader(shuffle=True),
+        policy_gradient.py:357-377) from ONE launch of osa_shuffle_rows -- a keyed bijection per row, seeded by one
+        int64 per row from torch's (seeded) device generator.  OSA_SHUFFLE=sort: the batched argsort of random
+        62-bit keys of rounds 1-3 (torch / rocPRIM merge sorts: ~45 launches, 0.3 ms for 8 x 65 536)."""
+        dev = self.ac.device
+        if os.environ.get('OSA_SHUFFLE', 'bijection') == 'sort':
+            keys = torch.randint(0, 1 << 62, (rows, M), generator=generator, device=dev, dtype=torch.int64)
+            p = keys.argsort(dim=1)
+            if out is None:
+                return p
+            out.copy_(p.reshape(out.shape))
+            return out
+        seeds = torch.randint(0, 1 << 62, (rows,), generator=generator, device=dev, dtype=torch.int64)
+        if out is None:
+            out = torch.empty((rows, M), dtype=torch.int64, device=dev)
+        assert out.is_contiguous() and out.numel() == rows * M
+        _lib.check(self.lib.osa_shuffle_rows(_lib.ptr(seeds), rows, M, _lib.ptr(out), _lib.stream_ptr()),
+                   'osa_shuffle_rows')
+        return out
+
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
                   stats_row: torch.Tensor) -> None:
         ac, lib, st = self.ac, self.lib, _lib.stream_ptr()
@@ -557,9 +579,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         st = self._dp_state(M, W, nmb)
         if perms_all is not None:
             st['perm'].copy_(perms_all.reshape(W, M))
-        else:  # W uniform shuffles in one batched sort of random 62-bit keys (3 launches instead of ~4 W)
-            keys = torch.randint(0, 1 << 62, (W, M), generator=st['gen'], device=ac.device, dtype=torch.int64)
-            st['perm'].copy_(keys.argsort(dim=1))
+        else:  # W shuffles, one launch (every rank draws the same seeds from the generator they all seeded alike)
+            self.shuffles(W, M, out=st['perm'], generator=st['gen'])
         if self._repl_wide:  # wide observations: the data-parallel split pass (no stepwise variant)
             ev = None
             if self.profile_events is not None:
@@ -703,12 +724,11 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # which machinery ran (tests assert the timed path, not a fallback)
         self.last_path = ('replicated-wide-split' if self._repl_wide else 'replicated') if use_repl else (
             ('persistent-wide' if self._use_wide else 'persistent') if use_pass else 'per-step')
-        # all passes' permutations in one batched sort of random 62-bit keys (a uniform shuffle per row,
-        # DataLoader(shuffle=True) semantics) instead of update_iters separate randperm launches
+        # all passes' permutations in one launch (one shuffle per row, DataLoader(shuffle=True) semantics) instead of
+        # update_iters separate randperm launches
         all_perms = None
         if perms is None and not use_repl:
-            keys = torch.randint(0, 1 << 62, (self.update_iters, M), device=ac.device, dtype=torch.int64)
-            all_perms = keys.argsort(dim=1)
+            all_perms = self.shuffles(self.update_iters, M)
         for i in range(self.update_iters):
             if use_repl:
                 perm = None

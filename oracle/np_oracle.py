@@ -762,3 +762,65 @@ def reach_env_obs(state: np.ndarray, obs_dim: int) -> np.ndarray:
     obs[:, 2:4] = s[:, 2:4] - s[:, 0:2]
     obs[:, 4:6] = s[:, 4:6] - s[:, 0:2]
     return obs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Minibatch shuffles.  The reference draws one torch.randperm per pass (DataLoader(shuffle=True),
+# policy_gradient.py:357-377); the product evaluates a keyed bijection instead of sorting random keys
+# (omnisafe_amd/csrc/shuffle_kernels.hip).  This is the numpy twin of that construction -- the checker of the index
+# arithmetic (bit-exact), not a restatement of torch's generator.
+SHUF_ROUNDS = 24
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(s: int):
+    s = (s + 0x9E3779B97F4A7C15) & _M64
+    z = s
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return s, z ^ (z >> 31)
+
+
+def _shuf_f(x: np.ndarray, k0: int, k1: int) -> np.ndarray:
+    x = x ^ np.uint32(k0)
+    x = x ^ (x >> np.uint32(16))
+    x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+    x = (x + np.uint32(k1)).astype(np.uint32)
+    x = x ^ (x >> np.uint32(15))
+    x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+    x = x ^ (x >> np.uint32(16))
+    return x
+
+
+def shuffle_rows(row_seeds, M: int) -> np.ndarray:
+    """perm[row][i] = the cycle-walked image of i under the row's 24-step alternating Feistel bijection."""
+    bits = 1
+    while (1 << bits) < M:
+        bits += 1
+    lo_bits = bits >> 1
+    hi_bits = bits - lo_bits
+    mask_lo = np.uint32((1 << lo_bits) - 1)
+    mask_hi = np.uint32((1 << hi_bits) - 1)
+    out = np.empty((len(row_seeds), M), np.int64)
+    with np.errstate(over='ignore'):
+        for row, seed in enumerate(row_seeds):
+            keys = []
+            for t in range(SHUF_ROUNDS):
+                s = (int(seed) & _M64) ^ ((0xD1B54A32D192ED03 * (t + 1)) & _M64)
+                _, z = _splitmix64(s)
+                keys += [z & 0xFFFFFFFF, z >> 32]
+            v = np.arange(M, dtype=np.uint64)
+            todo = np.ones(M, bool)
+            while todo.any():
+                w = v[todo]
+                hi = ((w >> np.uint64(lo_bits)).astype(np.uint32)) & mask_hi
+                lo = w.astype(np.uint32) & mask_lo
+                for r in range(0, SHUF_ROUNDS, 2):
+                    hi = hi ^ (_shuf_f(lo, keys[2 * r], keys[2 * r + 1]) & mask_hi)
+                    lo = lo ^ (_shuf_f(hi, keys[2 * r + 2], keys[2 * r + 3]) & mask_lo)
+                w = (hi.astype(np.uint64) << np.uint64(lo_bits)) | lo.astype(np.uint64)
+                v[todo] = w
+                idx = np.flatnonzero(todo)
+                todo[idx[w < M]] = False
+            out[row] = v.astype(np.int64)
+    return out

@@ -453,3 +453,19 @@ def test_model_cfgs_activation_and_width_checks():
                  linear_lr_decay=True)
         with pytest.raises(NotImplementedError):
             models.ConstraintActorCritic(Box(-1, 1, (4,)), Box(-1, 1, (2,)), cfg, 2, device='cuda:0')
+
+
+def test_shuffle_twin_is_a_bijection_for_every_size():
+    """oracle/np_oracle.py:shuffle_rows (the numpy twin of csrc/shuffle_kernels.hip): every row a permutation, also
+    where the domain is not a power of two (cycle walking) and for one-element inputs; seeds matter."""
+    import numpy as np
+
+    import np_oracle as O
+
+    for M in (1, 2, 3, 7, 8, 9, 100, 1000, 4097):
+        p = O.shuffle_rows([5, 6, (1 << 62) - 1], M)
+        for r in p:
+            assert np.array_equal(np.sort(r), np.arange(M))
+        if M > 8:
+            assert not np.array_equal(p[0], p[1])
+    assert np.array_equal(O.shuffle_rows([9], 50), O.shuffle_rows([9], 50))
