@@ -514,13 +514,17 @@ int osa_action_scale(const float* act, int ld_act, float* out, int ld_out, int N
  * bootstrap selection -- 0 if terminated, V(final_observation) (vfinal_*) if truncated, V(next_obs)
  * (vnext_*) at epoch end (:114-126) -- written into row t of the buffer's path_end/boot_r/boot_c, and
  * the finished episodes' metrics (_log_metrics :159-174) into row t of ep_done/ep_*_out, after which
- * the per-env accumulators reset (:128-134).  vnext_* / vfinal_* may be NULL when not needed. */
+ * the per-env accumulators reset (:128-134).  vnext_* / vfinal_* may be NULL when not needed.
+ * reward_row / cost_row (each may be NULL): row t of the buffer's reward / cost columns, filled with the step's
+ * reward / cost (buffer.store, :100-108) in the same launch -- for callers without a reward / cost normaliser or an
+ * adapter hook that rewrites the row in between (round 3: two copy launches per vector step less). */
 int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float* cost,
                           const uint8_t* terminated, const uint8_t* truncated, const float* vnext_r,
                           const float* vnext_c, const float* vfinal_r, const float* vfinal_c,
                           float* ep_ret, float* ep_cost, float* ep_len, uint8_t* path_end,
                           float* boot_r, float* boot_c, uint8_t* ep_done, float* ep_ret_out,
-                          float* ep_cost_out, float* ep_len_out, void* stream);
+                          float* ep_cost_out, float* ep_len_out, float* reward_row, float* cost_row,
+                          void* stream);
 
 /* SauteAdapter.step for all N envs (omnisafe/adapter/saute_adapter.py:124-196; SimmerAdapter shares it with
  * reset_value = relative budget): safety_obs <- (safety_obs - cost/budget)/saute_gamma; reward_out =

@@ -97,7 +97,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_normalizer_push': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'osa_normalizer_apply': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _F, _P]),
     'osa_action_scale': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _P]),
-    'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 19),
+    'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 21),
     'osa_synth_env_step': (_I, [_U, _U, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     'osa_reach_env_step': (_I, [_U, _U, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
@@ -175,6 +175,14 @@ def ptr(t: torch.Tensor | None) -> int | None:
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)  # pylint: disable=protected-access
+
+
 def stream_ptr() -> int:
-    """hipStream_t of torch's current stream, so kernels order with torch ops and RCCL."""
+    """hipStream_t of torch's current stream, so kernels order with torch ops and RCCL.
+    (torch.cuda.current_stream() builds a Python Stream object through five layers of device-index helpers: 9 us per
+    call, ~40 calls per epoch, all of them on the host path between a synchronisation and the next launch; the raw
+    getter is the same value in 0.2 us.)"""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

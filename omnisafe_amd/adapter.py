@@ -183,6 +183,7 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                      and getattr(self._env, 'graph_safe', False) and hasattr(agent, 'commit_rng'))
         if not use_graph:
             self._rollout_device(T, agent, buffer)
+            buffer.prefetch()
             self._flush_logs(logger, buffer)
             return
         st = self.__dict__.setdefault('_rollout_graph', {})
@@ -218,6 +219,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         else:
             self._rollout_device(T, agent, buffer)
         self.last_rollout_graphed = st.get('graph') is not None
+        # get()'s device work goes out before the host synchronises on the episode metrics (buffer.py:prefetch)
+        buffer.prefetch()
         self._flush_logs(logger, buffer)
 
     def _rollout_device(self, T: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer) -> None:
@@ -242,12 +245,20 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                                             _lib.ptr(self._old_max), -1.0, 1.0, st), 'osa_action_scale')
             next_raw, reward, cost, terminated, truncated, info = self._env.step(self._act_env)
             reward, cost = reward.reshape(N), cost.reshape(N)
+            # plain rows (no normaliser, no adapter hook that rewrites the reward row): written by the post-step
+            # kernel below instead of two copy launches per vector step
+            fuse_rows = type(self)._after_env_step is OnPolicyAdapter._after_env_step
+            reward_row = cost_row = None
             if self._reward_normalizer is not None:
                 self._reward_normalizer.normalize(reward.reshape(N, 1), out=b['reward'][t].view(N, 1))
+            elif fuse_rows:
+                reward_row = b['reward'][t]
             else:
                 b['reward'][t].copy_(reward)
             if self._cost_normalizer is not None:
                 self._cost_normalizer.normalize(cost.reshape(N, 1), out=b['cost'][t].view(N, 1))
+            elif fuse_rows:
+                cost_row = b['cost'][t]
             else:
                 b['cost'][t].copy_(cost)
             reward = reward.to(torch.float32).contiguous()  # original values for the episode metrics
@@ -272,7 +283,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(vfinal[1]), _lib.ptr(self._ep_ret), _lib.ptr(self._ep_cost),
                 _lib.ptr(self._ep_len), _lib.ptr(b['path_end'][t]), _lib.ptr(b['boot_r'][t]),
                 _lib.ptr(b['boot_c'][t]), _lib.ptr(ep['done'][t]), _lib.ptr(ep['ret'][t]),
-                _lib.ptr(ep['cost'][t]), _lib.ptr(ep['len'][t]), st), 'osa_rollout_post_step')
+                _lib.ptr(ep['cost'][t]), _lib.ptr(ep['len'][t]), _lib.ptr(reward_row), _lib.ptr(cost_row), st),
+                'osa_rollout_post_step')
             buffer.advance()
         if hasattr(self._env, 'commit'):  # fold the epoch's stream positions into their device-resident parts
             self._env.commit()
@@ -286,6 +298,9 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         # the three windowed keys only ever keep the last `window` episodes: copy no more than those to the host;
         # un-windowed extras (Metrics/EpBudget of Saute / Simmer) average EVERY episode of the epoch
         window = logger.window_length('Metrics/EpRet') if hasattr(logger, 'window_length') else None
+        # everything the host will read is enqueued BEFORE the first synchronisation (each later one then finds its
+        # result finished instead of leaving the device idle while the host enqueues the next reduction)
+        vmean = torch.stack([buffer.data['value_r'].mean(), buffer.data['value_c'].mean()])
         idx = ep['done'].reshape(-1).nonzero().reshape(-1)  # host sync (once per epoch)
         if idx.numel() > 0:
             widx = idx if window is None else idx[-window:]
@@ -294,9 +309,10 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             logger.extend('Metrics/EpCost', vals[1].tolist())
             logger.extend('Metrics/EpLen', vals[2].tolist())
             self._flush_extra(logger, idx)
-        logger.store({'Value/reward': float(buffer.data['value_r'].mean())})
+        vmean = vmean.tolist()
+        logger.store({'Value/reward': vmean[0]})
         if self._cfgs.algo_cfgs.use_cost:
-            logger.store({'Value/cost': float(buffer.data['value_c'].mean())})
+            logger.store({'Value/cost': vmean[1]})
 
 
 class SauteAdapter(OnPolicyAdapter):

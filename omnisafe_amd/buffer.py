@@ -129,10 +129,12 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         """Advance the write pointer after a producer filled ``row(...)`` in place."""
         assert self.ptr < self._size, 'No more space in the buffer!'
         self.ptr += 1
+        self._prefetched = False
 
     def store(self, **data: torch.Tensor) -> None:
         """Store one vector step (reference keys: obs, act, reward, cost, value_r, value_c, logp)."""
         assert self.ptr < self._size, 'No more space in the buffer!'  # onpolicy_buffer.py:143
+        self._prefetched = False
         d = {k: v.to(self._device, torch.float32).contiguous() for k, v in data.items()}
         N = self._num_buffers
         obs = d['obs'].reshape(N, self._obs_dim)
@@ -154,6 +156,7 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         buffer is scanned once in :meth:`get`.  Vector callers should use :meth:`finish_paths`."""
         t = self.ptr - 1
         assert t >= 0, 'finish_path() before any store()'
+        self._prefetched = False
         self.data['path_end'][t, idx] = 1
         for key, val in (('boot_r', last_value_r), ('boot_c', last_value_c)):
             if val is None:
@@ -167,6 +170,7 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         """Vector form: ends the path of every env with ``mask[n]`` after the last stored step."""
         t = self.ptr - 1
         assert t >= 0, 'finish_paths() before any store()'
+        self._prefetched = False
         m = mask.to(self._device).bool()
         self.data['path_end'][t] = m.to(torch.uint8)
         self.data['boot_r'][t] = torch.where(m, last_value_r.to(self._device, torch.float32), 0.0)
@@ -225,9 +229,24 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         (policy_gradient.py:345-349) and a partially filled buffer would feed stale rows of the previous epoch
         into the advantages and their statistics.  The returned tensors alias the buffer's staging block: the
         next `get()` overwrites them (the reference returns fresh concatenations)."""
-        from . import distributed as dist
-
         assert self.ptr == self._size, f'get() on a partially filled buffer (ptr {self.ptr} of {self._size})'
+        if not self.__dict__.pop('_prefetched', False):  # (else: enqueued by prefetch() right behind the rollout)
+            self._assemble()
+        self.ptr = 0
+        self.data['path_end'].zero_()
+        return dict(self._out)
+
+    def prefetch(self) -> None:
+        """Enqueue get()'s device work now -- advantages, their statistics, the env-major batch -- and leave the
+        buffer's visible state (ptr, path_end, the rows) as it is: the rollout adapter calls this right behind the last
+        vector step, BEFORE it synchronises to read the episode metrics, so the device does not sit idle while the
+        host walks from the logger through the Lagrange update to the first launch of get()."""
+        if self.ptr == self._size and not self.__dict__.get('_prefetched', False):
+            self._assemble()
+            self._prefetched = True
+
+    def _assemble(self) -> None:
+        from . import distributed as dist
 
         b, T, N = self.data, self._size, self._num_buffers
         M = T * N
@@ -252,9 +271,6 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
             self._act_dim, _lib.ptr(o['logp']), _lib.ptr(o['target_value_r']),
             _lib.ptr(o['target_value_c']), _lib.ptr(o['adv_r']), _lib.ptr(o['adv_c']),
             _lib.ptr(o['discounted_ret']), st), 'osa_buffer_get')
-        self.ptr = 0
-        self.data['path_end'].zero_()
-        return dict(o)
 
 
 class _EnvBufferView:

@@ -194,9 +194,12 @@ __global__ __launch_bounds__(256) void osa_rollout_post_step_kernel(
     float* __restrict__ ep_ret, float* __restrict__ ep_cost, float* __restrict__ ep_len,
     uint8_t* __restrict__ path_end, float* __restrict__ boot_r, float* __restrict__ boot_c,
     uint8_t* __restrict__ ep_done, float* __restrict__ ep_ret_out, float* __restrict__ ep_cost_out,
-    float* __restrict__ ep_len_out) {
+    float* __restrict__ ep_len_out, float* __restrict__ reward_row, float* __restrict__ cost_row) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  // buffer.store's reward / cost rows (:100-108) when the caller has no normaliser or adapter hook in between
+  if (reward_row) reward_row[n] = reward[n];
+  if (cost_row) cost_row[n] = cost[n];
   // _log_value (:155-157)
   float er = ep_ret[n] + reward[n];
   float ec = ep_cost[n] + cost[n];
@@ -468,7 +471,8 @@ int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float
                           const float* vnext_c, const float* vfinal_r, const float* vfinal_c,
                           float* ep_ret, float* ep_cost, float* ep_len, uint8_t* path_end,
                           float* boot_r, float* boot_c, uint8_t* ep_done, float* ep_ret_out,
-                          float* ep_cost_out, float* ep_len_out, void* stream) {
+                          float* ep_cost_out, float* ep_len_out, float* reward_row, float* cost_row,
+                          void* stream) {
   OSA_REQUIRE(N > 0 && reward && cost && terminated && truncated && ep_ret && ep_cost && ep_len);
   OSA_REQUIRE(path_end && boot_r && boot_c && ep_done && ep_ret_out && ep_cost_out && ep_len_out);
   OSA_REQUIRE((vnext_r == nullptr) == (vnext_c == nullptr));
@@ -476,7 +480,7 @@ int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float
   hipLaunchKernelGGL(osa_rollout_post_step_kernel, dim3((N + 255) / 256), dim3(256), 0,
                      osa_stream(stream), N, epoch_end, reward, cost, terminated, truncated, vnext_r,
                      vnext_c, vfinal_r, vfinal_c, ep_ret, ep_cost, ep_len, path_end, boot_r, boot_c,
-                     ep_done, ep_ret_out, ep_cost_out, ep_len_out);
+                     ep_done, ep_ret_out, ep_cost_out, ep_len_out, reward_row, cost_row);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

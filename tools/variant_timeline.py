@@ -32,13 +32,13 @@ def run():
         sync = lambda: torch.cuda.synchronize()  # noqa: E731
         bench.run_epochs(algo, 3, sync)
         mark = torch.zeros(7, device='cuda:0', dtype=torch.float64)
-        mark.cumsum_(0)  # marker: the only float64 cumsum of the process
+        mark.erfinv_()  # marker: the only erfinv of the process
         sync()
         import time
         t0 = time.perf_counter()
         bench.run_epochs(algo, EPOCHS, sync)
         dt = time.perf_counter() - t0
-        mark.cumsum_(0)
+        mark.erfinv_()
         sync()
         print(json.dumps({'ms_per_epoch_wall': dt / EPOCHS * 1e3, 'env_steps_per_s': 65536 * EPOCHS / dt}))
 
@@ -58,21 +58,28 @@ def analyse(path, out):
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if 'cumsum' in r[2].lower() or 'scan' in r[2].lower() and 'double' in r[2]]
+    marks = [i for i, r in enumerate(rows) if 'erfinv' in r[2].lower()]
     if len(marks) < 2:
         raise SystemExit(f'markers not found ({len(marks)})')
     seg = rows[marks[0] + 1: marks[-1]]
     t_begin, t_end = rows[marks[0]][1], rows[marks[-1]][0]
     busy, count = {}, {}
     idle_gaps = []
-    last_end = t_begin
+    gap_sites = {}
+    last_end, last_name = t_begin, 'marker'
     for s, e, n in seg:
         k = short(n)
         busy[k] = busy.get(k, 0) + (e - s)
         count[k] = count.get(k, 0) + 1
         if s > last_end:
             idle_gaps.append(s - last_end)
-        last_end = max(last_end, e)
+            if s - last_end > 20000:
+                site = f'{last_name} -> {k}'
+                g = gap_sites.setdefault(site, [0, 0])
+                g[0] += 1
+                g[1] += s - last_end
+        if e >= last_end:
+            last_end, last_name = e, k
     total = t_end - t_begin
     busy_total = sum(busy.values())
     rep = {'epochs': EPOCHS, 'us_per_epoch_device_span': total / EPOCHS / 1e3,
@@ -81,6 +88,8 @@ def analyse(path, out):
            'idle_gaps_per_epoch': len(idle_gaps) / EPOCHS,
            'idle_gaps_over_20us_per_epoch': sum(1 for g in idle_gaps if g > 20000) / EPOCHS,
            'us_in_gaps_over_20us_per_epoch': sum(g for g in idle_gaps if g > 20000) / EPOCHS / 1e3,
+           'gaps_over_20us': {k: {'per_epoch': v[0] / EPOCHS, 'us_per_epoch': v[1] / EPOCHS / 1e3}
+                              for k, v in sorted(gap_sites.items(), key=lambda kv: -kv[1][1])},
            'kernels': {k: {'launches_per_epoch': count[k] / EPOCHS, 'us_per_epoch': busy[k] / EPOCHS / 1e3,
                            'us_per_launch': busy[k] / count[k] / 1e3}
                        for k in sorted(busy, key=lambda k: -busy[k])}}
