@@ -755,6 +755,20 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     const float* s = a.slabs + (long)net * a.nblk * W + e;
     float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
     int b = 0;
+    for (; b + 64 <= a.nblk; b += 64) {  // 64 slabs' loads in flight (ONE round trip for the large-batch step's 64
+      // slabs instead of four: the loop is latency-bound, 99 workgroups x 256 threads x 4 bytes per load); the
+      // additions keep the order of the 16-slab loop below
+      float t[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) t[u] = s[(long)(b + u) * W];
+#pragma unroll
+      for (int v = 0; v < 64; v += 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += t[v + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += t[v + 8 + u];
+      }
+    }
     for (; b + 16 <= a.nblk; b += 16) {  // 16 slabs' loads in flight; q[u] receives b + u, b + 8 + u in this order
       float t[16];
 #pragma unroll
