@@ -170,7 +170,7 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // NETK: -1 = the network (actor / critic) is a run-time property of the workgroup; 0 / 1 = this body is the
 // actor's / a critic's (OSA_PASS_NET_SPLIT: the kernel then dispatches on its network once, and the loss code, the
 // gathers and the L2 / learning-rate selections lose their block-uniform branches)
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool SLICE, bool DPS, bool SO, int NETK>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool SLICE, bool DPS, bool SO, bool TWO, int NETK>
 __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const int net, const int rk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
@@ -325,8 +325,10 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
   // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
   const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
-  const int cstride = part ? a.part_stride : 1, cfirst = part ? rk : (chunked ? cchunk : 0);
-  const int nchunk = part ? (nchunk_all - cfirst + cstride - 1) / cstride : nchunk_all;
+  // (TWO: chunk mode with MORE chunks than peers -- peer c walks through the chunks c, c + cw, c + 2 cw, ...)
+  const bool strided = part || (TWO && chunked);
+  const int cstride = part ? a.part_stride : ((TWO && chunked) ? cw : 1), cfirst = part ? rk : (chunked ? cchunk : 0);
+  const int nchunk = strided ? (nchunk_all - cfirst + cstride - 1) / cstride : nchunk_all;
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
     const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
     const long inb = ch * 64 + 16 * wave + j;
@@ -917,7 +919,12 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     }
     if (ch + 1 < nchunk) __syncthreads();  // tiles free for the next chunk of this step
     }  // chunks
-    if (boff >= 0 && is_actor && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f && own_terms)
+    // (not in the partial-gradient mode: osa_slab_reduce_finalize_kernel adds the entropy term ONCE to the sum of
+    // the slabs -- until round 3 every partial slab carried it as well, i.e. the large-batch step applied it
+    // 1 + workgroups times whenever entropy_coef != 0 (the YAML default is 0; found by
+    // test_large_batch_pass_equals_per_step_launches))
+    if (boff >= 0 && is_actor && boff >= nd.oLS && (boff - nd.oLS) < nd.act_dim && a.hp.entropy_coef != 0.f && own_terms &&
+        !part)
       gb -= a.hp.entropy_coef / (float)nd.act_dim;
     // ================= + 2*coef*w (critics), squared norms (packed f32 math) =================
     // this lane's parameters: all LDS reads issued up front (one latency for the lot), kept in registers
@@ -1093,7 +1100,82 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (W == 2) {
+      float two_loss = 0.f, two_ratio = 0.f;  // (TWO: the minibatch's loss / ratio sums from the reduced tail)
+      if constexpr (TWO) {
+        // ---- two-stage sum for MANY peers (the large-batch pass: up to 64 chunk workgroups per network; every
+        // peer reading every slab would be W x 38 KB per peer and step).  A slab is EV 16-byte vectors (tiles, the
+        // bias-like row, the statistics tail); peer c owns the vectors c evp .. (c + 1) evp - 1: lane l of every
+        // wave takes the l-th of them, wave w adds the slabs w, w + 4, ... in that order, the four partial sums meet
+        // in LDS and are added in wave order -- one owner per vector, so every peer installs the same bits.  The
+        // reduced vectors go to the parity's x2 region in slab layout; after a second arrival everybody reads its
+        // own tiles from there (coalesced) and continues exactly as in the direct chunk mode.
+        constexpr int EV = NT * 256 + 64 + 1;
+        float* __restrict__ x2 = a.dp_slabs + (long)2 * 3 * a.dp_world * XS + ((long)((mb - a.mb0) & 1) * 3 + net) * XS;
+        f32x4* __restrict__ x2v = reinterpret_cast<f32x4*>(x2);
+        f32x4* sred = reinterpret_cast<f32x4*>(sH1);  // [4][64] (the tiles are dead until the next forward pass)
+        const int me = chunked ? cchunk : rk;
+        const int evp = (EV + W - 1) / W;  // a CONTIGUOUS range of vectors per peer: consecutive lanes read consecutive
+        // 16 bytes of a slab (with a stride of W vectors between the lanes every lane's load was its own cache line)
+        for (int l0 = 0; l0 < evp; l0 += 64) {
+          const int v = (l0 + lane < evp) ? me * evp + l0 + lane : EV;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if (v < EV) {
+            constexpr int RT = 8;
+            for (int r0 = wave; r0 < W; r0 += 4 * RT) {
+              f32x4 t[RT];
+#pragma unroll
+              for (int u = 0; u < RT; ++u) {
+                const int r = min(r0 + 4 * u, W - 1);
+                t[u] = reinterpret_cast<const f32x4*>(xbase + (long)r * XS)[v];
+              }
+#pragma unroll
+              for (int u = 0; u < RT; ++u)
+                if (r0 + 4 * u < W) acc = acc + t[u];
+            }
+          }
+          sred[wave * 64 + lane] = acc;
+          __syncthreads();
+          if (wave == 0 && v < EV) x2v[v] = ((sred[lane] + sred[64 + lane]) + sred[128 + lane]) + sred[192 + lane];
+          __syncthreads();
+        }
+        if (a.dp_uncached || a.dp_local) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_waitcnt(0);
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int* cnt = a.dp_sync + 8 + net;
+          const int target = W * (mb - a.mb0 + 1);
+          int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          if (!coop_dead) {
+            int spins = 0;
+            while (seen < target) {
+              __builtin_amdgcn_s_sleep(1);
+              seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (++spins > (1 << 21)) {
+                __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                coop_dead = true;
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) s2[ti] = x2v[ti * 256 + tid];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) s1[kb] = x2v[(HT + kb) * 256 + tid];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) s3[o] = x2v[(HT + KB + o) * 256 + tid];
+        sb_ = x2[NT * 1024 + tid];
+        if (leader) {
+          two_loss = x2[NT * 1024 + 256 + 0];
+          two_ratio = x2[NT * 1024 + 256 + 1];
+        }
+      } else if (W == 2) {
         // two peers (two chunks of a 128-row minibatch, or two ranks): own gradient from the registers + the
         // peer's slab.  Both sides form the same two products (g * clip factor; 1 in chunk mode) and a two-operand
         // float sum is commutative, so they get the same bits without walking the slabs in rank order.
@@ -1212,9 +1294,14 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       }
       if (leader && (chunked ? cchunk == 0 : rk == 0)) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < W; ++r) {
-          const float* t = xbase + (long)r * XS + NT * 1024 + 256;
-          for (int k = 0; k < 5; ++k) acc[k] += t[k];
+        if constexpr (TWO) {
+          acc[0] = two_loss;
+          acc[1] = two_ratio;
+        } else {
+          for (int r = 0; r < W; ++r) {
+            const float* t = xbase + (long)r * XS + NT * 1024 + 256;
+            for (int k = 0; k < 5; ++k) acc[k] += t[k];
+          }
         }
         if (chunked) {  // loss and ratio: sums of the chunks' shares; parameter norm and entropy: chunk 0's
           const float* t0 = xbase + NT * 1024 + 256;
@@ -1552,7 +1639,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
 #define OSA_PASS_NET_SPLIT 0
 #endif
 template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false,
-          bool SO = false>
+          bool SO = false, bool TWO = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
   if constexpr (!COOP) {
@@ -1572,10 +1659,10 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   const int net = net_, rk = rk_;
   if (!((a.nets_mask >> net) & 1)) return;
   if constexpr (OSA_PASS_NET_SPLIT != 0 && !MULTI && !COOP && !EXT && !DPS) {  // (the plain 64-row pass: the headline path)
-    if (net == 0) osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, 0>(a, net, rk);
-    else osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, 1>(a, net, rk);
+    if (net == 0) osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, 0>(a, net, rk);
+    else osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, 1>(a, net, rk);
   } else {
-    osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, -1>(a, net, rk);
+    osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, -1>(a, net, rk);
   }
 }
 
@@ -1588,14 +1675,14 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
 }
 
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false,
-          bool DPS = false, bool SO = false>
+          bool DPS = false, bool SO = false, bool TWO = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -1610,7 +1697,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -1619,14 +1706,14 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
@@ -1948,6 +2035,26 @@ int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                        loss_kind, nets_mask, exchange, sync, local, 1, 1, 0, step_stats, stream);
 }
 
+// The large-batch pass (batch sizes of thousands of rows: the GPU-env blocks of the reference's YAML files): ONE
+// cooperative launch per pass instead of two launches per optimiser step.  `peers` chunk workgroups per network
+// (<= ceil(B / 64), 3 peers <= CUs) keep the weights in LDS and the Adam moments in registers for the whole pass; per
+// step each walks through its chunks c, c + peers, ..., publishes its raw partial gradient, and the sum is formed in
+// two stages (every peer reduces ITS 1 / peers of the vectors over all slabs, then everybody reads the reduced
+// gradient): two hand-offs per step, 2 x 38 KB read per peer.  Clip on the norm of the sum, Adam replicated -- the
+// arithmetic of osa_ppo_chunked_pass (one B-row step of policy_gradient.py:366-382).  exchange: osa_ppo_dp_pass_ws_floats(
+// ..., peers) floats, zeroed once (uncached memory from osa_dp_exchange_alloc, or ordinary); sync: int[64] zeroed once.
+int osa_ppo_large_batch_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                             int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                             const float* logp, const float* target_value_r, const float* target_value_c,
+                             const float* adv_r, const float* adv_c, const long* perm, long M, int B, int peers,
+                             const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
+                             float* exchange, int* sync, float* step_stats, void* stream) {
+  if (B <= 64 || peers < 2 || peers > 85) return OSA_EUNSUPPORTED;
+  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
+                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, peers, lagrange, hp,
+                       loss_kind, nets_mask, exchange, sync, 0, 1, 1, 2, step_stats, stream);
+}
+
 size_t osa_ppo_dp_chunked_pass_ws_floats(int obs_dim, int act_dim, int hidden, int B, int world) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1 || B <= 64) return 0;
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
@@ -1975,7 +2082,10 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                          float* exchange, int* sync, int local, int chunk, int ranks, int slice, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
-  if (slice && (chunk || B > 64 || world < 3)) return OSA_EUNSUPPORTED;
+  // slice 1: the reduction sliced over the ranks + Adam on the slice (osa_ppo_dp_slice_pass); 2: chunk mode with
+  // `world` chunk workgroups walking through ceil(B / 64) >= world chunks and a two-stage sum (osa_ppo_large_batch_pass)
+  if (slice == 1 && (chunk || B > 64 || world < 3)) return OSA_EUNSUPPORTED;
+  if (slice == 2 && (!chunk || ranks != 1 || local || world > (B + 63) / 64)) return OSA_EUNSUPPORTED;
   if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
@@ -2016,7 +2126,8 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
+    return slice == 2 ? osa_launch_pass<K, O, true, true, false, false, false, false, false, true>(a, st, world) \
+           : slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
            : (chunk && ranks > 1) ? osa_launch_pass_so<K, O, false, true, false, true>(a, st, world) \
            : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \
                                 : osa_launch_pass_so<K, O, false, true>(a, st, world)

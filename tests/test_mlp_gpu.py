@@ -224,9 +224,12 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
     lam = 0.5
     l_r = O.critic_step(ref.reward_critic, ref.reward_critic_optimizer, cpu['obs'], cpu['target_value_r'])
     l_c = O.critic_step(ref.cost_critic, ref.cost_critic_optimizer, cpu['obs'], cpu['target_value_c'])
+    # (entropy bonus ON: the partial-gradient slabs must not carry the entropy term -- the slab reduction adds it once;
+    # until round 3 each of the up to 64 slabs did, invisible with the YAML default entropy_coef = 0)
     l_p, ent, ratio = O.actor_step(ref.actor, ref.actor_optimizer, cpu['obs'], cpu['act'], cpu['logp'],
-                                   cpu['adv_r'], cpu['adv_c'], lam)
-    up = PPOUpdater(ac, batch_size=M, update_iters=1, target_kl=0.02, kl_early_stop=False, max_blocks=64)
+                                   cpu['adv_r'], cpu['adv_c'], lam, entropy_coef=0.02)
+    up = PPOUpdater(ac, batch_size=M, update_iters=1, target_kl=0.02, kl_early_stop=False, max_blocks=64,
+                    entropy_coef=0.02)
     up.hp.lr_actor = up.hp.lr_critic = 3e-4
     stats = torch.zeros(16, device=DEV)
     up.minibatch(dev, None, M, torch.tensor([lam], device=DEV), stats)
@@ -318,6 +321,54 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
         s0, s1 = outs[k]['stats'].cpu().numpy(), outs[-1]['stats'].cpu().numpy()
         np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=1e-5, atol=2e-7)
         np.testing.assert_allclose(outs[k]['kl'], outs[-1]['kl'], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 16384, 4096), (60, 2, 20000, 8192), (27, 8, 9000, 2048),
+                                                (72, 17, 6144, 2048), (60, 2, 65536, 16384)])
+def test_large_batch_pass_equals_per_step_launches(obs_dim, act_dim, M, B, monkeypatch):
+    """osa_ppo_large_batch_pass (B >= 2048: one cooperative launch per pass; up to 64 chunk workgroups per network
+    walk through the minibatch's 64-row chunks, two-stage sum of their partial gradients, clip on the norm of the sum,
+    replicated Adam) vs the per-step launches (osa_ppo_minibatch: partial gradients + slab reduce / clip / Adam, pinned
+    to the oracle by test_large_batch_multiblock_equals_single_pass) on the same permutations: parameters, moments
+    and per-step statistics after two passes, incl. ragged last minibatches / chunks and both output-tile widths."""
+    from omnisafe_amd.update import PPOUpdater
+
+    torch.manual_seed(obs_dim + act_dim)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV) * 3, 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perms = [torch.randperm(M), torch.randperm(M)]
+    acs, outs, paths = [], [], []
+    for big in ('1', '0'):
+        monkeypatch.setenv('OSA_LARGE_BATCH_PASS', big)
+        torch.manual_seed(99)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        # max_grad_norm 0.1: the clip is active on the reward critic (targets x 3) in every step
+        up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01,
+                        max_grad_norm=0.1)
+        lam = torch.tensor([0.3], device=DEV)
+        outs.append(up.run(data, lam, perms=perms, actor_lr=3e-4, critic_lr=1e-3))
+        paths.append(up.last_path)
+        acs.append(ac)
+    assert paths == ['persistent-large-batch', 'per-step'], paths
+    nmb = (M + B - 1) // B
+    assert all(o['steps'] == 2 * nmb for o in outs)
+    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist() == [2 * nmb] * 3
+    for name in ('params', 'adam_m', 'adam_v'):
+        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
+        # (two summation orders of thousands of rows: the tolerance of the chunked pass against the per-step kernels)
+        bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)
+        assert bad.sum() <= 4, (name, int(bad.sum()), float(np.abs(a - b).max()))
+        if bad.any():
+            lim = 2.5e-4 if name == 'params' else 2e-3 * np.abs(b[bad]).max()
+            assert np.abs(a - b)[bad].max() <= lim, (name, float(np.abs(a - b)[bad].max()))
+    s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
+    assert (s1[:, 8] > 0.1).all()  # the clip was active
+    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=2e-5, atol=5e-7)
+    np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
 
 
 @pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),

@@ -38,7 +38,7 @@ def main():
     lam = torch.zeros(1, device=dev)
     perm = torch.randperm(M, device=dev)
     rows = []
-    for B in (2048, 4096, 8192, 12288, 16384, 32768, 65536):
+    for B in (2048, 4096, 8192, 16384):
         ac = ConstraintActorCritic(Box(-np.inf, np.inf, (d_o,)), Box(-1, 1, (d_a,)), mc, 4, device=dev)
         up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False)
         up.hp.lr_actor = up.hp.lr_critic = 3e-4
@@ -66,8 +66,27 @@ def main():
         pb = min(cus // 3, chunks)
         per = (chunks + pb - 1) // pb
         pb = (chunks + per - 1) // per
-        rows.append({'B': B, 'us_per_step_in_graph': round(us, 2), 'workgroups_per_network': pb,
-                     'chunks_per_workgroup': per})
+        rec = {'B': B, 'us_per_step_in_graph': round(us, 2), 'workgroups_per_network': pb,
+               'chunks_per_workgroup': per}
+        # the cooperative pass (osa_ppo_large_batch_pass): all steps of a pass in one launch
+        if B * 4 <= M and up._big_ok():
+            Mp = 4 * B
+            sub = {k: v[:Mp] for k, v in data.items()}
+            st = torch.zeros(4, 16, device=dev)
+            pp = torch.randperm(Mp, device=dev)
+            up._pass_fn = ('osa_ppo_pass_kernel', None)
+            for _ in range(3):
+                up.run_pass(sub, pp, lam, st)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                up.run_pass(sub, pp, lam, st)
+            e1.record()
+            torch.cuda.synchronize()
+            up.check_big_sync()
+            rec['us_per_step_cooperative_pass'] = round(e0.elapsed_time(e1) * 1e3 / 80, 2)
+            rec['peers'] = up._big['peers']
+        rows.append(rec)
         print(rows[-1], flush=True)
         del up, ac, g
     out = {'device': torch.cuda.get_device_name(0), 'shape': '60/2', 'rows': rows}
