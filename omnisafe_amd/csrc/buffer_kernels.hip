@@ -424,7 +424,9 @@ __global__ __launch_bounds__(64 * NWV) void osa_gae_tile_scan_kernel(
 // identity instead of the chain (float64 re-association: outputs equal the bit-exact kernel's in all but
 // ~1e-8 of the elements after rounding to float32; tests require rtol 1e-5 like K5b).  v-trace: K5 only.
 // ------------------------------------------------------------------------------------------------
+#ifndef OSA_GC_TC
 #define OSA_GC_TC 16                       // steps per wave
+#endif
 #ifndef OSA_GC_NW
 #define OSA_GC_NW 8                        // waves per workgroup
 #endif
@@ -529,8 +531,11 @@ __device__ __forceinline__ void osa_gc_chunk(const float (&r)[OSA_GC_TC], const 
   cy.v[0] = a_r; cy.v[1] = a_c; cy.v[2] = ret; cy.v[3] = rtg_r; cy.v[4] = rtg_c;
 }
 
+#ifndef OSA_GC_MINB
+#define OSA_GC_MINB 1  // (2 = two workgroups per compute unit: 159 v 165 us at 4096 x 4096 in one same-box A/B, nothing on other shapes: inside the box-to-box noise, not adopted)
+#endif
 template <int EST>
-__global__ __launch_bounds__(64 * OSA_GC_NW) void osa_gae_chain_scan_kernel(
+__global__ __launch_bounds__(64 * OSA_GC_NW, OSA_GC_MINB) void osa_gae_chain_scan_kernel(
     const float* __restrict__ reward, const float* __restrict__ cost,
     const float* __restrict__ value_r, const float* __restrict__ value_c,
     const uint8_t* __restrict__ path_end, const float* __restrict__ boot_r,
