@@ -26,7 +26,10 @@
 // partial gradients of one large minibatch (MULTI, grid 3 x nblk).
 #include "mlp_device.h"
 
+#ifndef PSLD
 #define PSLD 68  // leading dimension (floats) of [feature][sample] tiles and of W2/W3 rows
+#endif
+#define PSPAD (PSLD - 64)
 #define PNSTAT 16
 
 struct OsaPassHp {
@@ -150,7 +153,7 @@ __device__ __forceinline__ float osa_sym_sum1(float a, float sa, float b, float 
 
 // floats of dynamic LDS without the transposed W2 copy, and whether that copy still fits the 160 KB of a CU
 __host__ __device__ constexpr int osa_pass_lds_floats(int KB, int OT) {
-  return 64 * (16 * KB + 4) + 64 * PSLD + 16 * OT * PSLD + 2 * 64 + 2 * 16 * OT + 4 * 64 * PSLD + 16 * KB * PSLD +
+  return 64 * (16 * KB + PSPAD) + 64 * PSLD + 16 * OT * PSLD + 2 * 64 + 2 * 16 * OT + 4 * 64 * PSLD + 16 * KB * PSLD +
          2 * 16 * OT * PSLD + 64;
 }
 #ifndef OSA_PASS_W2T
@@ -190,7 +193,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   const float* __restrict__ advr_p = a.adv_r + roff;
   const float* __restrict__ advc_p = a.adv_c + roff;
   const long* __restrict__ perm_p = a.perm ? a.perm + roff : nullptr;
-  constexpr int H = 64, HT = 4, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + 4;
+  constexpr int H = 64, HT = 4, OUTP = 16 * OT, INP = 16 * KB, W1LD = INP + PSPAD;
   // ---- LDS carve-up (all offsets multiples of 4 floats)
   float* sW1 = smem;                    // [H][W1LD]
   float* sW2 = sW1 + H * W1LD;          // [H][PSLD]
