@@ -437,7 +437,8 @@ int osa_ppo_dp_slice_pass(int obs_dim, int act_dim, int hidden, float* params, f
  * the same Adam step: the arithmetic of one B-row step of policy_gradient.py:366-382 (float32 re-association of the sum
  * over chunks only), as osa_ppo_chunked_pass.  exchange: osa_ppo_dp_pass_ws_floats(.., world = peers) floats zeroed once
  * (uncached memory from osa_dp_exchange_alloc or ordinary device memory); sync: int[64] zeroed once, sticky sync[3]
- * (1: a workgroup never arrived).  OSA_EUNSUPPORTED when the workgroups cannot be co-resident. */
+ * (1: a workgroup never arrived).  OSA_EUNSUPPORTED when the workgroups cannot be co-resident or act_dim > 16 (one
+ * output tile only: the pass is an A/B alternative, measured slower than the per-step launches on MI355X). */
 int osa_ppo_large_batch_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                              int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
                              const float* logp, const float* target_value_r, const float* target_value_c,

@@ -1720,6 +1720,17 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
+// the two-stage large-batch pass (off by default, measured slower than two launches per step): one output tile only,
+// so that the library does not carry twelve more instantiations of the largest kernel for an A/B switch
+template <int KB, int OT>
+static int osa_launch_two(const OsaPassArgs& a, hipStream_t stream, int grid_y) {
+  if constexpr (OT == 1) {
+    return osa_launch_pass<KB, OT, true, true, false, false, false, false, false, true>(a, stream, grid_y);
+  } else {
+    return OSA_EUNSUPPORTED;
+  }
+}
+
 // the SO instantiation where it applies (one output tile and act_dim <= 2: every network then has 1-2 outputs)
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
 static int osa_launch_pass_so(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
@@ -2129,7 +2140,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return slice == 2 ? osa_launch_pass<K, O, true, true, false, false, false, false, false, true>(a, st, world) \
+    return slice == 2 ? osa_launch_two<K, O>(a, st, world) \
            : slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
            : (chunk && ranks > 1) ? osa_launch_pass_so<K, O, false, true, false, true>(a, st, world) \
            : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \

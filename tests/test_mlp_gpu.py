@@ -324,7 +324,7 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
 
 
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 16384, 4096), (60, 2, 20000, 8192), (27, 8, 9000, 2048),
-                                                (72, 17, 6144, 2048), (60, 2, 65536, 16384)])
+                                                (72, 16, 6144, 2048), (60, 2, 65536, 16384)])
 def test_large_batch_pass_equals_per_step_launches(obs_dim, act_dim, M, B, monkeypatch):
     """osa_ppo_large_batch_pass (B >= 2048: one cooperative launch per pass; up to 64 chunk workgroups per network
     walk through the minibatch's 64-row chunks, two-stage sum of their partial gradients, clip on the norm of the sum,
