@@ -172,6 +172,16 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
                     int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
                     float* mean_out, int ld_mean, void* stream);
 
+/* osa_policy_step with ActionScale.step (omnisafe/envs/wrapper.py:510-514) applied to the sampled action in the same
+ * launch: act_env[n][d] = old_min[d] + (old_max[d] - old_min[d]) * (act[n][d] - min_action) / (max_action - min_action)
+ * -- the bits of osa_action_scale on the same action.  act_env may be NULL (then exactly osa_policy_step). */
+int osa_policy_step_scaled(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
+                           int ld_obs, int N, const float* eps, unsigned long long seed,
+                           unsigned long long offset, const unsigned long long* offset_base, int deterministic,
+                           int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
+                           float* mean_out, int ld_mean, float* act_env, int ld_env, const float* old_min,
+                           const float* old_max, float min_action, float max_action, void* stream);
+
 /* Hyper-parameters of one optimiser step; field names follow algo_cfgs / model_cfgs of
  * omnisafe/configs/on-policy/PPOLag.yaml. */
 typedef struct osa_ppo_hparams {

@@ -38,6 +38,8 @@ SIGNATURES: dict[str, tuple] = {
     'osa_mlp_layout': (_I, [_I, _I, _I, _P]),
     'osa_policy_step': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I,
                              _P]),
+    'osa_policy_step_scaled': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I,
+                                    _P, _I, _P, _P, _F, _F, _P]),
     'osa_minibatch_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
     'osa_ppo_minibatch': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
                                _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void osa_policy_step_kernel(
     const float* __restrict__ eps, unsigned long long seed, unsigned long long offset,
     const unsigned long long* __restrict__ offset_base, int deterministic, int nets_mask,
     float* __restrict__ act, int ld_act, float* __restrict__ value_r, float* __restrict__ value_c,
-    float* __restrict__ logp, float* __restrict__ mean_out, int ld_mean) {
+    float* __restrict__ logp, float* __restrict__ mean_out, int ld_mean, float* __restrict__ act_env, int ld_env,
+    const float* __restrict__ old_min, const float* __restrict__ old_max, float min_a, float max_a) {
   const int net = blockIdx.y;
   if (!((nets_mask >> net) & 1)) return;
   if (offset_base) offset += *offset_base;  // device-resident part of the Philox stream position
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(256) void osa_policy_step_kernel(
             a = mu + e * sd;  // Normal.rsample: loc + eps * scale
           }
           if (act) act[row * ld_act + d] = a;
+          // ActionScale.step of the wrapper chain in the same launch (osa_policy_step_scaled)
+          if (act_env) act_env[row * ld_env + d] = osa_action_scale1(a, old_min[d], old_max[d], min_a, max_a);
           if (mean_out) mean_out[row * ld_mean + d] = mu;
           // Normal.log_prob: -((v - loc)^2) / (2 var) - log(scale) - log(sqrt(2 pi))
           const float z = a - mu;
@@ -1195,16 +1198,29 @@ int osa_policy_step(int obs_dim, int act_dim, int hidden, const float* params, c
                     unsigned long long offset, const unsigned long long* offset_base, int deterministic,
                     int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
                     float* mean_out, int ld_mean, void* stream) {
+  return osa_policy_step_scaled(obs_dim, act_dim, hidden, params, obs, ld_obs, N, eps, seed, offset, offset_base,
+                                deterministic, nets_mask, act, ld_act, value_r, value_c, logp, mean_out, ld_mean,
+                                nullptr, 0, nullptr, nullptr, 0.f, 1.f, stream);
+}
+
+int osa_policy_step_scaled(int obs_dim, int act_dim, int hidden, const float* params, const float* obs,
+                           int ld_obs, int N, const float* eps, unsigned long long seed,
+                           unsigned long long offset, const unsigned long long* offset_base, int deterministic,
+                           int nets_mask, float* act, int ld_act, float* value_r, float* value_c, float* logp,
+                           float* mean_out, int ld_mean, float* act_env, int ld_env, const float* old_min,
+                           const float* old_max, float min_action, float max_action, void* stream) {
   const int rc = osa_check_dims(obs_dim, act_dim, hidden);
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && obs && N > 0 && ld_obs >= obs_dim);
   OSA_REQUIRE(!act || ld_act >= act_dim);
+  OSA_REQUIRE(!act_env || (ld_env >= act_dim && old_min && old_max && max_action != min_action));
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
   const dim3 grid((N + 63) / 64, 3);
 #define OSA_CALL(HT, OT, NSB)                                                                          \
   hipLaunchKernelGGL((osa_policy_step_kernel<HT, OT>), grid, dim3(256), 0, osa_stream(stream), nd, \
                      params, obs, ld_obs, N, eps, seed, offset, offset_base, deterministic, nets_mask, act, \
-                     ld_act, value_r, value_c, logp, mean_out, ld_mean)
+                     ld_act, value_r, value_c, logp, mean_out, ld_mean, act_env, ld_env, old_min, old_max,    \
+                     min_action, max_action)
   OSA_DISPATCH_OT(nd, OSA_CALL);
 #undef OSA_CALL
   OSA_CHECK_LAUNCH();

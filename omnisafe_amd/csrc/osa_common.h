@@ -20,6 +20,13 @@
 
 static inline hipStream_t osa_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ActionScale.step (omnisafe/envs/wrapper.py:510-514), one element; no contraction so that every kernel that applies
+// it (osa_action_scale_kernel, the policy step's fused epilogue) produces the same bits
+__device__ __forceinline__ float osa_action_scale1(float a, float lo, float hi, float min_a, float max_a) {
+#pragma clang fp contract(off)
+  return lo + (hi - lo) * (a - min_a) / (max_a - min_a);
+}
+
 // ---- wave / block reductions (deterministic order) ------------------------------------------------
 __device__ __forceinline__ double osa_wave_sum(double v) {
 #pragma unroll

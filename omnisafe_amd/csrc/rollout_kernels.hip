@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void osa_action_scale_kernel(
   if (gid >= (long)N * D) return;
   const int r = (int)(gid / D), d = (int)(gid - (long)r * D);
   const float a = act[(long)r * ld_a + d];
-  out[(long)r * ld_o + d] = old_min[d] + (old_max[d] - old_min[d]) * (a - min_a) / (max_a - min_a);
+  out[(long)r * ld_o + d] = osa_action_scale1(a, old_min[d], old_max[d], min_a, max_a);
 }
 
 // ------------------------------------------------------------------------------------------------

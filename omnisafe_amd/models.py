@@ -280,12 +280,15 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
         if eps is not None:
             e = eps.reshape(N, self.act_dim).to(self.device, torch.float32).contiguous()
         self._rng_offset += 1
-        _lib.check(self._lib.osa_policy_step(
+        sc = o.get('scale')  # (act_env rows, old_min, old_max, min_action, max_action): ActionScale in the same launch
+        _lib.check(self._lib.osa_policy_step_scaled(
             self.obs_dim, self.act_dim, self.hidden, _lib.ptr(self.params), _lib.ptr(x), x.stride(0), N,
             _lib.ptr(e), self.seed, self._rng_offset, _lib.ptr(self._rng_base), int(deterministic), nets_mask,
             _lib.ptr(act),
-            self.act_dim, _lib.ptr(v_r), _lib.ptr(v_c), _lib.ptr(logp), None, 0, _lib.stream_ptr()),
-            'osa_policy_step')
+            self.act_dim, _lib.ptr(v_r), _lib.ptr(v_c), _lib.ptr(logp), None, 0,
+            _lib.ptr(sc[0]) if sc else None, sc[0].stride(0) if sc else 0, _lib.ptr(sc[1]) if sc else None,
+            _lib.ptr(sc[2]) if sc else None, float(sc[3]) if sc else 0.0, float(sc[4]) if sc else 1.0,
+            _lib.stream_ptr()), 'osa_policy_step_scaled')
         if single:
             return act[0], v_r[0], v_c[0], logp[0]
         return act, v_r, v_c, logp

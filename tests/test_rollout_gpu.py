@@ -652,3 +652,37 @@ def test_time_limit_and_auto_reset_wrappers():
     env2.num_envs = 2
     with pytest.raises(AssertionError, match='single environment'):
         OnPolicyAdapter('count', 2, 0, _cfgs(obs_normalize=False), env=env2)
+
+
+@pytest.mark.gpu
+def test_policy_step_with_fused_action_scale_equals_the_two_launches():
+    """osa_policy_step_scaled: ActionScale.step (envs/wrapper.py:510-514) in the policy step's launch -- the same
+    actions, values and log-probabilities as osa_policy_step, and the bits of osa_action_scale on those actions."""
+    import types
+
+    from omnisafe_amd import _lib
+    from omnisafe_amd.models import ConstraintActorCritic
+    from omnisafe_amd.spaces import Box
+
+    ns = types.SimpleNamespace
+    mc = ns(actor=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4),
+            critic=ns(hidden_sizes=[64, 64], activation='tanh', lr=3e-4),
+            weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning', linear_lr_decay=True)
+    lib = _lib.load(require_gpu=True)
+    for d_o, d_a, N in ((60, 2, 4096), (27, 8, 1000), (72, 17, 130)):
+        torch.manual_seed(d_o)
+        ac = ConstraintActorCritic(Box(-np.inf, np.inf, (d_o,)), Box(-1, 1, (d_a,)), mc, 4, device=DEV)
+        ac.set_seed(5)
+        ac._rng_offset = 0  # (the stream position advances with every step: same position for both calls)
+        obs = torch.randn(N, d_o, device=DEV)
+        lo = torch.linspace(-2.0, -0.5, d_a, device=DEV)
+        hi = torch.linspace(0.7, 3.0, d_a, device=DEV)
+        env_a = torch.full((N, d_a), 7.0, device=DEV)
+        a1, vr1, vc1, lp1 = ac.step(obs, out={'scale': (env_a, lo, hi, -1.0, 1.0)})
+        ac._rng_offset = 0
+        a2, vr2, vc2, lp2 = ac.step(obs)
+        env_b = torch.empty_like(env_a)
+        _lib.check(lib.osa_action_scale(_lib.ptr(a2), d_a, _lib.ptr(env_b), d_a, N, d_a, _lib.ptr(lo), _lib.ptr(hi),
+                                        -1.0, 1.0, _lib.stream_ptr()), 'osa_action_scale')
+        for x, y in ((a1, a2), (vr1, vr2), (vc1, vc2), (lp1, lp2), (env_a, env_b)):
+            assert torch.equal(x, y)
