@@ -555,6 +555,21 @@ int osa_rollout_post_step(int N, int epoch_end, const float* reward, const float
                           float* ep_cost_out, float* ep_len_out, float* reward_row, float* cost_row,
                           void* stream);
 
+/* End-of-epoch log flush of OnPolicyAdapter.rollout (_log_metrics onpolicy_adapter.py:159-174; logger.store of the
+ * value means :88-92) in two launches: the finished episodes (done[i] != 0, i = t N + n over the epoch's M = T N
+ * slots) compacted in (step, env) order -- out_idx[k] = i, out_vals[0 M + k] = ep_ret[i], [1 M + k] = ep_cost[i],
+ * [2 M + k] = ep_len[i], [3 M + k] = extra[i] (extra may be NULL) -- their number in out_count[0], and out_means =
+ * { mean(value_r), mean(value_c) } over the M slots (float64 sums in a fixed order).  out_idx: int[M], out_vals:
+ * float[4 M]; ws: osa_episode_flush_ws_doubles(M) doubles, zeroed once (every call leaves its ticket at 0). */
+size_t osa_episode_flush_ws_doubles(long M);
+int osa_episode_flush(const uint8_t* done, const float* ep_ret, const float* ep_cost, const float* ep_len,
+                      const float* extra, long M, const float* value_r, const float* value_c, int* out_count,
+                      int* out_idx, float* out_vals, float* out_means, double* ws, void* stream);
+
+/* *out = mean of x[idx[0 .. n)] (idx NULL: of x[0 .. n)), float64 accumulation in a fixed order: the Value/Adv the
+ * reference logs from the LAST minibatch of the update (policy_gradient.py:369-377, 402). */
+int osa_gather_mean(const float* x, const long* idx, long n, float* out, void* stream);
+
 /* SauteAdapter.step for all N envs (omnisafe/adapter/saute_adapter.py:124-196; SimmerAdapter shares it with
  * reset_value = relative budget): safety_obs <- (safety_obs - cost/budget)/saute_gamma; reward_out =
  * reward if safety_obs > 0 else unsafe_reward; finished envs (terminated | truncated) restart from

@@ -45,6 +45,9 @@ SIGNATURES: dict[str, tuple] = {
                                _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'osa_ppo_minibatch_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
                                    _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'osa_episode_flush_ws_doubles': (C.c_size_t, [_L]),
+    'osa_episode_flush': (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'osa_gather_mean': (_I, [_P, _P, _L, _P, _P]),
     'osa_saute_step': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     'osa_debug_set_clock_buffer': (_I, [_P]),
     'osa_debug_set_pass_clock_buffer': (_I, [_P]),

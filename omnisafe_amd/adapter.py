@@ -308,6 +308,39 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         # the three windowed keys only ever keep the last `window` episodes: copy no more than those to the host;
         # un-windowed extras (Metrics/EpBudget of Saute / Simmer) average EVERY episode of the epoch
         window = logger.window_length('Metrics/EpRet') if hasattr(logger, 'window_length') else None
+        import os
+
+        if (type(self)._flush_extra is OnPolicyAdapter._flush_extra and os.environ.get('OSA_FLUSH_KERNEL', '1') != '0'
+                and buffer.data['value_r'].numel() == ep['done'].numel()):
+            # osa_episode_flush: the finished episodes compacted in (step, env) order + the two value means in two
+            # launches and ONE synchronisation (the torch form below: nonzero, three gathers, two means, a stack)
+            M = ep['done'].numel()
+            fs = self.__dict__.setdefault('_flush_state', {})
+            if fs.get('M') != M:
+                dev = ep['done'].device
+                fs.update(M=M, hdr=torch.zeros(4, dtype=torch.int32, device=dev),
+                          idx=torch.empty(M, dtype=torch.int32, device=dev),
+                          vals=torch.empty(4 * M, dtype=torch.float32, device=dev),
+                          ws=torch.zeros(self._lib.osa_episode_flush_ws_doubles(M), dtype=torch.float64, device=dev))
+            hdr = fs['hdr']
+            _lib.check(self._lib.osa_episode_flush(
+                _lib.ptr(ep['done']), _lib.ptr(ep['ret']), _lib.ptr(ep['cost']), _lib.ptr(ep['len']), None, M,
+                _lib.ptr(buffer.data['value_r']), _lib.ptr(buffer.data['value_c']), _lib.ptr(hdr[0:1]),
+                _lib.ptr(fs['idx']), _lib.ptr(fs['vals']), _lib.ptr(hdr[1:3]), _lib.ptr(fs['ws']),
+                _lib.stream_ptr()), 'osa_episode_flush')
+            h = hdr.cpu()  # host sync (once per epoch)
+            cnt = int(h[0])
+            vmean = h[1:3].view(torch.float32).tolist()
+            if cnt > 0:
+                k0 = 0 if window is None else max(0, cnt - window)
+                vals = fs['vals'].view(4, M)[:3, k0:cnt].cpu()
+                logger.extend('Metrics/EpRet', vals[0].tolist())
+                logger.extend('Metrics/EpCost', vals[1].tolist())
+                logger.extend('Metrics/EpLen', vals[2].tolist())
+            logger.store({'Value/reward': vmean[0]})
+            if self._cfgs.algo_cfgs.use_cost:
+                logger.store({'Value/cost': vmean[1]})
+            return
         # everything the host will read is enqueued BEFORE the first synchronisation (each later one then finds its
         # result finished instead of leaving the device idle while the host enqueues the next reduction)
         vmean = torch.stack([buffer.data['value_r'].mean(), buffer.data['value_c'].mean()])

@@ -184,8 +184,19 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
             lg.store({'Loss/Loss_cost_critic': summ['Loss/Loss_cost_critic']})
         # the reference logs the LAST minibatch's adv_r.mean() here (the dataloader's loop variables shadow the
         # full batch: policy_gradient.py:369-377, 402) -- same here
-        lg.store({'Train/StopIter': out['stop_iter'],
-                  'Value/Adv': float(data['adv_r'][out['last_minibatch']].mean()), 'Train/KL': out['kl']})
+        lg.store({'Train/StopIter': out['stop_iter'], 'Value/Adv': self._gather_mean(data['adv_r'], out['last_minibatch']),
+                  'Train/KL': out['kl']})
+
+    def _gather_mean(self, x: torch.Tensor, idx: torch.Tensor) -> float:
+        """mean(x[idx]) in one launch (osa_gather_mean) instead of an index kernel, a reduction and a division."""
+        from .. import _lib
+
+        lib = _lib.load(require_gpu=True)
+        out = self.__dict__.setdefault('_gm_out', torch.empty(1, dtype=torch.float32, device=x.device))
+        idx = idx.contiguous()
+        _lib.check(lib.osa_gather_mean(_lib.ptr(x), _lib.ptr(idx), idx.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                   'osa_gather_mean')
+        return float(out)
 
 
 @register

@@ -420,6 +420,114 @@ __global__ __launch_bounds__(64) void osa_reach_env_kernel(
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// End-of-epoch log flush (onpolicy_adapter.py:159-174 _log_metrics, :88-92 logger.store Value/*): the finished
+// episodes of the epoch compacted in (step, env) order -- flat index, return, cost, length and an optional extra
+// column -- and the means of the two value columns.  Rounds 1-3 used torch for this (nonzero = rocPRIM partition +
+// scan, three gathers, two means, a stack: a dozen launches); here two: (1) every workgroup counts the finished
+// episodes of its contiguous range and sums its share of the value columns in float64, the LAST to arrive scans the
+// counts into offsets and finishes the means; (2) every workgroup compacts its range behind its offset.
+// ws (layout independent of the launch's grid, so that one zero-initialised workspace serves any M): ints [0] ticket
+// (left at 0 by every call), [1 .. 256] counts, [257 .. 512] offsets; doubles from OSA_FLUSH_DOFF: [2 G] value sums.
+// ------------------------------------------------------------------------------------------------
+#define OSA_FLUSH_MAXG 256
+#define OSA_FLUSH_DOFF 260  // doubles
+__global__ __launch_bounds__(256) void osa_flush_count_kernel(const uint8_t* __restrict__ done, long M,
+                                                              const float* __restrict__ value_r,
+                                                              const float* __restrict__ value_c, double* __restrict__ ws,
+                                                              int* __restrict__ out_count, float* __restrict__ out_means) {
+  __shared__ double red[17];
+  __shared__ int sc[4];
+  __shared__ int s_last;
+  const int G = gridDim.x, b = blockIdx.x;
+  int* iw = reinterpret_cast<int*>(ws);
+  double* dw = ws + OSA_FLUSH_DOFF;
+  const long per = (M + G - 1) / G, lo = (long)b * per, hi = min(M, lo + per);
+  int cnt = 0;
+  double sr = 0.0, sv = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    cnt += done[i] != 0;
+    sr += (double)value_r[i];
+    sv += (double)value_c[i];
+  }
+  sr = osa_block_sum<256>(sr, red);
+  sv = osa_block_sum<256>(sv, red);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    osa_ws_put(dw + 2 * b, sr);
+    osa_ws_put(dw + 2 * b + 1, sv);
+    __hip_atomic_store(iw + 1 + b, sc[0] + sc[1] + sc[2] + sc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(iw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == G - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  int run = 0;
+  double tr = 0.0, tv = 0.0;
+  for (int k = 0; k < G; ++k) {  // block order: offsets and sums do not depend on the arrival order
+    __hip_atomic_store(iw + 1 + OSA_FLUSH_MAXG + k, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    run += __hip_atomic_load(iw + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tr += osa_ws_get(dw + 2 * k);
+    tv += osa_ws_get(dw + 2 * k + 1);
+  }
+  *out_count = run;
+  out_means[0] = (float)(tr / (double)M);
+  out_means[1] = (float)(tv / (double)M);
+  __hip_atomic_store(iw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+}
+
+__global__ __launch_bounds__(256) void osa_flush_compact_kernel(const uint8_t* __restrict__ done,
+                                                                const float* __restrict__ ep_ret,
+                                                                const float* __restrict__ ep_cost,
+                                                                const float* __restrict__ ep_len,
+                                                                const float* __restrict__ extra, long M,
+                                                                const double* __restrict__ ws, int* __restrict__ out_idx,
+                                                                float* __restrict__ out_vals) {
+  __shared__ int s_cnt[256];
+  const int G = gridDim.x, b = blockIdx.x;
+  const int* iw = reinterpret_cast<const int*>(ws);
+  const long per = (M + G - 1) / G, lo = (long)b * per, hi = min(M, lo + per);
+  // thread t: the contiguous sub-range [lo + t q, lo + (t + 1) q) of the workgroup's range
+  const long q = (per + 255) / 256, tlo = min(hi, lo + (long)threadIdx.x * q), thi = min(hi, tlo + q);
+  int cnt = 0;
+  for (long i = tlo; i < thi; ++i) cnt += done[i] != 0;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive scan of 256 counts (serial: a few hundred cycles once per epoch)
+    int run = iw[1 + OSA_FLUSH_MAXG + b];
+    for (int k = 0; k < 256; ++k) {
+      const int c = s_cnt[k];
+      s_cnt[k] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  int pos = s_cnt[threadIdx.x];
+  for (long i = tlo; i < thi; ++i) {
+    if (done[i] != 0) {
+      out_idx[pos] = (int)i;
+      out_vals[pos] = ep_ret[i];
+      out_vals[M + pos] = ep_cost[i];
+      out_vals[2 * M + pos] = ep_len[i];
+      if (extra) out_vals[3 * M + pos] = extra[i];
+      ++pos;
+    }
+  }
+}
+
+// mean of x[idx[0 .. n)] (Value/Adv of the last minibatch, policy_gradient.py:369-377, 402): one workgroup, float64
+__global__ __launch_bounds__(1024) void osa_gather_mean_kernel(const float* __restrict__ x, const long* __restrict__ idx,
+                                                               long n, float* __restrict__ out) {
+  __shared__ double red[17];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += (double)x[idx ? idx[i] : i];
+  s = osa_block_sum<1024>(s, red);
+  if (threadIdx.x == 0) *out = (float)(s / (double)n);
+}
+
 extern "C" {
 
 size_t osa_normalizer_ws_doubles(int N, int D) {
@@ -527,6 +635,35 @@ int osa_reach_env_step(unsigned long long seed, unsigned long long step,
   hipLaunchKernelGGL(osa_reach_env_kernel, dim3(N), dim3(64), 0, osa_stream(stream), seed, step, step_base, N,
                      obs_dim, horizon, state, steps, action, ld_action, obs, ld_obs, reward, cost,
                      terminated, truncated, final_obs, ld_final, reset_only);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+
+size_t osa_episode_flush_ws_doubles(long M) {
+  (void)M;
+  return (size_t)OSA_FLUSH_DOFF + 2 * OSA_FLUSH_MAXG;
+}
+
+int osa_episode_flush(const uint8_t* done, const float* ep_ret, const float* ep_cost, const float* ep_len,
+                      const float* extra, long M, const float* value_r, const float* value_c, int* out_count,
+                      int* out_idx, float* out_vals, float* out_means, double* ws, void* stream) {
+  OSA_REQUIRE(done && ep_ret && ep_cost && ep_len && value_r && value_c && M > 0);
+  OSA_REQUIRE(out_count && out_idx && out_vals && out_means && ws);
+  if (M >= 2147483647L) return OSA_EUNSUPPORTED;
+  int G = (int)((M + 4095) / 4096);
+  if (G > OSA_FLUSH_MAXG) G = OSA_FLUSH_MAXG;
+  hipLaunchKernelGGL(osa_flush_count_kernel, dim3(G), dim3(256), 0, osa_stream(stream), done, M, value_r, value_c, ws,
+                     out_count, out_means);
+  hipLaunchKernelGGL(osa_flush_compact_kernel, dim3(G), dim3(256), 0, osa_stream(stream), done, ep_ret, ep_cost,
+                     ep_len, extra, M, ws, out_idx, out_vals);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_gather_mean(const float* x, const long* idx, long n, float* out, void* stream) {
+  OSA_REQUIRE(x && out && n > 0);
+  hipLaunchKernelGGL(osa_gather_mean_kernel, dim3(1), dim3(1024), 0, osa_stream(stream), x, idx, n, out);
   OSA_CHECK_LAUNCH();
   return OSA_OK;
 }

@@ -686,3 +686,45 @@ def test_policy_step_with_fused_action_scale_equals_the_two_launches():
                                         -1.0, 1.0, _lib.stream_ptr()), 'osa_action_scale')
         for x, y in ((a1, a2), (vr1, vr2), (vc1, vc2), (lp1, lp2), (env_a, env_b)):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,N,p', [(16, 4096, 0.06), (3, 5, 0.5), (1, 1, 1.0), (50, 100, 0.0), (300, 4096, 0.01),
+                                   (64, 16411, 0.2)])
+def test_episode_flush_kernel_equals_the_torch_form(T, N, p):
+    """osa_episode_flush (two launches) vs what rounds 1-3 did with torch (nonzero, gathers, means): the finished
+    episodes in (step, env) order with their return / cost / length / extra column, their count, and the means of the
+    two value columns -- over several grid sizes, a ragged last range, no finished episode at all, and twice on ONE
+    workspace with different sizes (the ticket has a fixed place)."""
+    from omnisafe_amd import _lib
+
+    lib = _lib.load(require_gpu=True)
+    ws = torch.zeros(lib.osa_episode_flush_ws_doubles(1 << 22), dtype=torch.float64, device=DEV)
+    for rep, (t, n) in enumerate(((T, N), (max(1, T // 2), N), (T, N))):
+        M = t * n
+        g = torch.Generator(device=DEV).manual_seed(7 + rep)
+        done = (torch.rand(M, device=DEV, generator=g) < p).to(torch.uint8)
+        ret, cost, ln, extra, vr, vc = (torch.randn(M, device=DEV, generator=g) for _ in range(6))
+        hdr = torch.zeros(4, dtype=torch.int32, device=DEV)
+        idx = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+        vals = torch.full((4 * M,), 7.0, device=DEV)
+        _lib.check(lib.osa_episode_flush(_lib.ptr(done), _lib.ptr(ret), _lib.ptr(cost), _lib.ptr(ln), _lib.ptr(extra), M,
+                                         _lib.ptr(vr), _lib.ptr(vc), _lib.ptr(hdr[0:1]), _lib.ptr(idx), _lib.ptr(vals),
+                                         _lib.ptr(hdr[1:3]), _lib.ptr(ws), _lib.stream_ptr()), 'osa_episode_flush')
+        want = done.nonzero().reshape(-1)
+        cnt = int(hdr[0])
+        assert cnt == want.numel()
+        assert torch.equal(idx[:cnt].long(), want) and bool((idx[cnt:] == -1).all())
+        v = vals.view(4, M)
+        for k, src in enumerate((ret, cost, ln, extra)):
+            assert torch.equal(v[k, :cnt], src[want])
+        means = hdr[1:3].view(torch.float32).cpu().numpy()
+        np.testing.assert_allclose(means, [float(vr.double().mean()), float(vc.double().mean())], rtol=1e-6, atol=1e-7)
+        assert int(ws.view(torch.int32)[0]) == 0  # ticket re-armed
+    out = torch.empty(1, device=DEV)
+    x = torch.randn(100000, device=DEV)
+    ii = torch.randint(0, 100000, (16384,), device=DEV)
+    _lib.check(lib.osa_gather_mean(_lib.ptr(x), _lib.ptr(ii), ii.numel(), _lib.ptr(out), _lib.stream_ptr()), 'osa_gather_mean')
+    np.testing.assert_allclose(float(out), float(x[ii].double().mean()), rtol=1e-6, atol=1e-8)
+    _lib.check(lib.osa_gather_mean(_lib.ptr(x), None, 77, _lib.ptr(out), _lib.stream_ptr()), 'osa_gather_mean')
+    np.testing.assert_allclose(float(out), float(x[:77].double().mean()), rtol=1e-6, atol=1e-8)
