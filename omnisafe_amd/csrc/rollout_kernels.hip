@@ -445,10 +445,24 @@ __global__ __launch_bounds__(256) void osa_flush_count_kernel(const uint8_t* __r
   const long per = (M + G - 1) / G, lo = (long)b * per, hi = min(M, lo + per);
   int cnt = 0;
   double sr = 0.0, sv = 0.0;
-  for (long i = lo + threadIdx.x; i < hi; i += 256) {
-    cnt += done[i] != 0;
-    sr += (double)value_r[i];
-    sv += (double)value_c[i];
+  for (long i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * 8) {  // 8 x 3 loads in flight, consumed in order
+    uint8_t f[8];
+    float a[8], c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long i = min(i0 + 256L * u, hi - 1);
+      f[u] = done[i];
+      a[u] = value_r[i];
+      c[u] = value_c[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + 256L * u < hi) {
+        cnt += f[u] != 0;
+        sr += (double)a[u];
+        sv += (double)c[u];
+      }
+    }
   }
   sr = osa_block_sum<256>(sr, red);
   sv = osa_block_sum<256>(sv, red);
@@ -464,19 +478,34 @@ __global__ __launch_bounds__(256) void osa_flush_count_kernel(const uint8_t* __r
     s_last = (t == G - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (!s_last || threadIdx.x != 0) return;
-  int run = 0;
-  double tr = 0.0, tv = 0.0;
-  for (int k = 0; k < G; ++k) {  // block order: offsets and sums do not depend on the arrival order
-    __hip_atomic_store(iw + 1 + OSA_FLUSH_MAXG + k, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    run += __hip_atomic_load(iw + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tr += osa_ws_get(dw + 2 * k);
-    tv += osa_ws_get(dw + 2 * k + 1);
+  if (!s_last) return;
+  // ---- the last workgroup to arrive: counts -> offsets (block order: nothing depends on the arrival order), means.
+  // Every thread fetches one workgroup's partials (one round trip for all), thread 0 scans them in LDS.
+  __shared__ int l_cnt[OSA_FLUSH_MAXG];
+  __shared__ double l_sum[2][OSA_FLUSH_MAXG];
+  for (int k = threadIdx.x; k < G; k += 256) {
+    l_cnt[k] = __hip_atomic_load(iw + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l_sum[0][k] = osa_ws_get(dw + 2 * k);
+    l_sum[1][k] = osa_ws_get(dw + 2 * k + 1);
   }
-  *out_count = run;
-  out_means[0] = (float)(tr / (double)M);
-  out_means[1] = (float)(tv / (double)M);
-  __hip_atomic_store(iw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    double tr = 0.0, tv = 0.0;
+    for (int k = 0; k < G; ++k) {
+      const int c = l_cnt[k];
+      l_cnt[k] = run;
+      run += c;
+      tr += l_sum[0][k];
+      tv += l_sum[1][k];
+    }
+    *out_count = run;
+    out_means[0] = (float)(tr / (double)M);
+    out_means[1] = (float)(tv / (double)M);
+    __hip_atomic_store(iw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < G; k += 256) iw[1 + OSA_FLUSH_MAXG + k] = l_cnt[k];
 }
 
 __global__ __launch_bounds__(256) void osa_flush_compact_kernel(const uint8_t* __restrict__ done,
@@ -486,34 +515,48 @@ __global__ __launch_bounds__(256) void osa_flush_compact_kernel(const uint8_t* _
                                                                 const float* __restrict__ extra, long M,
                                                                 const double* __restrict__ ws, int* __restrict__ out_idx,
                                                                 float* __restrict__ out_vals) {
-  __shared__ int s_cnt[256];
+  __shared__ int s_cnt[4];
   const int G = gridDim.x, b = blockIdx.x;
   const int* iw = reinterpret_cast<const int*>(ws);
   const long per = (M + G - 1) / G, lo = (long)b * per, hi = min(M, lo + per);
   // thread t: the contiguous sub-range [lo + t q, lo + (t + 1) q) of the workgroup's range
   const long q = (per + 255) / 256, tlo = min(hi, lo + (long)threadIdx.x * q), thi = min(hi, tlo + q);
   int cnt = 0;
-  for (long i = tlo; i < thi; ++i) cnt += done[i] != 0;
-  s_cnt[threadIdx.x] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {  // exclusive scan of 256 counts (serial: a few hundred cycles once per epoch)
-    int run = iw[1 + OSA_FLUSH_MAXG + b];
-    for (int k = 0; k < 256; ++k) {
-      const int c = s_cnt[k];
-      s_cnt[k] = run;
-      run += c;
-    }
+  for (long i0 = tlo; i0 < thi; i0 += 16) {
+    uint8_t f[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) f[u] = done[min(i0 + u, thi - 1)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cnt += (i0 + u < thi) && f[u] != 0;
   }
+  // exclusive scan of the 256 counts: inclusive scan inside each wave, then the waves' totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += v;
+  }
+  if (lane == 63) s_cnt[wave] = inc;
   __syncthreads();
-  int pos = s_cnt[threadIdx.x];
-  for (long i = tlo; i < thi; ++i) {
-    if (done[i] != 0) {
-      out_idx[pos] = (int)i;
-      out_vals[pos] = ep_ret[i];
-      out_vals[M + pos] = ep_cost[i];
-      out_vals[2 * M + pos] = ep_len[i];
-      if (extra) out_vals[3 * M + pos] = extra[i];
-      ++pos;
+  int pos = iw[1 + OSA_FLUSH_MAXG + b] + inc - cnt;
+  for (int w = 0; w < wave; ++w) pos += s_cnt[w];
+  if (cnt == 0) return;
+  for (long i0 = tlo; i0 < thi; i0 += 16) {
+    uint8_t f[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) f[u] = done[min(i0 + u, thi - 1)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const long i = i0 + u;
+      if (i < thi && f[u] != 0) {
+        out_idx[pos] = (int)i;
+        out_vals[pos] = ep_ret[i];
+        out_vals[M + pos] = ep_cost[i];
+        out_vals[2 * M + pos] = ep_len[i];
+        if (extra) out_vals[3 * M + pos] = extra[i];
+        ++pos;
+      }
     }
   }
 }
@@ -523,7 +566,20 @@ __global__ __launch_bounds__(1024) void osa_gather_mean_kernel(const float* __re
                                                                long n, float* __restrict__ out) {
   __shared__ double red[17];
   double s = 0.0;
-  for (long i = threadIdx.x; i < n; i += 1024) s += (double)x[idx ? idx[i] : i];
+  for (long i0 = threadIdx.x; i0 < n; i0 += 1024 * 8) {  // indices, then values: two round trips per 8 elements
+    long j[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long i = min(i0 + 1024L * u, n - 1);
+      j[u] = idx ? idx[i] : i;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[j[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 1024L * u < n) s += (double)v[u];
+  }
   s = osa_block_sum<1024>(s, red);
   if (threadIdx.x == 0) *out = (float)(s / (double)n);
 }
@@ -651,7 +707,7 @@ int osa_episode_flush(const uint8_t* done, const float* ep_ret, const float* ep_
   OSA_REQUIRE(done && ep_ret && ep_cost && ep_len && value_r && value_c && M > 0);
   OSA_REQUIRE(out_count && out_idx && out_vals && out_means && ws);
   if (M >= 2147483647L) return OSA_EUNSUPPORTED;
-  int G = (int)((M + 4095) / 4096);
+  int G = (int)((M + 1023) / 1024);  // (1024 slots per workgroup: four per thread at the headline's 65 536)
   if (G > OSA_FLUSH_MAXG) G = OSA_FLUSH_MAXG;
   hipLaunchKernelGGL(osa_flush_count_kernel, dim3(G), dim3(256), 0, osa_stream(stream), done, M, value_r, value_c, ws,
                      out_count, out_means);
