@@ -193,6 +193,8 @@ def roofline_from_events(events, batch_size):
                        'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
                        'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
     else:
+        steps = max(1, rows // len(events) // batch_size)  # (a captured pass of several steps is one timed event)
+        out['us_per_optimiser_step'] = round(us / steps, 3)
         out['kernel'] = 'osa_ppo_pass_kernel (partial-gradient mode) + osa_slab_reduce_kernel + osa_finalize_kernel'
         out['note'] = ('large-batch step: <= CUs/3 workgroups per network keep the weights in LDS and their partial '
                        'gradient in registers over several 64-row chunks, one slab each; slab reduce + clip/Adam launches')

@@ -195,6 +195,10 @@ typedef struct osa_ppo_hparams {
   int use_critic_norm;    /* algo_cfgs.use_critic_norm */
   int use_max_grad_norm;  /* algo_cfgs.use_max_grad_norm */
   int use_cost;           /* algo_cfgs.use_cost */
+  const float* lr_device; /* optional: { lr_actor, lr_critic } in DEVICE memory, read at execution time instead of the
+                           * two by-value fields -- lets a captured hipGraph of optimiser steps be replayed across
+                           * epochs while the LinearLR schedule moves.  Honoured by osa_ppo_minibatch(_ext) and
+                           * osa_adam_apply; NULL everywhere else */
 } osa_ppo_hparams;
 
 /* One minibatch step of PolicyGradient._update's inner loop for all three networks in one launch:

@@ -11,6 +11,7 @@ struct OsaHp {  // mirrors osa_ppo_hparams in include/omnisafe_amd.h
   float clip, entropy_coef, critic_norm_coef, max_grad_norm;
   float lr_actor, lr_critic, beta1, beta2, adam_eps;
   int use_critic_norm, use_max_grad_norm, use_cost;
+  const float* lr_dev;  // optional {lr_actor, lr_critic} in device memory (osa_ppo_hparams.lr_device)
 };
 
 struct OsaMbArgs {
@@ -212,7 +213,7 @@ __device__ void osa_finalize_net(const OsaMbArgs& a, int net, float* red) {
   const double b1 = a.hp.beta1, b2 = a.hp.beta2;
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+  const float lr = a.hp.lr_dev ? a.hp.lr_dev[critic ? 1 : 0] : (critic ? a.hp.lr_critic : a.hp.lr_actor);
   const float step_size = (float)((double)lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   OSA_TICK(11);
@@ -887,7 +888,7 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
       a.grads[(long)net * P + e] = gval * coef;
     } else {
       const double b1 = a.hp.beta1, b2 = a.hp.beta2;
-      const float lr = critic ? a.hp.lr_critic : a.hp.lr_actor;
+      const float lr = a.hp.lr_dev ? a.hp.lr_dev[critic ? 1 : 0] : (critic ? a.hp.lr_critic : a.hp.lr_actor);
       const float step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
       const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
       float* __restrict__ m = a.adam_m + (long)net * P;
@@ -1279,7 +1280,7 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   a.idx = idx; a.B = B; a.lagrange = lagrange;
   a.hp.clip = hp->clip; a.hp.entropy_coef = hp->entropy_coef;
   a.hp.critic_norm_coef = hp->critic_norm_coef; a.hp.max_grad_norm = hp->max_grad_norm;
-  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.lr_dev = hp->lr_device; a.hp.beta1 = hp->beta1;
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.mode = mode; a.stats = step_stats; a.loss_kind = loss_kind;
@@ -1364,7 +1365,7 @@ int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* a
   OsaMbArgs a = {};
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step; a.grads = grads;
-  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.beta1 = hp->beta1;
+  a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.lr_dev = hp->lr_device; a.hp.beta1 = hp->beta1;
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps;
   a.nets_mask = nets_mask;
   a.mode = 3;

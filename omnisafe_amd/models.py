@@ -33,7 +33,8 @@ class HParams(C.Structure):
     _fields_ = [('clip', C.c_float), ('entropy_coef', C.c_float), ('critic_norm_coef', C.c_float),
                 ('max_grad_norm', C.c_float), ('lr_actor', C.c_float), ('lr_critic', C.c_float),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('adam_eps', C.c_float),
-                ('use_critic_norm', C.c_int), ('use_max_grad_norm', C.c_int), ('use_cost', C.c_int)]
+                ('use_critic_norm', C.c_int), ('use_max_grad_norm', C.c_int), ('use_cost', C.c_int),
+                ('lr_device', C.c_void_p)]
 
 
 class SurrogateExt(C.Structure):

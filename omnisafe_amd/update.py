@@ -88,6 +88,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._split_tried = False
         self._chunk: dict = {}  # exchange buffer / sync words of osa_ppo_chunked_pass
         self._big: dict = {}  # ... of osa_ppo_large_batch_pass
+        self._ug: dict = {}  # captured hipGraph of one pass of per-step launches (large minibatches)
         self._split_local = False
         self._split_verified = False
         self._split_buf = None
@@ -226,6 +227,77 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         _lib.check(self.lib.osa_shuffle_rows(_lib.ptr(seeds), rows, M, _lib.ptr(out), _lib.stream_ptr()),
                    'osa_shuffle_rows')
         return out
+
+    def _graph_pass_ok(self, M: int) -> bool:
+        """The per-step launches of a pass go through a captured hipGraph: large minibatches (the launches, not the
+        rows, are what a step waits for), plain surrogate, single process.  OSA_UPDATE_GRAPH=0 keeps eager launches."""
+        return (self.batch_size >= 2048 and self.ext is None and not dist.collectives_active()
+                and os.environ.get('OSA_UPDATE_GRAPH', '1') != '0' and not self._ug.get('failed', False))
+
+    def _graph_pass(self, data: dict, perm: torch.Tensor, lagrange: torch.Tensor, stats_rows: torch.Tensor) -> None:
+        """One pass = ceil(M / B) optimiser steps of two launches each (partial gradients; slab reduce + clip + Adam),
+        captured ONCE and replayed for every pass of every epoch: the permutation and the statistics rows live in
+        fixed buffers, the learning rates in device memory (osa_ppo_hparams.lr_device) so that the LinearLR schedule
+        can move between replays.  54 instead of 58 us per 16 384-row step (tools/large_batch_step_timing.py)."""
+        ac, B = self.ac, self.batch_size
+        M = data['obs'].shape[0]
+        nmb = (M + B - 1) // B
+        hp = self.hp
+        key = (M, B, tuple(int(data[k].data_ptr()) for k in ('obs', 'act', 'logp', 'target_value_r', 'target_value_c',
+                                                             'adv_r', 'adv_c')), int(lagrange.data_ptr()),
+               self._nets_mask(), self.loss_kind, self.max_blocks,
+               (hp.clip, hp.entropy_coef, hp.critic_norm_coef, hp.max_grad_norm, hp.beta1, hp.beta2, hp.adam_eps,
+                hp.use_critic_norm, hp.use_max_grad_norm, hp.use_cost))
+        st = self._ug
+        if st.get('key') != key:
+            st.clear()
+            st.update(key=key, perm=torch.empty(M, dtype=torch.int64, device=ac.device),
+                      stats=torch.zeros(nmb, NSTAT, dtype=torch.float32, device=ac.device),
+                      lr=torch.zeros(2, dtype=torch.float32, device=ac.device),
+                      lr_host=torch.zeros(2, dtype=torch.float32).pin_memory(), graph=None, warm=False)
+        st['perm'].copy_(perm)
+        st['lr_host'][0], st['lr_host'][1] = float(hp.lr_actor), float(hp.lr_critic)
+        st['lr'].copy_(st['lr_host'], non_blocking=True)
+
+        def enqueue() -> None:
+            for k in range(nmb):
+                s0 = k * B
+                nb = min(B, M - s0)
+                self.minibatch(data, st['perm'][s0:s0 + nb], nb, lagrange, st['stats'][k])
+
+        hp.lr_device = st['lr'].data_ptr()
+        pe, self.profile_events = self.profile_events, None  # (one event pair around the pass, none inside a capture)
+        ev = None
+        if pe is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        try:
+            if st['graph'] is not None:
+                st['graph'].replay()
+            elif not st['warm']:  # first pass: eager (also sets the kernels' attributes, which must not happen under capture)
+                enqueue()
+                st['warm'] = True
+            else:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        enqueue()
+                    st['graph'] = g
+                    g.replay()
+                except Exception as exc:  # pragma: no cover - capture refused: stay on eager launches
+                    import warnings
+
+                    warnings.warn(f'omnisafe_amd: hipGraph capture of the update pass was refused ({exc!r}); the '
+                                  'steps stay on eager launches (OSA_UPDATE_GRAPH=0 silences this)', RuntimeWarning)
+                    st['failed'], st['graph'] = True, None
+                    enqueue()
+        finally:
+            hp.lr_device = None
+            self.profile_events = pe
+        if ev is not None:
+            ev[1].record()
+            pe.append(('osa_mb_grad_kernel', M, ev))
+        stats_rows.copy_(st['stats'])
 
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
                   stats_row: torch.Tensor) -> None:
@@ -813,6 +885,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 step += nmb
             elif use_pass:  # one persistent launch for the whole pass
                 self.run_pass(data, perm, lagrange, stats[step:step + nmb])
+                step += nmb
+            elif self._graph_pass_ok(M):  # large minibatches: the pass's steps (two launches each) as one hipGraph
+                self._graph_pass(data, perm, lagrange, stats[step:step + nmb])
                 step += nmb
             else:
                 for s in range(0, M, B):

@@ -371,6 +371,49 @@ def test_large_batch_pass_equals_per_step_launches(obs_dim, act_dim, M, B, monke
     np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
 
 
+def test_graph_captured_update_pass_equals_eager_launches(monkeypatch):
+    """Large minibatches: the steps of a pass (two launches each) are captured once as a hipGraph and replayed for every
+    later pass and epoch -- permutation and statistics rows in fixed buffers, the learning rates in device memory
+    (osa_ppo_hparams.lr_device) so that the schedule can move between replays.  Same kernels in the same order:
+    bit-identical parameters, moments and statistics to the eager launches over two updates with different rates."""
+    from omnisafe_amd.update import PPOUpdater
+
+    M, B, obs_dim, act_dim = 12000, 4096, 60, 2
+    torch.manual_seed(4)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perms = [[torch.randperm(M) for _ in range(4)] for _ in range(2)]
+    res = []
+    for graph in ('1', '0'):
+        monkeypatch.setenv('OSA_UPDATE_GRAPH', graph)
+        torch.manual_seed(99)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=4, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
+        lam = torch.tensor([0.3], device=DEV)
+        outs = [up.run(data, lam, perms=perms[0], actor_lr=3e-4, critic_lr=1e-3),
+                up.run(data, lam, perms=perms[1], actor_lr=1e-4, critic_lr=5e-4)]
+        assert up.last_path == 'per-step' and (up._ug.get('graph') is not None) == (graph == '1')
+        res.append((ac, [o['stats'].clone() for o in outs], [o['kl'] for o in outs]))
+    for name in ('params', 'adam_m', 'adam_v', 'adam_step'):
+        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert res[0][2] == res[1][2]
+    # the second update really used the smaller rates: one eager run with the first rates throughout differs
+    monkeypatch.setenv('OSA_UPDATE_GRAPH', '0')
+    torch.manual_seed(99)
+    ac = make_ac(obs_dim, act_dim)
+    up = PPOUpdater(ac, batch_size=B, update_iters=4, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
+    lam = torch.tensor([0.3], device=DEV)
+    up.run(data, lam, perms=perms[0], actor_lr=3e-4, critic_lr=1e-3)
+    up.run(data, lam, perms=perms[1], actor_lr=3e-4, critic_lr=1e-3)
+    assert not torch.equal(ac.params, res[0][0].params)
+
+
 @pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),
                                                   (3, 256, 128, True, False), (2, 512, 64, False, True),
                                                   (4, 300, 64, False, True), (3, 256, 128, False, True),
