@@ -99,9 +99,13 @@ int osa_gae_scan_tiled(const float* reward, const float* cost, const float* valu
  * where osa_gae_scan has too few lanes in flight and osa_gae_scan_tiled pays its log-depth scan.  Arithmetic: the
  * sequential kernel's step for step given the incoming carry; the carry is assembled by the affine identity
  * (float64 re-association): same tolerance class as osa_gae_scan_tiled, deterministic (independent of timing).
- * ws: osa_gae_chained_ws_doubles(T, N) doubles, contents irrelevant (initialised by every call).  v-trace:
- * OSA_EUNSUPPORTED. */
+ * ws: osa_gae_chained_ws_doubles(T, N) doubles; the carries and the ticket are initialised by every call, the LAST
+ * double is a sticky time-out word the caller zeroes ONCE after allocation: a lane that gives up waiting for a
+ * carry (bounded spin: a device shared with / preempted by another long-running kernel) sets it and its outputs
+ * are NaN -- osa_gae_chained_timed_out(ws, T, N, &flag) reads it (synchronous 4-byte copy; 0 = fine), which the
+ * caller does at its next host synchronisation.  v-trace: OSA_EUNSUPPORTED. */
 size_t osa_gae_chained_ws_doubles(int T, int N);
+int osa_gae_chained_timed_out(const double* ws, int T, int N, int* out);
 int osa_gae_scan_chained(const float* reward, const float* cost, const float* value_r, const float* value_c,
                          const uint8_t* path_end, const float* boot_r, const float* boot_c, int T, int N,
                          double gamma, double lam, double lam_c, float penalty_coef, int estimator,

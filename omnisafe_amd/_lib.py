@@ -29,6 +29,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_gae_scan': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
     'osa_gae_scan_tiled': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P]),
     'osa_gae_chained_ws_doubles': (C.c_size_t, [_I, _I]),
+    'osa_gae_chained_timed_out': (_I, [_P, _I, _I, _P]),
     'osa_gae_scan_chained': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     'osa_reduce_ws_bytes': (C.c_size_t, []),
     'osa_adv_stats_phase1': (_I, [_P, _P, _L, _P, _P, _P]),

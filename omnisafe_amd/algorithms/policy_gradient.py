@@ -172,6 +172,7 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         self._last_update_data, self._last_update_steps = data, out['steps']
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
+        self._buf.check_gae_sync()  # (the stream is drained here: sticky time-out word of the chained GAE scan)
         lg = self._logger
         ratio = summ['per_step']['ratio_mean']
         # min/max/std are over minibatch means, as in the reference (logger.py:277); one bulk append instead

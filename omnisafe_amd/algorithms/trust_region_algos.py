@@ -105,6 +105,7 @@ class NaturalPG(PolicyGradient):
                                 perms=getattr(self, '_perms_override', None))
         a = self._cfgs.algo_cfgs
         summ = PPOUpdater.summarize(out, a.critic_norm_coef, a.use_critic_norm)
+        self._buf.check_gae_sync()  # (the stream is drained here: sticky time-out word of the chained GAE scan)
         lg = self._logger
         lg.store({'Loss/Loss_reward_critic': summ['Loss/Loss_reward_critic']})
         if a.use_cost:

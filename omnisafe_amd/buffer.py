@@ -84,7 +84,8 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
             self._out[k] = torch.empty(M, **f32)
         self._stats = torch.zeros(8, dtype=torch.float64, device=dev)
         self._ws = torch.empty(self._lib.osa_reduce_ws_bytes() // 8, dtype=torch.float64, device=dev)
-        self.ptr = 0
+        self._ptr = 0
+        self._prefetched = False
 
     # ------------------------------------------------------------------ properties
     @property
@@ -205,8 +206,10 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         self.last_gae_variant = variant
         if variant == 'chained':
             need = self._lib.osa_gae_chained_ws_doubles(T, N)
-            if self._gae_ws is None or self._gae_ws.numel() < need:
-                self._gae_ws = torch.empty(need, dtype=torch.float64, device=self._device)
+            if self._gae_ws is None or self._gae_ws.numel() != need:
+                # (zeros: the last double is the scan's sticky time-out word, never reset by a launch)
+                self._gae_ws = torch.zeros(need, dtype=torch.float64, device=self._device)
+                self._gae_ws_shape = (T, N)
             _lib.check(self._lib.osa_gae_scan_chained(
                 _lib.ptr(b['reward']), _lib.ptr(b['cost']), _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),
                 _lib.ptr(b['path_end']), _lib.ptr(b['boot_r']), _lib.ptr(b['boot_c']), T, N, self._gamma,
@@ -222,6 +225,19 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
             _lib.ptr(b['adv_c']), _lib.ptr(b['target_value_r']), _lib.ptr(b['target_value_c']),
             _lib.ptr(b['discounted_ret']), _lib.stream_ptr()), 'osa_gae_scan')
 
+    @property
+    def ptr(self) -> int:
+        return self._ptr
+
+    @ptr.setter
+    def ptr(self, value: int) -> None:
+        """Every write of the pointer -- advance / store, get()'s reset, and the places that set it by hand (the
+        adapter's hipGraph replay: `ptr = 0 ... replay ... ptr = T`; the timing tools) -- invalidates a prefetched
+        batch: get() then re-assembles from the rows the buffer holds NOW, on the eager and the replayed path alike
+        (round-3 advisor finding: a second replay without a get() in between returned the previous rollout's batch)."""
+        self._ptr = int(value)
+        self._prefetched = False
+
     def get(self) -> dict[str, torch.Tensor]:
         """Finish all paths, standardise, and return the env-major batch (reference key set).
 
@@ -230,18 +246,35 @@ class VectorOnPolicyBuffer:  # pylint: disable=too-many-instance-attributes
         into the advantages and their statistics.  The returned tensors alias the buffer's staging block: the
         next `get()` overwrites them (the reference returns fresh concatenations)."""
         assert self.ptr == self._size, f'get() on a partially filled buffer (ptr {self.ptr} of {self._size})'
-        if not self.__dict__.pop('_prefetched', False):  # (else: enqueued by prefetch() right behind the rollout)
+        if not self._prefetched:  # (else: enqueued by prefetch() right behind the rollout)
             self._assemble()
-        self.ptr = 0
+        self.ptr = 0  # (also clears the prefetch mark)
         self.data['path_end'].zero_()
         return dict(self._out)
+
+    def check_gae_sync(self) -> None:
+        """Raise if a lane of the time-split GAE scan ever gave up waiting for a carry (its advantages and targets
+        are NaN then).  A 4-byte synchronous copy: the algorithms call it once per update where the stream is drained
+        anyway (behind the update's statistics)."""
+        if self._gae_ws is None:
+            return
+        import ctypes as C
+
+        flag = C.c_int(0)
+        T, N = self._gae_ws_shape
+        _lib.check(self._lib.osa_gae_chained_timed_out(_lib.ptr(self._gae_ws), T, N, C.byref(flag)),
+                   'osa_gae_chained_timed_out')
+        if flag.value:
+            raise _lib.OsaError('osa_gae_scan_chained: a carry never arrived within the bounded spin (device shared '
+                                'with another long-running kernel?) -- advantages of this epoch are invalid; set '
+                                'OSA_GAE_VARIANT=sequential')
 
     def prefetch(self) -> None:
         """Enqueue get()'s device work now -- advantages, their statistics, the env-major batch -- and leave the
         buffer's visible state (ptr, path_end, the rows) as it is: the rollout adapter calls this right behind the last
         vector step, BEFORE it synchronises to read the episode metrics, so the device does not sit idle while the
         host walks from the logger through the Lagrange update to the first launch of get()."""
-        if self.ptr == self._size and not self.__dict__.get('_prefetched', False):
+        if self.ptr == self._size and not self._prefetched:
             self._assemble()
             self._prefetched = True
 

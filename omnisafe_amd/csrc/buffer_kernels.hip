@@ -447,9 +447,16 @@ __device__ __forceinline__ double osa_gc_get(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(
       reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ double osa_gc_wait(const double* p) {  // bounded: NaN inputs must not hang the device
+// bounded (NaN inputs / a preempted device must not hang it); giving up raises the STICKY word `tmo` -- the carry
+// returned then is the sentinel itself, i.e. NaN outputs, and the host turns the word into an error at its next
+// synchronisation (osa_gae_chained_timed_out) instead of training on them silently
+__device__ __forceinline__ double osa_gc_wait(const double* p, unsigned int* tmo) {
   double v = osa_gc_get(p);
-  for (int spins = 0; !osa_gc_ready(v) && spins < (1 << 22); ++spins) {
+  for (int spins = 0; !osa_gc_ready(v); ++spins) {
+    if (spins >= (1 << 22)) {
+      __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
     __builtin_amdgcn_s_sleep(1);
     v = osa_gc_get(p);
   }
@@ -647,7 +654,12 @@ __global__ __launch_bounds__(64 * OSA_GC_NW, OSA_GC_MINB) void osa_gae_chain_sca
       constexpr int K0 = (KMASK & 1) ? 0 : 2;  // a carry every estimator has (polled first)
       // walk to later levels until one has published its inclusive carry (a level with a path end always has)
       int j = lev - 1;
-      for (int spins = 0; spins < (1 << 22); ++spins) {  // (bounded: never hang the device; the waits below are too)
+      unsigned int* tmo = ticket + 2;  // sticky time-out word: the double behind the ticket's
+      for (int spins = 0;; ++spins) {  // (bounded: never hang the device; the waits below are too)
+        if (spins >= (1 << 22)) {
+          __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
         const double* lv = ws + ((long)j * nlevslots) * N + nc;
         double vi = osa_gc_get(lv + (long)(5 + K0) * N);
         if (osa_gc_ready(vi)) break;
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(64 * OSA_GC_NW, OSA_GC_MINB) void osa_gae_chain_sca
         const double* lv = ws + ((long)j * nlevslots) * N + nc;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-          if ((KMASK >> k) & 1) cin[k] = osa_gc_wait(lv + (long)(5 + k) * N);
+          if ((KMASK >> k) & 1) cin[k] = osa_gc_wait(lv + (long)(5 + k) * N, tmo);
       }
       for (int q = j + 1; q < lev; ++q) {
         const double* lv = ws + ((long)q * nlevslots) * N + nc;
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(64 * OSA_GC_NW, OSA_GC_MINB) void osa_gae_chain_sca
         for (int k = 0; k < 5; ++k)
           if ((KMASK >> k) & 1) {
             const double m = p128[k] * cin[k];
-            cin[k] = osa_gc_wait(lv + (long)k * N) + m;
+            cin[k] = osa_gc_wait(lv + (long)k * N, tmo) + m;
           }
       }
       if (lopen) {  // this level's inclusive carry, by the same formula anybody else would use for it
@@ -969,7 +981,14 @@ int osa_gae_scan_tiled(const float* reward, const float* cost, const float* valu
 
 size_t osa_gae_chained_ws_doubles(int T, int N) {
   if (T < 1 || N < 1) return 0;
-  return (size_t)((T + OSA_GC_LEV - 1) / OSA_GC_LEV) * 10 * (size_t)N + 1;  // carries + the arrival ticket
+  // carries + the arrival ticket + the sticky time-out word (the LAST double: zeroed by the caller once, never by a scan)
+  return (size_t)((T + OSA_GC_LEV - 1) / OSA_GC_LEV) * 10 * (size_t)N + 2;
+}
+
+int osa_gae_chained_timed_out(const double* ws, int T, int N, int* out) {
+  OSA_REQUIRE(ws && out && T > 0 && N > 0);
+  const size_t nws = osa_gae_chained_ws_doubles(T, N);
+  return hipMemcpy(out, ws + (nws - 1), sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
 int osa_gae_scan_chained(const float* reward, const float* cost, const float* value_r, const float* value_c,
@@ -988,8 +1007,8 @@ int osa_gae_scan_chained(const float* reward, const float* cost, const float* va
   hipStream_t st = osa_stream(stream);
   // every carry slot starts as the "not yet there" NaN sentinel
   const size_t nws = osa_gae_chained_ws_doubles(T, N);
-  if (hipMemsetAsync(ws, 0xFF, (nws - 1) * sizeof(double), st) != hipSuccess) return OSA_EHIP;
-  unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + (nws - 1));
+  if (hipMemsetAsync(ws, 0xFF, (nws - 2) * sizeof(double), st) != hipSuccess) return OSA_EHIP;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + (nws - 2));  // (ticket[2] = the sticky time-out word)
   if (hipMemsetAsync(ticket, 0, sizeof(double), st) != hipSuccess) return OSA_EHIP;
 #define OSA_GAE_CHAIN_LAUNCH(E)                                                                             \
   hipLaunchKernelGGL((osa_gae_chain_scan_kernel<E>), dim3(nlev * nenvb), dim3(64 * OSA_GC_NW), 0, st, reward, \

@@ -77,11 +77,22 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def graph_capturable() -> bool:
+    """Collectives of this process group can be recorded into a hipGraph: the `nccl` (= RCCL) backend enqueues
+    kernels on a stream; gloo stages through the host and synchronises."""
+    return is_initialized() and dist.get_backend() == 'nccl'
+
+
 def all_reduce_avg_(t: torch.Tensor) -> torch.Tensor:
-    """SUM then divide by world size (avg_grads / avg_tensor semantics, distributed.py:160-198)."""
+    """SUM then divide by world size (avg_grads / avg_tensor semantics, distributed.py:160-198).  Over RCCL with a
+    power-of-two world the division rides in the collective (ReduceOp.AVG: every operand pre-scaled by 1 / world --
+    exact for powers of two, so the bits equal sum / world) instead of a separate elementwise launch behind it."""
     if collectives_active():
-        all_reduce_sum_(t)
         ws = world_size()
+        if ws > 1 and (ws & (ws - 1)) == 0 and t.is_contiguous() and dist.get_backend() == 'nccl':
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            return t
+        all_reduce_sum_(t)
         if ws > 1:
             t.div_(ws)
     return t

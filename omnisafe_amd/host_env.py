@@ -240,8 +240,13 @@ def make_reference_env(env_id: str, num_envs: int, device, **env_cfgs):
     if core is None:
         try:
             import omnisafe.envs.core as core  # noqa: PLC0415  the caller's installation
-        except Exception:  # noqa: BLE001 - not installed / not importable: no reference-registered envs
-            return None
+        except ModuleNotFoundError as exc:
+            if exc.name is not None and exc.name.split('.')[0] == 'omnisafe':
+                return None  # the reference is not installed: no reference-registered envs
+            raise ImportError(f'omnisafe is installed but failed to import while looking up {env_id!r} (missing '
+                              f'dependency {exc.name!r})') from exc
+        # (any other exception -- a broken reference installation -- propagates as what it is instead of being
+        # reported as "env not registered": round-3 advisor finding)
     if env_id not in core.support_envs():
         return None
     host = core.make(env_id, num_envs=num_envs, device=torch.device('cpu'), **env_cfgs)

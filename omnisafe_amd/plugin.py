@@ -32,10 +32,33 @@ def _as_subclass_of_reference(name: str, ours: type, ref_cls: type) -> type:
         return ours
     import types
 
+    def __new__(cls, *args, **kwargs):  # noqa: N807
+        """Dispatch on `cfgs.train_cfgs.device` (the reference's YAML default is `cpu`, PPOLag.yaml:22; BASELINE
+        config 1): a CPU run is the reference's business, so the registry call `registry.get(algo)(env_id=...,
+        cfgs=...)` (algo_wrapper.py:167-170) then returns an instance of the SAVED reference class -- fully
+        constructed by the reference's own `__init__`, incl. its `distributed.fork` / `setup_distributed`
+        handling of `train_cfgs.parallel > 1` upstream of this call -- and Python does not run our `__init__` on
+        it (it is not an instance of `cls`).  This is the user's explicit device choice, not a fallback: a
+        `cuda:N` request without a usable GPU still raises (base_algo.get_device)."""
+        cfgs = kwargs.get('cfgs', args[1] if len(args) > 1 else None)
+        device = getattr(getattr(cfgs, 'train_cfgs', None), 'device', None)
+        if device is not None and _is_cpu_device(device):
+            return ref_cls(*args, **kwargs)
+        return object.__new__(cls)
+
     cls = types.new_class(name, (ours, ref_cls), {}, lambda ns: ns.update(
-        {'__module__': ours.__module__, '__doc__': ours.__doc__, '__qualname__': name}))
+        {'__module__': ours.__module__, '__doc__': ours.__doc__, '__qualname__': name, '__new__': __new__}))
     _installed[name] = cls
     return cls
+
+
+def _is_cpu_device(device) -> bool:
+    import torch
+
+    try:
+        return torch.device(device).type == 'cpu'
+    except (RuntimeError, TypeError):
+        return False
 
 
 def install(algorithms: tuple[str, ...] | None = None) -> list[str]:

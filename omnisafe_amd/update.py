@@ -83,6 +83,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # torch's current stream (bench.py turns this on for the timed region)
         self.profile_events: list | None = None
         self.last_path: str | None = None
+        self._graphed_pass = False
         self._use_wide = False
         self._split_xch: int | None = None  # uncached exchange buffer of the split wide pass (raw pointer)
         self._split_tried = False
@@ -231,21 +232,32 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def _graph_pass_ok(self, M: int) -> bool:
         """The per-step launches of a pass go through a captured hipGraph: large minibatches (the launches, not the
         rows, are what a step waits for), plain surrogate, single process.  OSA_UPDATE_GRAPH=0 keeps eager launches."""
-        return (self.batch_size >= 2048 and self.ext is None and not dist.collectives_active()
+        return (self.batch_size >= 2048 and self.ext is None
+                and (not dist.collectives_active() or dist.graph_capturable())
                 and os.environ.get('OSA_UPDATE_GRAPH', '1') != '0' and not self._ug.get('failed', False))
 
     def _graph_pass(self, data: dict, perm: torch.Tensor, lagrange: torch.Tensor, stats_rows: torch.Tensor) -> None:
         """One pass = ceil(M / B) optimiser steps of two launches each (partial gradients; slab reduce + clip + Adam),
         captured ONCE and replayed for every pass of every epoch: the permutation and the statistics rows live in
         fixed buffers, the learning rates in device memory (osa_ppo_hparams.lr_device) so that the LinearLR schedule
-        can move between replays.  54 instead of 58 us per 16 384-row step (tools/large_batch_step_timing.py)."""
+        can move between replays.  54 instead of 58 us per 16 384-row step (tools/large_batch_step_timing.py).
+
+        Data parallelism (world_size > 1, round 4: `dp-large-batch-graph`): a step is partial gradients -> slab reduce +
+        LOCAL clip (mode 1) -> ONE flat RCCL all-reduce of grads[3][P] (average) -> osa_adam_apply -- the reference's
+        order (clip_grad_norm_, then avg_grads, then optimizer.step: policy_gradient.py:437-443; utils/distributed.py:
+        167-198) with one message where it sends 19 -- and the whole pass, collectives included, is one captured
+        hipGraph (RCCL enqueues kernels on its stream: capturable; over gloo the steps stay eager launches,
+        `dp-large-batch`)."""
         ac, B = self.ac, self.batch_size
         M = data['obs'].shape[0]
         nmb = (M + B - 1) // B
         hp = self.hp
         key = (M, B, tuple(int(data[k].data_ptr()) for k in ('obs', 'act', 'logp', 'target_value_r', 'target_value_c',
                                                              'adv_r', 'adv_c')), int(lagrange.data_ptr()),
-               self._nets_mask(), self.loss_kind, self.max_blocks,
+               self._nets_mask(), self.loss_kind, self.max_blocks, dist.collectives_active(),
+               # every pointer / stride the captured launches bake in (as the rollout graph's key does for params)
+               tuple(int(t.data_ptr()) for t in (ac.params, ac.adam_m, ac.adam_v, ac.adam_step, ac.grads, self._ws)),
+               (data['obs'].stride(0), data['act'].stride(0)),
                (hp.clip, hp.entropy_coef, hp.critic_norm_coef, hp.max_grad_norm, hp.beta1, hp.beta2, hp.adam_eps,
                 hp.use_critic_norm, hp.use_max_grad_norm, hp.use_cost))
         st = self._ug
@@ -298,6 +310,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev[1].record()
             pe.append(('osa_mb_grad_kernel', M, ev))
         stats_rows.copy_(st['stats'])
+        self._graphed_pass = st['graph'] is not None
 
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
                   stats_row: torch.Tensor) -> None:
@@ -832,6 +845,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         update_counts, final_kl, step = 0, 0.0, 0
         kl_dev = None
         self._pass_fn = None
+        self._graphed_pass = False
         # (with the minibatch's chunks on cooperating workgroups the persistent pass wins up to 1024 rows: 24.6 us per
         # step against 50.9 for the per-step launches; one workgroup walking through 16 chunks: 127)
         pmb = self.persistent_max_batch if self._chunk.get('off') or self.ext is not None or os.environ.get(
@@ -912,6 +926,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.check_wide_dp_sync()
         if not use_repl and not use_pass and B > 64:
             self.check_reduce_sync()
+        if not use_repl and not use_pass and B >= 2048 and dist.collectives_active() and self.ext is None:
+            # (what ran, for the tests and the bench line: the captured pass incl. its RCCL all-reduces, or eager steps)
+            self.last_path = 'dp-large-batch-graph' if getattr(self, '_graphed_pass', False) else 'dp-large-batch'
         if self._use_wide:
             self.check_split_sync()
         if self.last_path == 'persistent-chunked':

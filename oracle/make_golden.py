@@ -507,6 +507,141 @@ def gen_config_shape_updates(only=None):
               out['perms'].shape, {k: out[k] for k in out if k.startswith('log/Misc')})
 
 
+# ------------------------------------------------------------------------------------------------
+# data parallelism: the UNMODIFIED reference with TWO ranks (train_cfgs.parallel = 2, gloo on the CPU)
+#
+# The reference joins a process group when MASTER_ADDR is set (utils/distributed.py:83-104, called from
+# algo_wrapper.py:152), gives rank r the seed cfg.seed + 1000 r (base_algo.py:40), divides steps_per_epoch by the world
+# size (policy_gradient.py:73-77), broadcasts rank 0's parameters (:98-99, utils/distributed.py:201-226), standardises
+# the advantages with global statistics (vector_onpolicy_buffer.py:131-136 -> utils/distributed.py:382-392), averages the
+# window mean of EpCost for the Lagrange step (logger.py:359-374), clips every network's gradient LOCALLY and then
+# averages it over the ranks before each optimiser step (policy_gradient.py:437-442, 478-483, 519-524 ->
+# utils/distributed.py:167-198), averages the KL (:390), the Fisher-vector products (natural_pg.py:112) and the
+# line-search quantities (trpo.py:114-118, 181-185).  One `_update()` per config, everything a rank sees recorded.
+# (tag, algorithm, env id, N envs per rank, T steps per rank, extra algo_cfgs, lagrange_cfgs)
+DP2_CONFIGS = [
+    # BASELINE config 2's shapes under 2 ranks: 2 x 32 optimiser steps of 64 rows per rank
+    ('dp2_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', 16, 128, {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    # BASELINE config 4 (8-rank config: PPOLag on 376 / 17)
+    ('dp2_ppolag_humanoid', 'PPOLag', 'SynthHumanoid-v0', 16, 128, {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    # BASELINE config 5 (8-rank config: TRPOLag on 27 / 8; FVP / line-search averages + batch-128 critic passes)
+    ('dp2_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', 16, 128, {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    # the large-batch setting (PPOLag.yaml's GPU-env blocks: batch_size 8192, update_iters 8) under 2 ranks:
+    # 2 passes x 2 steps of 2048 rows per rank
+    ('dp2_ppolag_point_largebatch', 'PPOLag', 'SynthPointGoal1-v0', 16, 256, {'batch_size': 2048},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+]
+
+
+def _dp2_worker(rank, world, port, spec, tmp):
+    tag, algo_name, env_id, N, T, extra, lag = spec
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop('IN_DIST', None)
+    torch.set_num_threads(2)
+    ref_harness.import_reference()
+    import omnisafe
+    from omnisafe.utils import distributed as rdist
+    from omnisafe.utils.config import get_default_kwargs_yaml
+
+    base = get_default_kwargs_yaml(algo_name, env_id, 'on-policy').todict()
+    trust_region = 'cg_iters' in base['algo_cfgs']
+    ea = dict({'update_iters': 2, 'batch_size': 128 if trust_region else 64, 'kl_early_stop': False}, **extra)
+    ref_harness.register_synth_env()
+    ref_harness.DEFAULT_HORIZON = 16
+    spe = world * N * T  # the GLOBAL steps_per_epoch: every rank collects spe / world / N = T vector steps
+    cfg = {'seed': 0,
+           'train_cfgs': {'total_steps': spe * 4, 'vector_env_nums': N, 'torch_threads': 2, 'device': 'cpu',
+                          'parallel': world},
+           'algo_cfgs': dict({'steps_per_epoch': spe}, **ea),
+           'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': os.path.join(tmp, f'log{rank}')},
+           'lagrange_cfgs': lag}
+    algo = omnisafe.Agent(algo_name, env_id, custom_cfgs=cfg).agent  # (fork() joins the gloo group)
+    assert rdist.world_size() == world and rdist.get_rank() == rank
+    assert algo._steps_per_epoch == T and algo._seed == 1000 * rank
+    ac = algo._actor_critic
+    out = {'N': N, 'T': T, 'world': world, 'seed': 0}
+    for net in ('actor', 'reward_critic', 'cost_critic'):  # after sync_params: rank 0's parameters everywhere
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'init/{net}/{k}'] = v
+    torch.manual_seed(31 + 1000 * rank)
+    algo._env.rollout(steps_per_epoch=T, agent=ac, buffer=algo._buf, logger=algo._logger)
+    raw = _snapshot_buffer_raw(algo._buf)
+    out['raw/adv_r'], out['raw/adv_c'] = raw['adv_r'], raw['adv_c']  # (T, N), before the global standardisation
+    out['ep_cost_window'] = np.asarray(list(algo._logger._data['Metrics/EpCost']), np.float32)
+    out['Jc'] = np.float32(algo._logger.get_stats('Metrics/EpCost')[0])  # cross-rank mean (a collective: all ranks)
+    captured = {}
+    orig_get = algo._buf.get
+
+    def spy_get():
+        r = orig_get()
+        captured.update({k: v.clone() for k, v in r.items()})
+        return r
+
+    algo._buf.get = spy_get
+    out['lambda_before'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    with _Recorder() as rec:
+        torch.manual_seed(33 + 1000 * rank)
+        algo._update()
+    for k, v in captured.items():
+        out[f'data/{k}'] = _np(v)
+    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    out['perms'] = np.stack([_np(p) for p in rec.perms[::2]])  # RandomSampler draws two permutations per pass
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in _state(getattr(ac, net)).items():
+            out[f'post/{net}/{k}'] = v
+    for key, val in algo._logger._data.items():
+        if key.startswith(('Loss/', 'Train/', 'Misc/', 'Metrics/LagrangeMultiplier', 'Value/Adv')):
+            vals = list(val) if not isinstance(val, (int, float)) else [val]
+            if len(vals) and all(isinstance(x, (int, float, np.floating)) for x in vals):
+                out['log/' + key] = np.asarray(vals, np.float32)
+    np.savez(os.path.join(tmp, f'rank{rank}.npz'), **out)
+    import torch.distributed as tdist
+
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def gen_dp2_updates(only=None, world=2):
+    """tests/golden/dp2_<tag>.npz: what every rank of a 2-rank run of the unmodified reference fed into and got out
+    of one `_update()`.  Rank-specific arrays under `r<rank>/...` (data = the rank's `buf.get()` output, perms, raw
+    advantages, EpCost window, logged per-rank statistics); `init/`, `post/`, `Jc`, `lambda_*` are identical on all
+    ranks (asserted here) and stored once."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    for spec in DP2_CONFIGS:
+        tag = spec[0]
+        if only and tag not in only:
+            continue
+        tmp = tempfile.mkdtemp()
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_dp2_worker, args=(world, port, spec, tmp), nprocs=world, join=True)
+        parts = [dict(np.load(os.path.join(tmp, f'rank{r}.npz'))) for r in range(world)]
+        out = {}
+        for k, v in parts[0].items():
+            if k.startswith(('init/', 'post/')) or k in ('N', 'T', 'world', 'seed', 'Jc', 'lambda_before', 'lambda_after'):
+                for r in range(1, world):
+                    assert np.array_equal(v, parts[r][k]), (tag, k, 'differs between ranks')
+                out[k] = v
+        for r in range(world):
+            for k, v in parts[r].items():
+                if k.startswith(('data/', 'raw/', 'log/')) or k in ('perms', 'ep_cost_window'):
+                    out[f'r{r}/{k}'] = v
+        out['algo'], out['env_id'] = spec[1], spec[2]
+        np.savez_compressed(os.path.join(OUT, f'{tag}.npz'), **out)
+        moved = max(float(np.abs(out[k] - out['init/' + k[5:]]).max()) for k in out if k.startswith('post/actor/'))
+        print(tag, 'Jc', out['Jc'], 'lambda', out['lambda_before'], '->', out['lambda_after'], 'perms',
+              out['r0/perms'].shape, 'actor moved by', moved, os.path.getsize(os.path.join(OUT, f'{tag}.npz')), 'B')
+
+
+
 def _record_rollout(algo, T, seed):
     """Run the reference adapter's rollout with spies on the raw env and on the policy noise; returns the
     recorded trace + resulting buffer / normaliser / episode-metric contents (keys as in ppolag_epoch)."""
@@ -745,6 +880,7 @@ def main():
     gen_trust_region_updates()
     gen_sibling_updates()
     gen_config_shape_updates()
+    gen_dp2_updates()
     gen_saute_simmer()
     gen_early_terminated()
     gen_config_defaults()
@@ -758,6 +894,7 @@ if __name__ == '__main__':
     # `make_golden.py learning ALGO SEED`      one learning run -> tests/golden/_learning_part_ALGO_SEED.json
     #                                          (how the committed fixture was made: 8 of these in parallel,
     #                                          OMP_NUM_THREADS=1 each)
+    # `make_golden.py dp2 [TAG ...]`           the 2-rank (gloo) reference runs -> tests/golden/dp2_<tag>.npz
     # `make_golden.py merge-learning`          fold the part files into tests/golden/learning_reach.json
     if len(sys.argv) >= 4 and sys.argv[1] == 'learning':
         ref_harness.import_reference()
@@ -767,6 +904,8 @@ if __name__ == '__main__':
         ref_harness.import_reference()
         torch.set_num_threads(1)
         gen_config_shape_updates(only=sys.argv[2:] or None)
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'dp2':
+        gen_dp2_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
         if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there
             os.replace(os.path.join(OUT, 'learning_reach.json'), os.path.join(OUT, '_learning_part_0prev.json'))

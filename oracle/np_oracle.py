@@ -512,6 +512,107 @@ def ppolag_update(ac: ActorCritic, data: dict, lam: float, perms, batch_size=64,
     return stats
 
 
+def _dp_step(module, opt, losses, max_grad_norm, use_max_grad_norm):
+    """One data-parallel optimiser step of one network as the reference runs it on `world` ranks
+    (policy_gradient.py:434-443 / 474-483 / 517-524 with utils/distributed.py:167-198): every rank back-propagates
+    ITS loss, clips ITS gradient by ITS norm (`clip_grad_norm_` runs before `avg_grads`), then each parameter's
+    gradient becomes all_reduce(SUM) / world and every rank takes the same Adam step.  `losses` = one closure per
+    rank, each returning that rank's loss on its own minibatch.  The replicas are identical, so one copy of the
+    network stands for all of them.  Rank order of the sum = rank 0 first (for two ranks a float sum is
+    commutative: bit-exact against gloo)."""
+    world = len(losses)
+    grads, vals = [], []
+    params = list(module.parameters())
+    for fn in losses:
+        opt.zero_grad()
+        loss = fn()
+        loss.backward()
+        if use_max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        grads.append([p.grad.detach().clone() for p in params])
+        vals.append(float(loss.detach()))
+    for i, p in enumerate(params):
+        acc = grads[0][i].clone()
+        for r in range(1, world):
+            acc += grads[r][i]
+        p.grad = acc / world  # dist_avg: dist_sum(value) / world_size()
+    opt.step()
+    return vals
+
+
+def ppolag_update_dp(ac: ActorCritic, datas: list, lam: float, perms: list, batch_size=64, update_iters=40,
+                     target_kl=0.02, kl_early_stop=True, clip=0.2, entropy_coef=0.0, critic_norm_coef=0.001,
+                     max_grad_norm=40.0, use_critic_norm=True, use_max_grad_norm=True, use_cost=True):
+    """`ppolag_update` under data parallelism: `datas[r]` is rank r's (already globally standardised) batch,
+    `perms[r][i]` rank r's permutation of pass i.  Per-rank statistics are returned as lists over ranks; the KL is
+    the rank average (policy_gradient.py:390)."""
+    world = len(datas)
+    M = datas[0]['obs'].shape[0]
+    olds = []
+    with torch.no_grad():
+        for d in datas:
+            o = ac.actor.dist(d['obs'])
+            olds.append((o.mean.clone(), o.stddev.clone()))
+    stats = {'loss_r': [], 'loss_c': [], 'loss_pi': []}
+    update_counts, final_kl = 0, 0.0
+    for i in range(update_iters):
+        pm = [torch.as_tensor(perms[r][i], dtype=torch.long) for r in range(world)]
+        for s in range(0, M, batch_size):
+            idx = [pm[r][s:s + batch_size] for r in range(world)]
+
+            def critic_loss(critic, key, r):
+                def fn():
+                    d = datas[r]
+                    loss = torch.nn.functional.mse_loss(critic(d['obs'][idx[r]]), d[key][idx[r]])
+                    if use_critic_norm:
+                        for p in critic.parameters():
+                            loss = loss + p.pow(2).sum() * critic_norm_coef
+                    return loss
+                return fn
+
+            def actor_loss(r):
+                def fn():
+                    d = datas[r]
+                    adv = lag_adv_surrogate(d['adv_r'][idx[r]], d['adv_c'][idx[r]], lam)
+                    return ppo_loss_pi(ac.actor, d['obs'][idx[r]], d['act'][idx[r]], d['logp'][idx[r]], adv, clip,
+                                       entropy_coef)[0]
+                return fn
+
+            stats['loss_r'].append(_dp_step(ac.reward_critic, ac.reward_critic_optimizer,
+                                            [critic_loss(ac.reward_critic, 'target_value_r', r) for r in range(world)],
+                                            max_grad_norm, use_max_grad_norm))
+            if use_cost:
+                stats['loss_c'].append(_dp_step(ac.cost_critic, ac.cost_critic_optimizer,
+                                                [critic_loss(ac.cost_critic, 'target_value_c', r) for r in range(world)],
+                                                max_grad_norm, use_max_grad_norm))
+            stats['loss_pi'].append(_dp_step(ac.actor, ac.actor_optimizer, [actor_loss(r) for r in range(world)],
+                                             max_grad_norm, use_max_grad_norm))
+        kls = [kl_old_new(ac.actor, datas[r]['obs'], *olds[r]) for r in range(world)]
+        final_kl = float(np.float32(sum(np.float32(k) for k in kls)) / np.float32(world))
+        update_counts += 1
+        if kl_early_stop and final_kl > target_kl:
+            break
+    stats['stop_iter'], stats['kl'] = update_counts, final_kl
+    return stats
+
+
+def dp_standardise(raw_adv_r: list, raw_adv_c: list):
+    """VectorOnPolicyBuffer.get's statistics under `world` ranks (vector_onpolicy_buffer.py:131-136 ->
+    utils/distributed.py:382-392): global mean = all-reduced sum / all-reduced count; global (population) std from
+    the all-reduced sum of squared deviations from that mean; adv_r <- (adv_r - mean) / (std + 1e-8), adv_c <- adv_c -
+    mean_c.  Inputs: per-rank raw advantages, env-major float32 tensors.  float32 throughout, as the reference."""
+    def stats(parts):
+        gsum = sum(torch.sum(p) for p in parts)
+        gn = torch.tensor(float(sum(len(p) for p in parts)))
+        mean = gsum / gn
+        gss = sum(torch.sum((p - mean) ** 2) for p in parts)
+        return mean, torch.sqrt(gss / gn)
+
+    mr, sr = stats(raw_adv_r)
+    mc, _ = stats(raw_adv_c)
+    return [(p - mr) / (sr + 1e-8) for p in raw_adv_r], [p - mc for p in raw_adv_c], (mr, sr, mc)
+
+
 # --------------------------------------------------------------------------------------------------
 # K12-K16: natural gradient machinery (utils/math.py:86-132, base/natural_pg.py:74-182,
 #     base/trpo.py:56-222, second_order/cpo.py:57-462)

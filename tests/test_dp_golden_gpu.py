@@ -1,0 +1,132 @@
+"""GPU: every data-parallel update path pinned to the UNMODIFIED REFERENCE run with two ranks.
+
+tests/golden/dp2_<tag>.npz (oracle/make_golden.py::gen_dp2_updates) holds what each rank of a 2-rank gloo run of the
+reference (`train_cfgs.parallel = 2`: utils/distributed.py:83-104; seeds base_algo.py:40; step sharding
+policy_gradient.py:73-77) fed into and got out of one `_update()`: the rank's globally standardised `buf.get()` batch,
+its minibatch permutations, its EpCost window, and the post-update parameters (identical on both ranks).  Here two
+real ranks share the test box's GPU and talk over gloo (RCCL refuses two ranks on one device) -- the production code
+path of world_size > 1: Lagrange step on the cross-rank mean cost, then
+
+  replicated            all-gathered rollout + cooperative persistent pass (osa_ppo_dp_pass_placed), 60 / 2
+  replicated-wide-split osa_ppo_split_dp_pass, 376 / 17 (BASELINE config 4)
+  replicated + chunked  osa_ppo_dp_chunked_pass for TRPOLag's batch-128 critics, 27 / 8 (BASELINE config 5), behind the
+                        FVP / CG / line search whose products and losses are rank-averaged (natural_pg.py:112,
+                        trpo.py:114-118, 181-185)
+  replicated-steps      two launches per step from a hipGraph
+  allreduce             gradient kernel -> ONE flat all-reduce -> Adam per optimiser step
+  dp-large-batch        B = 2048: partial gradients -> local clip -> flat all-reduce -> Adam (graph-captured with RCCL;
+                        eager over gloo)
+
+each driven with the reference's inputs and compared with the reference's post-update parameters at the
+single-process tolerances of tests/test_config_shapes_gpu.py (first-order family atol 2e-6 after 64 chained Adam
+steps; TRPOLag: accepted line-search index identical, actor atol 5e-5, critics atol 2e-5)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+LAG = {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
+    os.environ.update(OSA_DP_MODE=dp_mode, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OSA_DIST_BACKEND='gloo',
+                      OSA_SINGLE_DEVICE_RANKS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, ROOT)
+    import omnisafe_amd
+    from omnisafe_amd import distributed as dist
+
+    g = dict(np.load(os.path.join(GOLDEN, f'{tag}.npz'), allow_pickle=False))
+    N, T, algo_name, env_id = int(g['N']), int(g['T']), str(g['algo']), str(g['env_id'])
+    assert int(g['world']) == world
+    trust_region = algo_name == 'TRPOLag'
+    M = N * T
+    bs = 128 if trust_region else (2048 if tag.endswith('largebatch') else 64)
+    cfg = {'seed': 0, 'train_cfgs': {'device': 'cuda:0', 'total_steps': 4 * world * M, 'vector_env_nums': N},
+           'algo_cfgs': {'steps_per_epoch': world * M, 'update_iters': 2, 'kl_early_stop': False, 'batch_size': bs},
+           'logger_cfgs': {'log_dir': os.path.join(tmpdir, f'r{rank}'), 'verbose': False}, 'lagrange_cfgs': LAG}
+    algo = omnisafe_amd.Agent(algo_name, env_id, custom_cfgs=cfg).agent
+    assert dist.world_size() == world and algo._steps_per_epoch == T and algo._seed == 1000 * rank
+    ac = algo._actor_critic
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        sd = {k[len('init/') + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
+              if k.startswith(f'init/{net}/')}
+        getattr(ac, net).load_state_dict(sd)
+    data = {k[len(f'r{rank}/data/'):]: torch.from_numpy(np.ascontiguousarray(v)).to('cuda:0')
+            for k, v in g.items() if k.startswith(f'r{rank}/data/')}
+    assert data['obs'].shape[0] == M
+    algo._buf.get = lambda: dict(data)
+    algo._logger.extend('Metrics/EpCost', [float(v) for v in g[f'r{rank}/ep_cost_window']])
+    perms = [g[f'r{r}/perms'] for r in range(world)]
+    up = algo._updater
+    # the replicated passes run ALL ranks' minibatches on every GPU: every rank needs every rank's order
+    repl = dp_mode.startswith('replicated') and bs <= 512
+    if repl:
+        algo._perms_override = [torch.from_numpy(np.stack([perms[r][i] for r in range(world)])) for i in range(2)]
+    else:
+        algo._perms_override = [torch.from_numpy(perms[rank][i].copy()) for i in range(2)]
+    algo._update()
+    torch.cuda.synchronize()
+    assert up.last_path == want_path, (up.last_path, want_path)
+    for k, v in (want or {}).items():
+        assert up._dp.get(k) == v, (k, up._dp.get(k), v)
+    np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+
+    def max_err(net):
+        return max(float(np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']).max())
+                   for k, v in getattr(ac, net).state_dict().items())
+
+    errs = {n: max_err(n) for n in ('actor', 'reward_critic', 'cost_critic')}
+    moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
+    if rank == 0:
+        print(tag, dp_mode, up.last_path, 'max |param - 2-rank reference|:', errs, 'actor moved', moved, flush=True)
+    assert moved > 1e-3
+    if trust_region:
+        lg = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
+        assert int(lg('Misc/AcceptanceStep')[-1]) == int(g['r0/log/Misc/AcceptanceStep'][-1])
+        for key, rtol in (('Misc/Alpha', 1e-2), ('Misc/xHx', 1e-2), ('Misc/gradient_norm', 1e-3),
+                          ('Misc/FinalStepNorm', 2e-2)):
+            np.testing.assert_allclose(lg(key)[-1], g['r0/log/' + key][-1], rtol=rtol, err_msg=key)
+        assert errs['actor'] < 5e-5 and max(errs['reward_critic'], errs['cost_critic']) < 2e-5, errs
+    else:
+        assert max(errs.values()) < 2e-6, errs
+        np.testing.assert_allclose(float(algo._logger._data['Train/KL'][-1]), g['r0/log/Train/KL'][-1], rtol=1e-2,
+                                   atol=1e-7)
+    # replicas identical
+    p = ac.params
+    lo, hi = p.clone(), p.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(lo, hi), 'replicas diverged'
+    torch.distributed.destroy_process_group()
+
+
+CASES = [
+    ('dp2_ppolag_point', 'replicated', 'replicated', {'chunked': False}),
+    ('dp2_ppolag_point', 'replicated-steps', 'replicated', None),
+    ('dp2_ppolag_point', 'allreduce', 'per-step', None),
+    ('dp2_ppolag_humanoid', 'replicated', 'replicated-wide-split', None),
+    ('dp2_ppolag_humanoid', 'allreduce', 'per-step', None),
+    ('dp2_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+    ('dp2_trpolag_ant', 'allreduce', 'per-step', None),
+    ('dp2_ppolag_point_largebatch', 'replicated', 'dp-large-batch', None),
+    ('dp2_ppolag_point_largebatch', 'allreduce', 'dp-large-batch', None),
+]
+
+
+@pytest.mark.parametrize('tag,dp_mode,want_path,want', CASES)
+def test_two_ranks_reproduce_the_two_rank_reference(tmp_path, tag, dp_mode, want_path, want):
+    mp.spawn(_worker, args=(2, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=2, join=True)

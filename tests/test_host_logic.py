@@ -3,6 +3,7 @@ scalar algebra (vs the reference), logger csv columns, plugin installation behin
 omnisafe.Agent, no-GPU failure mode."""
 import csv
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -469,3 +470,91 @@ def test_shuffle_twin_is_a_bijection_for_every_size():
         if M > 8:
             assert not np.array_equal(p[0], p[1])
     assert np.array_equal(O.shuffle_rows([9], 50), O.shuffle_rows([9], 50))
+
+
+@pytest.mark.reference
+def test_plugin_passes_cpu_device_through_to_the_reference(tmp_path):
+    """BASELINE config 1 ("PPOLag ..., torch CPU device (reference plumbing, no GPU)"): the reference's YAML default
+    is `device: cpu` (configs/on-policy/PPOLag.yaml:22; utils/tools.py:338-358), so a default-config script must
+    keep working after `omnisafe_amd.install()`: the registry entry dispatches on `cfgs.train_cfgs.device` and hands
+    a CPU run to the SAVED reference class (algo_wrapper.py:150-170).  Same seed => the csv of the installed run
+    equals the csv of an uninstalled run, column for column (wall-clock columns aside)."""
+    import csv
+    import glob
+
+    import ref_harness
+
+    omnisafe = ref_harness.import_reference()
+    ref_harness.import_simple_env()  # the reference's own tests/simple_env.py ('Test-v0')
+    import omnisafe_amd
+    from omnisafe.algorithms import registry as ref_registry
+
+    keep = dict(ref_registry.REGISTRY._module_dict)
+
+    def run(tag):
+        # no `device` key: the YAML default (cpu) decides
+        cfg = {'train_cfgs': {'total_steps': 400, 'vector_env_nums': 1, 'torch_threads': 1},
+               'algo_cfgs': {'steps_per_epoch': 200, 'update_iters': 2},
+               'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': str(tmp_path / tag)}}
+        agent = omnisafe.Agent('PPOLag', 'Test-v0', custom_cfgs=cfg)
+        assert agent.cfgs.train_cfgs.device == 'cpu'
+        agent.learn()
+        path, = glob.glob(str(tmp_path / tag / '**' / 'progress.csv'), recursive=True)
+        rows = list(csv.DictReader(open(path)))
+        return agent, rows
+
+    try:
+        plain_agent, plain = run('plain')
+        assert 'PPOLag' in omnisafe_amd.install()
+        agent, rows = run('installed')
+        assert type(agent.agent) is keep['PPOLag'] is type(plain_agent.agent)  # the reference's class, untouched
+        assert not type(agent.agent).__module__.startswith('omnisafe_amd')
+        assert len(rows) == len(plain) == 2 and list(rows[0]) == list(plain[0])
+        for a, b in zip(rows, plain):
+            for k in a:
+                if not k.startswith('Time/'):
+                    assert a[k] == b[k], (k, a[k], b[k])
+        # ... and a cuda request still reaches the HIP class (which refuses to run without a GPU: no CPU fallback)
+        if not torch.cuda.is_available():
+            import unittest.mock as mock
+
+            with mock.patch.object(torch.cuda, 'set_device', lambda *_a, **_k: None):
+                with pytest.raises(RuntimeError, match='no CPU fallback'):
+                    omnisafe.Agent('PPOLag', 'Test-v0', custom_cfgs={'train_cfgs': {'device': 'cuda:0'}})
+    finally:
+        omnisafe_amd.uninstall()
+        ref_registry.REGISTRY._module_dict.clear()
+        ref_registry.REGISTRY._module_dict.update(keep)
+
+
+@pytest.mark.reference
+def test_plugin_cpu_parallel_goes_through_the_reference_fork(tmp_path):
+    """`train_cfgs.parallel = 2` on the default CPU device with the plugin installed: the reference's own `fork`
+    (utils/distributed.py:83-139) re-launches the script under torchrun; both workers get the reference's class from
+    the swapped registry entry and the run's csv equals that of the same script without the plugin."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+
+    if shutil.which('torchrun') is None:
+        pytest.skip('torchrun not on PATH (the reference forks through it)')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_plugin_parallel_cpu_script.py')
+    rows = {}
+    for tag, flag in (('plain', '0'), ('installed', '1')):
+        env = dict(os.environ, WITH_PLUGIN=flag)
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'IN_DIST'):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, script, str(tmp_path / tag)], capture_output=True, text=True, env=env,
+                           timeout=600, cwd=str(tmp_path))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        classes = [ln for ln in p.stdout.splitlines() if ln.startswith('CLASS')]
+        assert len(classes) == 2 and all('omnisafe.algorithms' in c for c in classes), classes  # two workers
+        path, = glob.glob(str(tmp_path / tag / '**' / 'progress.csv'), recursive=True)  # rank 0 writes
+        rows[tag] = list(csv.DictReader(open(path)))
+    assert len(rows['plain']) == 2
+    for a, b in zip(rows['installed'], rows['plain']):
+        assert list(a) == list(b)
+        for k in a:
+            if not k.startswith('Time/'):
+                assert a[k] == b[k], (k, a[k], b[k])

@@ -199,35 +199,33 @@ SIBLINGS = ['PolicyGradient', 'PPO', 'NaturalPG', 'TRPO', 'PDO', 'RCPO', 'CPPOPI
             'CUP', 'IPO', 'P3O', 'OnCRPO', 'PPOSaute', 'TRPOSaute', 'PPOSimmerPID', 'TRPOSimmerPID']
 
 
+N_SIBLING_SEEDS = 32  # fixed: ONE training set, ONE assertion per comparison (no retry -- round-3 verdict / advisor)
+
+
 @pytest.mark.parametrize('algo', SIBLINGS)
 def test_sibling_learning_curve_within_one_sigma_of_reference(algo, tmp_path):
-    """Same statement for the other accelerated algorithms, 8 seeds against the reference's 20.  A comparison that
-    fails at 8 seeds is repeated with 32 before it counts: the 8-seed mean of one epoch is noisy enough that a
-    re-rounding of the update kernels moves it across the band (round 3, PPOSaute epoch 6: -0.32 with seeds 0-7,
-    -0.47 with seeds 0-31, reference -0.51 +- 0.11: profiles/r3_sibling_epochs_PPOSaute.json)."""
+    """Same statement for the other accelerated algorithms: 32 seeds against the reference's 20, asserted once.
+    (Round 3 trained 8 seeds and re-trained with 32 only after a failure -- two chances per comparison; an 8-seed
+    epoch mean is noisy enough to cross the band on a re-rounding of the update kernels: PPOSaute epoch 6 read -0.32
+    with seeds 0-7 and -0.47 with seeds 0-31 against the reference's -0.51 +- 0.11,
+    profiles/r3_sibling_epochs_PPOSaute.json.  The seed count is now fixed at the larger value.)"""
     g = json.load(open(GOLDEN))
     if algo not in g['curves']:
         pytest.skip(f'no reference curves for {algo} in tests/golden/learning_reach.json')
     cfg, ref = g['config'], g['curves'][algo]
     k = cfg['tail_epochs']
-    ours = {seed: train_reach(algo, seed, cfg, str(tmp_path)) for seed in range(8)}
-
-    def failures():
-        bad = []
-        for key in ('EpRet', 'EpCost'):
-            ok, rep = _within([_tail(c[key], k) for c in ours.values()], [_tail(c[key], k) for c in ref.values()])
-            if not ok:
-                bad.append((key, rep))
-        for e in range(cfg['epochs']):
-            ok, rep = _within([c['EpRet'][e] for c in ours.values()], [c['EpRet'][e] for c in ref.values()])
-            if not ok:
-                bad.append((e, rep))
-        return bad
-
-    if failures():
-        ours.update({seed: train_reach(algo, seed, cfg, str(tmp_path)) for seed in range(8, 32)})
+    ours = {seed: train_reach(algo, seed, cfg, str(tmp_path)) for seed in range(N_SIBLING_SEEDS)}
     _dump(algo, ours)
-    assert not failures(), (len(ours), failures())
+    bad = []
+    for key in ('EpRet', 'EpCost'):
+        ok, rep = _within([_tail(c[key], k) for c in ours.values()], [_tail(c[key], k) for c in ref.values()])
+        if not ok:
+            bad.append((key, rep))
+    for e in range(cfg['epochs']):
+        ok, rep = _within([c['EpRet'][e] for c in ours.values()], [c['EpRet'][e] for c in ref.values()])
+        if not ok:
+            bad.append((e, rep))
+    assert not bad, (len(ours), bad)
     if 'LagrangeMultiplier' in next(iter(ref.values())):
         # The multiplier integrates (EpCost - limit) over the epochs, so its seed-to-seed spread is far
         # smaller than its sensitivity to the sampling noise of the cost curve (which every algorithm of

@@ -205,3 +205,60 @@ def test_learning_golden_file_is_complete():
     # the reference learns the task: PPOLag's seed-mean return rises monotonically from ~0 to ~7
     m = np.mean([c['EpRet'] for c in g['curves']['PPOLag'].values()], axis=0)
     assert abs(m[0]) < 0.2 and m[-1] > 6 and np.all(np.diff(m) > 0)
+
+
+# ------------------------------------------------------------------ data parallelism: the 2-rank reference goldens
+def _dp2_datas(g, world):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    return [{k: t(g[f'r{r}/data/{k}']) for k in ('obs', 'act', 'logp', 'target_value_r', 'target_value_c', 'adv_r',
+                                                  'adv_c')} for r in range(world)]
+
+
+@pytest.mark.parametrize('tag,obs_dim,act_dim,bs', [('dp2_ppolag_point', 60, 2, 64),
+                                                    ('dp2_ppolag_humanoid', 376, 17, 64),
+                                                    ('dp2_ppolag_point_largebatch', 60, 2, 2048)])
+def test_dp2_ppolag_update_vs_reference(golden, tag, obs_dim, act_dim, bs):
+    """tests/golden/dp2_*.npz = one `_update()` of the UNMODIFIED reference on TWO ranks (gloo; oracle/make_golden.py::
+    gen_dp2_updates).  The oracle's data-parallel restatement -- local clip, then (g_0 + g_1) / 2 per parameter, one
+    Adam step; KL averaged over the ranks (policy_gradient.py:390, 437-442; utils/distributed.py:167-198) -- must
+    reproduce the reference's post-update parameters BIT FOR BIT (a two-operand float sum is commutative)."""
+    g = golden(f'{tag}.npz')
+    world = int(g['world'])
+    assert world == 2
+    torch.set_num_threads(1)
+    ac = load_ac(g, 'init/', obs_dim, act_dim)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    # Jc is the cross-rank mean of the per-rank window means (logger.py:359-374 through dist_statistics_scalar)
+    jc = np.mean([g[f'r{r}/ep_cost_window'].mean(dtype=np.float64) for r in range(world)])
+    np.testing.assert_allclose(jc, float(g['Jc']), rtol=1e-6)
+    perms = [g[f'r{r}/perms'] for r in range(world)]
+    assert not np.array_equal(perms[0], perms[1])  # per-rank seeds -> per-rank minibatch orders
+    stats = O.ppolag_update_dp(ac, _dp2_datas(g, world), lag.lagrangian_multiplier.item(), perms, batch_size=bs,
+                               update_iters=2, kl_early_stop=False)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'post/{net}/{k}']), (net, k, float(np.abs(v.numpy() - g[f'post/{net}/{k}']).max()))
+    for r in range(world):  # every rank logs ITS losses
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_pi']]), g[f'r{r}/log/Loss/Loss_pi'])
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_r']]),
+                                      g[f'r{r}/log/Loss/Loss_reward_critic'])
+    assert np.float32(stats['kl']) == g['r0/log/Train/KL'][-1] == g['r1/log/Train/KL'][-1]
+
+
+@pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant'])
+def test_dp2_advantage_statistics_vs_reference(golden, tag):
+    """VectorOnPolicyBuffer.get() on two ranks: the advantages every rank hands to `_update()` are standardised with
+    the GLOBAL mean / population std (utils/distributed.py:382-392)."""
+    g = golden(f'{tag}.npz')
+    world = int(g['world'])
+    raw_r = [torch.from_numpy(O.env_major(g[f'r{r}/raw/adv_r']).copy()) for r in range(world)]
+    raw_c = [torch.from_numpy(O.env_major(g[f'r{r}/raw/adv_c']).copy()) for r in range(world)]
+    a_r, a_c, (mr, sr, mc) = O.dp_standardise(raw_r, raw_c)
+    for r in range(world):
+        np.testing.assert_allclose(a_r[r].numpy(), g[f'r{r}/data/adv_r'], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a_c[r].numpy(), g[f'r{r}/data/adv_c'], rtol=0, atol=2e-6)
+    # ... and NOT with per-rank statistics (the comparison is not vacuous)
+    local = (raw_r[0] - raw_r[0].mean()) / (raw_r[0].std(unbiased=False) + 1e-8)
+    assert float((local - torch.from_numpy(g['r0/data/adv_r'])).abs().max()) > 1e-3

@@ -161,3 +161,91 @@ def _agent_worker(_rank, port, algo, dp_mode, tmpdir):
                                           ('CPO', 'allreduce')])
 def test_agents_over_rccl_world1(tmp_path, algo, dp_mode):
     mp.spawn(_agent_worker, args=(_free_port(), algo, dp_mode, str(tmp_path)), nprocs=1, join=True)
+
+
+def _large_batch_graph_worker(_rank, port, out_path):
+    """Round 4: the data-parallel form of the LARGE-BATCH update (B >= 2048) -- per optimiser step: partial gradients ->
+    slab reduce + LOCAL clip -> ONE flat RCCL all-reduce (average) -> Adam (policy_gradient.py:437-443 order), the whole
+    pass incl. its collectives captured in ONE hipGraph and replayed (`dp-large-batch-graph`).  World of one rank over
+    the real `nccl` backend: proves the capture of RCCL collectives, the stream ordering and the arithmetic (an average
+    over one rank is the identity: the result must equal the single-process step) and measures the per-step cost of
+    the path without wire time."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_mlp_gpu import make_ac
+    from omnisafe_amd.update import PPOUpdater
+
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    M, B, iters = 65536, 16384, 8
+    data = {'obs': torch.randn(M, 60, device=dev), 'act': torch.randn(M, 2, device=dev),
+            'logp': torch.randn(M, device=dev) * 0.1 - 2.8, 'target_value_r': torch.randn(M, device=dev),
+            'target_value_c': torch.randn(M, device=dev), 'adv_r': torch.randn(M, device=dev),
+            'adv_c': torch.randn(M, device=dev)}
+    lam = torch.tensor([0.2], device=dev)
+    g = torch.Generator().manual_seed(9)
+    perms = [[torch.randperm(M, generator=g) for _ in range(iters)] for _ in range(3)]
+
+    def run3(ac, up):
+        """three updates (eager warm-up pass / capture / replays); returns us per optimiser step of the third"""
+        t = None
+        for k in range(3):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = up.run(data, lam, perms=perms[k], actor_lr=3e-4, critic_lr=3e-4)
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b) * 1e3 / out['steps']
+        return t
+
+    # ---- single process (no process group yet): the reference point
+    ac0 = make_ac(60, 2)
+    p_init = ac0.params.clone()
+    up0 = PPOUpdater(ac0, batch_size=B, update_iters=iters, target_kl=0.02, kl_early_stop=False)
+    t0 = run3(ac0, up0)
+    assert up0.last_path == 'per-step' and up0._ug.get('graph') is not None
+    # ---- the same three updates as a world of one rank over RCCL
+    _env(port, 'replicated')
+    from omnisafe_amd import distributed as dist
+
+    dist.init_from_env('cuda:0')
+    assert torch.distributed.get_backend() == 'nccl' and dist.collectives_active() and dist.graph_capturable()
+    ac1 = make_ac(60, 2)
+    ac1.params.copy_(p_init)
+    up1 = PPOUpdater(ac1, batch_size=B, update_iters=iters, target_kl=0.02, kl_early_stop=False)
+    t1 = run3(ac1, up1)
+    assert up1.last_path == 'dp-large-batch-graph', up1.last_path
+    err = float((ac1.params - ac0.params).abs().max())
+    moved = float((ac0.params - p_init).abs().max())
+    assert moved > 1e-3 and err <= 2e-7, (err, moved)
+    assert ac1.adam_step.tolist() == ac0.adam_step.tolist() == [3 * iters * (M // B)] * 3
+    # eager launches of the same path (what gloo gets): same bits as the captured pass
+    os.environ['OSA_UPDATE_GRAPH'] = '0'
+    ac2 = make_ac(60, 2)
+    ac2.params.copy_(p_init)
+    up2 = PPOUpdater(ac2, batch_size=B, update_iters=iters, target_kl=0.02, kl_early_stop=False)
+    t2 = run3(ac2, up2)
+    os.environ.pop('OSA_UPDATE_GRAPH')
+    assert up2.last_path == 'dp-large-batch'
+    assert torch.equal(ac2.params, ac1.params), float((ac2.params - ac1.params).abs().max())
+    res = {'M': M, 'B': B, 'passes': iters, 'single_process_graph_us_per_step': round(t0, 2),
+           'dp_large_batch_graph_us_per_step_world1_rccl': round(t1, 2),
+           'dp_large_batch_eager_us_per_step_world1_rccl': round(t2, 2),
+           'exchange_us_per_step_world1': round(t1 - t0, 2), 'max_abs_param_diff_vs_single_process': err,
+           'bit_identical_to_single_process': bool(torch.equal(ac1.params, ac0.params)),
+           'note': 'incl. the KL pass and the shuffles of an update (same on both sides); exchange = the difference: '
+                   'grads-only finalize + RCCL all-reduce of 3 x 8448 floats + osa_adam_apply, no wire time at world 1'}
+    torch.distributed.destroy_process_group()
+    with open(out_path, 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+def test_large_batch_dp_pass_is_one_graph_with_its_rccl_allreduces(tmp_path):
+    out = str(tmp_path / 'lb.json')
+    mp.spawn(_large_batch_graph_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = json.load(open(out))
+    print('large-batch DP step (world 1 over RCCL):', json.dumps(res))
+    dst = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(dst, exist_ok=True)
+    json.dump(res, open(os.path.join(dst, 'r4_dp_large_batch_world1.json'), 'w'), indent=1)
