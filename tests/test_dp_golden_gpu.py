@@ -101,6 +101,15 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
                           ('Misc/FinalStepNorm', 2e-2)):
             np.testing.assert_allclose(lg(key)[-1], g['r0/log/' + key][-1], rtol=rtol, err_msg=key)
         assert errs['actor'] < 5e-5 and max(errs['reward_critic'], errs['cost_critic']) < 2e-5, errs
+    elif env_id == 'SynthHumanoid-v0':
+        # 376 inputs: the first layer is a 376-term float32 sum in MFMA-tile order (the split wide pass: over
+        # cooperating workgroups) where the reference's CPU sgemm has its own order (~1e-7 relative in every gradient); through Adam's first steps lr g / (|g| + eps) the handful of elements whose
+        # early gradients lie within ~1e-8 of zero move by a visible fraction of lr (the single-GPU
+        # test_wide_split_* asserts the same shape): all but a few of the 86 k parameters inside the single-process
+        # tolerance, the stragglers inside a twentieth of ONE learning-rate step
+        big = sum(int((np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']) > 2e-6).sum())
+                  for net in ('actor', 'reward_critic', 'cost_critic') for k, v in getattr(ac, net).state_dict().items())
+        assert big <= 8 and max(errs.values()) < 1.5e-5, (big, errs)
     else:
         assert max(errs.values()) < 2e-6, errs
         np.testing.assert_allclose(float(algo._logger._data['Train/KL'][-1]), g['r0/log/Train/KL'][-1], rtol=1e-2,
