@@ -501,6 +501,10 @@ int osa_ppo_dp_chunked_pass(int obs_dim, int act_dim, int hidden, float* params,
 int osa_debug_set_clock_buffer(long long* dev_ptr);
 /* same for osa_ppo_pass: accumulated cycles per phase over the pass, [3 networks][16]. */
 int osa_debug_set_pass_clock_buffer(long long* dev_ptr);
+/* Debug: per-workgroup {start, end} clocks of the balanced partial-gradient launch of the large-batch step
+ * (long long[16 x workgroups]: 100 MHz constant clock start, shader cycles start, the same two at the end; [4..6] shader
+ * cycles after the prologue / the first chunk / the last chunk in the -DOSA_PART_CLOCKS build); NULL = off. */
+int osa_debug_set_part_clock_buffer(long long* dev_ptr);
 
 /* Adam step on already clipped (and, for world_size > 1, all-reduce-averaged) gradients. */
 int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,

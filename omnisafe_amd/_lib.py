@@ -52,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     'osa_saute_step': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     'osa_debug_set_clock_buffer': (_I, [_P]),
     'osa_debug_set_pass_clock_buffer': (_I, [_P]),
+    'osa_debug_set_part_clock_buffer': (_I, [_P]),
     'osa_ppo_pass_supported': (_I, [_I, _I, _I]),
     'osa_ppo_dp_end_pass': (_I, [_P, _I, _I, _P]),
     'osa_ppo_dp_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),

@@ -322,3 +322,11 @@ int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, c
                           const float* target_value_c, const float* adv_r, const float* adv_c,
                           const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
                           int loss_kind, int nets_mask, int nblk, float* slabs, void* stream);
+// Balanced form (round 4): the chunk-tasks of all networks shared evenly by <= max_wg workgroups; per-network slab
+// counts in nslab[3], slab stride in *stride.
+int osa_pass_partial_grad_balanced(int obs_dim, int act_dim, int hidden, float* params, const float* obs, int ld_obs,
+                                   const float* act, int ld_act, const float* logp, const float* target_value_r,
+                                   const float* target_value_c, const float* adv_r, const float* adv_c,
+                                   const long* idx, int B, const float* lagrange, const osa_ppo_hparams* hp,
+                                   int loss_kind, int nets_mask, int max_wg, int max_stride, float* slabs,
+                                   int* nslab, int* stride, void* stream);

@@ -53,6 +53,9 @@ struct OsaMbArgs {
   float ext_ratio_scale;     // multiplies the ratio * adv surrogate term
   float ext_cost_kappa;      // > 0: + kappa * relu(mean(ratio * adv_c) + ext_cost_excess); single chunk only
   float ext_cost_excess;
+  // slabs actually written per network when they differ from nblk (the balanced partial-gradient launch of the
+  // large-batch step: nblk is then the slab STRIDE); nslab[0] < 0: every network has nblk slabs
+  int nslab[3];
 };
 
 #define OSA_TICK(k)                                                                  \
@@ -699,15 +702,16 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_kernel(OsaMbArgs a) {
   const int W = nd.P + OSA_NSTAT;
   if (e >= W) return;
   const float* s = a.slabs + (long)net * a.nblk * W + e;
+  const int ns = a.nslab[0] < 0 ? a.nblk : a.nslab[net];
   // eight independent partial sums (slab b goes to partial b mod 8), combined in a fixed order: eight
   // times the loads in flight of a single running sum, still deterministic
   float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int b = 0;
-  for (; b + 8 <= a.nblk; b += 8) {
+  for (; b + 8 <= ns; b += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) p[u] += s[(long)(b + u) * W];
   }
-  for (; b < a.nblk; ++b) p[0] += s[(long)b * W];
+  for (; b < ns; ++b) p[0] += s[(long)b * W];
   const float acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   if (e < nd.P) {
     a.grads[(long)net * nd.P + e] = acc;
@@ -757,9 +761,10 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
   float gval = 0.f, pval = 0.f, gsq = 0.f, psq = 0.f;
   if (e < W) {
     const float* s = a.slabs + (long)net * a.nblk * W + e;
+    const int ns = a.nslab[0] < 0 ? a.nblk : a.nslab[net];
     float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
     int b = 0;
-    for (; b + 64 <= a.nblk; b += 64) {  // 64 slabs' loads in flight (ONE round trip for the large-batch step's 64
+    for (; b + 64 <= ns; b += 64) {  // 64 slabs' loads in flight (ONE round trip for the large-batch step's 64
       // slabs instead of four: the loop is latency-bound, 99 workgroups x 256 threads x 4 bytes per load); the
       // additions keep the order of the 16-slab loop below
       float t[64];
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
         for (int u = 0; u < 8; ++u) q[u] += t[v + 8 + u];
       }
     }
-    for (; b + 16 <= a.nblk; b += 16) {  // 16 slabs' loads in flight; q[u] receives b + u, b + 8 + u in this order
+    for (; b + 16 <= ns; b += 16) {  // 16 slabs' loads in flight; q[u] receives b + u, b + 8 + u in this order
       float t[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) t[u] = s[(long)(b + u) * W];
@@ -782,11 +787,11 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
 #pragma unroll
       for (int u = 0; u < 8; ++u) q[u] += t[8 + u];
     }
-    for (; b + 8 <= a.nblk; b += 8) {
+    for (; b + 8 <= ns; b += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) q[u] += s[(long)(b + u) * W];
     }
-    for (; b < a.nblk; ++b) q[0] += s[(long)b * W];
+    for (; b < ns; ++b) q[0] += s[(long)b * W];
     const float acc = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     if (e < P) {
       pval = p[e];
@@ -817,6 +822,18 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
         a.stats[net - 1] = acc * invB;
       }
     }
+  }
+  // everything of the Adam step that does not depend on the clip factor is requested / computed BEFORE the grid barrier
+  // (round 4): the moments of this thread's element and the float64 bias corrections (two pow, a sqrt and two divisions
+  // per thread) used to sit behind it, on the critical path of every large-batch step
+  float mv0 = 0.f, vv0 = 0.f, step_size = 0.f, inv_bc2_sqrt = 0.f;
+  if (e < P && a.mode == 0) {
+    mv0 = a.adam_m[(long)net * P + e];
+    vv0 = a.adam_v[(long)net * P + e];
+    const double b1 = a.hp.beta1, b2 = a.hp.beta2;
+    const float lr = a.hp.lr_dev ? a.hp.lr_dev[critic ? 1 : 0] : (critic ? a.hp.lr_critic : a.hp.lr_actor);
+    step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
+    inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
   }
   gsq = osa_block_sum_f(gsq, red);
   psq = osa_block_sum_f(psq, red);
@@ -887,13 +904,9 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     if (a.mode != 0) {  // 1: the locally clipped gradient is the result (all-reduce follows); 2: raw gradient
       a.grads[(long)net * P + e] = gval * coef;
     } else {
-      const double b1 = a.hp.beta1, b2 = a.hp.beta2;
-      const float lr = a.hp.lr_dev ? a.hp.lr_dev[critic ? 1 : 0] : (critic ? a.hp.lr_critic : a.hp.lr_actor);
-      const float step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
-      const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
       float* __restrict__ m = a.adam_m + (long)net * P;
       float* __restrict__ v = a.adam_v + (long)net * P;
-      float mv = m[e], vv = v[e];
+      float mv = mv0, vv = vv0;
       p[e] = osa_adam_update(gval * coef, mv, vv, pval, a.hp.beta1, a.hp.beta2, step_size, inv_bc2_sqrt,
                              a.hp.adam_eps);
       m[e] = mv;
@@ -1262,6 +1275,7 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && step_stats && B > 0);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && mode >= 0 && mode <= 2);
   OsaMbArgs a = {};
+  a.nslab[0] = -1;
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   if (ext) {
     const bool need_old = ext->kl_coef != 0.f || ext->kl_mask_eta >= 0.f;
@@ -1308,6 +1322,29 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 3) {
+      // Round 4: BALANCED partial gradients -- the 64-row chunk-tasks of all networks of the mask laid end to end
+      // and shared evenly by one workgroup per compute unit (16 384 rows x 3 networks = 768 tasks = 3 per unit;
+      // the strided form below runs 64 workgroups x 4 chunks per network on 192 units).  OSA_LARGE_BATCH_BALANCED=0
+      // keeps the strided form (A/B switch).
+      const char* bal_env = getenv("OSA_LARGE_BATCH_BALANCED");  // (read per call: the tests toggle it in-process)
+      const bool balanced = !(bal_env && bal_env[0] == '0');
+      if (balanced) {
+        int stride = 0;
+        const int brc = osa_pass_partial_grad_balanced(obs_dim, act_dim, hidden, params, obs, ld_obs, act, ld_act, logp,
+                                                       target_value_r, target_value_c, adv_r, adv_c, idx, B, lagrange,
+                                                       hp, loss_kind, a.nets_mask, cus, max_blocks, ws, a.nslab, &stride,
+                                                       stream);
+        if (brc == OSA_OK) {
+          a.nblk = stride;
+          const int W = a.nd.P + OSA_NSTAT;
+          hipLaunchKernelGGL(osa_slab_reduce_finalize_kernel, dim3((W + 255) / 256, 3), dim3(256), 0,
+                             osa_stream(stream), a, partials, tickets);
+          OSA_CHECK_LAUNCH();
+          return OSA_OK;
+        }
+        a.nslab[0] = -1;
+        if (brc != OSA_EUNSUPPORTED) return brc;
+      }
       int pb = cus / 3;
       if (pb > nblk) pb = nblk;
       // the slowest workgroup walks through ceil(nchunk / pb) chunks whatever happens: take the FEWEST workgroups
@@ -1363,6 +1400,7 @@ int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* a
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && grads && hp);
   OsaMbArgs a = {};
+  a.nslab[0] = -1;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step; a.grads = grads;
   a.hp.lr_actor = hp->lr_actor; a.hp.lr_critic = hp->lr_critic; a.hp.lr_dev = hp->lr_device; a.hp.beta1 = hp->beta1;
@@ -1381,6 +1419,7 @@ int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && grads && obs && vec && ws && step_stats && M > 0 && ld_obs >= obs_dim);
   OsaMbArgs a = {};
+  a.nslab[0] = -1;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.grads = grads; a.obs = obs; a.ld_obs = ld_obs;
   a.B = (int)M; a.idx = nullptr; a.mode = 2; a.stats = step_stats; a.loss_kind = 2; a.nets_mask = 1;

@@ -244,6 +244,58 @@ def test_large_batch_multiblock_equals_single_pass(M, obs_dim, act_dim):
                                        rtol=1e-4, atol=2e-6, err_msg=f'{net}/{k}')
 
 
+@pytest.mark.parametrize('obs_dim,act_dim,B,critics_only', [(60, 2, 16384, False), (60, 2, 10000, False),
+                                                            (72, 17, 6000, False), (60, 2, 16384, True),
+                                                            (16, 1, 2048, False)])
+def test_balanced_partial_gradients_equal_the_strided_form(obs_dim, act_dim, B, critics_only, monkeypatch):
+    """Round 4: the large-batch step's partial gradients with the chunk-tasks of all networks shared evenly by one
+    workgroup per compute unit (osa_ppo_part_kernel: contiguous task ranges, ranges that cross a network boundary
+    processed in two segments with the weights reloaded) against the strided form (64 workgroups x 4 chunks per
+    network): same gradients up to the order of the slab sums.  Shapes: 256 chunks x 3 networks (3 tasks per
+    workgroup, workgroups 85 and 170 straddle two networks), a ragged 10 000-row minibatch (157 chunks, 2 tasks per
+    workgroup), two output tiles, critics only (2 networks in the mask), fewer tasks than compute units."""
+    from omnisafe_amd.update import PPOUpdater
+
+    M = B
+    torch.manual_seed(11)
+    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
+            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
+            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
+    perm = torch.randperm(M, device=DEV)
+    res = []
+    for balanced in ('1', '0'):
+        monkeypatch.setenv('OSA_LARGE_BATCH_BALANCED', balanced)
+        torch.manual_seed(5)
+        ac = make_ac(obs_dim, act_dim)
+        if 'logp' not in data:
+            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
+            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01,
+                        update_actor=not critics_only)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        p0 = ac.params.clone()
+        lam = torch.tensor([0.3], device=DEV)
+        stats = torch.zeros(2, 16, device=DEV)
+        for k in range(2):
+            up.minibatch(data, perm, B, lam, stats[k])
+        torch.cuda.synchronize()
+        up.check_reduce_sync()
+        res.append((ac.params.clone(), ac.adam_m.clone(), stats.clone(), p0))
+    (pa, ma, sa, p0), (pb, mb_, sb, _) = res
+    assert float((pa - p0).abs().max()) > 2e-4  # two Adam steps happened
+    if critics_only:
+        assert torch.equal(pa[0], p0[0])
+    # first moments = 0.1 g_1 (0.9) + 0.1 g_2: the gradients themselves, to summation-order accuracy
+    scale = float(mb_.abs().max())
+    assert float((ma - mb_).abs().max()) <= 2e-6 * scale + 1e-9, (float((ma - mb_).abs().max()), scale)
+    # parameters: Adam's first steps are lr g / (|g| + 1e-8) -- the few elements whose gradient is itself of the order
+    # of eps turn a 1e-9 difference of the slab sums into a visible fraction of ONE lr step; everything else agrees
+    # to float32 rounding
+    d = (pa - pb).abs()
+    assert float((d > 1e-6).float().mean()) < 1e-3 and float(d.max()) < 2e-3, (float((d > 1e-6).float().mean()), float(d.max()))
+    np.testing.assert_allclose(sa[:, :10].cpu().numpy(), sb[:, :10].cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 4096, 64), (27, 8, 1000, 64), (72, 2, 640, 32),
                                                 (90, 17, 512, 64), (5, 1, 130, 64), (60, 2, 1000, 128),
                                                 (72, 2, 700, 200), (72, 2, 4096, 128), (27, 8, 2048, 128),
