@@ -506,6 +506,57 @@ int osa_debug_set_pass_clock_buffer(long long* dev_ptr);
  * cycles after the prologue / the first chunk / the last chunk in the -DOSA_PART_CLOCKS build); NULL = off. */
 int osa_debug_set_part_clock_buffer(long long* dev_ptr);
 
+/* ---- General actor-critic MLPs (csrc/general_mlp.hip, round 4): ANY hidden_sizes the reference's model builder
+ * accepts (omnisafe/utils/model.py:73-111 build_mlp_network: any depth, any widths; actor and critics configured
+ * independently, models/actor_critic/actor_critic.py:60-136), e.g. the 1024 x 1024 networks of the reference's
+ * published timing table (docs/source/start/efficiency.rst:15-23).  Layer-wise on one float32-MFMA GEMM kernel
+ * (forward / backward-data / backward-weight with fused epilogues); the entry points mirror the per-step family
+ * above (osa_policy_step_scaled, osa_ppo_minibatch, osa_adam_apply, osa_actor_kl, osa_actor_eval,
+ * osa_actor_fvp_raw) with the network shapes in a descriptor instead of the `hidden` word.
+ * Parameter block of one network ([3][P] floats as everywhere): per linear layer l  W_l [out_l][ld_l] (ld_l = in_l
+ * rounded up to 4, padding zero) | b_l [out_l rounded up to 4]; the actor's log_std [act_dim] follows its last layer.
+ * osa_gmlp_layout fills out[0] = P, out[1] = offset of log_std, then {oW, ob, ld} for network 0..2 x layer
+ * 0..OSA_GMLP_MAX_LAYERS-1 (-1 / 0 for absent layers): 2 + 72 ints.
+ * ws: osa_gmlp_ws_floats(desc, rows) floats of scratch for a call over `rows` rows (layer outputs, dL/dz, partial
+ * gradient slabs); contents irrelevant between calls. */
+#define OSA_GMLP_MAX_LAYERS 8
+typedef struct osa_gmlp_desc {
+  int obs_dim, act_dim;
+  int n_layers[3];                    /* linear layers (hidden layers + 1) of actor, reward critic, cost critic */
+  int width[3][OSA_GMLP_MAX_LAYERS];  /* output width of every linear layer; the last one = act_dim (actor) / 1 */
+  int activation[3];                  /* hidden activation: 0 tanh 1 relu 2 sigmoid 3 softplus 4 identity */
+} osa_gmlp_desc;
+int osa_gmlp_layout(const osa_gmlp_desc* desc, int* out);
+size_t osa_gmlp_ws_floats(const osa_gmlp_desc* desc, long rows);
+/* ConstraintActorCritic.step (constraint_actor_critic.py:84-109) + ActionScale: arguments as osa_policy_step_scaled. */
+int osa_gmlp_policy_step(const osa_gmlp_desc* desc, const float* params, const float* obs, int ld_obs, long N,
+                         const float* eps, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* offset_base, int deterministic, int nets_mask, float* act,
+                         int ld_act, float* value_r, float* value_c, float* logp, float* mean_out, int ld_mean,
+                         float* act_env, int ld_env, const float* old_min, const float* old_max, float min_action,
+                         float max_action, float* ws, size_t ws_floats, void* stream);
+/* One optimiser step of PolicyGradient._update's inner loop (policy_gradient.py:428-445, 468-485, 514-524): arguments
+ * and modes as osa_ppo_minibatch (mode 0 grad + local clip + Adam, 1 grad + local clip -> grads[3][P], 2 raw grads).
+ * loss_kind 2 = the raw Fisher-vector product of the actor along `vec` (padded actor vector; fvp_scale = 1 / (M D_a);
+ * natural_pg.py:91-119) into grads[0], as osa_actor_fvp_raw. */
+int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                       float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
+                       const float* target_value_r, const float* target_value_c, const float* adv_r,
+                       const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
+                       int loss_kind, int mode, int nets_mask, const float* vec, float fvp_scale, float* ws,
+                       size_t ws_floats, float* step_stats, void* stream);
+/* osa_adam_apply for general networks; fin8x3: 24 floats of device scratch. */
+int osa_gmlp_adam_apply(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                        float* grads, const osa_ppo_hparams* hp, int nets_mask, float* fin8x3, void* stream);
+/* osa_actor_kl (kind 0: old_mean == NULL snapshots the mean into mean_out; otherwise KL(old || new) -> out[0] with
+ * reduce_mode as there) and osa_actor_eval (kind 1: out[0..3] = loss_pi, loss_cost, KL, mean ratio) for general
+ * networks.  actor_params: the actor's block (network 0 of a [3][P] tensor, or a candidate vector). */
+int osa_gmlp_actor_stats(const osa_gmlp_desc* desc, const float* actor_params, const float* obs, int ld_obs, long M,
+                         const float* old_mean, int ld_old, const float* old_log_std, int kind, int reduce_mode,
+                         const float* act, int ld_act, const float* logp, const float* adv_r, const float* adv_c,
+                         const float* lagrange, float* mean_out, int ld_mean, float* ws, size_t ws_floats, float* out,
+                         void* stream);
+
 /* Adam step on already clipped (and, for world_size > 1, all-reduce-averaged) gradients. */
 int osa_adam_apply(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                    int* adam_step, float* grads, const osa_ppo_hparams* hp, int nets_mask,

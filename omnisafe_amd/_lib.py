@@ -42,6 +42,16 @@ SIGNATURES: dict[str, tuple] = {
     'osa_policy_step_scaled': (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _U, _U, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I,
                                     _P, _I, _P, _P, _F, _F, _P]),
     'osa_minibatch_ws_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    # general networks (csrc/general_mlp.hip): shapes in an osa_gmlp_desc (models.GmlpDesc, passed by reference)
+    'osa_gmlp_layout': (_I, [_P, _P]),
+    'osa_gmlp_ws_floats': (C.c_size_t, [_P, _L]),
+    'osa_gmlp_policy_step': (_I, [_P, _P, _P, _I, _L, _P, _U, _U, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P,
+                                  _P, _F, _F, _P, C.c_size_t, _P]),
+    'osa_gmlp_minibatch': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I,
+                                _I, _P, _F, _P, C.c_size_t, _P, _P]),
+    'osa_gmlp_adam_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'osa_gmlp_actor_stats': (_I, [_P, _P, _P, _I, _L, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P,
+                                  C.c_size_t, _P, _P]),
     'osa_ppo_minibatch': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,
                                _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'osa_ppo_minibatch_ext': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P,

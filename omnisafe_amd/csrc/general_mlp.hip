@@ -1,0 +1,1053 @@
+// General actor-critic MLPs on gfx950 matrix cores: ANY `hidden_sizes` the reference's model builder accepts
+// (omnisafe/utils/model.py:73-111: any depth, any widths, actor and critics independent; the reference's one
+// published timing table has a 1024 x 1024 row, docs/source/start/efficiency.rst:15-23), where the fused kernels of
+// mlp_kernels.hip / ppo_pass_body.h cover [H, H] with H <= 256.
+//
+// Networks this wide do not fit a compute unit: a 1024 x 1024 layer is 4 MB of weights, so every layer is a real
+// GEMM over the minibatch and the path is layer-wise:
+//   forward     H_l  = act(H_{l-1} W_l^T + b_l)                          C[M = rows][N = out]  "NT"
+//   backward    dZ_{l-1} = (dZ_l W_l) * act'(H_{l-1})                     C[rows][in]           "NN"
+//               dW_l = dZ_l^T H_{l-1},  db_l = dZ_l^T 1                   C[out][in (+ 1)]      "TN", split over rows
+// all three on ONE hand-written float32 MFMA kernel (v_mfma_f32_32x32x2_f32: exact float32, bit-for-bit an fmaf
+// chain, 157 TFLOP/s peak): 128 x 128 (or 64-wide) output tile per 256-thread workgroup, K step 16 staged through
+// LDS ([row][k] images with a 20-float leading dimension: the 16-byte fragment reads of a lane group hit 16 distinct
+// bank quads), global -> register -> LDS double buffering, four waves as 2 x 2 with 2 x 2 MFMA tiles each, up to three
+// problems (the three networks) per launch, fused epilogues (bias + activation; act' of the stored output; C +=;
+// the bias gradient as one more output column fed by a column of ones).  Loss, clip and Adam are small elementwise /
+// reduction kernels around it; every reduction has a fixed order (slabs, block partials): deterministic.
+//
+// What bounds it: at hidden 1024 and batch 16 384 a step is 3 networks x 6 W rows = 2 x 10^11 FLOP: MFMA-bound
+// (roofline in bench.py --hidden 1024); at the YAML batch of 64 rows it streams 3 x 13 MB of weights, moments and
+// gradients per step: HBM / L2-bound.
+#include "mlp_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GM_MAXL OSA_GMLP_MAX_LAYERS
+#define GM_NSTAT 16
+
+namespace {
+
+struct GNet {
+  int L;                                   // linear layers (hidden layers + output layer)
+  int in[GM_MAXL], out[GM_MAXL];           // layer l: out[l] x in[l]
+  int ld[GM_MAXL];                         // leading dimension of W_l rows (in[l] rounded up to 4)
+  int ldh[GM_MAXL];                        // leading dimension of the layer's output rows (out[l] rounded up to 4)
+  int oW[GM_MAXL], ob[GM_MAXL];            // offsets into the network's parameter block
+  int oLS;                                 // actor: log_std; critics: end of the real parameters
+  int Pn;                                  // floats used by this network (<= P)
+  int act;                                 // hidden activation (OSA_ACT_*)
+  int maxldh;                              // widest layer output
+};
+struct GLayout {
+  GNet n[3];
+  int P, obs_dim, act_dim, ldx, lda;       // block stride; gathered observation / action row strides
+};
+
+inline int r4(int x) { return (x + 3) / 4 * 4; }
+
+int gm_make_layout(const osa_gmlp_desc* d, GLayout* lo) {
+  if (!d || d->obs_dim < 1 || d->act_dim < 1) return OSA_EINVAL;
+  lo->obs_dim = d->obs_dim;
+  lo->act_dim = d->act_dim;
+  lo->ldx = r4(d->obs_dim);
+  lo->lda = r4(d->act_dim);
+  int pmax = 0;
+  for (int net = 0; net < 3; ++net) {
+    GNet& g = lo->n[net];
+    g.L = d->n_layers[net];
+    if (g.L < 1 || g.L > GM_MAXL) return OSA_EUNSUPPORTED;
+    if (d->activation[net] < OSA_ACT_TANH || d->activation[net] > OSA_ACT_IDENTITY) return OSA_EUNSUPPORTED;
+    g.act = d->activation[net];
+    int off = 0, prev = d->obs_dim;
+    g.maxldh = 4;
+    for (int l = 0; l < g.L; ++l) {
+      const int w = d->width[net][l];
+      if (w < 1) return OSA_EINVAL;
+      g.in[l] = prev;
+      g.out[l] = w;
+      g.ld[l] = r4(prev);
+      g.ldh[l] = r4(w);
+      if (g.ldh[l] > g.maxldh) g.maxldh = g.ldh[l];
+      g.oW[l] = off;
+      off += w * g.ld[l];
+      g.ob[l] = off;
+      off += r4(w);
+      prev = w;
+    }
+    if (prev != (net == 0 ? d->act_dim : 1)) return OSA_EINVAL;  // the last width is the output width
+    g.oLS = off;
+    if (net == 0) off += r4(d->act_dim);
+    g.Pn = off;
+    if (off > pmax) pmax = off;
+  }
+  lo->P = (pmax + 15) / 16 * 16;
+  return OSA_OK;
+}
+
+// ---- workspace carve-up (floats; every offset a multiple of 4 -> 16-byte aligned rows)
+struct GWs {
+  size_t xg, actg, scal;          // gathered observations [R][ldx], actions [R][lda], scalars [6][R]
+  size_t h[3][GM_MAXL];           // layer outputs of every network [R][ldh]
+  size_t t[GM_MAXL];              // tangent layer outputs of the actor (Fisher-vector product)
+  size_t z[3][2];                 // ping-pong dL/d(pre-activation) [R][maxldh]
+  size_t dls, lpart;              // per-block partial sums: log_std gradient [nblk][lda], loss statistics [3][nblk][4]
+  size_t slabs;                   // [3][S][P] partial weight gradients
+  size_t npart, fin;              // norm partials [3][nb][2]; finals [3][8]
+  size_t dws;                     // double scratch of the KL / evaluation reductions (4 x 1024 doubles)
+  size_t total;
+  int S, nblk, nb;
+};
+
+int gm_splits(const GLayout& lo, long R) {
+  // split the row (= reduction) dimension of the weight-gradient GEMMs so that the launch fills the chip:
+  // tiles of the LARGEST layer x networks x splits ~ 512 workgroups, at least 256 rows per split, at most 16
+  long tiles = 1;
+  for (int net = 0; net < 3; ++net)
+    for (int l = 0; l < lo.n[net].L; ++l) {
+      const long t = (long)((lo.n[net].out[l] + 127) / 128) * ((lo.n[net].in[l] + 1 + 127) / 128);
+      if (t > tiles) tiles = t;
+    }
+  long s = 512 / (tiles * 3);
+  const long smax = R / 256;
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+GWs gm_ws(const GLayout& lo, long R) {
+  GWs w;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    const size_t o = off;
+    off += (n + 3) / 4 * 4;
+    return o;
+  };
+  w.xg = take((size_t)R * lo.ldx);
+  w.actg = take((size_t)R * lo.lda);
+  w.scal = take((size_t)6 * R);
+  for (int net = 0; net < 3; ++net)
+    for (int l = 0; l < GM_MAXL; ++l) w.h[net][l] = l < lo.n[net].L ? take((size_t)R * lo.n[net].ldh[l]) : 0;
+  for (int l = 0; l < GM_MAXL; ++l) w.t[l] = l < lo.n[0].L ? take((size_t)R * lo.n[0].ldh[l]) : 0;
+  for (int net = 0; net < 3; ++net)
+    for (int k = 0; k < 2; ++k) w.z[net][k] = take((size_t)R * lo.n[net].maxldh);
+  w.nblk = (int)((R + 255) / 256);
+  w.dls = take((size_t)w.nblk * lo.lda);
+  w.lpart = take((size_t)3 * w.nblk * 4);
+  w.S = gm_splits(lo, R);
+  w.slabs = take((size_t)3 * w.S * lo.P);
+  w.nb = (lo.P + 1023) / 1024;
+  w.npart = take((size_t)3 * w.nb * 2);
+  w.fin = take(3 * 8);
+  w.dws = take(2 * 4 * 1024);
+  w.total = off;
+  return w;
+}
+
+// ---- activations (scalar forms of mlp_device.h's)
+__device__ __forceinline__ float gm_act(float v, int act) {
+  if (act == OSA_ACT_TANH) return osa_tanhf(v);
+  if (act == OSA_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == OSA_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (act == OSA_ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+  return v;
+}
+__device__ __forceinline__ float gm_dact(float h, int act) {  // derivative through the OUTPUT h
+  if (act == OSA_ACT_TANH) return 1.f - h * h;
+  if (act == OSA_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+  if (act == OSA_ACT_SIGMOID) return h * (1.f - h);
+  if (act == OSA_ACT_SOFTPLUS) return 1.f - expf(-h);
+  return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------------
+struct GProb {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;   // epilogue: + bias[n]
+  const float* aux;    // epilogue: * act'(aux[m][n])
+  float* cb;           // ones_n >= 0: column ones_n of the product goes to cb[m] (the bias gradient)
+  int M, N, K, lda, ldb, ldc, ldaux;
+  int act;             // epilogue: activation code, or -1
+  int dact;            // epilogue: activation code whose derivative multiplies, or -1
+  int accumulate;      // C += product
+  int ones_n;          // >= 0: B(k, ones_n) = 1 for every k (only with BT)
+  int cb_pad;          // cb[M .. cb_pad) = 0 (padding of the bias block)
+  long slab_stride;    // split s writes C + s * slab_stride and cb + s * slab_stride
+};
+struct GArgs {
+  GProb p[3];
+  int nprob, splits;
+};
+
+__device__ __forceinline__ f32x4 gm_load4(const float* __restrict__ row, int c0, int limit, bool ok) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!ok || c0 >= limit) return v;
+  if (c0 + 3 < limit) return *reinterpret_cast<const f32x4*>(row + c0);
+  v.x = row[c0];
+  if (c0 + 1 < limit) v.y = row[c0 + 1];
+  if (c0 + 2 < limit) v.z = row[c0 + 2];
+  return v;
+}
+
+// C[m][n] = epi(sum_k A(m, k) B(k, n)).   AT: A(m, k) = A[k lda + m] (else A[m lda + k]);
+//                                          BT: B(k, n) = B[k ldb + n] (else B[n ldb + k]).
+template <int TM, int TN, bool AT, bool BT>
+__global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
+  constexpr int BK = 16, LD = BK + 4, MI = TM / 64, NJ = TN / 64, UA = TM / 64, UB = TN / 64;
+  __shared__ __attribute__((aligned(16))) float sA[2][TM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TN * LD];
+  const int pi = blockIdx.z / g.splits, sp = blockIdx.z - pi * g.splits;
+  // (selected with scalar moves: a run-time index into the by-value argument would go through scratch memory)
+  const GProb p = pi == 0 ? g.p[0] : (pi == 1 ? g.p[1] : g.p[2]);
+  const int M = p.M, N = p.N, K = p.K;
+  const int ncols = N + (p.ones_n >= 0 ? 1 : 0);
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  if (m0 >= M || n0 >= (ncols > p.ldc ? ncols : p.ldc)) return;
+  int kper = (K + g.splits - 1) / g.splits;
+  kper = (kper + BK - 1) / BK * BK;
+  const int kbeg = sp * kper;
+  const int kend = K < kbeg + kper ? K : kbeg + kper;
+  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+  const float* __restrict__ A = p.A;
+  const float* __restrict__ B = p.B;
+  f32x4 ra[UA], rb[UB];
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int q = 0; q < UA; ++q) {
+      const int u = tid + 256 * q;
+      if constexpr (!AT) {
+        const int r = u >> 2, c = u & 3, m = m0 + r;
+        ra[q] = gm_load4(A + (long)m * p.lda, k0 + 4 * c, kend, m < M);
+      } else {
+        // (k fastest across lanes: the transposed LDS stores below then hit 16 consecutive banks per 16 lanes;
+        // the global side reads 64-byte row segments)
+        const int c = u / BK, kq = u - c * BK, k = k0 + kq;
+        ra[q] = gm_load4(A + (long)k * p.lda, m0 + 4 * c, M, k < kend);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UB; ++q) {
+      const int u = tid + 256 * q;
+      if constexpr (!BT) {
+        const int r = u >> 2, c = u & 3, n = n0 + r;
+        rb[q] = gm_load4(B + (long)n * p.ldb, k0 + 4 * c, kend, n < N);
+      } else {
+        const int c = u / BK, kq = u - c * BK, k = k0 + kq, nn = n0 + 4 * c;
+        f32x4 v = gm_load4(B + (long)k * p.ldb, nn, N, k < kend);
+        if (p.ones_n >= 0 && k < kend) {  // the column of ones that turns the bias gradient into one more output column
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nn + i == p.ones_n) v[i] = 1.f;
+        }
+        rb[q] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < UA; ++q) {
+      const int u = tid + 256 * q;
+      if constexpr (!AT) {
+        *reinterpret_cast<f32x4*>(&sA[st][(u >> 2) * LD + 4 * (u & 3)]) = ra[q];
+      } else {
+        const int c = u / BK, kq = u - c * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sA[st][(4 * c + i) * LD + kq] = ra[q][i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UB; ++q) {
+      const int u = tid + 256 * q;
+      if constexpr (!BT) {
+        *reinterpret_cast<f32x4*>(&sB[st][(u >> 2) * LD + 4 * (u & 3)]) = rb[q];
+      } else {
+        const int c = u / BK, kq = u - c * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sB[st][(4 * c + i) * LD + kq] = rb[q][i];
+      }
+    }
+  };
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);  // the next tile's global loads are in flight under this tile's MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // K permutation inside a block of 8: lane group kk consumes k = 8 s + 4 kk + j in MFMA step j, for A and B
+      // alike -- each fragment is ONE 16-byte LDS read per lane and feeds four MFMAs
+      f32x4 af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&sA[st][(wm + 32 * i + l31) * LD + 8 * s + 4 * kk]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(&sB[st][(wn + 32 * j + l31) * LD + 8 * s + 4 * kk]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tile(st ^ 1);
+    __syncthreads();
+  }
+  // ---- epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 kk][col = l31] of every 32 x 32 tile
+  float* __restrict__ C = p.C + (long)sp * p.slab_stride;
+  float* __restrict__ cb = p.cb ? p.cb + (long)sp * p.slab_stride : nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        float v = acc[i][j][r];
+        if (m < M) {
+          if (n < N) {
+            float* dst = C + (long)m * p.ldc + n;
+            if (p.accumulate) v += *dst;
+            if (p.bias) v += p.bias[n];
+            if (p.act >= 0) v = gm_act(v, p.act);
+            if (p.dact >= 0) v *= gm_dact(p.aux[(long)m * p.ldaux + n], p.dact);
+            *dst = v;
+          } else {
+            if (n == p.ones_n && cb) cb[m] = v;
+            if (n < p.ldc && p.ones_n >= 0) C[(long)m * p.ldc + n] = 0.f;  // padding columns of the weight block
+          }
+        } else if (n == p.ones_n && cb && m < p.cb_pad) {
+          cb[m] = 0.f;  // padding of the bias block
+        }
+      }
+    }
+}
+
+template <int TM, int TN, bool AT, bool BT>
+int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
+  dim3 grid((maxN + TN - 1) / TN, (maxM + TM - 1) / TM, g.nprob * g.splits);
+  hipLaunchKernelGGL((gm_gemm_kernel<TM, TN, AT, BT>), grid, dim3(256), 0, st, g);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+// one grouped launch; the tile follows the largest problem (64-wide tiles for skinny ones)
+template <bool AT, bool BT>
+int gm_gemm(const GArgs& g, hipStream_t st) {
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const int nc = g.p[i].ones_n >= 0 ? (g.p[i].ldc > g.p[i].N + 1 ? g.p[i].ldc : g.p[i].N + 1) : g.p[i].N;
+    if (g.p[i].M > maxM) maxM = g.p[i].M;
+    if (nc > maxN) maxN = nc;
+  }
+  if (g.nprob == 0 || maxM == 0) return OSA_OK;
+  const bool bigM = maxM > 64, bigN = maxN > 64;
+  if (bigM && bigN) return gm_launch<128, 128, AT, BT>(g, maxM, maxN, st);
+  if (bigM) return gm_launch<128, 64, AT, BT>(g, maxM, maxN, st);
+  if (bigN) return gm_launch<64, 128, AT, BT>(g, maxM, maxN, st);
+  return gm_launch<64, 64, AT, BT>(g, maxM, maxN, st);
+}
+
+GProb gm_prob() {
+  GProb p = {};
+  p.act = -1;
+  p.dact = -1;
+  p.ones_n = -1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise / reduction kernels around the GEMMs
+// ------------------------------------------------------------------------------------------------
+// rows of the minibatch gathered into contiguous, 16-byte aligned, zero-padded rows (idx == nullptr: rows 0..R-1)
+__global__ __launch_bounds__(256) void gm_gather_kernel(
+    long R, const long* __restrict__ idx, const float* __restrict__ obs, int ld_obs, int obs_dim,
+    const float* __restrict__ act, int ld_act, int act_dim, const float* __restrict__ s0, const float* __restrict__ s1,
+    const float* __restrict__ s2, const float* __restrict__ s3, const float* __restrict__ s4, float* __restrict__ xg,
+    int ldx, float* __restrict__ actg, int lda, float* __restrict__ scal) {
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
+  if (b >= R) return;
+  const long row = idx ? idx[b] : b;
+  for (int c = t; c < ldx; c += 64) xg[b * ldx + c] = c < obs_dim ? obs[row * ld_obs + c] : 0.f;
+  if (act && actg)
+    for (int c = t; c < lda; c += 64) actg[b * lda + c] = c < act_dim ? act[row * ld_act + c] : 0.f;
+  if (scal && t == 0) {
+    if (s0) scal[0 * R + b] = s0[row];
+    if (s1) scal[1 * R + b] = s1[row];
+    if (s2) scal[2 * R + b] = s2[row];
+    if (s3) scal[3 * R + b] = s3[row];
+    if (s4) scal[4 * R + b] = s4[row];
+  }
+}
+
+__device__ __forceinline__ float gm_block_sum(float v, float* red) {  // deterministic; result to all; 256 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = osa_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const float s = (red[0] + red[1]) + (red[2] + red[3]);
+  return s;
+}
+
+struct GLossArgs {
+  long R;
+  int act_dim, lda, ldo[3];          // row strides of the action rows and of the three output layers
+  const float* out[3];               // output-layer rows of the three networks [R][ldo]
+  float* dz[3];                      // dL/d(output) [R][ldz]
+  int ldz[3];
+  const float* actg;
+  const float* scal;                 // [0] logp [1] adv_r [2] adv_c [3] target_value_r [4] target_value_c
+  const float* log_std;              // actor's log_std [act_dim]
+  const float* lagrange;
+  float clip;
+  int loss_kind, nets_mask;
+  float* dls;                        // [nblk][lda] per-block sums of dL/d(log_std)
+  float* lpart;                      // [3][nblk][4] per-block {loss, ratio} sums
+  // Fisher-vector product (loss_kind 2): dL/d(out) = tangent of the mean / sigma^2 * fvp_scale
+  const float* tmean;
+  int ldt;
+  float fvp_scale;
+};
+
+// grid (nblk, 3): one thread per row.  Actor (policy_gradient.py:514-524 with PPOLag's surrogate, ppo.py:66-87 /
+// policy_gradient.py:574-578) and critics (policy_gradient.py:428-433: mean squared error; the L2 term joins in
+// gm_reduce_kernel).
+__global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
+  __shared__ float red[4];
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  const long b = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = b < a.R;
+  const float invB = 1.f / (float)a.R;
+  float loss = 0.f, ratio_s = 0.f;
+  if (net != 0) {
+    if (valid) {
+      const float diff = a.out[net][b * a.ldo[net]] - a.scal[(net == 1 ? 3 : 4) * a.R + b];
+      loss = diff * diff;
+      a.dz[net][b * a.ldz[net]] = 2.f * diff * invB;
+    }
+  } else if (a.loss_kind == 2) {
+    if (valid)
+      for (int d = 0; d < a.act_dim; ++d) {
+        const float sd = expf(a.log_std[d]);
+        a.dz[0][b * a.ldz[0] + d] = a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale;
+      }
+  } else {
+    const float lam = a.lagrange ? *a.lagrange : 0.f;
+    float lp = 0.f;
+    if (valid)
+      for (int d = 0; d < a.act_dim; ++d) {
+        const float sd = expf(a.log_std[d]);
+        const float z = a.actg[b * a.lda + d] - a.out[0][b * a.ldo[0] + d];
+        lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+      }
+    float dlogp = 0.f;
+    if (valid) {
+      const float ratio = expf(lp - a.scal[0 * a.R + b]);
+      const float adv = (a.scal[1 * a.R + b] - lam * a.scal[2 * a.R + b]) / (1.f + lam);
+      float dratio;
+      if (a.loss_kind == 0) {
+        const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * adv, s2 = rc * adv;
+        const bool inrange = ratio >= lo && ratio <= hi;
+        loss = -fminf(s1, s2);
+        dratio = (s1 < s2 || inrange) ? -adv : 0.f;
+      } else {
+        loss = -(ratio * adv);
+        dratio = -adv;
+      }
+      ratio_s = ratio;
+      dlogp = dratio * ratio * invB;
+    }
+    // d logp / d mu = z / var;  d logp / d log_std = z^2 / var - 1; block sums of the latter, dimension by dimension
+    for (int d = 0; d < a.act_dim; ++d) {
+      float dl = 0.f;
+      if (valid) {
+        const float sd = expf(a.log_std[d]);
+        const float iv = 1.f / (sd * sd);
+        const float z = a.actg[b * a.lda + d] - a.out[0][b * a.ldo[0] + d];
+        a.dz[0][b * a.ldz[0] + d] = dlogp * z * iv;
+        dl = dlogp * (z * z * iv - 1.f);
+      }
+      dl = gm_block_sum(dl, red);
+      if (threadIdx.x == 0) a.dls[(long)blockIdx.x * a.lda + d] = dl;
+    }
+  }
+  loss = gm_block_sum(loss, red);
+  ratio_s = gm_block_sum(ratio_s, red);
+  if (threadIdx.x == 0) {
+    float* lp_ = a.lpart + ((long)net * gridDim.x + blockIdx.x) * 4;
+    lp_[0] = loss;
+    lp_[1] = ratio_s;
+  }
+}
+
+struct GRedArgs {
+  int P, S, nblk, nb, act_dim, lda;
+  int Pn[3], oLS[3];
+  const float* params;
+  float* grads;
+  const float* slabs;   // [3][S][P]
+  const float* dls;     // [nblk][lda]
+  const float* lpart;   // [3][nblk][4]
+  float* npart;         // [3][nb][2]
+  float* stats;         // step statistics [16]
+  float entropy_coef, critic_norm_coef;
+  int use_critic_norm, nets_mask, loss_kind;
+  long R;
+};
+
+// grads[net][e] = sum_s slab[net][s][e] (+ log_std: block partials - entropy term; critics: + 2 c w), partial squared
+// norms per 1024 elements; block 0 of every network also folds the loss statistics.   grid (nb, 3)
+__global__ __launch_bounds__(256) void gm_reduce_kernel(GRedArgs a) {
+  __shared__ float red[4];
+  const int net = blockIdx.y;
+  if (!((a.nets_mask >> net) & 1)) return;
+  const bool critic = net != 0;
+  const float* __restrict__ p = a.params + (long)net * a.P;
+  float gsq = 0.f, psq = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    if (e >= a.P) continue;
+    float g = 0.f;
+    if (e < a.oLS[net]) {
+      const float* s = a.slabs + (long)net * a.S * a.P + e;
+      for (int k = 0; k < a.S; ++k) g += s[(long)k * a.P];
+      const float w = p[e];
+      if (critic) {
+        if (a.use_critic_norm) g += 2.f * a.critic_norm_coef * w;
+        psq += w * w;
+      }
+    } else if (!critic && e < a.oLS[0] + a.act_dim && a.loss_kind != 2) {
+      const int d = e - a.oLS[0];
+      for (int k = 0; k < a.nblk; ++k) g += a.dls[(long)k * a.lda + d];
+      g -= a.entropy_coef / (float)a.act_dim;
+    }
+    a.grads[(long)net * a.P + e] = g;
+    gsq += g * g;
+  }
+  gsq = gm_block_sum(gsq, red);
+  psq = gm_block_sum(psq, red);
+  if (threadIdx.x == 0) {
+    a.npart[((long)net * a.nb + blockIdx.x) * 2 + 0] = gsq;
+    a.npart[((long)net * a.nb + blockIdx.x) * 2 + 1] = psq;
+  }
+  if (blockIdx.x == 0 && a.stats && a.loss_kind != 2) {
+    float l = 0.f, r = 0.f;
+    for (int k = threadIdx.x; k < a.nblk; k += 256) {
+      l += a.lpart[((long)net * a.nblk + k) * 4 + 0];
+      r += a.lpart[((long)net * a.nblk + k) * 4 + 1];
+    }
+    l = gm_block_sum(l, red);
+    r = gm_block_sum(r, red);
+    if (threadIdx.x == 0) {
+      const float invB = 1.f / (float)a.R;
+      if (net == 0) {
+        float ent = 0.f;
+        for (int d = 0; d < a.act_dim; ++d) ent += 1.41893853320467274178f + p[a.oLS[0] + d];
+        ent /= (float)a.act_dim;
+        a.stats[2] = l * invB - a.entropy_coef * ent;
+        a.stats[3] = r * invB;
+        a.stats[4] = ent;
+      } else {
+        a.stats[net - 1] = l * invB;
+      }
+    }
+  }
+}
+
+struct GFinArgs {
+  int nb, nets_mask, mode;  // mode 0 clip + Adam, 1 clip only, 2 raw, 3 Adam only (gradients clipped and averaged already)
+  const float* npart;
+  float* fin;               // [3][8]: {clip factor, step_size, inv_bc2_sqrt, lr}
+  int* adam_step;
+  float* stats;
+  float max_grad_norm, lr_actor, lr_critic, beta1, beta2;
+  int use_max_grad_norm;
+  const float* lr_dev;
+};
+
+// one workgroup per network: total norm in block order, clip factor, Adam's bias corrections of THIS step (float64
+// like torch), step counter advanced.   grid (3)
+__global__ __launch_bounds__(256) void gm_final_kernel(GFinArgs a) {
+  __shared__ float red[4];
+  const int net = blockIdx.x;
+  if (!((a.nets_mask >> net) & 1)) return;
+  float coef = 1.f;
+  if (a.mode != 3) {
+    float g = 0.f, q = 0.f;
+    // (a strided walk per thread, then the fixed-order block sum: deterministic)
+    for (int k = threadIdx.x; k < a.nb; k += 256) {
+      g += a.npart[((long)net * a.nb + k) * 2 + 0];
+      q += a.npart[((long)net * a.nb + k) * 2 + 1];
+    }
+    g = gm_block_sum(g, red);
+    q = gm_block_sum(q, red);
+    const float total_norm = sqrtf(g);
+    if (threadIdx.x == 0 && a.stats) {
+      a.stats[7 + net] = total_norm;
+      if (net != 0) a.stats[4 + net] = q;
+    }
+    if (a.use_max_grad_norm && a.mode != 2) {
+      coef = a.max_grad_norm / (total_norm + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float* f = a.fin + net * 8;
+    f[0] = coef;
+    if (a.mode == 0 || a.mode == 3) {
+      const int step = a.adam_step[net] + 1;
+      const bool critic = net != 0;
+      const float lr = a.lr_dev ? a.lr_dev[critic ? 1 : 0] : (critic ? a.lr_critic : a.lr_actor);
+      f[1] = (float)((double)lr / (1.0 - pow((double)a.beta1, (double)step)));
+      f[2] = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, (double)step)));
+      a.adam_step[net] = step;
+    }
+  }
+}
+
+// grid (ceil(P / 1024), 3): clip (+ Adam).  torch.optim.Adam single-tensor step (mlp_device.h osa_adam_update4)
+__global__ __launch_bounds__(256) void gm_apply_kernel(int P, int nets_mask, int mode, const float* __restrict__ fin,
+                                                       float* __restrict__ params, float* __restrict__ adam_m,
+                                                       float* __restrict__ adam_v, float* __restrict__ grads,
+                                                       float beta1, float beta2, float eps) {
+  const int net = blockIdx.y;
+  if (!((nets_mask >> net) & 1)) return;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= P) return;
+  const float coef = fin[net * 8 + 0];
+  const long o = (long)net * P + e;
+  f32x4 g = *reinterpret_cast<f32x4*>(grads + o);
+  g = g * coef;
+  if (mode == 1) {
+    *reinterpret_cast<f32x4*>(grads + o) = g;
+    return;
+  }
+  f32x4 m = *reinterpret_cast<f32x4*>(adam_m + o), v = *reinterpret_cast<f32x4*>(adam_v + o);
+  const f32x4 w = *reinterpret_cast<f32x4*>(params + o);
+  const f32x4 wn = osa_adam_update4(g, m, v, w, beta1, beta2, fin[net * 8 + 1], fin[net * 8 + 2], eps);
+  *reinterpret_cast<f32x4*>(params + o) = wn;
+  *reinterpret_cast<f32x4*>(adam_m + o) = m;
+  *reinterpret_cast<f32x4*>(adam_v + o) = v;
+}
+
+// rollout: sample the action from the mean rows, log-probability, ActionScale, critics' values
+__global__ __launch_bounds__(256) void gm_sample_kernel(
+    long N, int act_dim, const float* __restrict__ mean, int ldm, const float* __restrict__ vr, int ldvr,
+    const float* __restrict__ vc, int ldvc, const float* __restrict__ log_std, const float* __restrict__ eps,
+    unsigned long long seed, unsigned long long offset, const unsigned long long* __restrict__ offset_base,
+    int deterministic, int nets_mask, float* __restrict__ act, int ld_act, float* __restrict__ value_r,
+    float* __restrict__ value_c, float* __restrict__ logp, float* __restrict__ mean_out, int ld_mean,
+    float* __restrict__ act_env, int ld_env, const float* __restrict__ old_min, const float* __restrict__ old_max,
+    float min_a, float max_a) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= N) return;
+  if (offset_base) offset += *offset_base;
+  if (nets_mask & 1) {
+    float lp = 0.f;
+    for (int d = 0; d < act_dim; ++d) {
+      const float mu = mean[row * ldm + d];
+      const float sd = expf(log_std[d]);
+      float a = mu;
+      if (!deterministic) {
+        float e;
+        if (eps != nullptr) {
+          e = eps[row * act_dim + d];
+        } else {  // the same counter mapping as osa_policy_step_kernel: one Philox block per (row, dimension)
+          uint32_t w[4];
+          osa_philox(seed, offset, (unsigned long long)row * act_dim + d, w);
+          float e1;
+          osa_box_muller(w[0], w[1], e, e1);
+        }
+        a = mu + e * sd;
+      }
+      if (act) act[row * ld_act + d] = a;
+      if (act_env) act_env[row * ld_env + d] = osa_action_scale1(a, old_min[d], old_max[d], min_a, max_a);
+      if (mean_out) mean_out[row * ld_mean + d] = mu;
+      const float z = a - mu;
+      lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+    }
+    if (logp) logp[row] = lp;
+  }
+  if ((nets_mask & 2) && value_r) value_r[row] = vr[row * ldvr];
+  if ((nets_mask & 4) && value_c) value_c[row] = vc[row * ldvc];
+}
+
+// full-batch actor statistics from the mean rows: KL(old || new) sums and the line-search sums of osa_actor_eval
+__global__ __launch_bounds__(256) void gm_rowstat_kernel(
+    long M, int act_dim, const float* __restrict__ mean, int ldm, const float* __restrict__ log_std,
+    const float* __restrict__ old_mean, int ld_old, const float* __restrict__ old_log_std,
+    const float* __restrict__ act, int ld_act, const float* __restrict__ logp, const float* __restrict__ adv_r,
+    const float* __restrict__ adv_c, const float* __restrict__ lagrange, float* __restrict__ mean_out, int ld_mean,
+    double* __restrict__ ws) {
+  __shared__ double red[17];
+  const float lam = lagrange ? *lagrange : 0.f;
+  double s_sur = 0.0, s_cost = 0.0, s_kl = 0.0, s_ratio = 0.0;
+  for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < M; row += (long)gridDim.x * 256) {
+    float lp = 0.f, klp = 0.f;
+    for (int d = 0; d < act_dim; ++d) {
+      const float mu = mean[row * ldm + d];
+      if (mean_out) mean_out[row * ld_mean + d] = mu;
+      if (old_mean) {
+        const float qs = expf(log_std[d]), ps = expf(old_log_std[d]);
+        const float vr = (ps / qs) * (ps / qs);
+        const float t1 = (old_mean[row * ld_old + d] - mu) / qs;
+        klp += 0.5f * (vr + t1 * t1 - 1.f - logf(vr));
+        if (act) {
+          const float z = act[row * ld_act + d] - mu;
+          lp += -(z * z) / (2.f * (qs * qs)) - logf(qs) - 0.91893853320467274178f;
+        }
+      }
+    }
+    s_kl += (double)klp;
+    if (act && old_mean) {
+      const float ratio = expf(lp - logp[row]);
+      const float adv = (adv_r[row] - lam * adv_c[row]) / (1.f + lam);
+      s_sur += (double)(ratio * adv);
+      s_cost += (double)(ratio * adv_c[row]);
+      s_ratio += (double)ratio;
+    }
+  }
+  s_sur = osa_block_sum<256>(s_sur, red);
+  s_cost = osa_block_sum<256>(s_cost, red);
+  s_kl = osa_block_sum<256>(s_kl, red);
+  s_ratio = osa_block_sum<256>(s_ratio, red);
+  if (threadIdx.x == 0 && ws) {
+    ws[4 * blockIdx.x + 0] = s_sur;
+    ws[4 * blockIdx.x + 1] = s_cost;
+    ws[4 * blockIdx.x + 2] = s_kl;
+    ws[4 * blockIdx.x + 3] = s_ratio;
+  }
+}
+
+// mode 0: *out = kl_sum / denom (osa_actor_kl);  1: the four outputs of osa_actor_eval
+__global__ __launch_bounds__(256) void gm_rowstat_final_kernel(const double* __restrict__ ws, int nblk, int mode,
+                                                               double M, double act_dim, double denom,
+                                                               float* __restrict__ out) {
+  __shared__ double red[17];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = threadIdx.x; k < nblk; k += 256)
+    for (int q = 0; q < 4; ++q) s[q] += ws[4 * k + q];
+  for (int q = 0; q < 4; ++q) s[q] = osa_block_sum<256>(s[q], red);
+  if (threadIdx.x == 0) {
+    if (mode == 0) {
+      out[0] = (float)(s[2] / denom);
+    } else {
+      out[0] = (float)(-s[0] / M);
+      out[1] = (float)(s[1] / M);
+      out[2] = (float)(s[2] / (M * act_dim));
+      out[3] = (float)(s[3] / M);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+// forward of the networks in `mask` over R gathered rows: layer by layer, the networks of a layer in one launch
+int gm_forward(const GLayout& lo, const GWs& w, float* ws, const float* params, long R, int mask, hipStream_t st) {
+  int maxL = 0;
+  for (int net = 0; net < 3; ++net)
+    if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
+  for (int l = 0; l < maxL; ++l) {
+    GArgs g = {};
+    g.splits = 1;
+    for (int net = 0; net < 3; ++net) {
+      const GNet& n = lo.n[net];
+      if (!((mask >> net) & 1) || l >= n.L) continue;
+      GProb p = gm_prob();
+      const float* pn = params + (long)net * lo.P;
+      p.A = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
+      p.lda = l == 0 ? lo.ldx : n.ldh[l - 1];
+      p.B = pn + n.oW[l];
+      p.ldb = n.ld[l];
+      p.C = ws + w.h[net][l];
+      p.ldc = n.ldh[l];
+      p.M = (int)R;
+      p.N = n.out[l];
+      p.K = n.in[l];
+      p.bias = pn + n.ob[l];
+      p.act = l + 1 < n.L ? n.act : -1;
+      g.p[g.nprob++] = p;
+    }
+    const int rc = gm_gemm<false, false>(g, st);
+    if (rc != OSA_OK) return rc;
+  }
+  return OSA_OK;
+}
+
+int gm_gather(const GLayout& lo, const GWs& w, float* ws, long R, const long* idx, const float* obs, int ld_obs,
+              const float* act, int ld_act, const float* s0, const float* s1, const float* s2, const float* s3,
+              const float* s4, hipStream_t st) {
+  hipLaunchKernelGGL(gm_gather_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, R, idx, obs, ld_obs, lo.obs_dim,
+                     act, ld_act, lo.act_dim, s0, s1, s2, s3, s4, ws + w.xg, lo.ldx, act ? ws + w.actg : nullptr,
+                     lo.lda, ws + w.scal);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osa_gmlp_layout(const osa_gmlp_desc* desc, int* out) {
+  OSA_REQUIRE(desc && out);
+  GLayout lo;
+  const int rc = gm_make_layout(desc, &lo);
+  if (rc != OSA_OK) return rc;
+  out[0] = lo.P;
+  out[1] = lo.n[0].oLS;
+  int k = 2;
+  for (int net = 0; net < 3; ++net)
+    for (int l = 0; l < GM_MAXL; ++l) {
+      const bool on = l < lo.n[net].L;
+      out[k++] = on ? lo.n[net].oW[l] : -1;
+      out[k++] = on ? lo.n[net].ob[l] : -1;
+      out[k++] = on ? lo.n[net].ld[l] : 0;
+    }
+  return OSA_OK;
+}
+
+size_t osa_gmlp_ws_floats(const osa_gmlp_desc* desc, long rows) {
+  GLayout lo;
+  if (!desc || rows < 1 || gm_make_layout(desc, &lo) != OSA_OK) return 0;
+  return gm_ws(lo, rows).total;
+}
+
+int osa_gmlp_policy_step(const osa_gmlp_desc* desc, const float* params, const float* obs, int ld_obs, long N,
+                         const float* eps, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* offset_base, int deterministic, int nets_mask, float* act,
+                         int ld_act, float* value_r, float* value_c, float* logp, float* mean_out, int ld_mean,
+                         float* act_env, int ld_env, const float* old_min, const float* old_max, float min_action,
+                         float max_action, float* ws, size_t ws_floats, void* stream) {
+  OSA_REQUIRE(desc && params && obs && ws && N > 0 && ld_obs >= desc->obs_dim);
+  GLayout lo;
+  int rc = gm_make_layout(desc, &lo);
+  if (rc != OSA_OK) return rc;
+  const GWs w = gm_ws(lo, N);
+  if (ws_floats < w.total) return OSA_EINVAL;
+  hipStream_t st = osa_stream(stream);
+  if ((rc = gm_gather(lo, w, ws, N, nullptr, obs, ld_obs, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      st)) != OSA_OK)
+    return rc;
+  if ((rc = gm_forward(lo, w, ws, params, N, nets_mask & 7, st)) != OSA_OK) return rc;
+  const GNet &a = lo.n[0], &r = lo.n[1], &c = lo.n[2];
+  hipLaunchKernelGGL(gm_sample_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, lo.act_dim,
+                     ws + w.h[0][a.L - 1], a.ldh[a.L - 1], ws + w.h[1][r.L - 1], r.ldh[r.L - 1], ws + w.h[2][c.L - 1],
+                     c.ldh[c.L - 1], params + a.oLS, eps, seed, offset, offset_base, deterministic, nets_mask, act,
+                     ld_act, value_r, value_c, logp, mean_out, ld_mean, act_env, ld_env, old_min, old_max, min_action,
+                     max_action);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                       float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
+                       const float* target_value_r, const float* target_value_c, const float* adv_r,
+                       const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
+                       int loss_kind, int mode, int nets_mask, const float* vec, float fvp_scale, float* ws,
+                       size_t ws_floats, float* step_stats, void* stream) {
+  OSA_REQUIRE(desc && params && adam_m && adam_v && adam_step && grads && obs && hp && ws && B > 0);
+  OSA_REQUIRE(mode >= 0 && mode <= 2 && loss_kind >= 0 && loss_kind <= 2);
+  OSA_REQUIRE(loss_kind == 2 ? vec != nullptr : (act && logp && target_value_r && target_value_c && adv_r && adv_c));
+  GLayout lo;
+  int rc = gm_make_layout(desc, &lo);
+  if (rc != OSA_OK) return rc;
+  const GWs w = gm_ws(lo, B);
+  if (ws_floats < w.total) return OSA_EINVAL;
+  hipStream_t st = osa_stream(stream);
+  int mask = nets_mask & (hp->use_cost ? 7 : 3);
+  if (loss_kind == 2) mask = 1;
+  if ((rc = gm_gather(lo, w, ws, B, idx, obs, ld_obs, loss_kind == 2 ? nullptr : act, ld_act, logp, adv_r, adv_c,
+                      target_value_r, target_value_c, st)) != OSA_OK)
+    return rc;
+  if ((rc = gm_forward(lo, w, ws, params, B, mask, st)) != OSA_OK) return rc;
+  const GNet& an = lo.n[0];
+  if (loss_kind == 2) {
+    // forward-mode tangent of the mean network along `vec` (natural_pg.py:91-119 without a double backward: for a
+    // Gaussian policy with state-independent log_std the Hessian of mean KL at theta_old is J^T diag(1/sigma^2) J /
+    // (M D_a)):  T_l = (H_{l-1} Vw_l^T + vb_l + T_{l-1} W_l^T) * act'(H_l)
+    for (int l = 0; l < an.L; ++l) {
+      GArgs g = {};
+      g.splits = 1;
+      g.nprob = 1;
+      GProb p = gm_prob();
+      p.A = l == 0 ? ws + w.xg : ws + w.h[0][l - 1];
+      p.lda = l == 0 ? lo.ldx : an.ldh[l - 1];
+      p.B = vec + an.oW[l];
+      p.ldb = an.ld[l];
+      p.C = ws + w.t[l];
+      p.ldc = an.ldh[l];
+      p.M = (int)B; p.N = an.out[l]; p.K = an.in[l];
+      p.bias = vec + an.ob[l];
+      if (l == 0 && l + 1 < an.L) { p.dact = an.act; p.aux = ws + w.h[0][l]; p.ldaux = an.ldh[l]; }
+      g.p[0] = p;
+      if ((rc = gm_gemm<false, false>(g, st)) != OSA_OK) return rc;
+      if (l > 0) {
+        GProb q = gm_prob();
+        q.A = ws + w.t[l - 1]; q.lda = an.ldh[l - 1];
+        q.B = params + an.oW[l]; q.ldb = an.ld[l];
+        q.C = ws + w.t[l]; q.ldc = an.ldh[l];
+        q.M = (int)B; q.N = an.out[l]; q.K = an.in[l];
+        q.accumulate = 1;
+        if (l + 1 < an.L) { q.dact = an.act; q.aux = ws + w.h[0][l]; q.ldaux = an.ldh[l]; }
+        g.p[0] = q;
+        if ((rc = gm_gemm<false, false>(g, st)) != OSA_OK) return rc;
+      }
+    }
+  }
+  // ---- loss and dL/d(output)
+  GLossArgs la = {};
+  la.R = B; la.act_dim = lo.act_dim; la.lda = lo.lda;
+  int cur[3] = {0, 0, 0};  // which ping-pong buffer holds dZ of the layer in flight
+  for (int net = 0; net < 3; ++net) {
+    const GNet& n = lo.n[net];
+    la.out[net] = ws + w.h[net][n.L - 1];
+    la.ldo[net] = n.ldh[n.L - 1];
+    la.dz[net] = ws + w.z[net][0];
+    la.ldz[net] = n.ldh[n.L - 1];
+  }
+  la.actg = ws + w.actg; la.scal = ws + w.scal; la.log_std = params + an.oLS; la.lagrange = lagrange;
+  la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
+  la.dls = ws + w.dls; la.lpart = ws + w.lpart;
+  la.tmean = ws + w.t[an.L - 1]; la.ldt = an.ldh[an.L - 1]; la.fvp_scale = fvp_scale;
+  hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
+  OSA_CHECK_LAUNCH();
+  // ---- backward: weight (+ bias) gradients into the slabs, then dZ of the layer below
+  int maxL = 0;
+  for (int net = 0; net < 3; ++net)
+    if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
+  for (int step = 0; step < maxL; ++step) {  // step counts layers from the top of EACH network
+    GArgs gw = {}, gd = {};
+    gw.splits = w.S;
+    gd.splits = 1;
+    for (int net = 0; net < 3; ++net) {
+      const GNet& n = lo.n[net];
+      const int l = n.L - 1 - step;
+      if (!((mask >> net) & 1) || l < 0) continue;
+      float* slab = ws + w.slabs + (long)net * w.S * lo.P;
+      GProb p = gm_prob();  // dW_l[out][in] (+ db_l) = dZ_l^T [out][rows] . {H_{l-1}, 1}[rows][in + 1]
+      p.A = ws + w.z[net][cur[net]]; p.lda = n.ldh[l];
+      p.B = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
+      p.ldb = l == 0 ? lo.ldx : n.ldh[l - 1];
+      p.C = slab + n.oW[l]; p.ldc = n.ld[l];
+      p.cb = slab + n.ob[l]; p.cb_pad = r4(n.out[l]);
+      p.M = n.out[l]; p.N = n.in[l]; p.K = (int)B;
+      p.ones_n = n.in[l];
+      p.slab_stride = lo.P;
+      gw.p[gw.nprob++] = p;
+      if (l > 0) {  // dZ_{l-1}[rows][in] = (dZ_l[rows][out] . W_l[out][in]) * act'(H_{l-1})
+        GProb q = gm_prob();
+        q.A = ws + w.z[net][cur[net]]; q.lda = n.ldh[l];
+        q.B = params + (long)net * lo.P + n.oW[l]; q.ldb = n.ld[l];
+        q.C = ws + w.z[net][cur[net] ^ 1]; q.ldc = n.ldh[l - 1];
+        q.M = (int)B; q.N = n.in[l]; q.K = n.out[l];
+        q.dact = n.act; q.aux = ws + w.h[net][l - 1]; q.ldaux = n.ldh[l - 1];
+        gd.p[gd.nprob++] = q;
+      }
+    }
+    if ((rc = gm_gemm<true, true>(gw, st)) != OSA_OK) return rc;
+    if (gd.nprob > 0 && (rc = gm_gemm<false, true>(gd, st)) != OSA_OK) return rc;
+    for (int net = 0; net < 3; ++net)
+      if (((mask >> net) & 1) && lo.n[net].L - 1 - step > 0) cur[net] ^= 1;
+  }
+  // ---- slab sum, L2 / entropy terms, norms; clip factor and Adam scalars; clip (+ Adam)
+  GRedArgs ra = {};
+  ra.P = lo.P; ra.S = w.S; ra.nblk = w.nblk; ra.nb = w.nb; ra.act_dim = lo.act_dim; ra.lda = lo.lda;
+  for (int net = 0; net < 3; ++net) { ra.Pn[net] = lo.n[net].Pn; ra.oLS[net] = lo.n[net].oLS; }
+  ra.params = params; ra.grads = grads; ra.slabs = ws + w.slabs; ra.dls = ws + w.dls; ra.lpart = ws + w.lpart;
+  ra.npart = ws + w.npart; ra.stats = step_stats; ra.entropy_coef = hp->entropy_coef;
+  ra.critic_norm_coef = hp->critic_norm_coef; ra.use_critic_norm = hp->use_critic_norm; ra.nets_mask = mask;
+  ra.loss_kind = loss_kind; ra.R = B;
+  hipLaunchKernelGGL(gm_reduce_kernel, dim3(w.nb, 3), dim3(256), 0, st, ra);
+  GFinArgs fa = {};
+  fa.nb = w.nb; fa.nets_mask = mask; fa.mode = mode; fa.npart = ws + w.npart; fa.fin = ws + w.fin;
+  fa.adam_step = adam_step; fa.stats = step_stats; fa.max_grad_norm = hp->max_grad_norm;
+  fa.lr_actor = hp->lr_actor; fa.lr_critic = hp->lr_critic; fa.beta1 = hp->beta1; fa.beta2 = hp->beta2;
+  fa.use_max_grad_norm = hp->use_max_grad_norm; fa.lr_dev = hp->lr_device;
+  hipLaunchKernelGGL(gm_final_kernel, dim3(3), dim3(256), 0, st, fa);
+  if (mode != 2)
+    hipLaunchKernelGGL(gm_apply_kernel, dim3((lo.P / 4 + 255) / 256, 3), dim3(256), 0, st, lo.P, mask, mode,
+                       ws + w.fin, params, adam_m, adam_v, grads, hp->beta1, hp->beta2, hp->adam_eps);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+int osa_gmlp_adam_apply(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                        float* grads, const osa_ppo_hparams* hp, int nets_mask, float* fin8x3, void* stream) {
+  OSA_REQUIRE(desc && params && adam_m && adam_v && adam_step && grads && hp && fin8x3);
+  GLayout lo;
+  const int rc = gm_make_layout(desc, &lo);
+  if (rc != OSA_OK) return rc;
+  hipStream_t st = osa_stream(stream);
+  GFinArgs fa = {};
+  fa.nb = 0; fa.nets_mask = nets_mask; fa.mode = 3; fa.npart = nullptr; fa.fin = fin8x3; fa.adam_step = adam_step;
+  fa.stats = nullptr; fa.lr_actor = hp->lr_actor; fa.lr_critic = hp->lr_critic; fa.beta1 = hp->beta1;
+  fa.beta2 = hp->beta2; fa.lr_dev = hp->lr_device;
+  hipLaunchKernelGGL(gm_final_kernel, dim3(3), dim3(256), 0, st, fa);
+  hipLaunchKernelGGL(gm_apply_kernel, dim3((lo.P / 4 + 255) / 256, 3), dim3(256), 0, st, lo.P, nets_mask, 3, fin8x3,
+                     params, adam_m, adam_v, grads, hp->beta1, hp->beta2, hp->adam_eps);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+// osa_actor_kl / osa_actor_eval for general networks: actor forward over M rows + row statistics.
+//   kind 0: snapshot (old_mean == NULL: only mean_out) or KL(old || new) -> out[0] (reduce_mode as osa_actor_kl)
+//   kind 1: the four line-search sums of osa_actor_eval -> out[0..3]
+int osa_gmlp_actor_stats(const osa_gmlp_desc* desc, const float* actor_params, const float* obs, int ld_obs, long M,
+                         const float* old_mean, int ld_old, const float* old_log_std, int kind, int reduce_mode,
+                         const float* act, int ld_act, const float* logp, const float* adv_r, const float* adv_c,
+                         const float* lagrange, float* mean_out, int ld_mean, float* ws, size_t ws_floats, float* out,
+                         void* stream) {
+  OSA_REQUIRE(desc && actor_params && obs && ws && M > 0);
+  OSA_REQUIRE(kind == 0 || (old_mean && old_log_std && act && logp && adv_r && adv_c && out));
+  GLayout lo;
+  int rc = gm_make_layout(desc, &lo);
+  if (rc != OSA_OK) return rc;
+  const GWs w = gm_ws(lo, M);
+  if (ws_floats < w.total) return OSA_EINVAL;
+  hipStream_t st = osa_stream(stream);
+  if ((rc = gm_gather(lo, w, ws, M, nullptr, obs, ld_obs, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      st)) != OSA_OK)
+    return rc;
+  // (actor_params points at the actor's block: network 0 of a [3][P] tensor or a candidate vector)
+  if ((rc = gm_forward(lo, w, ws, actor_params, M, 1, st)) != OSA_OK) return rc;
+  const GNet& an = lo.n[0];
+  double* dws = reinterpret_cast<double*>(ws + w.dws);
+  int nblk = (int)((M + 255) / 256);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(gm_rowstat_kernel, dim3(nblk), dim3(256), 0, st, M, lo.act_dim, ws + w.h[0][an.L - 1],
+                     an.ldh[an.L - 1], actor_params + an.oLS, old_mean, ld_old, old_log_std, kind == 1 ? act : nullptr,
+                     ld_act, logp, adv_r, adv_c, lagrange, mean_out, ld_mean, dws);
+  if (old_mean && out) {
+    const double denom = reduce_mode == 0 ? (double)M : (double)M * lo.act_dim;
+    hipLaunchKernelGGL(gm_rowstat_final_kernel, dim3(1), dim3(256), 0, st, dws, nblk, kind, (double)M,
+                       (double)lo.act_dim, denom, out);
+  }
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
+}
+
+}  // extern "C"

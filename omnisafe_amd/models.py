@@ -85,6 +85,50 @@ class Layout:
         return items
 
 
+GMLP_MAX_LAYERS = 8
+
+
+class GmlpDesc(C.Structure):
+    """ctypes mirror of ``osa_gmlp_desc`` (include/omnisafe_amd.h): the shapes of a GENERAL actor-critic."""
+
+    _fields_ = [('obs_dim', C.c_int), ('act_dim', C.c_int), ('n_layers', C.c_int * 3),
+                ('width', (C.c_int * GMLP_MAX_LAYERS) * 3), ('activation', C.c_int * 3)]
+
+
+class GeneralLayout:
+    """Parameter blocks of general networks (any hidden_sizes; csrc/general_mlp.hip): same interface as Layout."""
+
+    def __init__(self, desc: GmlpDesc, sizes: list[list[int]]):
+        lib = _lib.load()
+        out = (C.c_int * (2 + 3 * GMLP_MAX_LAYERS * 3))()
+        _lib.check(lib.osa_gmlp_layout(C.byref(desc), out), 'osa_gmlp_layout')
+        self.P, self.oLS = int(out[0]), int(out[1])
+        self.obs_dim, self.act_dim = int(desc.obs_dim), int(desc.act_dim)
+        self.OUTP = (self.act_dim + 3) // 4 * 4
+        self._layers = []  # per network: [(oW, ob, ld, out, in)]
+        k = 2
+        for net in range(3):
+            rows = []
+            for l in range(GMLP_MAX_LAYERS):
+                oW, ob, ld = int(out[k]), int(out[k + 1]), int(out[k + 2])
+                k += 3
+                if oW >= 0:
+                    rows.append((oW, ob, ld, sizes[net][l + 1], sizes[net][l]))
+            self._layers.append(rows)
+
+    def tensors(self, net: int) -> list[tuple[str, tuple[int, ...], np.ndarray]]:
+        """Reference `named_parameters` order (utils/model.py:103-111: Linear layers at Sequential indices 0, 2, 4 ...)."""
+        prefix = 'mean' if net == ACTOR else 'critic_0'
+        items = []
+        if net == ACTOR:
+            items.append(('log_std', (self.act_dim,), self.oLS + np.arange(self.act_dim)))
+        for j, (oW, ob, ld, n_out, n_in) in enumerate(self._layers[net]):
+            ix = (oW + np.arange(n_out)[:, None] * ld + np.arange(n_in)[None, :]).reshape(-1)
+            items.append((f'{prefix}.{2 * j}.weight', (n_out, n_in), ix))
+            items.append((f'{prefix}.{2 * j}.bias', (n_out,), ob + np.arange(n_out)))
+        return items
+
+
 class NetView:
     """One network of the actor-critic: reference-shaped access to its padded parameter block."""
 
@@ -189,26 +233,50 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
             raise NotImplementedError  # models/base.py:66-74
         self.device = torch.device(device)
         self.obs_dim, self.act_dim = int(obs_space.shape[0]), int(act_space.shape[0])
-        a_h, c_h = list(model_cfgs.actor.hidden_sizes), list(model_cfgs.critic.hidden_sizes)
-        if a_h != c_h or len(a_h) != 2 or a_h[0] != a_h[1]:
-            raise NotImplementedError(f'hidden_sizes {a_h}/{c_h}: omnisafe_amd supports [H, H] for both')
-        # hidden activation (utils/model.py:47-70: identity / relu / sigmoid / softplus / tanh).  tanh -- every
-        # on-policy YAML default -- runs on the persistent pass kernels; the others on the per-step kernels, which
-        # take the activation code in bits 16-19 of the `hidden` word of the C ABI (csrc/mlp_device.h)
-        if model_cfgs.actor.activation != model_cfgs.critic.activation:
-            raise NotImplementedError('omnisafe_amd: actor and critics must share one activation')
-        if model_cfgs.actor.activation not in ACTIVATIONS:
-            raise NotImplementedError(f'activation {model_cfgs.actor.activation!r}: one of {list(ACTIVATIONS)}')
+        a_h, c_h = [int(h) for h in model_cfgs.actor.hidden_sizes], [int(h) for h in model_cfgs.critic.hidden_sizes]
+        # hidden activation (utils/model.py:47-70: identity / relu / sigmoid / softplus / tanh)
+        for act_name in (model_cfgs.actor.activation, model_cfgs.critic.activation):
+            if act_name not in ACTIVATIONS:
+                raise NotImplementedError(f'activation {act_name!r}: one of {list(ACTIVATIONS)}')
         if getattr(model_cfgs, 'actor_type', 'gaussian_learning') != 'gaussian_learning':
             raise NotImplementedError('only actor_type gaussian_learning is on the accelerated path')
+        if any(h < 1 for h in a_h + c_h) or max(len(a_h), len(c_h)) + 1 > GMLP_MAX_LAYERS:
+            raise NotImplementedError(f'hidden_sizes {a_h}/{c_h}: 0 .. {GMLP_MAX_LAYERS - 1} hidden layers of width >= 1')
         self.activation = model_cfgs.actor.activation
-        self.width = int(a_h[0])
-        if self.width not in (32, 64, 128, 256):
-            raise NotImplementedError(f'hidden_sizes {a_h}: the kernels implement [H, H] with H in 32, 64, 128, 256 '
-                                      '(64 = every on-policy YAML default, the only width of the persistent passes)')
-        self.hidden = self.width | (ACTIVATIONS[self.activation] << 16)  # what the C ABI calls `hidden`
+        self.hidden_sizes = (a_h, c_h)
+        # Two kernel families behind one interface:
+        #   FUSED    [H, H] with H in 32, 64, 128, 256, one activation for actor and critics -- a network fits a compute
+        #            unit (mlp_kernels.hip; H = 64 with tanh, every on-policy YAML default, also runs the persistent
+        #            passes); the activation code rides in bits 16-19 of the `hidden` word of the C ABI
+        #   GENERAL  everything else utils/model.py:73-111 builds (any depth / widths, actor != critics, e.g. the
+        #            1024 x 1024 networks of docs/source/start/efficiency.rst:15-23): layer-wise on the float32-MFMA GEMM
+        #            of general_mlp.hip, shapes in an osa_gmlp_desc.  OSA_FORCE_GENERAL_MLP=1 sends fused-family shapes
+        #            there too (how the tests pin the general path to the reference goldens)
+        fused_ok = (a_h == c_h and len(a_h) == 2 and a_h[0] == a_h[1] and a_h[0] in (32, 64, 128, 256)
+                    and model_cfgs.actor.activation == model_cfgs.critic.activation)
+        import os as _os
+
+        self.general = (not fused_ok) or _os.environ.get('OSA_FORCE_GENERAL_MLP', '0') == '1'
+        self.width = int(a_h[0]) if a_h else 0
         self._lib = _lib.load(require_gpu=True)  # (after the configuration checks: those need no GPU)
-        self.layout = Layout(self.obs_dim, self.act_dim, self.hidden)
+        if self.general:
+            self.hidden = 0  # (no fused kernel takes this network: every osa_*_supported(..., hidden = 0) says no)
+            sizes = [[self.obs_dim] + a_h + [self.act_dim], [self.obs_dim] + c_h + [1], [self.obs_dim] + c_h + [1]]
+            d = GmlpDesc()
+            d.obs_dim, d.act_dim = self.obs_dim, self.act_dim
+            acts = (model_cfgs.actor.activation, model_cfgs.critic.activation, model_cfgs.critic.activation)
+            for net in range(3):
+                d.n_layers[net] = len(sizes[net]) - 1
+                for l, w in enumerate(sizes[net][1:]):
+                    d.width[net][l] = w
+                d.activation[net] = ACTIVATIONS[acts[net]]
+            self.desc = d
+            self.layout = GeneralLayout(d, sizes)
+            self._gws: torch.Tensor | None = None
+            self._gfin = torch.zeros(24, dtype=torch.float32, device=self.device)
+        else:
+            self.hidden = self.width | (ACTIVATIONS[self.activation] << 16)  # what the C ABI calls `hidden`
+            self.layout = Layout(self.obs_dim, self.act_dim, self.hidden)
         P = self.layout.P
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(3, P, **f32)
@@ -253,12 +321,21 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
                 sd[f'{prefix}.{2 * j}.bias'] = lin.bias.detach()
             return sd
 
-        H = self.width
-        sd = mlp_state([self.obs_dim, H, H, self.act_dim], 'mean')
+        a_h, c_h = self.hidden_sizes
+        sd = mlp_state([self.obs_dim] + a_h + [self.act_dim], 'mean')
         sd['log_std'] = torch.zeros(self.act_dim)
         self.actor.load_state_dict(sd)
-        self.reward_critic.load_state_dict(mlp_state([self.obs_dim, H, H, 1], 'critic_0'))
-        self.cost_critic.load_state_dict(mlp_state([self.obs_dim, H, H, 1], 'critic_0'))
+        self.reward_critic.load_state_dict(mlp_state([self.obs_dim] + c_h + [1], 'critic_0'))
+        self.cost_critic.load_state_dict(mlp_state([self.obs_dim] + c_h + [1], 'critic_0'))
+
+    # ------------------------------------------------------------------ general networks: scratch
+    def gmlp_ws(self, rows: int) -> tuple[torch.Tensor, int]:
+        """Scratch of the layer-wise path for a call over `rows` rows (grow-only; the library carves it up by `rows`)."""
+        need = int(self._lib.osa_gmlp_ws_floats(C.byref(self.desc), int(rows)))
+        assert need > 0
+        if self._gws is None or self._gws.numel() < need:
+            self._gws = torch.empty(need, dtype=torch.float32, device=self.device)
+        return self._gws, int(self._gws.numel())
 
     # ------------------------------------------------------------------ rollout step
     def step(self, obs: torch.Tensor, deterministic: bool = False, eps: torch.Tensor | None = None,
@@ -282,6 +359,18 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
             e = eps.reshape(N, self.act_dim).to(self.device, torch.float32).contiguous()
         self._rng_offset += 1
         sc = o.get('scale')  # (act_env rows, old_min, old_max, min_action, max_action): ActionScale in the same launch
+        if self.general:
+            ws, nws = self.gmlp_ws(N)
+            _lib.check(self._lib.osa_gmlp_policy_step(
+                C.byref(self.desc), _lib.ptr(self.params), _lib.ptr(x), x.stride(0), N, _lib.ptr(e), self.seed,
+                self._rng_offset, _lib.ptr(self._rng_base), int(deterministic), nets_mask, _lib.ptr(act), self.act_dim,
+                _lib.ptr(v_r), _lib.ptr(v_c), _lib.ptr(logp), None, 0,
+                _lib.ptr(sc[0]) if sc else None, sc[0].stride(0) if sc else 0, _lib.ptr(sc[1]) if sc else None,
+                _lib.ptr(sc[2]) if sc else None, float(sc[3]) if sc else 0.0, float(sc[4]) if sc else 1.0,
+                _lib.ptr(ws), nws, _lib.stream_ptr()), 'osa_gmlp_policy_step')
+            if single:
+                return act[0], v_r[0], v_c[0], logp[0]
+            return act, v_r, v_c, logp
         _lib.check(self._lib.osa_policy_step_scaled(
             self.obs_dim, self.act_dim, self.hidden, _lib.ptr(self.params), _lib.ptr(x), x.stride(0), N,
             _lib.ptr(e), self.seed, self._rng_offset, _lib.ptr(self._rng_base), int(deterministic), nets_mask,

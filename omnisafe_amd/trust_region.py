@@ -31,7 +31,7 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         dev, P = ac.device, ac.layout.P
         f32 = dict(dtype=torch.float32, device=dev)
         nws = self.lib.osa_minibatch_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, max_blocks)
-        self._ws = torch.zeros(nws, **f32)  # tail = arrival tickets (start at 0)
+        self._ws = torch.zeros(max(nws, 1), **f32)  # tail = arrival tickets (start at 0)
         self._stats = torch.zeros(16, **f32)
         self._eval_ws = torch.empty(4096, dtype=torch.float64, device=dev)
         self._scal = torch.zeros(4, **f32)
@@ -50,6 +50,20 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         distributed.avg_grads / dist_avg, trpo.py:181-185)."""
         ac, lib = self.ac, self.lib
         M = data['obs'].shape[0]
+        if getattr(ac, 'general', False):
+            ws, nws = ac.gmlp_ws(M)
+            _lib.check(lib.osa_gmlp_minibatch(
+                C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step),
+                _lib.ptr(ac.grads), _lib.ptr(data['obs']), data['obs'].stride(0), _lib.ptr(data['act']),
+                data['act'].stride(0), _lib.ptr(data['logp']), _lib.ptr(data['target_value_r']),
+                _lib.ptr(data['target_value_c']), _lib.ptr(data[adv_key_r]), _lib.ptr(data[adv_key_c]), None, M,
+                _lib.ptr(lagrange), C.byref(self._hp), 1, 2, 1, None, 0.0, _lib.ptr(ws), nws, _lib.ptr(self._stats),
+                _lib.stream_ptr()), 'osa_gmlp_minibatch(full-batch actor gradient)')
+            grad = ac.grads[0].clone()
+            loss = self._stats[2:3].clone()
+            dist.all_reduce_avg_(grad)
+            dist.all_reduce_avg_(loss)
+            return loss, grad
         _lib.check(lib.osa_ppo_minibatch(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
             _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']), data['obs'].stride(0),
@@ -70,10 +84,17 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         ac, M = self.ac, obs.shape[0]
         if self._old_mean is None or self._old_mean.shape[0] != M:
             self._old_mean = torch.empty(M, ac.act_dim, dtype=torch.float32, device=ac.device)
-        _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
-                                         _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0,
-                                         _lib.ptr(self._old_mean), ac.act_dim, None, None,
-                                         _lib.stream_ptr()), 'osa_actor_kl(snapshot)')
+        if getattr(ac, 'general', False):
+            ws, nws = ac.gmlp_ws(M)
+            _lib.check(self.lib.osa_gmlp_actor_stats(
+                C.byref(ac.desc), _lib.ptr(ac.params[0]), _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0, 0, None, 0,
+                None, None, None, None, _lib.ptr(self._old_mean), ac.act_dim, _lib.ptr(ws), nws, None,
+                _lib.stream_ptr()), 'osa_gmlp_actor_stats(snapshot)')
+        else:
+            _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
+                                             _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0,
+                                             _lib.ptr(self._old_mean), ac.act_dim, None, None,
+                                             _lib.stream_ptr()), 'osa_actor_kl(snapshot)')
         lay = ac.layout
         self._old_log_std[:lay.act_dim].copy_(ac.params[0, lay.oLS:lay.oLS + lay.act_dim])
         self._fvp_obs = obs[::self.fvp_sample_freq]
@@ -85,10 +106,18 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         obs = self._fvp_obs
         M = obs.shape[0]
         raw = self._vecs['raw']
-        _lib.check(lib.osa_actor_fvp_raw(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params),
-                                         _lib.ptr(ac.grads), _lib.ptr(obs), obs.stride(0), M, _lib.ptr(v),
-                                         self.max_blocks, _lib.ptr(self._ws), _lib.ptr(self._stats),
-                                         _lib.stream_ptr()), 'osa_actor_fvp_raw')
+        if getattr(ac, 'general', False):
+            ws, nws = ac.gmlp_ws(M)
+            _lib.check(lib.osa_gmlp_minibatch(
+                C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step),
+                _lib.ptr(ac.grads), _lib.ptr(obs), obs.stride(0), None, 0, None, None, None, None, None, None, M, None,
+                C.byref(self._hp), 2, 2, 1, _lib.ptr(v), 1.0 / (M * ac.act_dim), _lib.ptr(ws), nws,
+                _lib.ptr(self._stats), _lib.stream_ptr()), 'osa_gmlp_minibatch(fvp)')
+        else:
+            _lib.check(lib.osa_actor_fvp_raw(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params),
+                                             _lib.ptr(ac.grads), _lib.ptr(obs), obs.stride(0), M, _lib.ptr(v),
+                                             self.max_blocks, _lib.ptr(self._ws), _lib.ptr(self._stats),
+                                             _lib.stream_ptr()), 'osa_actor_fvp_raw')
         raw.copy_(ac.grads[0])
         dist.all_reduce_avg_(raw)  # C2: one flat message
         out = out if out is not None else torch.empty_like(v)
@@ -140,6 +169,15 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         cand = torch.empty(3, lay.P, dtype=torch.float32, device=ac.device)  # eval reads block 0 only
         for k, frac in enumerate(fracs):
             self.lincomb(1.0, theta_old, frac, step, out=cand[0])
+            if getattr(ac, 'general', False):
+                ws, nws = ac.gmlp_ws(M)
+                _lib.check(lib.osa_gmlp_actor_stats(
+                    C.byref(ac.desc), _lib.ptr(cand), _lib.ptr(data['obs']), data['obs'].stride(0), M,
+                    _lib.ptr(self._old_mean), ac.act_dim, _lib.ptr(self._old_log_std), 1, 1, _lib.ptr(data['act']),
+                    data['act'].stride(0), _lib.ptr(data['logp']), _lib.ptr(data[adv_key_r]), _lib.ptr(data['adv_c']),
+                    _lib.ptr(lagrange), None, 0, _lib.ptr(ws), nws, _lib.ptr(res[k]), _lib.stream_ptr()),
+                    'osa_gmlp_actor_stats(eval)')
+                continue
             _lib.check(lib.osa_actor_eval(
                 ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(cand), _lib.ptr(data['obs']),
                 data['obs'].stride(0), M, _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),

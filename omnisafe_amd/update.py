@@ -51,6 +51,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.ac = ac
         # extended actor surrogate (FOCOPS / CUP / P3O): runs on the per-step kernels
         self.ext = ext
+        # general networks (hidden_sizes outside the fused family: csrc/general_mlp.hip) run every optimiser step on
+        # the layer-wise GEMM path -- no persistent pass, data parallelism by per-step all-reduce
+        self.general = bool(getattr(ac, 'general', False))
+        if self.general and ext is not None:
+            raise NotImplementedError('FOCOPS / CUP / P3O surrogates are implemented for the fused network family '
+                                      '([H, H], H in 32 .. 256) only')
         self.update_critics = update_critics
         self.lib = _lib.load(require_gpu=True)
         self.batch_size, self.update_iters = int(batch_size), int(update_iters)
@@ -232,7 +238,10 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
     def _graph_pass_ok(self, M: int) -> bool:
         """The per-step launches of a pass go through a captured hipGraph: large minibatches (the launches, not the
         rows, are what a step waits for), plain surrogate, single process.  OSA_UPDATE_GRAPH=0 keeps eager launches."""
-        return (self.batch_size >= 2048 and self.ext is None
+        nmb = (M + self.batch_size - 1) // self.batch_size
+        # (general networks: a step is ~13 launches of the layer-wise path -- captured whenever the pass stays below a
+        # few thousand graph nodes, whatever the batch size)
+        return ((self.batch_size >= 2048 or (self.general and nmb <= 256)) and self.ext is None
                 and (not dist.collectives_active() or dist.graph_capturable())
                 and os.environ.get('OSA_UPDATE_GRAPH', '1') != '0' and not self._ug.get('failed', False))
 
@@ -257,6 +266,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                self._nets_mask(), self.loss_kind, self.max_blocks, dist.collectives_active(),
                # every pointer / stride the captured launches bake in (as the rollout graph's key does for params)
                tuple(int(t.data_ptr()) for t in (ac.params, ac.adam_m, ac.adam_v, ac.adam_step, ac.grads, self._ws)),
+               int(ac.gmlp_ws(B)[0].data_ptr()) if self.general else 0,
                (data['obs'].stride(0), data['act'].stride(0)),
                (hp.clip, hp.entropy_coef, hp.critic_norm_coef, hp.max_grad_norm, hp.beta1, hp.beta2, hp.adam_eps,
                 hp.use_critic_norm, hp.use_max_grad_norm, hp.use_cost))
@@ -321,6 +331,25 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if self.profile_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        if self.general:
+            ws, nws = ac.gmlp_ws(B)
+            _lib.check(lib.osa_gmlp_minibatch(
+                C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+                _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']), data['obs'].stride(0),
+                _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
+                _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
+                _lib.ptr(data['adv_c']), _lib.ptr(idx), B, _lib.ptr(lagrange), C.byref(self.hp), self.loss_kind,
+                mode, self._nets_mask(), None, 0.0, _lib.ptr(ws), nws, _lib.ptr(stats_row), st), 'osa_gmlp_minibatch')
+            if ev is not None:
+                ev[1].record()
+                self.profile_events.append(('gm_gemm_kernel', B, ev))
+            if dp:
+                dist.all_reduce_avg_(ac.grads)
+                _lib.check(lib.osa_gmlp_adam_apply(C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
+                                                   _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads),
+                                                   C.byref(self.hp), self._nets_mask(), _lib.ptr(ac._gfin), st),
+                           'osa_gmlp_adam_apply')
+            return
         ext = None
         if self.ext is not None:
             self.ext.old_mean = self._old_mean.data_ptr()
@@ -806,16 +835,31 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         ac, M = self.ac, obs.shape[0]
         if self._old_mean is None or self._old_mean.shape[0] != M:
             self._old_mean = torch.empty(M, ac.act_dim, dtype=torch.float32, device=ac.device)
-        _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
-                                         _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0,
-                                         _lib.ptr(self._old_mean), ac.act_dim, None, None,
-                                         _lib.stream_ptr()), 'osa_actor_kl(snapshot)')
+        if self.general:
+            ws, nws = ac.gmlp_ws(M)
+            _lib.check(self.lib.osa_gmlp_actor_stats(
+                C.byref(ac.desc), _lib.ptr(ac.params[0]), _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0, 0, None, 0,
+                None, None, None, None, _lib.ptr(self._old_mean), ac.act_dim, _lib.ptr(ws), nws, None,
+                _lib.stream_ptr()), 'osa_gmlp_actor_stats(snapshot)')
+        else:
+            _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
+                                             _lib.ptr(obs), obs.stride(0), M, None, 0, None, 0,
+                                             _lib.ptr(self._old_mean), ac.act_dim, None, None,
+                                             _lib.stream_ptr()), 'osa_actor_kl(snapshot)')
         lay = ac.layout
         self._old_log_std[:lay.act_dim].copy_(ac.params[0, lay.oLS:lay.oLS + lay.act_dim])
 
     def kl(self, obs: torch.Tensor, reduce_mode: int = 0) -> torch.Tensor:
         """Device scalar KL(old || new), rank-averaged (dist_avg, policy_gradient.py:390)."""
         ac, M = self.ac, obs.shape[0]
+        if self.general:
+            ws, nws = ac.gmlp_ws(M)
+            _lib.check(self.lib.osa_gmlp_actor_stats(
+                C.byref(ac.desc), _lib.ptr(ac.params[0]), _lib.ptr(obs), obs.stride(0), M, _lib.ptr(self._old_mean),
+                ac.act_dim, _lib.ptr(self._old_log_std), 0, reduce_mode, None, 0, None, None, None, None, None, 0,
+                _lib.ptr(ws), nws, _lib.ptr(self._kl), _lib.stream_ptr()), 'osa_gmlp_actor_stats(kl)')
+            dist.all_reduce_avg_(self._kl)
+            return self._kl
         _lib.check(self.lib.osa_actor_kl(ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params[0]),
                                          _lib.ptr(obs), obs.stride(0), M, _lib.ptr(self._old_mean),
                                          ac.act_dim, _lib.ptr(self._old_log_std), reduce_mode, None, 0,
@@ -850,15 +894,15 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # step against 50.9 for the per-step launches; one workgroup walking through 16 chunks: 127)
         pmb = self.persistent_max_batch if self._chunk.get('off') or self.ext is not None or os.environ.get(
             'OSA_CHUNKED_PASS', '1') == '0' else max(self.persistent_max_batch, 1024)
-        if (self.persistent and (self.ext is None or B <= 64) and not dist.collectives_active()
+        if (self.persistent and not self.general and (self.ext is None or B <= 64) and not dist.collectives_active()
                 and B <= pmb and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
-        if self._pass_fn is None and self.persistent and not dist.collectives_active() and self._big_ok():
+        if self._pass_fn is None and self.persistent and not self.general and not dist.collectives_active() and self._big_ok():
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_large_batch_pass)
         self._use_wide = False
-        if (self._pass_fn is None and self.persistent and self.ext is None and not dist.collectives_active()
-                and B <= 64 and self.loss_kind in (0, 1)
+        if (self._pass_fn is None and self.persistent and not self.general and self.ext is None
+                and not dist.collectives_active() and B <= 64 and self.loss_kind in (0, 1)
                 and bool(self.lib.osa_ppo_wide_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_wide_pass_kernel', self.lib.osa_ppo_wide_pass)
             self._use_wide = True
@@ -868,12 +912,13 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self._split_alloc()
         use_pass = self._pass_fn is not None
         W = dist.world_size()
-        data = self._aligned_rows(data)
-        use_repl = (dist.collectives_active() and self.ext is None and self.update_critics
+        if not self.general:  # (the layer-wise path gathers its rows into aligned scratch itself)
+            data = self._aligned_rows(data)
+        use_repl = (dist.collectives_active() and not self.general and self.ext is None and self.update_critics
                     and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
         # wide observations (BASELINE config 4): the data-parallel form of the split pass
-        self._repl_wide = (not use_repl and dist.collectives_active() and self.update_critics
+        self._repl_wide = (not use_repl and not self.general and dist.collectives_active() and self.update_critics
                            and self.dp_mode in ('replicated', 'replicated-steps') and self._wide_dp_fits(W))
         use_repl = use_repl or self._repl_wide
         if use_repl:
@@ -924,11 +969,13 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if use_repl:
             self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
             self.check_wide_dp_sync()
-        if not use_repl and not use_pass and B > 64:
+        if not use_repl and not use_pass and B > 64 and not self.general:
             self.check_reduce_sync()
         if not use_repl and not use_pass and B >= 2048 and dist.collectives_active() and self.ext is None:
             # (what ran, for the tests and the bench line: the captured pass incl. its RCCL all-reduces, or eager steps)
             self.last_path = 'dp-large-batch-graph' if getattr(self, '_graphed_pass', False) else 'dp-large-batch'
+        if self.general:
+            self.last_path = 'general-' + self.last_path  # (layer-wise GEMM path, csrc/general_mlp.hip)
         if self._use_wide:
             self.check_split_sync()
         if self.last_path == 'persistent-chunked':

@@ -434,12 +434,14 @@ def test_host_env_bridge_single_env_wrappers_cpu():
 
 
 def test_model_cfgs_activation_and_width_checks():
-    """models.py: activation names of the reference (utils/model.py:47-70) map to the ABI's codes; anything else,
-    unequal actor / critic activations and widths other than 64 raise NotImplementedError BEFORE the library is
-    touched (as the reference raises for unknown names)."""
+    """models.py: activation names of the reference (utils/model.py:47-70) map to the ABI's codes; unknown activations,
+    an unknown actor type and more hidden layers than the descriptor holds raise NotImplementedError BEFORE the
+    library is touched (as the reference raises for unknown names).  Round 4: every hidden_sizes list the reference's
+    builder accepts is taken -- the shapes outside the fused [H, H] family go to the layer-wise path
+    (csrc/general_mlp.hip) and fail here, in the GPU-less container, only at the library's GPU requirement."""
     import types
 
-    from omnisafe_amd import models
+    from omnisafe_amd import _lib, models
 
     assert models.ACTIVATIONS == {'tanh': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3, 'identity': 4}
     src = open(models.__file__).read()
@@ -447,13 +449,24 @@ def test_model_cfgs_activation_and_width_checks():
     ns = types.SimpleNamespace
     from omnisafe_amd.spaces import Box
 
-    for a_act, c_act, hid in (('gelu', 'gelu', [64, 64]), ('relu', 'tanh', [64, 64]), ('tanh', 'tanh', [96, 96]),
-                              ('tanh', 'tanh', [64, 32]), ('tanh', 'tanh', [64, 64, 64])):
-        cfg = ns(actor=ns(hidden_sizes=hid, activation=a_act, lr=3e-4), critic=ns(hidden_sizes=hid, activation=c_act,
-                 lr=3e-4), weight_initialization_mode='kaiming_uniform', actor_type='gaussian_learning',
-                 linear_lr_decay=True)
+    def build(a_act, c_act, a_hid, c_hid, actor_type='gaussian_learning'):
+        cfg = ns(actor=ns(hidden_sizes=a_hid, activation=a_act, lr=3e-4),
+                 critic=ns(hidden_sizes=c_hid, activation=c_act, lr=3e-4),
+                 weight_initialization_mode='kaiming_uniform', actor_type=actor_type, linear_lr_decay=True)
+        return models.ConstraintActorCritic(Box(-1, 1, (4,)), Box(-1, 1, (2,)), cfg, 2, device='cuda:0')
+
+    for args in (('gelu', 'gelu', [64, 64], [64, 64]), ('tanh', 'swish', [64, 64], [64, 64]),
+                 ('tanh', 'tanh', [64] * 8, [64] * 8), ('tanh', 'tanh', [64, 0], [64, 64]),
+                 ('tanh', 'tanh', [64, 64], [64, 64], 'mlp')):
         with pytest.raises(NotImplementedError):
-            models.ConstraintActorCritic(Box(-1, 1, (4,)), Box(-1, 1, (2,)), cfg, 2, device='cuda:0')
+            build(*args)
+    if not torch.cuda.is_available():  # accepted shapes get as far as the library's GPU requirement
+        for args in (('relu', 'tanh', [64, 64], [64, 64]), ('tanh', 'tanh', [96, 96], [96, 96]),
+                     ('tanh', 'tanh', [64, 32], [64, 32]), ('tanh', 'tanh', [64, 64, 64], [64]),
+                     ('tanh', 'tanh', [1024, 1024], [1024, 1024]), ('tanh', 'tanh', [64, 64], [64, 64])):
+            with pytest.raises((_lib.OsaError, RuntimeError)) as ei:
+                build(*args)
+            assert not isinstance(ei.value, NotImplementedError)
 
 
 def test_shuffle_twin_is_a_bijection_for_every_size():
