@@ -50,6 +50,14 @@ PEAK_HBM_GBPS = 8000.0                                         # MI355X_MICROARC
 # dW1: 64; the 1-2-output layer runs on the VALU), 32 issue cycles each, at the 2.4 GHz engine clock; the three
 # networks run concurrently on three CUs.  The B = 64 chain cannot go below this however the rest is scheduled.
 MFMA_PER_STEP, MFMA_CYCLES, ENGINE_GHZ = 320, 32, 2.4
+W_PI_RUN, W_V_RUN = W_PI, W_V  # (set from --hidden-sizes in main)
+
+
+def weights_of(hidden):
+    """(W_pi, W_V): weight counts without biases of the actor / one critic for the given hidden sizes."""
+    sizes = [OBS_DIM] + list(hidden)
+    body = sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+    return body + sizes[-1] * ACT_DIM, body + sizes[-1]
 
 
 def parse():
@@ -65,6 +73,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variant', action='store_true')
     ap.add_argument('--algo', default='PPOLag')
+    # hidden layers of actor and critics (YAML default 64 64; e.g. 1024 1024 = the large-network row of the
+    # reference's published timing table, docs/source/start/efficiency.rst:15-23: the layer-wise GEMM path)
+    ap.add_argument('--hidden-sizes', type=int, nargs='*', default=[64, 64])
+    ap.add_argument('--variant-batch', type=int, default=16384)
     # passes of the reference's update actually executed by the cpu_baseline leg (of --update-iters): 4 passes
     # + the rollout are ~13 s on the GPU box's host (2.7 s rollout + 2.55 s per pass at 16 threads)
     ap.add_argument('--ref-sample-iters', type=int, default=4)
@@ -87,6 +99,9 @@ def make_algo(args, world, batch_size, update_iters, epochs, log_dir):
         # onpolicy_adapter.py:80; with longer episodes EpCost is empty and ppo_lag.py:74 asserts)
         'env_cfgs': {'horizon': args.steps_per_env, 'cost_p': 0.05},
     }
+    if list(args.hidden_sizes) != [64, 64]:
+        cfg['model_cfgs'] = {'actor': {'hidden_sizes': list(args.hidden_sizes)},
+                             'critic': {'hidden_sizes': list(args.hidden_sizes)}}
     return omnisafe_amd.Agent(args.algo, 'SynthPointGoal1-v0', custom_cfgs=cfg).agent
 
 
@@ -125,30 +140,32 @@ def timed(algo, steps, warmup, world, dev):
     return dt
 
 
-def pmc_traffic(kernel_name, variant=False):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r3_pmc_traffic*.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction --
-    tools/r3_gpu_batch8.sh + tools/pmc_summary.py); PMC counters cannot be read from inside the process, so this is
-    the offline measurement of the same command.  None if no matching entry.  The large-batch step (`variant`) is two
-    launches -- partial gradients on the pass kernel's machinery, then slab reduce + clip + Adam -- and reports their
-    sum."""
-    prof = os.path.join(ROOT, 'profiles')
-    if variant:
-        path = os.path.join(prof, 'r3_pmc_traffic_variant.json')
-        if not os.path.exists(path):
+def pmc_traffic(kernel_prefixes, tag):
+    """HBM-side bytes per launch of the dominant kernel(s) from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r4_pmc_traffic_<tag>.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction --
+    tools/gpu_round_check.sh + tools/pmc_summary.py); PMC counters cannot be read from inside the process, so this is
+    the offline measurement of the same command.  The file records the digest of the kernel sources it was measured on
+    (`_abi_digest` = osa_abi_digest()); a file measured on OTHER kernels is stale and yields None (round-3 verdict:
+    the traffic of a previous build must not ride along with a new kernel's time).  Several prefixes = a step made of
+    several launches: their sum."""
+    path = os.path.join(ROOT, 'profiles', f'r4_pmc_traffic_{tag}.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    try:
+        from omnisafe_amd import build as _b
+
+        if d.get('_abi_digest') != _b.source_digest():
             return None
-        d = json.load(open(path))
-        parts = [v['traffic_bytes_per_launch'] for k, v in d.items()
-                 if k.startswith('osa_ppo_pass_kernel') or k.startswith('osa_slab_reduce_finalize_kernel')]
-        return sum(parts) if len(parts) == 2 else None
-    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):  # newest PMC passes first
-        path = os.path.join(prof, name)
-        if not os.path.exists(path):
-            continue
-        for k, v in json.load(open(path)).items():
-            if k.startswith(kernel_name):
-                return v['traffic_bytes_per_launch']
-    return None
+    except Exception:  # noqa: BLE001
+        return None
+    total = 0
+    for pre in kernel_prefixes:
+        hit = [v['traffic_bytes_per_launch'] for k, v in d.items() if k.startswith(pre)]
+        if len(hit) != 1:
+            return None
+        total += hit[0]
+    return total
 
 
 def roofline_from_events(events, batch_size):
@@ -159,15 +176,22 @@ def roofline_from_events(events, batch_size):
     name = events[0][0]
     rows = sum(e[1] for e in events)
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    flops_per_sample = 6 * (W_PI_RUN + 2 * W_V_RUN)
     if name in ('osa_ppo_dp_step', 'osa_ppo_dp_pass'):
         rows //= world  # algorithmic work of a rank = its own M rows (it executes world x that, redundantly)
     ms = sum(e[2][0].elapsed_time(e[2][1]) for e in events)
-    flops = FLOPS_PER_SAMPLE_STEP * rows
+    flops = flops_per_sample * rows
     achieved = flops / (ms * 1e-3) / 1e12
     us = ms * 1e3 / len(events)
+    if name == 'osa_mb_grad_kernel':
+        traffic = pmc_traffic(['osa_ppo_part_kernel', 'osa_slab_reduce_finalize_kernel'], 'variant')
+    elif name == 'osa_ppo_pass_kernel' and batch_size <= 64:
+        traffic = pmc_traffic(['osa_ppo_pass_kernel'], 'bench')
+    else:
+        traffic = None
     out = {'bound': 'mfma', 'achieved': round(achieved, 4), 'peak': PEAK_F32_MFMA_TFLOPS,
            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
-           'traffic': pmc_traffic(name, variant=name == 'osa_mb_grad_kernel'),
+           'traffic': traffic,
            'kernel': name, 'launches_timed': len(events), 'us_per_launch': round(us, 2),
            'flops_per_launch': flops // len(events), 'rows_per_launch': rows // len(events)}
     if name == 'osa_ppo_dp_step':
@@ -192,12 +216,19 @@ def roofline_from_events(events, batch_size):
         out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
                        'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
                        'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
+    elif name == 'gm_gemm_kernel':
+        steps = max(1, rows // len(events) // batch_size)
+        out['us_per_optimiser_step'] = round(us / steps, 3)
+        out['kernel'] = 'gm_gemm_kernel (csrc/general_mlp.hip: forward / backward-data / backward-weight GEMMs) + loss / reduce / Adam'
+        out['note'] = ('general networks, layer-wise: ~13 launches per optimiser step on one float32-MFMA GEMM kernel '
+                       '(v_mfma_f32_32x32x2_f32), three networks per launch; the timed unit is a whole step (or captured pass)')
     else:
         steps = max(1, rows // len(events) // batch_size)  # (a captured pass of several steps is one timed event)
         out['us_per_optimiser_step'] = round(us / steps, 3)
-        out['kernel'] = 'osa_ppo_pass_kernel (partial-gradient mode) + osa_slab_reduce_kernel + osa_finalize_kernel'
-        out['note'] = ('large-batch step: <= CUs/3 workgroups per network keep the weights in LDS and their partial '
-                       'gradient in registers over several 64-row chunks, one slab each; slab reduce + clip/Adam launches')
+        out['kernel'] = 'osa_ppo_part_kernel (balanced partial gradients) + osa_slab_reduce_finalize_kernel'
+        out['note'] = ('large-batch step: the 64-row chunk-tasks of the three networks shared evenly by one workgroup '
+                       'per compute unit (weights in LDS, partial gradient in registers, one slab per segment); slab '
+                       'reduce + clip + Adam in a second launch')
     return out
 
 
@@ -207,7 +238,7 @@ def whole_path(args, value, world, update_iters, kl_passes):
     6 (W_pi + 2 W_V) FLOP) per env-step, + one full-batch KL pass (4 D_o B, 2 W_pi FLOP) per pass that runs one) and
     what the measured env-steps/s turn them into, against the vendor peaks.  Per GPU."""
     bytes_step = (4 * OBS_DIM + 4 * ACT_DIM + 72) + update_iters * 4 * (OBS_DIM + ACT_DIM + 5) + kl_passes * 4 * OBS_DIM
-    flops_step = update_iters * FLOPS_PER_SAMPLE_STEP + kl_passes * 2 * W_PI
+    flops_step = update_iters * 6 * (W_PI_RUN + 2 * W_V_RUN) + kl_passes * 2 * W_PI_RUN
     per_gpu = value / world
     gbps, tflops = bytes_step * per_gpu / 1e9, flops_step * per_gpu / 1e12
     return {'bytes_per_env_step': bytes_step, 'flops_per_env_step': flops_step,
@@ -321,13 +352,21 @@ def main():
     torch.cuda.set_device(dev)
     import tempfile
 
+    global W_PI_RUN, W_V_RUN
+    W_PI_RUN, W_V_RUN = weights_of(args.hidden_sizes)
+    general = list(args.hidden_sizes) != [64, 64]
+    hid = 'x'.join(str(h) for h in args.hidden_sizes)
     log_dir = tempfile.mkdtemp(prefix='osa_bench_')
     algo = make_algo(args, world, args.batch_size, args.update_iters, args.steps + args.warmup + 1, log_dir)
-    events = []
+    events, fvp_events = [], []
     run_epochs(algo, args.warmup, lambda: torch.cuda.synchronize(dev))
     algo._updater.profile_events = events
+    if hasattr(algo, '_solver'):  # trust-region family (--algo CPO / TRPOLag): HIP events around every Fisher-vector product
+        algo._solver.profile_events = fvp_events
     dt = timed(algo, args.steps, 0, world, dev)
     algo._updater.profile_events = None
+    if hasattr(algo, '_solver'):
+        algo._solver.profile_events = None
     per_gpu_steps = args.envs * args.steps_per_env
     value = world * per_gpu_steps * args.steps / dt
     out = {
@@ -335,36 +374,75 @@ def main():
         'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': (f'PPOLag, SafetyPointGoal1 shapes (obs 60, act 2, 64x64 tanh), '
+        'config': {'workload': (f'{args.algo}, SafetyPointGoal1 shapes (obs 60, act 2, {hid} tanh), '
                                 f'{args.envs} vectorized envs/GPU, steps_per_epoch={per_gpu_steps}/GPU '
                                 f'(T={args.steps_per_env}), batch_size={args.batch_size}, '
                                 f'update_iters={args.update_iters}, kl_early_stop='
                                 f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
                    'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}',
-                   'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None)},
+                   'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None),
+                   'update_path': algo._updater.last_path},
     }
-    out['roofline'] = roofline_from_events(events, args.batch_size)
+    if args.algo != 'PPOLag':
+        out['metric'] = f'env-steps/sec (rollout+update), {args.algo} SafetyPointGoal1 shapes'
+    # (the trust-region family updates critics only in the minibatch loop: its events carry 2 of the 3 networks)
+    out['roofline'] = roofline_from_events(events, int(algo._updater.batch_size))
+    if hasattr(algo, '_solver') and not algo._updater.update_actor:
+        r = out['roofline']
+        scale = (4 * W_V_RUN) / (2 * (W_PI_RUN + 2 * W_V_RUN))  # critics only: 6 x 2 W_V of the 6 (W_pi + 2 W_V)
+        r['achieved'] = round(r['achieved'] * scale, 4)
+        r['frac'] = round(r['frac'] * scale, 5)
+        r['flops_per_launch'] = int(r['flops_per_launch'] * scale)
+        r['note'] = 'critic passes of the trust-region family (actor excluded from the FLOP count); ' + r.get('note', '')
+    if fvp_events:
+        # Fisher-vector product (natural_pg.py:91-119 as JVP -> VJP): forward 2 W, tangent forward 2 x 2 W
+        # (two products per layer), backward 4 W = 8 W_pi FLOP... per row the count the round-3 verdict prescribes
+        ms = sum(e[2][0].elapsed_time(e[2][1]) for e in fvp_events)
+        rows = sum(e[1] for e in fvp_events)
+        fl = 8 * W_PI_RUN * rows
+        ach = fl / (ms * 1e-3) / 1e12
+        out['roofline_fvp'] = {
+            'bound': 'mfma', 'achieved': round(ach, 4), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None, 'kernel': fvp_events[0][0],
+            'launches_timed': len(fvp_events), 'us_per_launch': round(ms * 1e3 / len(fvp_events), 2),
+            'rows_per_launch': rows // len(fvp_events), 'flops_per_launch': fl // len(fvp_events),
+            'fvp_per_epoch': len(fvp_events) // max(args.steps, 1),
+            'note': 'one launch = one Fisher-vector product over the whole rollout (8 W_pi FLOP per row); per epoch: '
+                    'cg_iters + 2 products (TRPO-Lag) or 2 x cg_iters + 3 (CPO: a second CG for the cost gradient), '
+                    'then the line-search evaluations (forward only)'}
     # (without early stop only the last pass's KL is evaluated; with it, one per pass: update.py)
     out['whole_path'] = whole_path(args, value, world, args.update_iters,
                                    args.update_iters if args.kl_early_stop else 1)
-    if world == 1 and not args.no_variant and rank == 0:
+    if not args.no_variant and args.algo == 'PPOLag':
+        # the large-batch setting on EVERY rank (round 4): under world_size > 1 the update is the data-parallel
+        # large-batch pass -- partial gradients, local clip, ONE flat RCCL all-reduce, Adam per step, the whole pass
+        # incl. its collectives one captured hipGraph (`dp-large-batch-graph`)
         del algo
         torch.cuda.empty_cache()
-        v_algo = make_algo(args, world, 16384, 8, 14, log_dir)
-        v_steps = 10
+        vb = args.variant_batch
+        v_algo = make_algo(args, world, vb, 8, 14, log_dir)
+        v_steps = 10 if not general else 3
         v_events = []
         run_epochs(v_algo, 3, lambda: torch.cuda.synchronize(dev))  # eager epoch, capture epoch, one replay
         v_algo._updater.profile_events = v_events
         v_dt = timed(v_algo, v_steps, 0, world, dev)
         v_algo._updater.profile_events = None
+        v_val = world * per_gpu_steps * v_steps / v_dt
         out['throughput_variant'] = {
-            'workload': 'same shapes, batch_size=16384, update_iters=8 (large-batch setting of PPOLag.yaml '
+            'workload': f'same shapes, batch_size={vb}, update_iters=8 (large-batch setting of PPOLag.yaml '
                         'GPU-env blocks)',
-            'value': round(per_gpu_steps * v_steps / v_dt, 1), 'unit': 'env-steps/s',
+            'value': round(v_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
             'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
             'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
-            'roofline': roofline_from_events(v_events, 16384),
-            'whole_path': whole_path(args, per_gpu_steps * v_steps / v_dt, 1, 8, 1)}
+            'update_path': v_algo._updater.last_path,
+            'roofline': roofline_from_events(v_events, vb),
+            'whole_path': whole_path(args, v_val, world, 8, 1)}
+        if world > 1:
+            # per-step exchange time = what a step costs beyond the single-GPU step measured on the same kernels
+            # (profiles/r4_dp_large_batch_world1_rccl.json: +8.9 us at world 1, no wire time)
+            out['throughput_variant']['note'] = (
+                'data-parallel large-batch pass: us_per_optimiser_step includes the flat RCCL all-reduce of '
+                f'{3 * 8448 * 4} bytes and osa_adam_apply of every step; compare with the N = 1 line')
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         port = cpu_baseline(args)
         ref = cpu_baseline_reference(args)

@@ -91,26 +91,26 @@ struct GWs {
   size_t t[GM_MAXL];              // tangent layer outputs of the actor (Fisher-vector product)
   size_t z[3][2];                 // ping-pong dL/d(pre-activation) [R][maxldh]
   size_t dls, lpart;              // per-block partial sums: log_std gradient [nblk][lda], loss statistics [3][nblk][4]
-  size_t slabs;                   // [3][S][P] partial weight gradients
+  size_t slab[3][GM_MAXL];        // partial gradients of layer l: [S_l][W block + bias block]
+  int S[3][GM_MAXL];              // splits of the row (= reduction) dimension of layer l's weight-gradient GEMM
   size_t npart, fin;              // norm partials [3][nb][2]; finals [3][8]
   size_t dws;                     // double scratch of the KL / evaluation reductions (4 x 1024 doubles)
   size_t total;
-  int S, nblk, nb;
+  int nblk, nb;
 };
 
-int gm_splits(const GLayout& lo, long R) {
-  // split the row (= reduction) dimension of the weight-gradient GEMMs so that the launch fills the chip:
-  // tiles of the LARGEST layer x networks x splits ~ 512 workgroups, at least 256 rows per split, at most 16
-  long tiles = 1;
-  for (int net = 0; net < 3; ++net)
-    for (int l = 0; l < lo.n[net].L; ++l) {
-      const long t = (long)((lo.n[net].out[l] + 127) / 128) * ((lo.n[net].in[l] + 1 + 127) / 128);
-      if (t > tiles) tiles = t;
-    }
-  long s = 512 / (tiles * 3);
-  const long smax = R / 256;
+// Splits of the row (= reduction) dimension of ONE layer's weight-gradient GEMM: the launch (three networks) should
+// fill the chip -- output tiles x networks x splits >= ~512 workgroups -- with at least 128 rows per split and at most
+// 32 splits.  Per layer: the skinny first / last layers (1024 x 61, 2 x 1025) have a handful of output tiles and
+// need many splits, the square ones few (a global split count chosen for the largest layer left them on 48
+// workgroups: 1.35 of the 5.3 ms of a 1024 x 1024 step at 16 384 rows).
+int gm_splits(const GNet& n, int l, long R) {
+  const int tm = n.out[l] > 64 ? 128 : 64, tn = n.in[l] + 1 > 64 ? 128 : 64;
+  const long tiles = (long)((n.out[l] + tm - 1) / tm) * ((n.in[l] + 1 + tn - 1) / tn);
+  long s = (512 + tiles * 3 - 1) / (tiles * 3);
+  const long smax = R / 128;
   if (s > smax) s = smax;
-  if (s > 16) s = 16;
+  if (s > 32) s = 32;
   if (s < 1) s = 1;
   return (int)s;
 }
@@ -134,8 +134,15 @@ GWs gm_ws(const GLayout& lo, long R) {
   w.nblk = (int)((R + 255) / 256);
   w.dls = take((size_t)w.nblk * lo.lda);
   w.lpart = take((size_t)3 * w.nblk * 4);
-  w.S = gm_splits(lo, R);
-  w.slabs = take((size_t)3 * w.S * lo.P);
+  for (int net = 0; net < 3; ++net)
+    for (int l = 0; l < GM_MAXL; ++l) {
+      w.S[net][l] = 0;
+      w.slab[net][l] = 0;
+      if (l >= lo.n[net].L) continue;
+      const GNet& n = lo.n[net];
+      w.S[net][l] = gm_splits(n, l, R);
+      w.slab[net][l] = take((size_t)w.S[net][l] * (n.out[l] * n.ld[l] + r4(n.out[l])));
+    }
   w.nb = (lo.P + 1023) / 1024;
   w.npart = take((size_t)3 * w.nb * 2);
   w.fin = take(3 * 8);
@@ -177,6 +184,7 @@ struct GProb {
   int ones_n;          // >= 0: B(k, ones_n) = 1 for every k (only with BT)
   int cb_pad;          // cb[M .. cb_pad) = 0 (padding of the bias block)
   long slab_stride;    // split s writes C + s * slab_stride and cb + s * slab_stride
+  int splits;          // this problem's splits of K (<= GArgs.splits, the launch's grid.z per problem)
 };
 struct GArgs {
   GProb p[3];
@@ -193,21 +201,36 @@ __device__ __forceinline__ f32x4 gm_load4(const float* __restrict__ row, int c0,
   return v;
 }
 
+// Unit u of a TRANSPOSED operand tile (the operand is contiguous along the tile's row index, not along k): a wave's 64
+// lanes cover 16 consecutive k x 4 consecutive 16-byte pieces -- 64-byte row segments on the global side, and the
+// transposed LDS stores of 32 lanes hit 32 distinct banks (16 consecutive k per piece, pieces 4 LD = 16 banks apart).
+template <int BK>
+__device__ __forceinline__ void gm_tunit(int u, int& kq, int& c) {
+  const int hi = u >> 6;
+  kq = (u & 15) + 16 * (hi % (BK / 16));
+  c = ((u >> 4) & 3) + 4 * (hi / (BK / 16));
+}
+
 // C[m][n] = epi(sum_k A(m, k) B(k, n)).   AT: A(m, k) = A[k lda + m] (else A[m lda + k]);
 //                                          BT: B(k, n) = B[k ldb + n] (else B[n ldb + k]).
-template <int TM, int TN, bool AT, bool BT>
+// BK: K step per LDS stage.  16 when the launch has enough workgroups to hide memory latency behind each other; 64
+// when it has few (the skinny GEMMs of a 64-row minibatch stream megabytes of weights through a few dozen workgroups:
+// a step of 16 with one tile of lookahead paid a full L2 round trip per 0.2 us of MFMA work -- 40-70 us per layer at
+// hidden 1024; four times the bytes in flight per barrier).
+template <int TM, int TN, int BK, bool AT, bool BT>
 __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
-  constexpr int BK = 16, LD = BK + 4, MI = TM / 64, NJ = TN / 64, UA = TM / 64, UB = TN / 64;
-  __shared__ __attribute__((aligned(16))) float sA[2][TM * LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][TN * LD];
+  constexpr int LD = BK + 4, MI = TM / 64, NJ = TN / 64, UA = TM * BK / 1024, UB = TN * BK / 1024;
+  extern __shared__ __attribute__((aligned(16))) float gm_smem[];
+  float(*sA)[TM * LD] = reinterpret_cast<float(*)[TM * LD]>(gm_smem);
+  float(*sB)[TN * LD] = reinterpret_cast<float(*)[TN * LD]>(gm_smem + 2 * TM * LD);
   const int pi = blockIdx.z / g.splits, sp = blockIdx.z - pi * g.splits;
   // (selected with scalar moves: a run-time index into the by-value argument would go through scratch memory)
   const GProb p = pi == 0 ? g.p[0] : (pi == 1 ? g.p[1] : g.p[2]);
   const int M = p.M, N = p.N, K = p.K;
   const int ncols = N + (p.ones_n >= 0 ? 1 : 0);
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  if (m0 >= M || n0 >= (ncols > p.ldc ? ncols : p.ldc)) return;
-  int kper = (K + g.splits - 1) / g.splits;
+  if (m0 >= M || n0 >= (ncols > p.ldc ? ncols : p.ldc) || sp >= p.splits) return;
+  int kper = (K + p.splits - 1) / p.splits;
   kper = (kper + BK - 1) / BK * BK;
   const int kbeg = sp * kper;
   const int kend = K < kbeg + kper ? K : kbeg + kper;
@@ -223,12 +246,12 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     for (int q = 0; q < UA; ++q) {
       const int u = tid + 256 * q;
       if constexpr (!AT) {
-        const int r = u >> 2, c = u & 3, m = m0 + r;
+        const int r = u / (BK / 4), c = u % (BK / 4), m = m0 + r;
         ra[q] = gm_load4(A + (long)m * p.lda, k0 + 4 * c, kend, m < M);
       } else {
-        // (k fastest across lanes: the transposed LDS stores below then hit 16 consecutive banks per 16 lanes;
-        // the global side reads 64-byte row segments)
-        const int c = u / BK, kq = u - c * BK, k = k0 + kq;
+        int kq, c;
+        gm_tunit<BK>(u, kq, c);
+        const int k = k0 + kq;
         ra[q] = gm_load4(A + (long)k * p.lda, m0 + 4 * c, M, k < kend);
       }
     }
@@ -236,10 +259,12 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     for (int q = 0; q < UB; ++q) {
       const int u = tid + 256 * q;
       if constexpr (!BT) {
-        const int r = u >> 2, c = u & 3, n = n0 + r;
+        const int r = u / (BK / 4), c = u % (BK / 4), n = n0 + r;
         rb[q] = gm_load4(B + (long)n * p.ldb, k0 + 4 * c, kend, n < N);
       } else {
-        const int c = u / BK, kq = u - c * BK, k = k0 + kq, nn = n0 + 4 * c;
+        int kq, c;
+        gm_tunit<BK>(u, kq, c);
+        const int k = k0 + kq, nn = n0 + 4 * c;
         f32x4 v = gm_load4(B + (long)k * p.ldb, nn, N, k < kend);
         if (p.ones_n >= 0 && k < kend) {  // the column of ones that turns the bias gradient into one more output column
 #pragma unroll
@@ -255,9 +280,10 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     for (int q = 0; q < UA; ++q) {
       const int u = tid + 256 * q;
       if constexpr (!AT) {
-        *reinterpret_cast<f32x4*>(&sA[st][(u >> 2) * LD + 4 * (u & 3)]) = ra[q];
+        *reinterpret_cast<f32x4*>(&sA[st][(u / (BK / 4)) * LD + 4 * (u % (BK / 4))]) = ra[q];
       } else {
-        const int c = u / BK, kq = u - c * BK;
+        int kq, c;
+        gm_tunit<BK>(u, kq, c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) sA[st][(4 * c + i) * LD + kq] = ra[q][i];
       }
@@ -266,9 +292,10 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     for (int q = 0; q < UB; ++q) {
       const int u = tid + 256 * q;
       if constexpr (!BT) {
-        *reinterpret_cast<f32x4*>(&sB[st][(u >> 2) * LD + 4 * (u & 3)]) = rb[q];
+        *reinterpret_cast<f32x4*>(&sB[st][(u / (BK / 4)) * LD + 4 * (u % (BK / 4))]) = rb[q];
       } else {
-        const int c = u / BK, kq = u - c * BK;
+        int kq, c;
+        gm_tunit<BK>(u, kq, c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) sB[st][(4 * c + i) * LD + kq] = rb[q][i];
       }
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     const int st = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);  // the next tile's global loads are in flight under this tile's MFMAs
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BK / 8; ++s) {
       // K permutation inside a block of 8: lane group kk consumes k = 8 s + 4 kk + j in MFMA step j, for A and B
       // alike -- each fragment is ONE 16-byte LDS read per lane and feeds four MFMAs
       f32x4 af[MI], bf[NJ];
@@ -342,14 +369,25 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
     }
 }
 
-template <int TM, int TN, bool AT, bool BT>
+template <int TM, int TN, int BK, bool AT, bool BT>
 int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (TM + TN) * (BK + 4) * sizeof(float);
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gm_gemm_kernel<TM, TN, BK, AT, BT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return OSA_EHIP;
+      attr_set = true;
+    }
+  }
   dim3 grid((maxN + TN - 1) / TN, (maxM + TM - 1) / TM, g.nprob * g.splits);
-  hipLaunchKernelGGL((gm_gemm_kernel<TM, TN, AT, BT>), grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gm_gemm_kernel<TM, TN, BK, AT, BT>), grid, dim3(256), lds, st, g);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
-// one grouped launch; the tile follows the largest problem (64-wide tiles for skinny ones)
+// one grouped launch; the tile follows the largest problem (64-wide tiles for skinny ones), the K step the number of
+// workgroups the launch will have
 template <bool AT, bool BT>
 int gm_gemm(const GArgs& g, hipStream_t st) {
   int maxM = 0, maxN = 0;
@@ -359,15 +397,27 @@ int gm_gemm(const GArgs& g, hipStream_t st) {
     if (nc > maxN) maxN = nc;
   }
   if (g.nprob == 0 || maxM == 0) return OSA_OK;
-  const bool bigM = maxM > 64, bigN = maxN > 64;
-  if (bigM && bigN) return gm_launch<128, 128, AT, BT>(g, maxM, maxN, st);
-  if (bigM) return gm_launch<128, 64, AT, BT>(g, maxM, maxN, st);
-  if (bigN) return gm_launch<64, 128, AT, BT>(g, maxM, maxN, st);
-  return gm_launch<64, 64, AT, BT>(g, maxM, maxN, st);
+  bool bigM = maxM > 64, bigN = maxN > 64;
+  auto count = [&](int tm, int tn) {
+    return (long)((maxM + tm - 1) / tm) * ((maxN + tn - 1) / tn) * g.nprob * g.splits;
+  };
+  // a launch that would leave most of the chip idle takes the 64-wide tiles (twice / four times the workgroups)
+  if (bigN && count(bigM ? 128 : 64, 128) < 128) bigN = false;
+  if (bigM && count(128, bigN ? 128 : 64) < 128) bigM = false;
+  const long wgs = count(bigM ? 128 : 64, bigN ? 128 : 64);
+  const bool deep = wgs < 256;  // few workgroups: latency-bound -> K step 64
+#define GM_GO(TM_, TN_)                                                              \
+  return deep ? gm_launch<TM_, TN_, 64, AT, BT>(g, maxM, maxN, st) : gm_launch<TM_, TN_, 16, AT, BT>(g, maxM, maxN, st)
+  if (bigM && bigN) GM_GO(128, 128);
+  if (bigM) GM_GO(128, 64);
+  if (bigN) GM_GO(64, 128);
+  GM_GO(64, 64);
+#undef GM_GO
 }
 
 GProb gm_prob() {
   GProb p = {};
+  p.splits = 1;
   p.act = -1;
   p.dact = -1;
   p.ones_n = -1;
@@ -504,11 +554,15 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
 }
 
 struct GRedArgs {
-  int P, S, nblk, nb, act_dim, lda;
+  int P, nblk, nb, act_dim, lda;
   int Pn[3], oLS[3];
   const float* params;
   float* grads;
-  const float* slabs;   // [3][S][P]
+  const float* ws;      // workspace base: the slab regions
+  int L[3];
+  int oW[3][GM_MAXL];   // first parameter of layer l; its block (weights + bias) ends where the next one begins
+  int S[3][GM_MAXL];
+  long slab[3][GM_MAXL];
   const float* dls;     // [nblk][lda]
   const float* lpart;   // [3][nblk][4]
   float* npart;         // [3][nb][2]
@@ -533,8 +587,12 @@ __global__ __launch_bounds__(256) void gm_reduce_kernel(GRedArgs a) {
     if (e >= a.P) continue;
     float g = 0.f;
     if (e < a.oLS[net]) {
-      const float* s = a.slabs + (long)net * a.S * a.P + e;
-      for (int k = 0; k < a.S; ++k) g += s[(long)k * a.P];
+      int l = 0;  // the layer of this parameter (block-uniform except at a handful of boundaries)
+      for (int q2 = 1; q2 < a.L[net]; ++q2)
+        if (e >= a.oW[net][q2]) l = q2;
+      const int size = (l + 1 < a.L[net] ? a.oW[net][l + 1] : a.oLS[net]) - a.oW[net][l];
+      const float* s = a.ws + a.slab[net][l] + (e - a.oW[net][l]);
+      for (int k = 0; k < a.S[net][l]; ++k) g += s[(long)k * size];
       const float w = p[e];
       if (critic) {
         if (a.use_critic_norm) g += 2.f * a.critic_norm_coef * w;
@@ -941,22 +999,24 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
     if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
   for (int step = 0; step < maxL; ++step) {  // step counts layers from the top of EACH network
     GArgs gw = {}, gd = {};
-    gw.splits = w.S;
+    gw.splits = 1;
     gd.splits = 1;
     for (int net = 0; net < 3; ++net) {
       const GNet& n = lo.n[net];
       const int l = n.L - 1 - step;
       if (!((mask >> net) & 1) || l < 0) continue;
-      float* slab = ws + w.slabs + (long)net * w.S * lo.P;
+      float* slab = ws + w.slab[net][l];  // [S_l][out x ld | bias block]
       GProb p = gm_prob();  // dW_l[out][in] (+ db_l) = dZ_l^T [out][rows] . {H_{l-1}, 1}[rows][in + 1]
       p.A = ws + w.z[net][cur[net]]; p.lda = n.ldh[l];
       p.B = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
       p.ldb = l == 0 ? lo.ldx : n.ldh[l - 1];
-      p.C = slab + n.oW[l]; p.ldc = n.ld[l];
-      p.cb = slab + n.ob[l]; p.cb_pad = r4(n.out[l]);
+      p.C = slab; p.ldc = n.ld[l];
+      p.cb = slab + (long)n.out[l] * n.ld[l]; p.cb_pad = r4(n.out[l]);
       p.M = n.out[l]; p.N = n.in[l]; p.K = (int)B;
       p.ones_n = n.in[l];
-      p.slab_stride = lo.P;
+      p.slab_stride = (long)n.out[l] * n.ld[l] + r4(n.out[l]);
+      p.splits = w.S[net][l];
+      if (p.splits > gw.splits) gw.splits = p.splits;
       gw.p[gw.nprob++] = p;
       if (l > 0) {  // dZ_{l-1}[rows][in] = (dZ_l[rows][out] . W_l[out][in]) * act'(H_{l-1})
         GProb q = gm_prob();
@@ -975,9 +1035,16 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
   }
   // ---- slab sum, L2 / entropy terms, norms; clip factor and Adam scalars; clip (+ Adam)
   GRedArgs ra = {};
-  ra.P = lo.P; ra.S = w.S; ra.nblk = w.nblk; ra.nb = w.nb; ra.act_dim = lo.act_dim; ra.lda = lo.lda;
-  for (int net = 0; net < 3; ++net) { ra.Pn[net] = lo.n[net].Pn; ra.oLS[net] = lo.n[net].oLS; }
-  ra.params = params; ra.grads = grads; ra.slabs = ws + w.slabs; ra.dls = ws + w.dls; ra.lpart = ws + w.lpart;
+  ra.P = lo.P; ra.nblk = w.nblk; ra.nb = w.nb; ra.act_dim = lo.act_dim; ra.lda = lo.lda;
+  for (int net = 0; net < 3; ++net) {
+    ra.Pn[net] = lo.n[net].Pn; ra.oLS[net] = lo.n[net].oLS; ra.L[net] = lo.n[net].L;
+    for (int l = 0; l < GM_MAXL; ++l) {
+      ra.oW[net][l] = l < lo.n[net].L ? lo.n[net].oW[l] : 0;
+      ra.S[net][l] = w.S[net][l];
+      ra.slab[net][l] = (long)w.slab[net][l];
+    }
+  }
+  ra.params = params; ra.grads = grads; ra.ws = ws; ra.dls = ws + w.dls; ra.lpart = ws + w.lpart;
   ra.npart = ws + w.npart; ra.stats = step_stats; ra.entropy_coef = hp->entropy_coef;
   ra.critic_norm_coef = hp->critic_norm_coef; ra.use_critic_norm = hp->use_critic_norm; ra.nets_mask = mask;
   ra.loss_kind = loss_kind; ra.R = B;

@@ -40,6 +40,8 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         self._old_mean: torch.Tensor | None = None
         self._old_log_std = torch.zeros(ac.layout.OUTP, **f32)
         self._fvp_obs: torch.Tensor | None = None
+        # optional profiling: (start, end) HIP events around every Fisher-vector product's kernel (bench.py --algo CPO)
+        self.profile_events: list | None = None
         self.fvp_calls = 0
         self.cg_solves = 0  # the reference's CG evaluates F(0) once more per solve (math.py:116-118: r = b - Ax(x))
 
@@ -106,6 +108,10 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
         obs = self._fvp_obs
         M = obs.shape[0]
         raw = self._vecs['raw']
+        ev = None
+        if self.profile_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if getattr(ac, 'general', False):
             ws, nws = ac.gmlp_ws(M)
             _lib.check(lib.osa_gmlp_minibatch(
@@ -118,6 +124,9 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
                                              _lib.ptr(ac.grads), _lib.ptr(obs), obs.stride(0), M, _lib.ptr(v),
                                              self.max_blocks, _lib.ptr(self._ws), _lib.ptr(self._stats),
                                              _lib.stream_ptr()), 'osa_actor_fvp_raw')
+        if ev is not None:
+            ev[1].record()
+            self.profile_events.append(('osa_mb_grad_kernel<loss_kind 2: Fisher-vector product>', M, ev))
         raw.copy_(ac.grads[0])
         dist.all_reduce_avg_(raw)  # C2: one flat message
         out = out if out is not None else torch.empty_like(v)

@@ -318,7 +318,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.profile_events = pe
         if ev is not None:
             ev[1].record()
-            pe.append(('osa_mb_grad_kernel', M, ev))
+            pe.append(('gm_gemm_kernel' if self.general else 'osa_mb_grad_kernel', M, ev))
         stats_rows.copy_(st['stats'])
         self._graphed_pass = st['graph'] is not None
 

@@ -16,6 +16,7 @@ path of world_size > 1: Lagrange step on the cross-rank mean cost, then
   allreduce             gradient kernel -> ONE flat all-reduce -> Adam per optimiser step
   dp-large-batch        B = 2048: partial gradients -> local clip -> flat all-reduce -> Adam (graph-captured with RCCL;
                         eager over gloo)
+  general-*             the same exchanges around the layer-wise GEMM path for general network shapes
 
 each driven with the reference's inputs and compared with the reference's post-update parameters at the
 single-process tolerances of tests/test_config_shapes_gpu.py (first-order family atol 2e-6 after 64 chained Adam
@@ -45,6 +46,8 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     os.environ.update(OSA_DP_MODE=dp_mode, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OSA_DIST_BACKEND='gloo',
                       OSA_SINGLE_DEVICE_RANKS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if want_path.startswith('general-'):  # the layer-wise path for general networks, on the YAML-default shapes
+        os.environ['OSA_FORCE_GENERAL_MLP'] = '1'
     sys.path.insert(0, ROOT)
     import omnisafe_amd
     from omnisafe_amd import distributed as dist
@@ -133,6 +136,11 @@ CASES = [
     ('dp2_trpolag_ant', 'allreduce', 'per-step', None),
     ('dp2_ppolag_point_largebatch', 'replicated', 'dp-large-batch', None),
     ('dp2_ppolag_point_largebatch', 'allreduce', 'dp-large-batch', None),
+    # general networks (csrc/general_mlp.hip) under data parallelism: gradient GEMMs -> local clip -> flat all-reduce
+    # -> osa_gmlp_adam_apply per step; FVP / line-search averages of the trust-region family
+    ('dp2_ppolag_point', 'allreduce', 'general-per-step', None),
+    ('dp2_trpolag_ant', 'allreduce', 'general-per-step', None),
+    ('dp2_ppolag_point_largebatch', 'allreduce', 'general-dp-large-batch', None),
 ]
 
 

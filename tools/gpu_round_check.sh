@@ -1,35 +1,67 @@
-# End-of-round measurement set on one MI355X (run through gpurun): GPU tests, default bench, 2-rank code-path
-# check, rocprofv3 kernel stats of the default bench, the PMC passes (separate runs, --kernel-trace only:
-# FETCH_SIZE, WRITE_SIZE, one SQ pass), the same two traffic passes for the buffer kernels at M = 16 M.
+# End-of-round measurement set on one MI355X (run through gpurun; ROUND tag as first argument, default r4).
+#   stage 1  GPU suite, default bench, 2-rank code-path check (both ranks on the one GPU over gloo; incl. the
+#            large-batch variant under data parallelism)
+#   stage 2  rocprofv3 kernel stats of the bench command; FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace
+#            only) of the headline workload and of the large-batch variant -> profiles-ready JSON incl. the source
+#            digest (tools/pmc_summary.py); one SQ pass each
+#   stage 3  trust-region family: bench lines of CPO and TRPOLag (roofline_fvp), kernel stats, SQ pass
+#   stage 4  general networks: bench line at hidden 1024 x 1024, kernel stats, SQ pass, timing table
+#   stage 5  buffer kernels (GAE bandwidth), BASELINE configs on one GPU, pass timings
+# Everything lands under gpurun_out/<ROUND>_*; copy what is to be judged into profiles/.
 set -x
+T=${1:-r4}
+STAGES=${2:-12345}
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
 cd $R
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json
-OSA_DIST_BACKEND=gloo OSA_SINGLE_DEVICE_RANKS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 2 > gpurun_out/bench_2rank_1gpu.json 2> gpurun_out/bench_2rank.err; tail -c 400 gpurun_out/bench_2rank_1gpu.json
+mkdir -p $O
+SQ="SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
+if [[ $STAGES == *1* ]]; then
+timeout 1500 python -m pytest tests -q -m gpu --tb=short --show-capture=no 2>&1 | tail -60 > $O/${T}_final_pytest.log; tail -4 $O/${T}_final_pytest.log
+timeout 600 python bench.py > $O/${T}_bench_final.json 2> $O/${T}_bench_final.err; tail -c 600 $O/${T}_bench_final.json
+OSA_DIST_BACKEND=gloo OSA_SINGLE_DEVICE_RANKS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 2 > $O/${T}_bench_2ranks_on_1gpu.json 2> $O/${T}_bench_2rank.err; tail -c 400 $O/${T}_bench_2ranks_on_1gpu.json
+fi
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_final $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE $R/gpurun_out/pmc_sq $R/gpurun_out/pmc_gae_FETCH_SIZE $R/gpurun_out/pmc_gae_WRITE_SIZE
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python $R/bench.py --steps 2 --warmup 2 > $R/gpurun_out/prof_final.log 2>&1
+if [[ $STAGES == *2* ]]; then
+rm -rf $O/${T}_prof $O/${T}_pmc_*
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/${T}_prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 1 --warmup 2 --update-iters 4 --no-cpu-baseline --no-variant > $R/gpurun_out/pmc_$c.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_gae_$c -- python $R/tools/gae_bandwidth.py --pmc-run --shapes 16,1048576 4096,4096 > $R/gpurun_out/pmc_gae_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${T}_pmc_bench_$c -- python $R/bench.py --steps 1 --warmup 2 --update-iters 4 --no-cpu-baseline --no-variant > $O/${T}_pmc_bench_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${T}_pmc_variant_$c -- python $R/bench.py --steps 1 --warmup 3 --batch-size 16384 --update-iters 8 --no-cpu-baseline --no-variant > $O/${T}_pmc_variant_$c.log 2>&1
 done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 1 --warmup 2 --update-iters 2 --no-cpu-baseline --no-variant > $R/gpurun_out/pmc_sq.log 2>&1
-ls $R/gpurun_out/prof_final/* $R/gpurun_out/pmc_FETCH_SIZE/* $R/gpurun_out/pmc_gae_FETCH_SIZE/* | head
-# wide-observation passes (config 4) and the BASELINE configs end to end next to the unmodified reference
-cd $R
-timeout 300 python tools/wide_pass_timing.py 65536 > gpurun_out/wide_pass_timing.log 2>&1; tail -25 gpurun_out/wide_pass_timing.log
-timeout 1500 python tools/baseline_configs.py > gpurun_out/baseline_configs.log 2>&1; tail -8 gpurun_out/baseline_configs.log
-timeout 300 python tools/chunked_pass_timing.py > gpurun_out/chunked_pass_timing.log 2>&1; tail -16 gpurun_out/chunked_pass_timing.log
-timeout 300 python tools/dp_timing.py 2>&1 | grep "^W=" > gpurun_out/dp_timing.log; cat gpurun_out/dp_timing.log
-# per-kernel time of the BASELINE configs 3 and 4 (trust-region family with chunked critic passes; wide observations)
-cd /tmp
-for c in 3 4; do
-  rm -rf $R/gpurun_out/prof_cfg$c
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg$c -- python $R/tools/config_epoch_profile.py $c 4 > $R/gpurun_out/prof_cfg$c.log 2>&1
-  grep epoch $R/gpurun_out/prof_cfg$c.log | tail -2
+python $R/tools/pmc_summary.py $O/${T}_pmc_bench_FETCH_SIZE $O/${T}_pmc_bench_WRITE_SIZE $O/${T}_pmc_traffic_bench | head -12
+python $R/tools/pmc_summary.py $O/${T}_pmc_variant_FETCH_SIZE $O/${T}_pmc_variant_WRITE_SIZE $O/${T}_pmc_traffic_variant | head -12
+timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_bench -- python $R/bench.py --steps 1 --warmup 2 --update-iters 2 --no-cpu-baseline --no-variant > $O/${T}_pmc_sq_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_variant -- python $R/bench.py --steps 1 --warmup 3 --batch-size 16384 --update-iters 8 --no-cpu-baseline --no-variant > $O/${T}_pmc_sq_variant.log 2>&1
+python $R/tools/pmc_sq_summary.py $O/${T}_pmc_sq_bench $O/${T}_pmc_sq_mfma_busy_bench | head -20
+python $R/tools/pmc_sq_summary.py $O/${T}_pmc_sq_variant $O/${T}_pmc_sq_mfma_busy_variant | head -20
+rm -rf $O/${T}_pmc_bench_* $O/${T}_pmc_variant_* $O/${T}_pmc_sq_bench $O/${T}_pmc_sq_variant
+f=$(find $O/${T}_prof -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_bench.csv; rm -rf $O/${T}_prof
+fi
+if [[ $STAGES == *3* ]]; then
+for A in CPO TRPOLag; do
+  cd $R; timeout 600 python bench.py --algo $A --batch-size 128 --update-iters 10 --no-cpu-baseline > $O/${T}_bench_$A.json 2> $O/${T}_bench_$A.err; tail -c 700 $O/${T}_bench_$A.json
+  cd /tmp; rm -rf $O/${T}_prof_$A $O/${T}_pmc_sq_$A
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_$A -- python $R/bench.py --algo $A --batch-size 128 --update-iters 10 --steps 2 --warmup 2 --no-cpu-baseline > $O/${T}_prof_$A.log 2>&1
+  f=$(find $O/${T}_prof_$A -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_$A.csv; rm -rf $O/${T}_prof_$A
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_$A -- python $R/bench.py --algo $A --batch-size 128 --update-iters 10 --steps 1 --warmup 2 --no-cpu-baseline > $O/${T}_pmc_sq_$A.log 2>&1
+  python $R/tools/pmc_sq_summary.py $O/${T}_pmc_sq_$A $O/${T}_pmc_sq_mfma_busy_$A | head -16; rm -rf $O/${T}_pmc_sq_$A
 done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq_cfg4 -- python $R/tools/config_epoch_profile.py 4 2 > $R/gpurun_out/pmc_sq_cfg4.log 2>&1
+fi
+if [[ $STAGES == *4* ]]; then
+cd $R; timeout 900 python bench.py --hidden-sizes 1024 1024 --update-iters 1 --steps 2 --no-cpu-baseline > $O/${T}_bench_hidden1024.json 2> $O/${T}_bench_hidden1024.err; tail -c 900 $O/${T}_bench_hidden1024.json
+timeout 600 python tools/general_mlp_timing.py --out $O/${T}_general_mlp_timing.json 2>&1 | grep -v amdgpu
+cd /tmp; rm -rf $O/${T}_prof_gm $O/${T}_pmc_sq_gm
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_gm -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:16384 --reps 5 > /dev/null 2>&1
+f=$(find $O/${T}_prof_gm -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_general_1024_B16384.csv; rm -rf $O/${T}_prof_gm
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_gm -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:16384 --reps 2 > /dev/null 2>&1
+python $R/tools/pmc_sq_summary.py $O/${T}_pmc_sq_gm $O/${T}_pmc_sq_mfma_busy_general_1024 | head -16; rm -rf $O/${T}_pmc_sq_gm
+fi
+if [[ $STAGES == *5* ]]; then
 cd $R
-timeout 600 python tools/gae_bandwidth.py > gpurun_out/gae_bandwidth.log 2>&1; tail -2 gpurun_out/gae_bandwidth.log
+timeout 900 python tools/baseline_configs.py --no-reference > $O/${T}_baseline_configs.log 2>&1; tail -8 $O/${T}_baseline_configs.log
+timeout 900 python tools/gae_bandwidth.py --out $O/${T}_gae_bandwidth > $O/${T}_gae_bandwidth.log 2>&1; tail -2 $O/${T}_gae_bandwidth.log
+timeout 300 python tools/large_batch_step_timing.py --out $O/${T}_large_batch_step.json 2>&1 | grep -v amdgpu | tail -5
+timeout 300 python tools/part_kernel_timeline.py --out $O/${T}_part_timeline.json 2>&1 | grep -v amdgpu | tail -6 | cut -c1-300
+timeout 600 python tools/dp_shapes_timing.py --out $O/${T}_dp_shapes_timing.json 2>&1 | grep -v "^{" | grep -v amdgpu | tail -12
+fi

@@ -23,8 +23,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(path)):
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        if not name.startswith('osa_'):
+        name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+        if not name.startswith(('osa_', 'gm_')):
             continue
         agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
         if r['Counter_Name'] == 'SQ_WAVE_CYCLES':

@@ -1,5 +1,5 @@
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
-profiles/r2_pmc_traffic.{md,json} (default; pass another base name as third argument): HBM-side bytes per launch of every libomnisafe_amd kernel.
+<out_base>.{json,_table.md} (third argument): HBM-side bytes per launch of every libomnisafe_amd kernel.
 
     python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 
@@ -19,8 +19,8 @@ def load(d, counter):
         for r in csv.DictReader(open(path)):
             if r['Counter_Name'] != counter:
                 continue
-            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
-            if not name.startswith('osa_'):
+            name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+            if not name.startswith(('osa_', 'gm_')):
                 continue
             e = out.setdefault(name, [0, 0.0])
             e[0] += 1
@@ -37,7 +37,12 @@ def main(fetch_dir, write_dir, out_base):
         wk = (w.get(k, [1, 0.0])[1] / max(w.get(k, [1, 0.0])[0], 1))
         res[k] = {'launches': n, 'fetch_size_kib_raw': round(fk, 1), 'write_size_kib': round(wk, 1),
                   'traffic_bytes_per_launch': int((2 * fk + wk) * 1024)}
-    json.dump(res, open(out_base + '.json', 'w'), indent=1)
+    # the digest of the kernel sources this was measured on: bench.py ignores the file once the kernels change
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from omnisafe_amd import build as _b
+
+    out = dict(res, _abi_digest=_b.source_digest())
+    json.dump(out, open(out_base + '.json', 'w'), indent=1)
     lines = ['| kernel | launches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | traffic bytes / launch (2xFETCH + WRITE) |',
              '|---|---|---|---|---|']
     for k, v in res.items():
