@@ -40,8 +40,16 @@ class Lagrange:
         return -self._param * (mean_ep_cost - self.cost_limit)
 
     def update_lagrange_multiplier(self, Jc: float) -> None:
-        self._opt.zero_grad()
-        self.compute_lambda_loss(Jc).backward()
+        # d/d(lambda) of -lambda * (Jc - limit) is -(Jc - limit) rounded to float32 -- exactly what autograd's
+        # mul / neg backward produce for the python-scalar operand -- so the gradient is set directly: no autograd
+        # graph, no backward pass on the host between the rollout's one synchronisation and the update's first launch
+        # (half of the ~0.2 ms this step kept the device idle per epoch; same bits: tests/test_host_logic.py::
+        # test_lagrange_vs_reference_golden, test_oracle_vs_reference.py::test_lagrange_and_pid_live)
+        g = torch.tensor(-(Jc - self.cost_limit), dtype=torch.float32)
+        if self._param.grad is None:
+            self._param.grad = g
+        else:
+            self._param.grad.copy_(g)
         self._opt.step()
         self._param.data.clamp_(0.0, self.lagrangian_upper_bound)
         if self._device_copy is not None:
