@@ -285,6 +285,27 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             self._normalize(next_raw, out=nxt)
             self._after_env_step(t, reward, cost, term, trunc, nxt, self._final_norm if have_final else None,
                                  b['reward'][t])
+            # Host env (HostEnvBridge): the bootstrap values and the episode accounting of this step are not needed
+            # for the next action -- they are handed to the bridge, which enqueues them behind the next action's
+            # device-to-host copy: the device does them while the host steps the env (round 4; device envs: in line)
+            if getattr(self._env, 'host_resident', False) and not epoch_end and os.environ.get('OSA_HOST_DEFER', '1') != '0':
+                # (self._final_norm is rewritten by the NEXT step's normalisation, which is enqueued behind this work)
+                final_src = self._final_norm if have_final else None
+
+                def post_step(t=t, reward=reward, cost=cost, term=term, trunc=trunc, final_src=final_src,
+                              reward_row=reward_row, cost_row=cost_row):
+                    vfin = agent.values(final_src) if final_src is not None else (None, None)
+                    _lib.check(lib.osa_rollout_post_step(
+                        N, 0, _lib.ptr(reward), _lib.ptr(cost), _lib.ptr(term), _lib.ptr(trunc), None, None,
+                        _lib.ptr(vfin[0]), _lib.ptr(vfin[1]), _lib.ptr(self._ep_ret), _lib.ptr(self._ep_cost),
+                        _lib.ptr(self._ep_len), _lib.ptr(b['path_end'][t]), _lib.ptr(b['boot_r'][t]),
+                        _lib.ptr(b['boot_c'][t]), _lib.ptr(ep['done'][t]), _lib.ptr(ep['ret'][t]),
+                        _lib.ptr(ep['cost'][t]), _lib.ptr(ep['len'][t]), _lib.ptr(reward_row), _lib.ptr(cost_row),
+                        _lib.stream_ptr()), 'osa_rollout_post_step')
+
+                self._env.deferred_device_work = post_step
+                buffer.advance()
+                continue
             vfinal = agent.values(self._final_norm) if have_final else (None, None)
             vnext = agent.values(nxt) if epoch_end else (None, None)
             _lib.check(lib.osa_rollout_post_step(

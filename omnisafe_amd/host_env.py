@@ -150,6 +150,13 @@ class HostEnvBridge:  # pylint: disable=too-many-instance-attributes
         self.bytes_down = 0  # running totals (PCIe bytes per env-step); reset by the caller at will
         self.bytes_up = 0
         self.steps = 0
+        # device work of the PREVIOUS vector step that the next action does not depend on (bootstrap values, episode
+        # accounting: adapter.py): enqueued behind the action's device-to-host copy, so that it runs while the host
+        # steps the env instead of in front of the next policy step
+        self.deferred_device_work = None
+        self._copied = torch.cuda.Event() if pin else None
+        # optional wall-clock split of a step (tools/host_env_bridge_timing.py): seconds accumulated per phase
+        self.timing: dict | None = None
 
     # ------------------------------------------------------------------ reference surface
     def __getattr__(self, name):  # spaces, env_spec_log, max_episode_steps, render, need_evaluation, ...
@@ -176,6 +183,9 @@ class HostEnvBridge:  # pylint: disable=too-many-instance-attributes
         self.bytes_up += 4 * n_floats
 
     def reset(self, seed: int | None = None, options: dict | None = None):
+        if self.deferred_device_work is not None:
+            work, self.deferred_device_work = self.deferred_device_work, None
+            work()
         obs, info = self._env.reset(seed=seed, options=options)
         if self._device.type == 'cuda':
             torch.cuda.current_stream(self._device).synchronize()  # an earlier upload may still read the staging block
@@ -188,12 +198,27 @@ class HostEnvBridge:  # pylint: disable=too-many-instance-attributes
         N = self._num_envs
         # ---- down: one device-to-host copy; its completion is the one host synchronisation of the step (it also
         # orders this step's staging writes after the previous step's upload, which sits earlier in the stream)
+        import time
+
+        tm = self.timing
+        t0 = time.perf_counter() if tm is not None else 0.0
         self._act_h.copy_(action.detach().reshape(N, self._act_dim), non_blocking=True)
         if self._device.type == 'cuda':
-            torch.cuda.current_stream(self._device).synchronize()
+            # wait for the COPY only (an event behind it), not for the stream: what the previous step left to do on the
+            # device goes out first and overlaps the host env's step
+            self._copied.record(torch.cuda.current_stream(self._device))
+            work, self.deferred_device_work = self.deferred_device_work, None
+            if work is not None:
+                work()
+            self._copied.synchronize()
+        elif self.deferred_device_work is not None:
+            work, self.deferred_device_work = self.deferred_device_work, None
+            work()
+        t1 = time.perf_counter() if tm is not None else 0.0
         self.bytes_down += 4 * self._act_h.numel()
         act = self._act_h[0] if N == 1 else self._act_h  # Unsqueeze.step squeezes the action (wrapper.py:600)
         obs, reward, cost, terminated, truncated, info = self._env.step(act)
+        t2 = time.perf_counter() if tm is not None else 0.0
         v = self._v
         v['obs'][0].copy_(_host_f32(obs, (N, self._obs_dim)))
         v['reward'][0].copy_(_host_f32(reward, (N,)))
@@ -218,6 +243,11 @@ class HostEnvBridge:  # pylint: disable=too-many-instance-attributes
             v['fmask'][0].zero_()
             self._upload(self._head)
         self.steps += 1
+        if tm is not None:
+            t3 = time.perf_counter()
+            tm['wait_device_and_d2h'] = tm.get('wait_device_and_d2h', 0.0) + (t1 - t0)
+            tm['host_env_step'] = tm.get('host_env_step', 0.0) + (t2 - t1)
+            tm['staging_and_h2d_enqueue'] = tm.get('staging_and_h2d_enqueue', 0.0) + (t3 - t2)
         if have_final:
             out_info['final_observation'] = v['final'][1]
             out_info['_final_observation'] = v['fmask'][1]
