@@ -381,7 +381,9 @@ def main():
                                 f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
                    'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}',
                    'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None),
-                   'update_path': algo._updater.last_path},
+                   'update_path': algo._updater.last_path,
+                   'rollout_path': ('graph of launches' if getattr(algo._env, 'last_rollout_graphed', False)
+                                    else getattr(algo._env, 'last_rollout_path', 'launches'))},
     }
     if args.algo != 'PPOLag':
         out['metric'] = f'env-steps/sec (rollout+update), {args.algo} SafetyPointGoal1 shapes'
@@ -434,6 +436,7 @@ def main():
             'value': round(v_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
             'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
             'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
+            'rollout_path': getattr(v_algo._env, 'last_rollout_path', 'launches'),
             'update_path': v_algo._updater.last_path,
             'roofline': roofline_from_events(v_events, vb),
             'whole_path': whole_path(args, v_val, world, 8, 1)}

@@ -4,6 +4,7 @@
 // blockIdx.y selects the network (0 actor, 1 reward critic, 2 cost critic) so the three
 // independent networks of ConstraintActorCritic run concurrently in one launch.
 #include "mlp_device.h"
+#include "policy_rows.h"
 
 #define OSA_NSTAT 16
 
@@ -77,52 +78,14 @@ __global__ __launch_bounds__(256) void osa_policy_step_kernel(
   const int net = blockIdx.y;
   if (!((nets_mask >> net) & 1)) return;
   if (offset_base) offset += *offset_base;  // device-resident part of the Philox stream position
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15;
   const long row = (long)blockIdx.x * 64 + 16 * wave + j;
   const bool valid = row < N;
   const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
-  const float* p = params + (long)net * nd.P;
-  f32x4 h1[HT], h2[HT], out[OT];
-  osa_mlp_forward<HT, OT>(nd, p, valid ? obs + row * ld : nullptr, ld, vec_ok, h1, h2, out);
-  if (net == 0) {
-    float lp = 0.f;
-#pragma unroll
-    for (int o = 0; o < OT; ++o) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int d = 16 * o + 4 * g + r;
-        if (d < nd.act_dim && valid) {
-          const float mu = out[o][r];
-          const float sd = expf(p[nd.oLS + d]);
-          float a = mu;
-          if (!deterministic) {
-            float e;
-            if (eps != nullptr) {
-              e = eps[row * nd.act_dim + d];
-            } else {
-              uint32_t w[4];
-              osa_philox(seed, offset, (unsigned long long)row * nd.act_dim + d, w);
-              float e1;
-              osa_box_muller(w[0], w[1], e, e1);
-            }
-            a = mu + e * sd;  // Normal.rsample: loc + eps * scale
-          }
-          if (act) act[row * ld_act + d] = a;
-          // ActionScale.step of the wrapper chain in the same launch (osa_policy_step_scaled)
-          if (act_env) act_env[row * ld_env + d] = osa_action_scale1(a, old_min[d], old_max[d], min_a, max_a);
-          if (mean_out) mean_out[row * ld_mean + d] = mu;
-          // Normal.log_prob: -((v - loc)^2) / (2 var) - log(scale) - log(sqrt(2 pi))
-          const float z = a - mu;
-          lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
-        }
-      }
-    }
-    lp = osa_sum_over_groups(lp);
-    if (g == 0 && valid && logp) logp[row] = lp;
-  } else {
-    float* __restrict__ dst = (net == 1) ? value_r : value_c;
-    if (g == 0 && valid && dst) dst[row] = out[0][0];
-  }
+  // (the rows' arithmetic lives in policy_rows.h: the persistent rollout kernel runs the same function)
+  osa_policy_rows<HT, OT>(nd, params, net, valid ? obs + row * ld : nullptr, ld, vec_ok, row, valid, eps, seed, offset,
+                          deterministic, act, ld_act, value_r, value_c, logp, mean_out, ld_mean, act_env, ld_env,
+                          old_min, old_max, min_a, max_a);
 }
 
 // ------------------------------------------------------------------------------------------------
