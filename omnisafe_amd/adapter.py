@@ -184,6 +184,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             self._rollout_persistent(T, agent, buffer)
             self.last_rollout_path, self.last_rollout_graphed = 'persistent', False
             buffer.prefetch()
+            if hasattr(logger, 'flush'):
+                logger.flush()
             self._flush_logs(logger, buffer)
             self._check_persistent_rollout()
             return
@@ -192,6 +194,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         if not use_graph:
             self._rollout_device(T, agent, buffer)
             buffer.prefetch()
+            if hasattr(logger, 'flush'):
+                logger.flush()
             self._flush_logs(logger, buffer)
             return
         st = self.__dict__.setdefault('_rollout_graph', {})
@@ -229,6 +233,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         self.last_rollout_graphed = st.get('graph') is not None
         # get()'s device work goes out before the host synchronises on the episode metrics (buffer.py:prefetch)
         buffer.prefetch()
+        if hasattr(logger, 'flush'):  # the previous epoch's csv row, while the device runs this epoch's rollout
+            logger.flush()
         self._flush_logs(logger, buffer)
 
     # ------------------------------------------------------------------ one launch per epoch

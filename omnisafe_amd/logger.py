@@ -36,6 +36,7 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         self._headers_delta: dict[str, bool] = {}
         self._current_row: dict[str, float] = {}
         self._csv = None
+        self._pending = None  # (snapshot of the epoch's values, epoch) of a deferred dump_tabular
         # Optional sinks of the reference (logger.py:130-150, 312-318): the epoch row goes to TensorBoard
         # (`<log_dir>/tb`) and / or Weights & Biases when their packages are importable; when one is asked for and
         # missing, the run continues on csv alone and SAYS so (a drop-in must not silently ignore a config key).
@@ -134,25 +135,50 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         one rank both columns equal the mean.  (Round 1 logged the true extrema; the csv values of a drop-in
         have to be the reference's.)"""
         if not dist.collectives_active():
-            # float32 numpy reductions: torch CPU ops would open an OpenMP region per call, which costs
-            # milliseconds on many-core hosts and sits on the epoch's critical path (the GPU idles meanwhile)
-            vals = np.asarray(self._data[key], dtype=np.float32)
-            n = vals.size
-            if n == 0:
-                nan = float('nan')
-                return (nan, nan, nan, nan) if min_and_max else (nan,)
-            mean = vals.sum(dtype=np.float32) / np.float32(n)
-            if not min_and_max:
-                return (float(mean),)
-            std = np.sqrt(((vals - mean) ** 2).sum(dtype=np.float32) / np.float32(n))
-            elem_mean = float(vals.mean(dtype=np.float32))  # min_val.mean() / max_val.mean() of the reference
-            return float(mean), elem_mean, elem_mean, float(std)
+            return _local_stats(np.asarray(self._data[key], dtype=np.float32), min_and_max)
         vals = torch.tensor(list(self._data[key]), dtype=torch.float32)
         return _dist_stats(vals, min_and_max)
 
     def dump_tabular(self) -> None:
-        """logger.py:284-319: compute this epoch's row, write csv, reset non-window keys."""
+        """logger.py:284-319: compute this epoch's row, write csv, reset non-window keys.
+
+        The row's statistics, the csv line and the optional sinks are host work the device would sit idle through
+        (the epoch's kernels are finished by now, the next rollout is not enqueued yet: 0.15 ms of a 2.9 ms epoch at
+        the large-batch setting).  Without cross-rank statistics the epoch's values are therefore only SNAPSHOT here
+        and the row is written by `flush()` -- which the adapter calls right after it has enqueued the next epoch's
+        rollout, `close()` / `torch_save()` / the next `dump_tabular()` at the latest: same rows, same order, one
+        epoch later on disk at most.  OSA_LOG_DEFER=0 writes in place."""
+        self.flush()
+        if not dist.collectives_active() and os.environ.get('OSA_LOG_DEFER', '1') != '0':
+            snap = {key: np.asarray(self._data[key], dtype=np.float32) for key in self._data}
+            for key in self._data:
+                if self._headers_windows[key] is None:
+                    self._data[key] = []
+            self._pending = (snap, self._epoch)
+            self._epoch += 1
+            return
         self._update_current_row()
+        self._write_row(self._epoch)
+        self._epoch += 1
+
+    def flush(self) -> None:
+        """Write the row a deferred `dump_tabular()` left pending (no-op otherwise)."""
+        pending, self._pending = getattr(self, '_pending', None), None
+        if pending is None:
+            return
+        snap, epoch = pending
+        for key, vals in snap.items():
+            old = self._current_row[key]
+            st = _local_stats(vals, self._headers_minmax[key])
+            self._current_row[key] = st[0]
+            if self._headers_minmax[key]:
+                self._current_row[key + '/Min'], self._current_row[key + '/Max'] = st[1], st[2]
+                self._current_row[key + '/Std'] = st[3]
+            if self._headers_delta[key]:
+                self._current_row[key + '/Delta'] = st[0] - old
+        self._write_row(epoch)
+
+    def _write_row(self, epoch: int) -> None:
         if self._maste_proc:
             if self._first_row:
                 self._csv_writer.writerow(self._current_row.keys())
@@ -161,14 +187,13 @@ class Logger:  # pylint: disable=too-many-instance-attributes
             self._output_file.flush()
             if self._tb_writer is not None:
                 for key, val in self._current_row.items():
-                    self._tb_writer.add_scalar(key, val, global_step=self._epoch)
+                    self._tb_writer.add_scalar(key, val, global_step=epoch)
                 self._tb_writer.flush()
             if self._wandb is not None:
-                self._wandb.log(self._current_row, step=self._epoch)
+                self._wandb.log(self._current_row, step=epoch)
             if self._verbose:
                 width = max(len(k) for k in self._current_row)
                 print('\n'.join(f'  {k:<{width}}  {v}' for k, v in self._current_row.items()), flush=True)
-        self._epoch += 1
 
     def _update_current_row(self) -> None:
         for key in self._data:
@@ -191,6 +216,7 @@ class Logger:  # pylint: disable=too-many-instance-attributes
 
     def torch_save(self) -> None:
         """logger.py:183-194: {'pi': state_dict, 'obs_normalizer': state_dict} (CPU tensors)."""
+        self.flush()
         if not self._maste_proc:
             return
         assert self._what_to_save is not None, 'Please setup torch saver first'
@@ -203,12 +229,28 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         torch.save(params, path)
 
     def close(self) -> None:
+        self.flush()
         if self._maste_proc:
             self._output_file.close()
             if self._tb_writer is not None:
                 self._tb_writer.close()
             if self._wandb is not None:
                 self._wandb.finish()
+
+
+def _local_stats(vals: np.ndarray, min_and_max: bool) -> tuple[float, ...]:
+    """get_stats without other ranks.  float32 numpy reductions: torch CPU ops would open an OpenMP region per call,
+    which costs milliseconds on many-core hosts and sits on the epoch's critical path (the GPU idles meanwhile)."""
+    n = vals.size
+    if n == 0:
+        nan = float('nan')
+        return (nan, nan, nan, nan) if min_and_max else (nan,)
+    mean = vals.sum(dtype=np.float32) / np.float32(n)
+    if not min_and_max:
+        return (float(mean),)
+    std = np.sqrt(((vals - mean) ** 2).sum(dtype=np.float32) / np.float32(n))
+    elem_mean = float(vals.mean(dtype=np.float32))  # min_val.mean() / max_val.mean() of the reference
+    return float(mean), elem_mean, elem_mean, float(std)
 
 
 def _dist_stats(vals: torch.Tensor, min_and_max: bool):
