@@ -226,6 +226,8 @@ def roofline_from_events(events, batch_size):
         steps = max(1, rows // len(events) // batch_size)  # (a captured pass of several steps is one timed event)
         out['us_per_optimiser_step'] = round(us / steps, 3)
         out['kernel'] = 'osa_ppo_part_kernel (balanced partial gradients) + osa_slab_reduce_finalize_kernel'
+        out['steps_per_timed_launch'] = steps  # the timed unit is a captured graph of `steps` optimiser steps
+        out['traffic_per'] = 'optimiser step (one launch of each of the two kernels); algorithmic: batch_size x 268 B'
         out['note'] = ('large-batch step: the 64-row chunk-tasks of the three networks shared evenly by one workgroup '
                        'per compute unit (weights in LDS, partial gradient in registers, one slab per segment); slab '
                        'reduce + clip + Adam in a second launch')

@@ -184,8 +184,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             self._rollout_persistent(T, agent, buffer)
             self.last_rollout_path, self.last_rollout_graphed = 'persistent', False
             buffer.prefetch()
-            if hasattr(logger, 'flush'):
-                logger.flush()
             self._flush_logs(logger, buffer)
             self._check_persistent_rollout()
             return
@@ -194,8 +192,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         if not use_graph:
             self._rollout_device(T, agent, buffer)
             buffer.prefetch()
-            if hasattr(logger, 'flush'):
-                logger.flush()
             self._flush_logs(logger, buffer)
             return
         st = self.__dict__.setdefault('_rollout_graph', {})
@@ -233,8 +229,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         self.last_rollout_graphed = st.get('graph') is not None
         # get()'s device work goes out before the host synchronises on the episode metrics (buffer.py:prefetch)
         buffer.prefetch()
-        if hasattr(logger, 'flush'):  # the previous epoch's csv row, while the device runs this epoch's rollout
-            logger.flush()
         self._flush_logs(logger, buffer)
 
     # ------------------------------------------------------------------ one launch per epoch
@@ -455,6 +449,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                 _lib.ptr(buffer.data['value_r']), _lib.ptr(buffer.data['value_c']), _lib.ptr(hdr[0:1]),
                 _lib.ptr(fs['idx']), _lib.ptr(fs['vals']), _lib.ptr(hdr[1:3]), _lib.ptr(fs['ws']),
                 _lib.stream_ptr()), 'osa_episode_flush')
+            if hasattr(logger, 'flush'):  # the previous epoch's csv row: host work while the device runs this rollout
+                logger.flush()
             h = hdr.cpu()  # host sync (once per epoch)
             cnt = int(h[0])
             vmean = h[1:3].view(torch.float32).tolist()
@@ -471,6 +467,8 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         # everything the host will read is enqueued BEFORE the first synchronisation (each later one then finds its
         # result finished instead of leaving the device idle while the host enqueues the next reduction)
         vmean = torch.stack([buffer.data['value_r'].mean(), buffer.data['value_c'].mean()])
+        if hasattr(logger, 'flush'):
+            logger.flush()
         idx = ep['done'].reshape(-1).nonzero().reshape(-1)  # host sync (once per epoch)
         if idx.numel() > 0:
             widx = idx if window is None else idx[-window:]

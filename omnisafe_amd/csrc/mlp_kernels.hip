@@ -1153,6 +1153,10 @@ static int osa_check_dims(int obs_dim, int act_dim, int hidden) {
 
 static long long* g_osa_dbg_clocks = nullptr;
 
+// fvp_kernel.hip: the Fisher-vector product with the parameters in LDS (OSA_EUNSUPPORTED: shape outside that kernel)
+int osa_launch_fvp_fast(const OsaNet& nd, const float* params, float* grads, const float* obs, int ld_obs, long M,
+                        const float* vec, int max_blocks, float* ws, float* step_stats, hipStream_t st);
+
 extern "C" {
 
 int osa_debug_set_clock_buffer(long long* dev_ptr) {
@@ -1381,6 +1385,11 @@ int osa_actor_fvp_raw(int obs_dim, int act_dim, int hidden, float* params, float
   const int rc = osa_check_dims(obs_dim, act_dim, hidden);
   if (rc != OSA_OK) return rc;
   OSA_REQUIRE(params && grads && obs && vec && ws && step_stats && M > 0 && ld_obs >= obs_dim);
+  {  // hidden width 64, observations up to 64 wide: both parameter blocks in LDS, gradient in registers (fvp_kernel.hip)
+    const int rc2 = osa_launch_fvp_fast(osa_make_net(obs_dim, act_dim, hidden), params, grads, obs, ld_obs, M, vec,
+                                        max_blocks, ws, step_stats, osa_stream(stream));
+    if (rc2 != OSA_EUNSUPPORTED) return rc2;
+  }
   OsaMbArgs a = {};
   a.nslab[0] = -1;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);

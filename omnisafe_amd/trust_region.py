@@ -126,7 +126,16 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
                                              _lib.stream_ptr()), 'osa_actor_fvp_raw')
         if ev is not None:
             ev[1].record()
-            self.profile_events.append(('osa_mb_grad_kernel<loss_kind 2: Fisher-vector product>', M, ev))
+            import os
+
+            if getattr(ac, 'general', False):
+                name = 'gm_gemm_kernel (layer-wise Fisher-vector product)'
+            elif ((ac.hidden & 0xFFFF) == 64 and ac.obs_dim <= 64 and ac.act_dim <= 16 and M > 64
+                  and os.environ.get('OSA_FVP_FAST', '1') != '0'):  # the shapes of csrc/fvp_kernel.hip
+                name = 'osa_fvp_kernel + osa_fvp_reduce_kernel'
+            else:
+                name = 'osa_mb_grad_kernel<loss_kind 2: Fisher-vector product> + osa_slab_reduce_kernel'
+            self.profile_events.append((name, M, ev))
         raw.copy_(ac.grads[0])
         dist.all_reduce_avg_(raw)  # C2: one flat message
         out = out if out is not None else torch.empty_like(v)

@@ -245,7 +245,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 and (not dist.collectives_active() or dist.graph_capturable())
                 and os.environ.get('OSA_UPDATE_GRAPH', '1') != '0' and not self._ug.get('failed', False))
 
-    def _graph_pass(self, data: dict, perm: torch.Tensor, lagrange: torch.Tensor, stats_rows: torch.Tensor) -> None:
+    def _graph_pass(self, data: dict, perm: torch.Tensor | None, lagrange: torch.Tensor, stats_rows: torch.Tensor,
+                    passes: int = 1) -> None:
         """One pass = ceil(M / B) optimiser steps of two launches each (partial gradients; slab reduce + clip + Adam),
         captured ONCE and replayed for every pass of every epoch: the permutation and the statistics rows live in
         fixed buffers, the learning rates in device memory (osa_ppo_hparams.lr_device) so that the LinearLR schedule
@@ -256,13 +257,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         order (clip_grad_norm_, then avg_grads, then optimizer.step: policy_gradient.py:437-443; utils/distributed.py:
         167-198) with one message where it sends 19 -- and the whole pass, collectives included, is one captured
         hipGraph (RCCL enqueues kernels on its stream: capturable; over gloo the steps stay eager launches,
-        `dp-large-batch`)."""
+        `dp-large-batch`).
+
+        `passes` > 1 (`perm` None): ALL passes of the update are one graph -- their permutations are drawn straight into
+        the graph's index buffer by the one shuffle launch of the epoch, so that the per-pass copies (permutation in,
+        learning rates in, statistics out: 32 `copyBuffer` operations per epoch of the large-batch benchmark, each a
+        stream operation of its own between two graph launches) and 7 of the 8 graph launches disappear.  Used when no
+        host decision sits between the passes (no KL early stop); same launches on the same data: same bits."""
         ac, B = self.ac, self.batch_size
         M = data['obs'].shape[0]
         nmb = (M + B - 1) // B
         hp = self.hp
-        key = (M, B, tuple(int(data[k].data_ptr()) for k in ('obs', 'act', 'logp', 'target_value_r', 'target_value_c',
-                                                             'adv_r', 'adv_c')), int(lagrange.data_ptr()),
+        key = (M, B, passes, tuple(int(data[k].data_ptr()) for k in ('obs', 'act', 'logp', 'target_value_r',
+                                                                     'target_value_c', 'adv_r', 'adv_c')),
+               int(lagrange.data_ptr()),
                self._nets_mask(), self.loss_kind, self.max_blocks, dist.collectives_active(),
                # every pointer / stride the captured launches bake in (as the rollout graph's key does for params)
                tuple(int(t.data_ptr()) for t in (ac.params, ac.adam_m, ac.adam_v, ac.adam_step, ac.grads, self._ws)),
@@ -273,19 +281,24 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         st = self._ug
         if st.get('key') != key:
             st.clear()
-            st.update(key=key, perm=torch.empty(M, dtype=torch.int64, device=ac.device),
-                      stats=torch.zeros(nmb, NSTAT, dtype=torch.float32, device=ac.device),
+            st.update(key=key, perm=torch.empty(passes * M, dtype=torch.int64, device=ac.device),
+                      stats=torch.zeros(passes * nmb, NSTAT, dtype=torch.float32, device=ac.device),
                       lr=torch.zeros(2, dtype=torch.float32, device=ac.device),
                       lr_host=torch.zeros(2, dtype=torch.float32).pin_memory(), graph=None, warm=False)
-        st['perm'].copy_(perm)
+        if perm is None:  # one shuffle launch for all passes, written where the captured launches read
+            self.shuffles(passes, M, out=st['perm'].view(passes, M))
+        else:
+            assert passes == 1
+            st['perm'].copy_(perm)
         st['lr_host'][0], st['lr_host'][1] = float(hp.lr_actor), float(hp.lr_critic)
         st['lr'].copy_(st['lr_host'], non_blocking=True)
 
         def enqueue() -> None:
-            for k in range(nmb):
-                s0 = k * B
-                nb = min(B, M - s0)
-                self.minibatch(data, st['perm'][s0:s0 + nb], nb, lagrange, st['stats'][k])
+            for ip in range(passes):
+                for k in range(nmb):
+                    s0 = k * B
+                    nb = min(B, M - s0)
+                    self.minibatch(data, st['perm'][ip * M + s0:ip * M + s0 + nb], nb, lagrange, st['stats'][ip * nmb + k])
 
         hp.lr_device = st['lr'].data_ptr()
         pe, self.profile_events = self.profile_events, None  # (one event pair around the pass, none inside a capture)
@@ -318,7 +331,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.profile_events = pe
         if ev is not None:
             ev[1].record()
-            pe.append(('gm_gemm_kernel' if self.general else 'osa_mb_grad_kernel', M, ev))
+            pe.append(('gm_gemm_kernel' if self.general else 'osa_mb_grad_kernel', passes * M, ev))  # rows of the launch
         stats_rows.copy_(st['stats'])
         self._graphed_pass = st['graph'] is not None
 
@@ -929,9 +942,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # all passes' permutations in one launch (one shuffle per row, DataLoader(shuffle=True) semantics) instead of
         # update_iters separate randperm launches
         all_perms = None
-        if perms is None and not use_repl:
+        # all passes as ONE captured graph when nothing on the host sits between them (see _graph_pass)
+        whole = (perms is None and not use_repl and not use_pass and self._graph_pass_ok(M)
+                 and not (self.update_actor and self.kl_early_stop)
+                 and self.update_iters * nmb * (16 if self.general else 1) <= 1024
+                 and os.environ.get('OSA_UPDATE_GRAPH_WHOLE', '1') != '0')
+        if whole:
+            self._graph_pass(data, None, lagrange, stats[:total], passes=self.update_iters)
+            step, update_counts = total, self.update_iters
+            last_perm = self._ug['perm'][(self.update_iters - 1) * M:]
+            if self.update_actor:
+                kl_dev = self.kl(obs)
+        elif perms is None and not use_repl:
             all_perms = self.shuffles(self.update_iters, M)
-        for i in range(self.update_iters):
+        for i in range(0 if whole else self.update_iters):
             if use_repl:
                 perm = None
             elif perms is not None:

@@ -128,6 +128,33 @@ def test_fvp_is_symmetric_positive_and_matches_oracle_autograd():
     assert float(res) < 0.2  # 15 iterations on an 8964-dim system: residual clearly reduced
 
 
+@pytest.mark.parametrize('obs_dim,act_dim,M', [(60, 2, 65536), (27, 8, 4096 + 37), (6, 2, 200), (64, 16, 1000),
+                                               (60, 2, 64 * 300 + 1)])
+def test_fast_fvp_is_bit_identical_to_the_general_kernel(monkeypatch, obs_dim, act_dim, M):
+    """The throughput-shaped Fisher-vector product (csrc/fvp_kernel.hip: theta and v in LDS, gradient in registers, one
+    slab per workgroup) against the general gradient kernel it replaces for hidden width 64 / observations up to 64
+    wide: the same MFMA sequences and summation orders, hence torch.equal -- for full and ragged last chunks, fewer
+    chunks than workgroups, several chunks per workgroup, act_dim 2 ... 16; and through CG the same solution."""
+    from omnisafe_amd.trust_region import TrustRegionSolver
+    from test_mlp_gpu import make_ac
+
+    torch.manual_seed(9)
+    ac = make_ac(obs_dim, act_dim)
+    with torch.no_grad():
+        ac.params[0, ac.layout.oLS:ac.layout.oLS + act_dim] = torch.linspace(-0.4, 0.3, act_dim, device=DEV)
+    obs = torch.randn(M, obs_dim, device=DEV)
+    v = ac.actor.pad(torch.randn(ac.actor.num_params))
+    b = ac.actor.pad(torch.randn(ac.actor.num_params) * 0.1)
+    out = {}
+    for fast in ('1', '0'):
+        monkeypatch.setenv('OSA_FVP_FAST', fast)
+        s = TrustRegionSolver(ac, cg_iters=10, cg_damping=0.1)
+        s.begin(obs)
+        out[fast] = (s.fvp(v).clone(), s.conjugate_gradients(b).clone())
+    assert torch.equal(out['1'][0], out['0'][0]) and torch.equal(out['1'][1], out['0'][1])
+    assert float(out['1'][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize('algo_name', ['TRPOLag', 'CPO', 'TRPO', 'NaturalPG', 'PPO', 'PolicyGradient'])
 def test_agents_end_to_end(tmp_path, algo_name):
     import omnisafe_amd
