@@ -376,6 +376,17 @@ __global__ __launch_bounds__(256) void osa_fvp_reduce_kernel(OsaFvpArgs a) {
   const int ns = a.nblk;
   float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int b = 0;
+  for (; b + 64 <= ns; b += 64) {  // 64 slabs' loads in flight (the loop is nothing but latency: 256 slabs = 4 round trips
+    // instead of 32); the additions keep the order of the 8-slab loop: partial u receives b + u, b + 8 + u, ...
+    float t[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) t[u] = s[(long)(b + u) * W];
+#pragma unroll
+    for (int v = 0; v < 64; v += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += t[v + u];
+    }
+  }
   for (; b + 8 <= ns; b += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) p[u] += s[(long)(b + u) * W];

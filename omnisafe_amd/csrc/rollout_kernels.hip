@@ -44,27 +44,26 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
     const double c = (col < D) ? (double)mean[col] : 0.0;
     double a1 = 0.0, a2 = 0.0;
     int cnt = 0;
-    // (loads of 8 rows in flight per trip, from clamped addresses, consumed afterwards in row order: the
-    // row-by-row loop was a chain of 32 dependent memory round trips per thread -- 25 us per call for 1 MB)
+    // (ALL of a thread's 32 rows requested before the first is consumed -- from clamped addresses, consumed in row
+    // order: the row-by-row loop was a chain of 32 dependent memory round trips per thread, 25 us per call for 1 MB;
+    // 8 rows per trip still were four round trips of a kernel that is nothing but latency)
     const int cl = (col < D) ? col : 0;
-    for (int rb = r0 + ry; rb < r1; rb += 32) {
-      float xv[8];
-      uint8_t mv[8];
+    float xv[OSA_NORM_ROWS / 4];
+    uint8_t mv[OSA_NORM_ROWS / 4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = min(rb + 4 * u, r1 - 1);
-        xv[u] = x[(long)r * ld + cl];
-        mv[u] = mask ? mask[r] : (uint8_t)1;
-      }
+    for (int u = 0; u < OSA_NORM_ROWS / 4; ++u) {
+      const int r = min(r0 + ry + 4 * u, r1 - 1);
+      xv[u] = x[(long)r * ld + cl];
+      mv[u] = mask ? mask[r] : (uint8_t)1;
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (rb + 4 * u < r1 && mv[u] != 0) {
-          ++cnt;
-          if (col < D) {
-            const double d = (double)xv[u] - c;
-            a1 += d;
-            a2 = __builtin_fma(d, d, a2);
-          }
+    for (int u = 0; u < OSA_NORM_ROWS / 4; ++u) {
+      if (r0 + ry + 4 * u < r1 && mv[u] != 0) {
+        ++cnt;
+        if (col < D) {
+          const double d = (double)xv[u] - c;
+          a1 += d;
+          a2 = __builtin_fma(d, d, a2);
         }
       }
     }
@@ -95,12 +94,15 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
   __syncthreads();
   if (!s_last) return;
   // ---- merge (Normalizer._push, normalizer.py:109-139): every other workgroup has finished reading `mean`
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // the selected rows: a sum of small integers (exact in any order) -- one wave, all loads at once
     double n = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < nrb; ++b) n += osa_ws_get(ws + (long)nrb * D * 2 + b);
-    s_n = (long)n;
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    for (int b = threadIdx.x; b < nrb; b += 64) n += osa_ws_get(ws + (long)nrb * D * 2 + b);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if (threadIdx.x == 0) {
+      s_n = (long)n;
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    }
   }
   __syncthreads();
   const long n_raw = s_n;
@@ -109,16 +111,16 @@ __global__ __launch_bounds__(256) void osa_norm_push_kernel(
   const long cnt_new = cnt_old + n_raw;
   for (int c0 = threadIdx.x; c0 < D; c0 += blockDim.x) {
     double S1 = 0.0, S2 = 0.0;
-    for (int b0 = 0; b0 < nrb; b0 += 8) {  // 8 partials' loads in flight, summed in order
-      double p1[8], p2[8];
+    for (int b0 = 0; b0 < nrb; b0 += 32) {  // 32 partials' loads in flight (4096 envs: all of them), summed in order
+      double p1[32], p2[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const int b = min(b0 + u, nrb - 1);
         p1[u] = osa_ws_get(ws + ((long)b * D + c0) * 2);
         p2[u] = osa_ws_get(ws + ((long)b * D + c0) * 2 + 1);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 32; ++u) {
         if (b0 + u < nrb) {
           S1 += p1[u];
           S2 += p2[u];

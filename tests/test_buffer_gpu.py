@@ -164,7 +164,9 @@ def test_tiled_scan_equals_lane_per_env_kernel(est, T, N, pc):
 @pytest.mark.parametrize('T,N,pc,p_end', [
     (16, 4096, 0.0, 0.05), (1, 64, 0.0, 0.05), (7, 1, 0.3, 0.05), (128, 64, 0.0, 0.05), (129, 33, 0.3, 0.05),
     (257, 300, 0.0, 0.05), (1000, 4, 0.3, 0.002), (5000, 70, 0.0, 0.0005), (256, 16384, 0.0, 0.01),
-    (4096, 256, 0.0, 0.0), (2048, 512, 0.3, 0.001)])
+    (4096, 256, 0.0, 0.0), (2048, 512, 0.3, 0.001),
+    # (added with the env-pair experiment of round 4, profiles/r4_gae_ab.md: a last workgroup with two live lanes, ...)
+    (65, 130, 0.3, 0.05), (1000, 258, 0.3, 0.002), (4096, 128, 0.0, 0.0), (63, 1024, 0.0, 0.2)])
 def test_chained_scan_equals_lane_per_env_kernel(est, T, N, pc, p_end):
     """osa_gae_scan_chained (time split over workgroups: levels of 128 steps, chunks of 16 steps in registers,
     per-env carries chained by a decoupled look-back) vs osa_gae_scan (bit-exact to the reference).  Given its
