@@ -2,7 +2,7 @@
 """Single-GPU env-steps/s (rollout + update, = the reference's Time/FPS) of BASELINE.json configs 2-5 at their
 observation / action shapes, 4096 device envs x 16 steps per epoch, each algorithm's YAML defaults
 (kl_early_stop off = maximum work), next to the UNMODIFIED reference on this box's host cores
-(oracle/ref_cpu_baseline.py).  -> gpurun_out/r3_baseline_configs.{json,md}
+(oracle/ref_cpu_baseline.py).  -> gpurun_out/r4_baseline_configs.{json,md}
 
     python tools/baseline_configs.py [--no-reference]
 """
@@ -63,7 +63,7 @@ for tag, algo, env_id, label, iters, ref_sample in CONFIGS:
     print(json.dumps(row), flush=True)
     del a
     torch.cuda.empty_cache()
-out = os.path.join(ROOT, 'gpurun_out', 'r3_baseline_configs')
+out = os.path.join(ROOT, 'gpurun_out', 'r4_baseline_configs')
 os.makedirs(os.path.dirname(out), exist_ok=True)
 json.dump(rows, open(out + '.json', 'w'), indent=1)
 with open(out + '.md', 'w') as f:
