@@ -236,7 +236,7 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         """The epoch's device work as ONE persistent launch (csrc/rollout_persistent.hip): opt-in with
         OSA_ROLLOUT_PERSISTENT=1, for the plain adapter on the synthetic env with the observation normaliser only and
         fused [64, 64] tanh networks.  Same bits as the launch-per-step sequence below (tests/test_rollout_gpu.py), but
-        not faster than its captured graph on the benchmark's 4096 envs (0.72 vs 0.69 ms per 16-step epoch, profiles/
+        not faster than its captured graph on the benchmark's 4096 envs (0.76 vs 0.71 ms per 16-step epoch, profiles/
         r4_rollout_timing.json): one workgroup per 128 envs -- the blocking of the normaliser's partial sums, which
         fixes the bits -- keeps 32 of the 256 compute units busy, and the env's Philox draws and the forward passes
         then cost what the graph's chip-wide launches spend on launch gaps."""
