@@ -17,8 +17,8 @@
 // the JVP / backward / contraction loops are the same MFMA sequences, a workgroup's chunks are the same
 // (blockIdx.x + k * nblk) and are added in the same order -- so the product is BIT-IDENTICAL to the old path
 // (tests/test_trust_region_gpu.py::test_fast_fvp_is_bit_identical_to_the_general_kernel) and every reference golden of
-// the trust-region family holds unchanged.  Shapes: hidden width 64 (the YAML default), observations up to 64 wide
-// (the two padded parameter blocks + the four [64][68] tiles fill 155 of the 160 KB); everything else keeps the
+// the trust-region family holds unchanged.  Shapes: hidden width 64 (the YAML default), observations up to 80 wide
+// (the two padded parameter blocks + the four [64][68] tiles fill 150 - 158 of the 160 KB); everything else keeps the
 // general kernel (osa_actor_fvp_raw decides).
 #include <stdlib.h>
 
@@ -82,6 +82,61 @@ __device__ __forceinline__ void ofv_stage(const OsaNet& nd, const OsaNet& nl, co
   }
 }
 
+// osa_mlp_forward (mlp_device.h) on x fragments that are already in registers: the same MFMA sequence (K blocks outer,
+// hidden tiles inner, the four k of a fragment in order), weights from the padded LDS block
+template <int OT, int KBT>
+__device__ __forceinline__ void ofv_forward(const OsaNet& nl, const float* __restrict__ p, const f32x4 (&xf)[KBT], int act,
+                                            f32x4 (&h1)[4], f32x4 (&h2)[4], f32x4 (&out)[OT]) {
+  constexpr int HT = 4;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const float* __restrict__ W1 = p + nl.oW1;
+  const float* __restrict__ W2 = p + nl.oW2;
+  const float* __restrict__ W3 = p + nl.oW3;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(p + nl.ob1 + 16 * t + 4 * g);
+#pragma unroll
+  for (int kb = 0; kb < KBT; ++kb) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
+      h1[t] = OSA_MFMA(w.x, xf[kb].x, h1[t]);
+      h1[t] = OSA_MFMA(w.y, xf[kb].y, h1[t]);
+      h1[t] = OSA_MFMA(w.z, xf[kb].z, h1[t]);
+      h1[t] = OSA_MFMA(w.w, xf[kb].w, h1[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h1[t] = osa_act4(h1[t], act);
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(p + nl.ob2 + 16 * t + 4 * g);
+#pragma unroll
+  for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
+      h2[t] = OSA_MFMA(w.x, h1[kb].x, h2[t]);
+      h2[t] = OSA_MFMA(w.y, h1[kb].y, h2[t]);
+      h2[t] = OSA_MFMA(w.z, h1[kb].z, h2[t]);
+      h2[t] = OSA_MFMA(w.w, h1[kb].w, h2[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t) h2[t] = osa_act4(h2[t], act);
+#pragma unroll
+  for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(p + nl.ob3 + 16 * o + 4 * g);
+#pragma unroll
+  for (int kb = 0; kb < HT; ++kb) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
+      out[o] = OSA_MFMA(w.x, h2[kb].x, out[o]);
+      out[o] = OSA_MFMA(w.y, h2[kb].y, out[o]);
+      out[o] = OSA_MFMA(w.z, h2[kb].z, out[o]);
+      out[o] = OSA_MFMA(w.w, h2[kb].w, out[o]);
+    }
+  }
+}
+
 template <int OT, int KBT>
 __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
   constexpr int HT = 4, NSB = 4, SPC = 64, SLD = SPC + 4, H = 64, INP = 16 * KBT, OUTP = 16 * OT;
@@ -116,15 +171,27 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
   float gB = 0.f;  // thread tid < 2 H + OUTP: one bias entry
   const int nchunk = (a.M + SPC - 1) / SPC;
   bool first = true;
+  // this lane's row of the chunk as S-layout fragments (zero past the end and past obs_dim); the NEXT chunk's are
+  // requested as soon as the forward and tangent passes have consumed the current ones (one wave per SIMD: nothing
+  // else would hide the first touch of the rows in HBM)
+  f32x4 xn[KBT];
+  {
+    const int pos0 = blockIdx.x * SPC + 16 * wave + j;
+    const float* xr0 = pos0 < a.M ? a.obs + (long)pos0 * a.ld_obs : nullptr;
+#pragma unroll
+    for (int kb = 0; kb < KBT; ++kb) xn[kb] = osa_load_x(xr0, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+  }
   for (int chunk = blockIdx.x; chunk < nchunk; chunk += a.nblk, first = false) {
     const int pos = chunk * SPC + 16 * wave + j;
     const bool valid = pos < a.M;
-    const long row = pos;
-    const float* xrow = valid ? a.obs + row * a.ld_obs : nullptr;
+    f32x4 xf[KBT];
+#pragma unroll
+    for (int kb = 0; kb < KBT; ++kb) xf[kb] = xn[kb];
     __syncthreads();  // previous chunk's tiles fully consumed
 
     f32x4 h1[HT], h2[HT], out[OT];
-    osa_mlp_forward<HT, OT>(nl, p, xrow, a.ld_obs, vec_ok, h1, h2, out);
+    ofv_forward<OT, KBT>(nl, p, xf, OSA_ACT_TANH, h1, h2, out);  // (tanh only: a run-time activation switch is a branch,
+    // i.e. a scheduling barrier, between the MFMA groups of every layer; other activations keep the general kernel)
     // ---- JVP: t = d(mean) along v
     f32x4 dO[OT];
 #pragma unroll
@@ -135,7 +202,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       for (int t = 0; t < HT; ++t) t1[t] = *reinterpret_cast<const f32x4*>(v + nl.ob1 + 16 * t + 4 * g);
 #pragma unroll
       for (int kb = 0; kb < KBT; ++kb) {
-        const f32x4 x = osa_load_x(xrow, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+        const f32x4 x = xf[kb];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(v + nl.oW1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
@@ -146,7 +213,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < HT; ++t) t1[t] = t1[t] * osa_dact4(h1[t], nd.act);
+      for (int t = 0; t < HT; ++t) t1[t] = t1[t] * osa_dact4(h1[t], OSA_ACT_TANH);
 #pragma unroll
       for (int t = 0; t < HT; ++t) t2[t] = *reinterpret_cast<const f32x4*>(v + nl.ob2 + 16 * t + 4 * g);
 #pragma unroll
@@ -166,7 +233,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < HT; ++t) t2[t] = t2[t] * osa_dact4(h2[t], nd.act);
+      for (int t = 0; t < HT; ++t) t2[t] = t2[t] * osa_dact4(h2[t], OSA_ACT_TANH);
 #pragma unroll
       for (int o = 0; o < OT; ++o) tm[o] = *reinterpret_cast<const f32x4*>(v + nl.ob3 + 16 * o + 4 * g);
 #pragma unroll
@@ -197,6 +264,12 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
         }
       }
     }
+    {  // the next chunk's rows (the loads ride under the backward pass and the contractions)
+      const int posn = (chunk + a.nblk) * SPC + 16 * wave + j;
+      const float* xrn = (chunk + a.nblk < nchunk && posn < a.M) ? a.obs + (long)posn * a.ld_obs : nullptr;
+#pragma unroll
+      for (int kb = 0; kb < KBT; ++kb) xn[kb] = osa_load_x(xrn, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+    }
     // ---- backward through the hidden layers (S layout, activations stay in registers)
     const float* __restrict__ W2 = p + nl.oW2;
     const float* __restrict__ W3 = p + nl.oW3;
@@ -212,7 +285,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
           acc = OSA_MFMA(w, dO[o][s], acc);
         }
       }
-      z2[t] = acc * osa_dact4(h2[t], nd.act);
+      z2[t] = acc * osa_dact4(h2[t], OSA_ACT_TANH);
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
@@ -225,7 +298,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
           acc = OSA_MFMA(w, z2[kb][s], acc);
         }
       }
-      z1[t] = acc * osa_dact4(h1[t], nd.act);
+      z1[t] = acc * osa_dact4(h1[t], OSA_ACT_TANH);
     }
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f * SLD + c]
     const int c = 16 * wave + j;
@@ -247,17 +320,11 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
     }
     __syncthreads();
     // ---- weight gradients: contraction over the 64 samples of the chunk.  D tile: lane (cc = l & 15, g) holds
-    // dW[row 4g + r][col cc]; wave w owns row tile w of dW2 and dW1 (all column tiles)
-    const int cc = j;
+    // dW[row 4g + r][col cc]; wave w owns row tile w of dW2 and dW1 (all column tiles) and column tile w of dW3
+    f32x4 a1[NSB];
     {
       const int rt = wave;
-      long rows[4 * NSB];  // this lane's sample rows (constant over the K blocks); -1 past the end
-#pragma unroll
-      for (int q = 0; q < 4 * NSB; ++q) {
-        const long rq = (long)chunk * SPC + 16 * (q >> 2) + 4 * g + (q & 3);
-        rows[q] = rq < a.M ? rq : -1;
-      }
-      f32x4 a2[NSB], a1[NSB];
+      f32x4 a2[NSB];
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) {
         a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * rt + i) * SLD + 16 * sb + 4 * g);
@@ -275,31 +342,6 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
           acc = OSA_MFMA(a2[sb].w, b.w, acc);
         }
         gW2[ti] = first ? acc : gW2[ti] + acc;
-      }
-      // the gathered x values of block kb + 1 are requested before the MFMAs of block kb issue
-      float xq[4 * NSB], xnq[4 * NSB];
-#pragma unroll
-      for (int q = 0; q < 4 * NSB; ++q)
-        xnq[q] = (rows[q] >= 0 && cc < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + cc] : 0.f;
-#pragma unroll
-      for (int kb = 0; kb < KBT; ++kb) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4 * NSB; ++q) xq[q] = xnq[q];
-        if (kb + 1 < KBT) {
-          const int coln = 16 * (kb + 1) + cc;
-#pragma unroll
-          for (int q = 0; q < 4 * NSB; ++q)
-            xnq[q] = (rows[q] >= 0 && coln < nd.obs_dim) ? a.obs[rows[q] * a.ld_obs + coln] : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)  // B[k = sample 16sb+4g+s][j = input feature col]
-            acc = OSA_MFMA(a1[sb][s], xq[4 * sb + s], acc);
-        }
-        gW1[kb] = first ? acc : gW1[kb] + acc;
       }
     }
     {  // dW3: output tiles o x column tile `wave`
@@ -324,9 +366,40 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       const int tid = threadIdx.x;
       const float* srow = tid < H ? sZ1 + tid * SLD : (tid < 2 * H ? sZ2 + (tid - H) * SLD : sDO + (tid - 2 * H) * SLD);
       float s = 0.f;
-#pragma unroll 16
-      for (int k = 0; k < SPC; ++k) s += srow[k];
+#pragma unroll
+      for (int k = 0; k < SPC; k += 4) {  // (16-byte reads; the additions in sample order, as the general kernel's)
+        const f32x4 q = *reinterpret_cast<const f32x4*>(srow + k);
+        s += q.x;
+        s += q.y;
+        s += q.z;
+        s += q.w;
+      }
       gB = first ? s : gB + s;
+    }
+    // dW1's second operand -- the chunk's rows, element (input feature f, sample c) -- takes the place of the h1 / h2
+    // tiles once dW2 and dW3 have consumed them (the general kernel gathers these values from global memory again, 64 scalar loads per
+    // lane; the 155 KB of parameters and tiles leave no room for a fifth tile): same values, same MFMA order
+    __syncthreads();
+    float* sX = sH1;  // (the h1 and h2 tiles are adjacent and both consumed: up to 128 input features)
+#pragma unroll
+    for (int kb = 0; kb < KBT; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sX[(16 * kb + 4 * g + r) * SLD + c] = xf[kb][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < KBT; ++kb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb) {
+        // B[k = sample 16 sb + 4 g + s][j = input feature 16 kb + cc]
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * SLD + 16 * sb + 4 * g);
+        acc = OSA_MFMA(a1[sb].x, b.x, acc);
+        acc = OSA_MFMA(a1[sb].y, b.y, acc);
+        acc = OSA_MFMA(a1[sb].z, b.z, acc);
+        acc = OSA_MFMA(a1[sb].w, b.w, acc);
+      }
+      gW1[kb] = first ? acc : gW1[kb] + acc;
     }
   }  // chunks
   // ---- this workgroup's slab
@@ -401,7 +474,7 @@ int osa_launch_fvp_fast(const OsaNet& nd, const float* params, float* grads, con
   const char* sw = getenv("OSA_FVP_FAST");  // (read per call: the parity test switches between the two kernels)
   const bool off = sw != nullptr && sw[0] == '0' && sw[1] == 0;
   if (off) return OSA_EUNSUPPORTED;
-  if (nd.H != 64 || nd.KB > 4 || nd.OUTP > 32 || M <= 64 || M > (1l << 30)) return OSA_EUNSUPPORTED;
+  if (nd.act != OSA_ACT_TANH || nd.H != 64 || nd.KB > 5 || nd.OUTP > 32 || M <= 64 || M > (1l << 30)) return OSA_EUNSUPPORTED;
   OsaFvpArgs a = {};
   a.nd = nd; a.params = params; a.vec = vec; a.obs = obs; a.ld_obs = ld_obs; a.M = (int)M;
   a.grads = grads; a.stats = step_stats; a.slabs = ws;
@@ -428,9 +501,11 @@ int osa_launch_fvp_fast(const OsaNet& nd, const float* params, float* grads, con
   } while (0)
   const int OT = nd.OUTP / 16;
   if (OT == 1) {
-    if (nd.KB == 1) OFV_GO(1, 1); else if (nd.KB == 2) OFV_GO(1, 2); else if (nd.KB == 3) OFV_GO(1, 3); else OFV_GO(1, 4);
+    if (nd.KB == 1) OFV_GO(1, 1); else if (nd.KB == 2) OFV_GO(1, 2); else if (nd.KB == 3) OFV_GO(1, 3);
+    else if (nd.KB == 4) OFV_GO(1, 4); else OFV_GO(1, 5);
   } else {
-    if (nd.KB == 1) OFV_GO(2, 1); else if (nd.KB == 2) OFV_GO(2, 2); else if (nd.KB == 3) OFV_GO(2, 3); else OFV_GO(2, 4);
+    if (nd.KB == 1) OFV_GO(2, 1); else if (nd.KB == 2) OFV_GO(2, 2); else if (nd.KB == 3) OFV_GO(2, 3);
+    else if (nd.KB == 4) OFV_GO(2, 4); else OFV_GO(2, 5);
   }
 #undef OFV_GO
   hipLaunchKernelGGL(osa_fvp_reduce_kernel, dim3((nd.P + 1 + 255) / 256), dim3(256), 0, st, a);

@@ -130,7 +130,7 @@ class TrustRegionSolver:  # pylint: disable=too-many-instance-attributes
 
             if getattr(ac, 'general', False):
                 name = 'gm_gemm_kernel (layer-wise Fisher-vector product)'
-            elif ((ac.hidden & 0xFFFF) == 64 and ac.obs_dim <= 64 and ac.act_dim <= 16 and M > 64
+            elif ((ac.hidden & 0xFFFF) == 64 and ac.obs_dim <= 80 and ac.act_dim <= 16 and M > 64 and (ac.hidden >> 16) == 0
                   and os.environ.get('OSA_FVP_FAST', '1') != '0'):  # the shapes of csrc/fvp_kernel.hip
                 name = 'osa_fvp_kernel + osa_fvp_reduce_kernel'
             else:

@@ -129,7 +129,7 @@ def test_fvp_is_symmetric_positive_and_matches_oracle_autograd():
 
 
 @pytest.mark.parametrize('obs_dim,act_dim,M', [(60, 2, 65536), (27, 8, 4096 + 37), (6, 2, 200), (64, 16, 1000),
-                                               (60, 2, 64 * 300 + 1)])
+                                               (60, 2, 64 * 300 + 1), (72, 2, 8192 + 5), (80, 3, 300)])
 def test_fast_fvp_is_bit_identical_to_the_general_kernel(monkeypatch, obs_dim, act_dim, M):
     """The throughput-shaped Fisher-vector product (csrc/fvp_kernel.hip: theta and v in LDS, gradient in registers, one
     slab per workgroup) against the general gradient kernel it replaces for hidden width 64 / observations up to 64
