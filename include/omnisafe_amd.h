@@ -430,39 +430,6 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                     const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                     const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                     float* exchange, int* sync, int local, float* step_stats, void* stream);
-/* osa_ppo_dp_pass_placed with the reduction SLICED over the ranks (world >= 3, B <= 64): after the gradients have
- * been published, rank r sums only the tiles q with q mod world == r of all `world` slabs (rank order), applies
- * Adam to them -- it alone keeps the Adam moments of those tiles for the whole pass -- and publishes the new
- * PARAMETERS; after a second arrival everybody installs the tiles it does not own.  Per replica and step
- * 1 + 1 slabs are read instead of `world`, and Adam runs on 1 / world of the parameters; the price is the second
- * hand-off -- which on MI355X costs MORE than it saves (17.9 v 15.7 us per step at world 8): kept as
- * the measured alternative, not used by default.  Same arguments, arithmetic (sum in rank order, / world, Adam)
- * and results as osa_ppo_dp_pass_placed; sync: int[64], zero before the first call. */
-int osa_ppo_dp_slice_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
-                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
-                          const float* logp, const float* target_value_r, const float* target_value_c,
-                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
-                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                          float* exchange, int* sync, int local, float* step_stats, void* stream);
-
-/* Single-process persistent pass for LARGE minibatches (thousands of rows: the GPU-env blocks of the reference's
- * YAML files, e.g. batch_size 16 384 x update_iters 8): one cooperative launch per pass instead of two launches per
- * optimiser step (osa_ppo_minibatch).  `peers` chunk workgroups per network (2 <= peers <= ceil(B / 64), 3 peers <=
- * compute units) keep the network in LDS and the Adam moments in registers for the whole pass; per step peer c walks
- * through the 64-row chunks c, c + peers, ... of the minibatch, publishes its raw partial gradient (scaled by 1 / rows
- * of the minibatch), the sum is formed in TWO stages (every peer reduces its 1 / peers of the vectors over all slabs;
- * after a second arrival everybody reads the reduced gradient), the SUM is clipped by its norm and everybody applies
- * the same Adam step: the arithmetic of one B-row step of policy_gradient.py:366-382 (float32 re-association of the sum
- * over chunks only), as osa_ppo_chunked_pass.  exchange: osa_ppo_dp_pass_ws_floats(.., world = peers) floats zeroed once
- * (uncached memory from osa_dp_exchange_alloc or ordinary device memory); sync: int[64] zeroed once, sticky sync[3]
- * (1: a workgroup never arrived).  OSA_EUNSUPPORTED when the workgroups cannot be co-resident or act_dim > 16 (one
- * output tile only: the pass is an A/B alternative, measured slower than the per-step launches on MI355X). */
-int osa_ppo_large_batch_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
-                             int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
-                             const float* logp, const float* target_value_r, const float* target_value_c,
-                             const float* adv_r, const float* adv_c, const long* perm, long M, int B, int peers,
-                             const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                             float* exchange, int* sync, float* step_stats, void* stream);
 
 /* Single-process persistent pass for minibatches of 64 < B <= 2048 rows (the trust-region family's critic
  * updates: batch_size 128, natural_pg.py:205-223) with the ceil(B / 64) 64-row CHUNKS of a minibatch on cooperating

@@ -74,10 +74,6 @@ SIGNATURES: dict[str, tuple] = {
                         _P, _P, _I, _I, _P, _P, _P, _P]),
     'osa_ppo_dp_pass_placed': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                                _P, _P, _I, _I, _P, _P, _I, _P, _P]),
-    'osa_ppo_dp_slice_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
-                                   _P, _P, _I, _I, _P, _P, _I, _P, _P]),
-    'osa_ppo_large_batch_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
-                                      _P, _P, _I, _I, _P, _P, _P, _P]),
     'osa_ppo_chunked_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                                   _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_dp_chunked_pass_ws_floats': (C.c_size_t, [_I, _I, _I, _I, _I]),

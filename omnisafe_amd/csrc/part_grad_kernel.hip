@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_part_kernel(OsaPassArgs a) {
   {
     const int net = t_lo / nchunk, n_lo = net * nchunk;
     const int hi = t_hi < n_lo + nchunk ? t_hi : n_lo + nchunk;
-    osa_ppo_pass_body<KB, OT, true, false, false, false, false, true, SO, false, -1>(a, net, blockIdx.x - n_lo / a.part_tpw,
+    osa_ppo_pass_body<KB, OT, true, false, false, false, true, SO>(a, net, blockIdx.x - n_lo / a.part_tpw,
                                                                                      t_lo - n_lo, hi - t_lo);
     return;
   }
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_part_kernel(OsaPassArgs a) {
     const int lo = t_lo > n_lo ? t_lo : n_lo, hi = t_hi < n_hi ? t_hi : n_hi;
     if (lo < hi) {  // (block-uniform)
       const int wfirst = n_lo / a.part_tpw;  // first workgroup with a task of this network: slab 0
-      osa_ppo_pass_body<KB, OT, true, false, false, false, false, true, SO, false, -1>(a, net, blockIdx.x - wfirst,
+      osa_ppo_pass_body<KB, OT, true, false, false, false, true, SO>(a, net, blockIdx.x - wfirst,
                                                                                        lo - n_lo, hi - lo);
       __syncthreads();  // the next segment reloads the LDS master copy
     }

@@ -118,13 +118,6 @@ struct OsaPassArgs {
   // dp_ranks rank sums x clip factor in rank order, / dp_ranks (clip-then-average), same Adam step everywhere.
   // dp_sync then is int[64]: [net] stage-2 arrivals, [3] sticky flag, [4..7] placement, [8 + 16 net + rank] stage 1.
   int dp_ranks;
-  // SLICE instantiation of the cooperative data-parallel pass (osa_ppo_dp_slice_pass; world >= 3): after the
-  // gradients have been published, rank r REDUCES only the tiles q with q mod world == r (the bias-like row counts
-  // as tile NT), applies Adam to them with the moments it alone keeps for them, and publishes the new PARAMETERS;
-  // after a second hand-off everybody installs the tiles it does not own.  Per replica and step world x 1/world +
-  // 1 slabs are read instead of world, Adam runs on 1/world of the parameters; the price is the second hand-off.
-  // dp_sync is int[64] ([8 + net]: arrivals of the second hand-off); the parameter slabs follow the gradient
-  // slabs in dp_slabs.
   // plain pass (grid 3): 1 = the three networks' workgroups are blocks 0, 8, 16 of a 17-block grid, i.e. (block b
   // runs on XCC b mod 8) they share ONE XCC and its L2: the rows all three gather (observations: 240 of the 268
   // bytes of a sample) are then fetched from HBM once instead of three times
@@ -183,10 +176,9 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // the VALU form of the output layer is taken at compile time: the run-time switch stood in front of every one of
 // the 8 output-layer groups of the unrolled forward loop and in the backward / weight-gradient phases -- 16 scheduling
 // barriers in the hottest code (same-box A/B: 9.11 -> 8.87 us per step)
-// NETK: -1 = the network (actor / critic) is a run-time property of the workgroup; 0 / 1 = this body is the
-// actor's / a critic's (OSA_PASS_NET_SPLIT: the kernel then dispatches on its network once, and the loss code, the
-// gathers and the L2 / learning-rate selections lose their block-uniform branches)
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool SLICE, bool DPS, bool SO, bool TWO, int NETK>
+// (Round 3's sliced data-parallel reduction, the two-stage large-batch pass and the per-network body split were
+// measured slower and removed in round 4: DESIGN.md 7.)
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool DPS, bool SO>
 __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const int net, const int rk, const int pc0 = 0,
                                                   const int pn = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -255,7 +247,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   float* __restrict__ gp = a.params + (long)net * P;
   float* __restrict__ gm = a.adam_m + (long)net * P;
   float* __restrict__ gv = a.adam_v + (long)net * P;
-  const bool critic = NETK < 0 ? net != 0 : NETK != 0;  // (compile-time when NETK >= 0)
+  const bool critic = net != 0;
   const bool is_actor = !critic;
   const int out_dim = critic ? 1 : nd.act_dim;
   // 1-2 real outputs (every critic; the actor of the 2-D action spaces): the output layer, its backward and
@@ -369,9 +361,8 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
   // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
   const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
-  // (TWO: chunk mode with MORE chunks than peers -- peer c walks through the chunks c, c + cw, c + 2 cw, ...)
-  const bool strided = part || (TWO && chunked);
-  const int cstride = part ? (contig ? 1 : a.part_stride) : ((TWO && chunked) ? cw : 1);
+  const bool strided = part;
+  const int cstride = part ? (contig ? 1 : a.part_stride) : 1;
   const int cfirst = part ? (contig ? pc0 : rk) : (chunked ? cchunk : 0);
   const int nchunk = strided ? (contig ? pn : (nchunk_all - cfirst + cstride - 1) / cstride) : nchunk_all;
   auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
@@ -1180,82 +1171,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       for (int kb = 0; kb < KB; ++kb) s1[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < OT; ++o) s3[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float two_loss = 0.f, two_ratio = 0.f;  // (TWO: the minibatch's loss / ratio sums from the reduced tail)
-      if constexpr (TWO) {
-        // ---- two-stage sum for MANY peers (the large-batch pass: up to 64 chunk workgroups per network; every
-        // peer reading every slab would be W x 38 KB per peer and step).  A slab is EV 16-byte vectors (tiles, the
-        // bias-like row, the statistics tail); peer c owns the vectors c evp .. (c + 1) evp - 1: lane l of every
-        // wave takes the l-th of them, wave w adds the slabs w, w + 4, ... in that order, the four partial sums meet
-        // in LDS and are added in wave order -- one owner per vector, so every peer installs the same bits.  The
-        // reduced vectors go to the parity's x2 region in slab layout; after a second arrival everybody reads its
-        // own tiles from there (coalesced) and continues exactly as in the direct chunk mode.
-        constexpr int EV = NT * 256 + 64 + 1;
-        float* __restrict__ x2 = a.dp_slabs + (long)2 * 3 * a.dp_world * XS + ((long)((mb - a.mb0) & 1) * 3 + net) * XS;
-        f32x4* __restrict__ x2v = reinterpret_cast<f32x4*>(x2);
-        f32x4* sred = reinterpret_cast<f32x4*>(sH1);  // [4][64] (the tiles are dead until the next forward pass)
-        const int me = chunked ? cchunk : rk;
-        const int evp = (EV + W - 1) / W;  // a CONTIGUOUS range of vectors per peer: consecutive lanes read consecutive
-        // 16 bytes of a slab (with a stride of W vectors between the lanes every lane's load was its own cache line)
-        for (int l0 = 0; l0 < evp; l0 += 64) {
-          const int v = (l0 + lane < evp) ? me * evp + l0 + lane : EV;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          if (v < EV) {
-            constexpr int RT = 8;
-            for (int r0 = wave; r0 < W; r0 += 4 * RT) {
-              f32x4 t[RT];
-#pragma unroll
-              for (int u = 0; u < RT; ++u) {
-                const int r = min(r0 + 4 * u, W - 1);
-                t[u] = reinterpret_cast<const f32x4*>(xbase + (long)r * XS)[v];
-              }
-#pragma unroll
-              for (int u = 0; u < RT; ++u)
-                if (r0 + 4 * u < W) acc = acc + t[u];
-            }
-          }
-          sred[wave * 64 + lane] = acc;
-          __syncthreads();
-          if (wave == 0 && v < EV) x2v[v] = ((sred[lane] + sred[64 + lane]) + sred[128 + lane]) + sred[192 + lane];
-          __syncthreads();
-        }
-        if (a.dp_uncached || a.dp_local) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_s_waitcnt(0);
-        } else {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int* cnt = a.dp_sync + 8 + net;
-          const int target = W * (mb - a.mb0 + 1);
-          int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-          if (!coop_dead) {
-            int spins = 0;
-            while (seen < target) {
-              __builtin_amdgcn_s_sleep(1);
-              seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (++spins > (1 << 21)) {
-                __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                coop_dead = true;
-                break;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-        for (int ti = 0; ti < HT; ++ti) s2[ti] = x2v[ti * 256 + tid];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) s1[kb] = x2v[(HT + kb) * 256 + tid];
-#pragma unroll
-        for (int o = 0; o < OT; ++o) s3[o] = x2v[(HT + KB + o) * 256 + tid];
-        sb_ = x2[NT * 1024 + tid];
-        if (leader) {
-          two_loss = x2[NT * 1024 + 256 + 0];
-          two_ratio = x2[NT * 1024 + 256 + 1];
-        }
-      } else if (W == 2) {
+      if (W == 2) {
         // two peers (two chunks of a 128-row minibatch, or two ranks): own gradient from the registers + the
         // peer's slab.  Both sides form the same two products (g * clip factor; 1 in chunk mode) and a two-operand
         // float sum is commutative, so they get the same bits without walking the slabs in rank order.
@@ -1274,41 +1190,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
 #pragma unroll
         for (int o = 0; o < OT; ++o) s3[o] = osa_sym_sum(g3[o], gs, t[HT + KB + o], tg);
         sb_ = osa_sym_sum1((boff >= 0) ? gb : 0.f, gs, tb, tg);
-      } else if constexpr (SLICE) {
-        // only the tiles this rank owns: all `world` copies of one tile in flight together, summed in rank order
-        constexpr int RS = 8;
-        auto reduce_tile = [&](int q) -> f32x4 {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          for (int r0 = 0; r0 < W; r0 += RS) {
-            f32x4 t[RS];
-            float tg[RS];
-#pragma unroll
-            for (int u = 0; u < RS; ++u) {
-              const float* __restrict__ xr = xbase + (long)min(r0 + u, W - 1) * XS;
-              t[u] = reinterpret_cast<const f32x4*>(xr)[q * 256 + tid];
-              tg[u] = xr[NT * 1024 + 256 + 5];
-            }
-#pragma unroll
-            for (int u = 0; u < RS; ++u)
-              if (r0 + u < W) acc = acc + t[u] * tg[u];
-          }
-          return acc;
-        };
-#pragma unroll
-        for (int ti = 0; ti < HT; ++ti)
-          if (ti % W == rk) s2[ti] = reduce_tile(ti);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-          if ((HT + kb) % W == rk) s1[kb] = reduce_tile(HT + kb);
-#pragma unroll
-        for (int o = 0; o < OT; ++o)
-          if ((HT + KB + o) % W == rk) s3[o] = reduce_tile(HT + KB + o);
-        if (NT % W == rk) {
-          for (int r = 0; r < W; ++r) {
-            const float* __restrict__ xr = xbase + (long)r * XS;
-            sb_ += xr[NT * 1024 + tid] * xr[NT * 1024 + 256 + 5];
-          }
-        }
       } else {
       // RU ranks per trip: their loads are all in flight together (one memory round trip per trip,
       // not per rank); the clamped duplicate loads of a ragged last trip are simply not added
@@ -1374,14 +1255,9 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       }
       if (leader && (chunked ? cchunk == 0 : rk == 0)) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if constexpr (TWO) {
-          acc[0] = two_loss;
-          acc[1] = two_ratio;
-        } else {
-          for (int r = 0; r < W; ++r) {
-            const float* t = xbase + (long)r * XS + NT * 1024 + 256;
-            for (int k = 0; k < 5; ++k) acc[k] += t[k];
-          }
+        for (int r = 0; r < W; ++r) {
+          const float* t = xbase + (long)r * XS + NT * 1024 + 256;
+          for (int k = 0; k < 5; ++k) acc[k] += t[k];
         }
         if (chunked) {  // loss and ratio: sums of the chunks' shares; parameter norm and entropy: chunk 0's
           const float* t0 = xbase + NT * 1024 + 256;
@@ -1497,14 +1373,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     }
     // ================= Adam on the owned parameters; LDS master updated in place =================
     const float gscale = apply_clip ? coef : 1.f;
-    // SLICE: this replica applies Adam to the tiles q with q mod world == rank only and publishes their new values
-    // (pslab: [NT][256] f32x4 + the bias-like row, parity of the step); the rest arrives after the second hand-off
-    const int sW_ = SLICE ? a.dp_world : 1;
-    auto mine = [&](int q) -> bool { return !SLICE || (q % sW_) == rk; };
-    float* __restrict__ pslab = nullptr;
-    if constexpr (SLICE)
-      pslab = a.dp_slabs + (long)2 * 3 * a.dp_world * XS + ((long)((mb - a.mb0) & 1) * 3 + net) * XS;
-    f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(pslab);
     auto put_w2 = [&](int ti, f32x4 w) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sW2[(16 * wave + 4 * g + r) * PSLD + 16 * ti + cc] = w[r];
@@ -1520,32 +1388,29 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     };
 #pragma unroll
     for (int ti = 0; ti < HT; ++ti) {
-      if (mine(ti)) {
+      {
         f32x4 w = w2r[ti];
         w = osa_adam_update4(g2[ti] * gscale, m2[ti], v2[ti], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
         put_w2(ti, w);
-        if constexpr (SLICE) p4[ti * 256 + tid] = w;
       }
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      if (mine(HT + kb)) {
+      {
         f32x4 w = w1r[kb];
         w = osa_adam_update4(g1[kb] * gscale, m1[kb], v1[kb], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
         put_w1(kb, w);
-        if constexpr (SLICE) p4[(HT + kb) * 256 + tid] = w;
       }
     }
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-      if (mine(HT + KB + o)) {
+      {
         f32x4 w = w3r[o];
         w = osa_adam_update4(g3[o] * gscale, m3[o], v3[o], w, beta1, beta2, step_size, inv_bc2_sqrt, aeps);
         put_w3(o, w);
-        if constexpr (SLICE) p4[(HT + KB + o) * 256 + tid] = w;
       }
     }
-    if (mine(HT + KB + OT)) {
+    {
       float nb = wb;
       if (boff >= 0) {
         float mv_ = mb_, vv_ = vb_;
@@ -1554,51 +1419,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
         mb_ = mv_;
         vb_ = vv_;
       }
-      if constexpr (SLICE) pslab[(HT + KB + OT) * 1024 + tid] = nb;
-    }
-    if constexpr (SLICE) {
-      // ---- second hand-off: the new parameters of every slice
-      if (a.dp_uncached || a.dp_local) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int* cnt = a.dp_sync + 8 + net;
-        const int target = a.dp_world * (mb - a.mb0 + 1);
-        int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        if (!coop_dead) {
-          int spins = 0;
-          while (seen < target) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > (1 << 21)) {
-              __hip_atomic_store(a.dp_sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              coop_dead = true;
-              break;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      // install the tiles of the other ranks (all loads in flight, then the LDS writes)
-      f32x4 nw[HT + KB + OT];
-#pragma unroll
-      for (int q = 0; q < HT + KB + OT; ++q) nw[q] = p4[q * 256 + tid];
-      const float nbias = pslab[(HT + KB + OT) * 1024 + tid];
-#pragma unroll
-      for (int ti = 0; ti < HT; ++ti)
-        if (!mine(ti)) put_w2(ti, nw[ti]);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        if (!mine(HT + kb)) put_w1(kb, nw[HT + kb]);
-#pragma unroll
-      for (int o = 0; o < OT; ++o)
-        if (!mine(HT + KB + o)) put_w3(o, nw[HT + KB + o]);
-      if (!mine(HT + KB + OT) && boff >= 0) *sbias = nbias;
     }
     PTICK(8);
     // ---- statistics of this optimiser step
@@ -1625,46 +1445,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   if (a.dbg && tid == 0 && rk == 0)
     for (int k = 0; k < 13; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
 #endif
-  if constexpr (SLICE) {
-    // every rank writes back the Adam moments of the tiles IT updated (nobody else has them); the parameters
-    // (identical in every replica) and the step counter are rank 0's job below
-    constexpr int NTW = HT + KB + OT;
-    const int sw = a.dp_world;
-    if (rk != 0) {
-#pragma unroll
-      for (int ti = 0; ti < HT; ++ti)
-        if (ti % sw == rk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
-            gm[off] = m2[ti][r];
-            gv[off] = v2[ti][r];
-          }
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        if ((HT + kb) % sw == rk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
-            gm[off] = m1[kb][r];
-            gv[off] = v1[kb][r];
-          }
-#pragma unroll
-      for (int o = 0; o < OT; ++o)
-        if ((HT + KB + o) % sw == rk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
-            gm[off] = m3[o][r];
-            gv[off] = v3[o][r];
-          }
-      if (NTW % sw == rk && boff >= 0) {
-        gm[boff] = mb_;
-        gv[boff] = vb_;
-      }
-      return;
-    }
-  }
   if (rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
   // ---- write back parameters and Adam state
   for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
@@ -1678,11 +1458,8 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     gp[nd.ob3 + tid] = sB3[tid];
     if (!critic) gp[nd.oLS + tid] = sLS[tid];
   }
-  // (SLICE: rank 0 holds valid moments only for the tiles it updated: q mod world == 0)
-  const int swb = SLICE ? a.dp_world : 1;
 #pragma unroll
   for (int ti = 0; ti < HT; ++ti)
-    if (ti % swb == 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int off = nd.oW2 + (16 * wave + 4 * g + r) * H + 16 * ti + cc;
@@ -1691,7 +1468,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
-    if ((HT + kb) % swb == 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int off = nd.oW1 + (16 * wave + 4 * g + r) * INP + 16 * kb + cc;
@@ -1700,14 +1476,13 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       }
 #pragma unroll
   for (int o = 0; o < OT; ++o)
-    if ((HT + KB + o) % swb == 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int off = nd.oW3 + (16 * o + 4 * g + r) * H + 16 * wave + cc;
         gm[off] = m3[o][r];
         gv[off] = v3[o][r];
       }
-  if (boff >= 0 && (HT + KB + OT) % swb == 0) {
+  if (boff >= 0) {
     gm[boff] = mb_;
     gv[boff] = vb_;
   }

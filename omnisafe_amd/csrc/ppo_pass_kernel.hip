@@ -2,11 +2,7 @@
 // modes) lives in ppo_pass_body.h, shared with part_grad_kernel.hip (balanced partial gradients, round 4).
 #include "ppo_pass_body.h"
 
-#ifndef OSA_PASS_NET_SPLIT
-#define OSA_PASS_NET_SPLIT 0
-#endif
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool SLICE = false, bool DPS = false,
-          bool SO = false, bool TWO = false>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER = false, bool DPS = false, bool SO = false>
 __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   int net_ = blockIdx.x, rk_ = blockIdx.y;  // rk: virtual rank (0 outside the data-parallel mode)
   if constexpr (!COOP) {
@@ -25,12 +21,7 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
   }
   const int net = net_, rk = rk_;
   if (!((a.nets_mask >> net) & 1)) return;
-  if constexpr (OSA_PASS_NET_SPLIT != 0 && !MULTI && !COOP && !EXT && !DPS) {  // (the plain 64-row pass: the headline path)
-    if (net == 0) osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, 0>(a, net, rk);
-    else osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, 1>(a, net, rk);
-  } else {
-    osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO, -1>(a, net, rk);
-  }
+  osa_ppo_pass_body<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>(a, net, rk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -41,15 +32,15 @@ static size_t osa_pass_lds_bytes(int KB, int OT) {
   return fl * sizeof(float);
 }
 
-template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool SLICE = false,
-          bool DPS = false, bool SO = false, bool TWO = false>
+template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false, bool DPS = false,
+          bool SO = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
   static bool attr_set = false;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
     attr_set = true;
@@ -64,7 +55,7 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
       OsaPassArgs arg = a;
       void* kargs[] = {&arg};
       const hipError_t e = hipLaunchCooperativeKernel(
-          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), grid,
+          reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>), grid,
           dim3(256), kargs, (unsigned)lds, stream);
       if (e == hipSuccess) return OSA_OK;
       (void)hipGetLastError();
@@ -73,33 +64,22 @@ static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y 
     }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), 256, lds) !=
+            &per_cu, reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>), 256, lds) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return OSA_EHIP;
     if ((long)per_cu * cus < (long)grid.x * grid.y) return OSA_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, SLICE, DPS, SO, TWO>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>), grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
-}
-
-// the two-stage large-batch pass (off by default, measured slower than two launches per step): one output tile only,
-// so that the library does not carry twelve more instantiations of the largest kernel for an A/B switch
-template <int KB, int OT>
-static int osa_launch_two(const OsaPassArgs& a, hipStream_t stream, int grid_y) {
-  if constexpr (OT == 1) {
-    return osa_launch_pass<KB, OT, true, true, false, false, false, false, false, true>(a, stream, grid_y);
-  } else {
-    return OSA_EUNSUPPORTED;
-  }
 }
 
 // the SO instantiation where it applies (one output tile and act_dim <= 2: every network then has 1-2 outputs)
 template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool HIER = false>
 static int osa_launch_pass_so(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   if constexpr (OT == 1) {
-    if (a.nd.act_dim <= 2) return osa_launch_pass<KB, OT, MULTI, COOP, EXT, HIER, false, false, true>(a, stream, grid_y);
+    if (a.nd.act_dim <= 2) return osa_launch_pass<KB, OT, MULTI, COOP, EXT, HIER, false, true>(a, stream, grid_y);
   }
   return osa_launch_pass<KB, OT, MULTI, COOP, EXT, HIER>(a, stream, grid_y);
 }
@@ -297,8 +277,8 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   int rc = OSA_EUNSUPPORTED;
 #define OSA_DP_CASE(K, O)                                                                        \
   if (KB == K && OT == O)                                                                        \
-    rc = (B > 64) ? osa_launch_pass<K, O, true, false, false, false, false, true>(a, st, world)  \
-                  : osa_launch_pass<K, O, false, false, false, false, false, true>(a, st, world)
+    rc = (B > 64) ? osa_launch_pass<K, O, true, false, false, false, true>(a, st, world)  \
+                  : osa_launch_pass<K, O, false, false, false, false, true>(a, st, world)
   OSA_DP_CASE(1, 1); OSA_DP_CASE(2, 1); OSA_DP_CASE(3, 1); OSA_DP_CASE(4, 1); OSA_DP_CASE(5, 1);
   OSA_DP_CASE(6, 1); OSA_DP_CASE(1, 2); OSA_DP_CASE(2, 2); OSA_DP_CASE(3, 2); OSA_DP_CASE(4, 2);
   OSA_DP_CASE(5, 2); OSA_DP_CASE(6, 2);
@@ -358,7 +338,7 @@ static size_t osa_dp_pass_xs(const OsaNet& nd) {
 size_t osa_ppo_dp_pass_ws_floats(int obs_dim, int act_dim, int hidden, int world) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden) || world < 1) return 0;
   const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
-  return (size_t)2 * 3 * world * osa_dp_pass_xs(nd) + (size_t)2 * 3 * osa_dp_pass_xs(nd);  // + parameter slabs (slice pass)
+  return (size_t)2 * 3 * world * osa_dp_pass_xs(nd) + (size_t)2 * 3 * osa_dp_pass_xs(nd);  // (+ one spare slab set)
 }
 
 int osa_ppo_dp_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -377,7 +357,7 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, int ranks, int slice, float* step_stats, void* stream);
+                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream);
 
 int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
                            int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
@@ -387,18 +367,7 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                            float* exchange, int* sync, int local, float* step_stats, void* stream) {
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
-                       nets_mask, exchange, sync, local, 0, 1, 0, step_stats, stream);
-}
-
-int osa_ppo_dp_slice_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
-                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
-                          const float* logp, const float* target_value_r, const float* target_value_c,
-                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
-                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                          float* exchange, int* sync, int local, float* step_stats, void* stream) {
-  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
-                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, lagrange, hp, loss_kind,
-                       nets_mask, exchange, sync, local, 0, 1, 1, step_stats, stream);
+                       nets_mask, exchange, sync, local, 0, 1, step_stats, stream);
 }
 
 int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -410,27 +379,7 @@ int osa_ppo_chunked_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   if (B <= 64 || B > 64 * 32) return OSA_EUNSUPPORTED;  // one chunk: osa_ppo_pass
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, (B + 63) / 64, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, local, 1, 1, 0, step_stats, stream);
-}
-
-// The large-batch pass (batch sizes of thousands of rows: the GPU-env blocks of the reference's YAML files): ONE
-// cooperative launch per pass instead of two launches per optimiser step.  `peers` chunk workgroups per network
-// (<= ceil(B / 64), 3 peers <= CUs) keep the weights in LDS and the Adam moments in registers for the whole pass; per
-// step each walks through its chunks c, c + peers, ..., publishes its raw partial gradient, and the sum is formed in
-// two stages (every peer reduces ITS 1 / peers of the vectors over all slabs, then everybody reads the reduced
-// gradient): two hand-offs per step, 2 x 38 KB read per peer.  Clip on the norm of the sum, Adam replicated -- the
-// arithmetic of osa_ppo_chunked_pass (one B-row step of policy_gradient.py:366-382).  exchange: osa_ppo_dp_pass_ws_floats(
-// ..., peers) floats, zeroed once (uncached memory from osa_dp_exchange_alloc, or ordinary); sync: int[64] zeroed once.
-int osa_ppo_large_batch_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
-                             int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
-                             const float* logp, const float* target_value_r, const float* target_value_c,
-                             const float* adv_r, const float* adv_c, const long* perm, long M, int B, int peers,
-                             const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                             float* exchange, int* sync, float* step_stats, void* stream) {
-  if (B <= 64 || peers < 2 || peers > 85) return OSA_EUNSUPPORTED;
-  return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
-                       target_value_r, target_value_c, adv_r, adv_c, perm, M, B, peers, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, 0, 1, 1, 2, step_stats, stream);
+                       loss_kind, nets_mask, exchange, sync, local, 1, 1, step_stats, stream);
 }
 
 size_t osa_ppo_dp_chunked_pass_ws_floats(int obs_dim, int act_dim, int hidden, int B, int world) {
@@ -450,7 +399,7 @@ int osa_ppo_dp_chunked_pass(int obs_dim, int act_dim, int hidden, float* params,
   const int chunks = (B + 63) / 64;
   return osa_coop_pass(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act, logp,
                        target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world * chunks, lagrange, hp,
-                       loss_kind, nets_mask, exchange, sync, local, 1, world, 0, step_stats, stream);
+                       loss_kind, nets_mask, exchange, sync, local, 1, world, step_stats, stream);
 }
 
 static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
@@ -458,12 +407,8 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
                          const float* logp, const float* target_value_r, const float* target_value_c,
                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
                          const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
-                         float* exchange, int* sync, int local, int chunk, int ranks, int slice, float* step_stats, void* stream) {
+                         float* exchange, int* sync, int local, int chunk, int ranks, float* step_stats, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
-  // slice 1: the reduction sliced over the ranks + Adam on the slice (osa_ppo_dp_slice_pass); 2: chunk mode with
-  // `world` chunk workgroups walking through ceil(B / 64) >= world chunks and a two-stage sum (osa_ppo_large_batch_pass)
-  if (slice == 1 && (chunk || B > 64 || world < 3)) return OSA_EUNSUPPORTED;
-  if (slice == 2 && (!chunk || ranks != 1 || local || world > (B + 63) / 64)) return OSA_EUNSUPPORTED;
   if (local && osa_is_exchange_ptr(exchange)) return OSA_EINVAL;  // the XCC's L2 serves ordinary memory
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
@@ -500,13 +445,11 @@ static int osa_coop_pass(int obs_dim, int act_dim, int hidden, float* params, fl
   if (hipMemsetAsync(sync, 0, 3 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   if (local && hipMemsetAsync(sync + 4, 0, 4 * sizeof(int), st) != hipSuccess) return OSA_EHIP;  // XCC masks, arrivals
   // (chunk mode under data parallelism: the per-rank arrival counters of the first hand-off; sync is int[64] there)
-  if (((chunk && ranks > 1) || slice) && hipMemsetAsync(sync + 8, 0, 48 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
+  if ((chunk && ranks > 1) && hipMemsetAsync(sync + 8, 0, 48 * sizeof(int), st) != hipSuccess) return OSA_EHIP;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
 #define OSA_DPP_CASE(K, O)                                                                       \
   if (KB == K && OT == O)                                                                        \
-    return slice == 2 ? osa_launch_two<K, O>(a, st, world) \
-           : slice ? osa_launch_pass<K, O, false, true, false, false, true>(a, st, world)          \
-           : (chunk && ranks > 1) ? osa_launch_pass_so<K, O, false, true, false, true>(a, st, world) \
+    return (chunk && ranks > 1) ? osa_launch_pass_so<K, O, false, true, false, true>(a, st, world) \
            : (B > 64 && !chunk) ? osa_launch_pass<K, O, true, true>(a, st, world)                \
                                 : osa_launch_pass_so<K, O, false, true>(a, st, world)
   OSA_DPP_CASE(1, 1); OSA_DPP_CASE(2, 1); OSA_DPP_CASE(3, 1); OSA_DPP_CASE(4, 1); OSA_DPP_CASE(5, 1);
@@ -545,7 +488,7 @@ int osa_pass_partial_grad(int obs_dim, int act_dim, int hidden, float* params, c
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);
 #define OSA_PG_CASE(K, O) \
-  if (KB == K && OT == O) return osa_launch_pass<K, O, true, false, false, false, false, true>(a, st, nblk)
+  if (KB == K && OT == O) return osa_launch_pass<K, O, true, false, false, false, true>(a, st, nblk)
   OSA_PG_CASE(1, 1); OSA_PG_CASE(2, 1); OSA_PG_CASE(3, 1); OSA_PG_CASE(4, 1); OSA_PG_CASE(5, 1);
   OSA_PG_CASE(6, 1); OSA_PG_CASE(1, 2); OSA_PG_CASE(2, 2); OSA_PG_CASE(3, 2); OSA_PG_CASE(4, 2);
   OSA_PG_CASE(5, 2); OSA_PG_CASE(6, 2);

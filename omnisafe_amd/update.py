@@ -94,7 +94,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self._split_xch: int | None = None  # uncached exchange buffer of the split wide pass (raw pointer)
         self._split_tried = False
         self._chunk: dict = {}  # exchange buffer / sync words of osa_ppo_chunked_pass
-        self._big: dict = {}  # ... of osa_ppo_large_batch_pass
         self._ug: dict = {}  # captured hipGraph of one pass of per-step launches (large minibatches)
         self._split_local = False
         self._split_verified = False
@@ -120,45 +119,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                       sync=torch.zeros(8, dtype=torch.int32, device=ac.device),
                       local=0 if _PLACEMENT['local_ok'] is False else 1, verified=False)
         return True
-
-    def _big_ok(self) -> bool:
-        """osa_ppo_large_batch_pass applies: plain surrogate, B >= 2048 rows, single process, OSA_LARGE_BATCH_PASS=1.
-        OFF by default: measured SLOWER than two launches per step on MI355X (65.1 v 54.1 us per 16 384-row step, 44.1 v
-        32.1 at 4096 rows: the 64 chunk workgroups of a network span all XCCs, and two software grid barriers through
-        uncached memory cost more than two kernel boundaries inside a hipGraph -- DESIGN.md 7.4,
-        profiles/r3_large_batch_step.json).  Allocates the exchange buffer (uncached device memory) on first use."""
-        B, bg, ac = self.batch_size, self._big, self.ac
-        if (bg.get('off') or self.ext is not None or B < 2048 or self.loss_kind not in (0, 1)
-                or os.environ.get('OSA_LARGE_BATCH_PASS', '0') != '1'
-                or not bool(self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
-            return False
-        if bg.get('B') != B:
-            cus = torch.cuda.get_device_properties(ac.device).multi_processor_count
-            nchunk = (B + 63) // 64
-            peers = min(cus // 3, nchunk, 85)
-            per = (nchunk + peers - 1) // peers  # the slowest peer walks through `per` chunks whatever happens:
-            peers = (nchunk + per - 1) // per    # the FEWEST peers with that maximum (16 384 rows: 64 x 4 chunks)
-            if peers < 2:
-                bg['off'] = True
-                return False
-            if bg.get('xch_ptr') and bg.get('xch') is None:
-                self.lib.osa_dp_exchange_free(C.c_void_p(bg['xch_ptr']))
-            n = self.lib.osa_ppo_dp_pass_ws_floats(ac.obs_dim, ac.act_dim, ac.hidden, peers)
-            p = C.c_void_p()
-            if self.lib.osa_dp_exchange_alloc(max(n, 1), C.byref(p)) == _lib.OSA_OK and p.value:
-                bg.update(xch=None, xch_ptr=p.value)
-            else:  # ordinary memory: agent-scope release / acquire fences around the hand-offs
-                t = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
-                bg.update(xch=t, xch_ptr=t.data_ptr())
-            bg.update(B=B, peers=peers, sync=torch.zeros(64, dtype=torch.int32, device=ac.device))
-        return True
-
-    def check_big_sync(self) -> None:
-        """Sticky flag of the large-batch pass (a cooperating workgroup never arrived)."""
-        bg = self._big
-        if 'sync' in bg and int(bg['sync'][3]) != 0:
-            raise _lib.OsaError('osa_ppo_large_batch_pass: a cooperating workgroup never arrived (results invalid); '
-                                'unset OSA_LARGE_BATCH_PASS')
 
     def check_chunk_sync(self) -> None:
         """Sticky flag of the chunked pass (a workgroup never arrived: 1; a network's workgroups not on one XCC: 2)."""
@@ -444,31 +404,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 ev[1].record()
                 self.profile_events.append(('osa_wide_pass_kernel', M, ev))
             return
-        if self._big_ok():  # B >= 2048: the whole pass as one cooperative launch, two-stage sum of the chunk gradients
-            bg = self._big
-            rc = self.lib.osa_ppo_large_batch_pass(
-                ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
-                _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0),
-                _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
-                _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
-                _lib.ptr(data['adv_c']), _lib.ptr(perm), M, self.batch_size, bg['peers'], _lib.ptr(lagrange),
-                C.byref(self.hp), self.loss_kind, self._nets_mask(), C.c_void_p(bg['xch_ptr']), _lib.ptr(bg['sync']),
-                _lib.ptr(stats_rows), _lib.stream_ptr())
-            if rc == _lib.OSA_EUNSUPPORTED:  # not co-resident: per-step launches
-                bg['off'] = True
-                nmb = (M + self.batch_size - 1) // self.batch_size
-                for k in range(nmb):
-                    s0 = k * self.batch_size
-                    nb = min(self.batch_size, M - s0)
-                    self.minibatch(data, perm[s0:s0 + nb], nb, lagrange, stats_rows[k])
-                self.last_path = 'per-step'
-                return
-            _lib.check(rc, 'osa_ppo_large_batch_pass')
-            self.last_path = 'persistent-large-batch'
-            if ev is not None:
-                ev[1].record()
-                self.profile_events.append(('osa_ppo_pass_kernel', M, ev))
-            return
         if self._chunk_ok(data):  # 64 < B: the minibatch's 64-row chunks on cooperating workgroups (one XCC per network)
             ck = self._chunk
             rc = self.lib.osa_ppo_chunked_pass(
@@ -583,10 +518,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if st.get('wide_xch'):
             self.lib.osa_dp_exchange_free(C.c_void_p(st['wide_xch']))
         st.pop('wide_xch', None)
-        bg = self.__dict__.get('_big', {})
-        if bg.get('xch') is None and bg.get('xch_ptr'):
-            self.lib.osa_dp_exchange_free(C.c_void_p(bg['xch_ptr']))
-        bg.pop('xch_ptr', None)
 
     def _wide_dp_fits(self, W: int) -> bool:
         """The data-parallel split pass (osa_ppo_split_dp_pass) applies: wide observations, B <= 64, plain surrogate,
@@ -690,14 +621,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 st['xch'] = torch.zeros(max(n, 1), dtype=torch.float32, device=ac.device)
                 st['xch_ptr'] = st['xch'].data_ptr()
             st['sync'] = torch.zeros(64, dtype=torch.int32, device=ac.device)
-        # OSA_DP_SLICE=1: the reduction sliced over the ranks + Adam on the slice + parameters exchanged
-        # (osa_ppo_dp_slice_pass, world >= 3).  OFF by default: measured 17.9 us per step at 8 virtual ranks against
-        # 15.7 for the direct sum (15.9 v 13.2 at 4) -- the second hand-off costs more than the W - 2 slab reads and
-        # the 7/8 of Adam it saves (profiles/r3_dp_shapes_timing.md)
-        sliced = (not chunked and self.batch_size <= 64 and W >= 3 and os.environ.get('OSA_DP_SLICE', '0') == '1')
-        st['sliced'] = sliced
-        fn = lib.osa_ppo_dp_chunked_pass if chunked else (lib.osa_ppo_dp_slice_pass if sliced
-                                                          else lib.osa_ppo_dp_pass_placed)
+        # (the reduction sliced over the ranks + Adam on the slice + parameters exchanged -- round 3's
+        # osa_ppo_dp_slice_pass -- measured 17.9 us per step at 8 virtual ranks against 15.7 for the direct sum, 15.9 v
+        # 13.2 at 4: the second hand-off costs more than the W - 2 slab reads and the 7/8 of Adam it saves; removed in
+        # round 4, DESIGN.md 5.2, profiles/r3_dp_shapes_timing.md)
+        st['sliced'] = False
+        fn = lib.osa_ppo_dp_chunked_pass if chunked else lib.osa_ppo_dp_pass_placed
         rc = fn(
             ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m),
             _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(data_all['obs']),
@@ -911,8 +840,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                 and B <= pmb and bool(
                 self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden))):
             self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_pass)
-        if self._pass_fn is None and self.persistent and not self.general and not dist.collectives_active() and self._big_ok():
-            self._pass_fn = ('osa_ppo_pass_kernel', self.lib.osa_ppo_large_batch_pass)
         self._use_wide = False
         if (self._pass_fn is None and self.persistent and not self.general and self.ext is None
                 and not dist.collectives_active() and B <= 64 and self.loss_kind in (0, 1)
@@ -1004,8 +931,6 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             self.check_split_sync()
         if self.last_path == 'persistent-chunked':
             self.check_chunk_sync()
-        if self.last_path == 'persistent-large-batch':
-            self.check_big_sync()
         used = stats[:step]
         # rows of the LAST minibatch of the last executed pass (the reference logs Value/Adv from the loop variable
         # that shadows the full batch: policy_gradient.py:369-377, 402)

@@ -375,106 +375,13 @@ def test_persistent_pass_equals_per_minibatch_launches(obs_dim, act_dim, M, B, m
         np.testing.assert_allclose(outs[k]['kl'], outs[-1]['kl'], rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize('obs_dim,act_dim,M,B', [(60, 2, 16384, 4096), (60, 2, 20000, 8192), (27, 8, 9000, 2048),
-                                                (72, 16, 6144, 2048), (60, 2, 65536, 16384)])
-def test_large_batch_pass_equals_per_step_launches(obs_dim, act_dim, M, B, monkeypatch):
-    """osa_ppo_large_batch_pass (B >= 2048: one cooperative launch per pass; up to 64 chunk workgroups per network
-    walk through the minibatch's 64-row chunks, two-stage sum of their partial gradients, clip on the norm of the sum,
-    replicated Adam) vs the per-step launches (osa_ppo_minibatch: partial gradients + slab reduce / clip / Adam, pinned
-    to the oracle by test_large_batch_multiblock_equals_single_pass) on the same permutations: parameters, moments
-    and per-step statistics after two passes, incl. ragged last minibatches / chunks and both output-tile widths."""
-    from omnisafe_amd.update import PPOUpdater
-
-    torch.manual_seed(obs_dim + act_dim)
-    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
-            'target_value_r': torch.randn(M, device=DEV) * 3, 'target_value_c': torch.randn(M, device=DEV),
-            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
-    perms = [torch.randperm(M), torch.randperm(M)]
-    acs, outs, paths = [], [], []
-    for big in ('1', '0'):
-        monkeypatch.setenv('OSA_LARGE_BATCH_PASS', big)
-        torch.manual_seed(99)
-        ac = make_ac(obs_dim, act_dim)
-        if 'logp' not in data:
-            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
-            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
-        # max_grad_norm 0.1: the clip is active on the reward critic (targets x 3) in every step
-        up = PPOUpdater(ac, batch_size=B, update_iters=2, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01,
-                        max_grad_norm=0.1)
-        lam = torch.tensor([0.3], device=DEV)
-        outs.append(up.run(data, lam, perms=perms, actor_lr=3e-4, critic_lr=1e-3))
-        paths.append(up.last_path)
-        acs.append(ac)
-    assert paths == ['persistent-large-batch', 'per-step'], paths
-    nmb = (M + B - 1) // B
-    assert all(o['steps'] == 2 * nmb for o in outs)
-    assert acs[0].adam_step.cpu().tolist() == acs[1].adam_step.cpu().tolist() == [2 * nmb] * 3
-    for name in ('params', 'adam_m', 'adam_v'):
-        a, b = getattr(acs[0], name).cpu().numpy(), getattr(acs[1], name).cpu().numpy()
-        # (two summation orders of thousands of rows: the tolerance of the chunked pass against the per-step kernels)
-        bad = np.abs(a - b) > 5e-6 + 1e-5 * np.abs(b)
-        assert bad.sum() <= 4, (name, int(bad.sum()), float(np.abs(a - b).max()))
-        if bad.any():
-            lim = 2.5e-4 if name == 'params' else 2e-3 * np.abs(b[bad]).max()
-            assert np.abs(a - b)[bad].max() <= lim, (name, float(np.abs(a - b)[bad].max()))
-    s0, s1 = outs[0]['stats'].cpu().numpy(), outs[1]['stats'].cpu().numpy()
-    assert (s1[:, 8] > 0.1).all()  # the clip was active
-    np.testing.assert_allclose(s0[:, :10], s1[:, :10], rtol=2e-5, atol=5e-7)
-    np.testing.assert_allclose(outs[0]['kl'], outs[1]['kl'], rtol=1e-4, atol=1e-8)
-
-
-def test_graph_captured_update_pass_equals_eager_launches(monkeypatch):
-    """Large minibatches: the steps of a pass (two launches each) are captured once as a hipGraph and replayed for every
-    later pass and epoch -- permutation and statistics rows in fixed buffers, the learning rates in device memory
-    (osa_ppo_hparams.lr_device) so that the schedule can move between replays.  Same kernels in the same order:
-    bit-identical parameters, moments and statistics to the eager launches over two updates with different rates."""
-    from omnisafe_amd.update import PPOUpdater
-
-    M, B, obs_dim, act_dim = 12000, 4096, 60, 2
-    torch.manual_seed(4)
-    data = {'obs': torch.randn(M, obs_dim, device=DEV), 'act': torch.randn(M, act_dim, device=DEV),
-            'target_value_r': torch.randn(M, device=DEV), 'target_value_c': torch.randn(M, device=DEV),
-            'adv_r': torch.randn(M, device=DEV), 'adv_c': torch.randn(M, device=DEV)}
-    perms = [[torch.randperm(M) for _ in range(4)] for _ in range(2)]
-    res = []
-    for graph in ('1', '0'):
-        monkeypatch.setenv('OSA_UPDATE_GRAPH', graph)
-        torch.manual_seed(99)
-        ac = make_ac(obs_dim, act_dim)
-        if 'logp' not in data:
-            _, _, _, lp = ac.step(data['obs'], eps=(data['act'] * 0))
-            data['logp'] = lp + 0.2 * torch.randn(M, device=DEV)
-        up = PPOUpdater(ac, batch_size=B, update_iters=4, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
-        lam = torch.tensor([0.3], device=DEV)
-        outs = [up.run(data, lam, perms=perms[0], actor_lr=3e-4, critic_lr=1e-3),
-                up.run(data, lam, perms=perms[1], actor_lr=1e-4, critic_lr=5e-4)]
-        assert up.last_path == 'per-step' and (up._ug.get('graph') is not None) == (graph == '1')
-        res.append((ac, [o['stats'].clone() for o in outs], [o['kl'] for o in outs]))
-    for name in ('params', 'adam_m', 'adam_v', 'adam_step'):
-        assert torch.equal(getattr(res[0][0], name), getattr(res[1][0], name)), name
-    for a, b in zip(res[0][1], res[1][1]):
-        assert torch.equal(a, b)
-    assert res[0][2] == res[1][2]
-    # the second update really used the smaller rates: one eager run with the first rates throughout differs
-    monkeypatch.setenv('OSA_UPDATE_GRAPH', '0')
-    torch.manual_seed(99)
-    ac = make_ac(obs_dim, act_dim)
-    up = PPOUpdater(ac, batch_size=B, update_iters=4, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
-    lam = torch.tensor([0.3], device=DEV)
-    up.run(data, lam, perms=perms[0], actor_lr=3e-4, critic_lr=1e-3)
-    up.run(data, lam, perms=perms[1], actor_lr=3e-4, critic_lr=1e-3)
-    assert not torch.equal(ac.params, res[0][0].params)
-
-
 @pytest.mark.parametrize('W,M,B,use_graph,coop', [(2, 512, 64, False, False), (4, 300, 64, True, False),
                                                   (3, 256, 128, True, False), (2, 512, 64, False, True),
                                                   (4, 300, 64, False, True), (3, 256, 128, False, True),
                                                   (8, 1024, 64, False, True), (1, 200, 64, False, True),
                                                   (6, 320, 64, False, True), (16, 128, 64, False, True),
                                                   (2, 384, 64, False, 'wrong-placement'),
-                                                  (3, 256, 64, False, 'slice'), (4, 300, 64, False, 'slice'),
-                                                  (8, 1024, 64, False, 'slice'), (11, 128, 64, False, 'slice'),
-                                                  (8, 256, 64, False, 'noslice')])
+                                                  (11, 128, 64, False, True), (8, 256, 64, False, True)])
 def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_graph, coop, monkeypatch):
     """osa_ppo_dp_step (every rank computes the whole global step on the all-gathered rollout: W
     workgroups per network -> average of the locally clipped gradients -> Adam) vs the reference's
@@ -486,9 +393,6 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
     from omnisafe_amd import update as U
     from omnisafe_amd.update import PPOUpdater
 
-    # 'slice': osa_ppo_dp_slice_pass (each rank reduces + Adam-updates the tiles q = rank mod world, parameters are
-    # exchanged: second hand-off) switched on; it is off by default (measured slower than the direct sum)
-    monkeypatch.setenv('OSA_DP_SLICE', '1' if coop == 'slice' else '0')
     if coop == 'wrong-placement':  # test hook: the one-XCC protocol on the spread grid -> the kernel's placement
         # check trips before anything is modified, the updater repeats the pass spread over the XCCs
         monkeypatch.setenv('OSA_DEBUG_PLACEMENT', 'wrong')
@@ -519,7 +423,6 @@ def test_replicated_data_parallel_step_equals_allreduce_semantics(W, M, B, use_g
             if coop:  # the cooperative persistent launch ran (no silent fallback) and every peer arrived
                 assert up._dp.get('coop_passes') == 3
                 up.check_dp_sync()
-                assert up._dp['sliced'] is (coop == 'slice')  # (off by default: measured slower)
             if coop == 'wrong-placement':
                 assert U._PLACEMENT['local_ok'] is False and up._dp['local'] is False
             if use_graph:

@@ -84,15 +84,11 @@ def main():
             ms = timed(lambda: up.run_pass(data, perm, lam, st))
             rec['single_gpu']['us_per_step'] = round(ms * 1e3 / nmb, 2)
         del up, ac
-        # wide shape: owner groups placed / spread; narrow B <= 64 shape: direct sum ('noslice') / sliced reduction
-        modes = ['place', 'spread'] if d_o > 96 else (['noslice', 'slice'] if B <= 64 else [''])
+        # wide shape: owner groups placed / spread
+        modes = ['place', 'spread'] if d_o > 96 else ['']
         for W, wide_mode in [(w, m) for w in args.worlds for m in modes]:
             if wide_mode in ('place', 'spread'):
                 os.environ['OSA_WIDE_DP'] = wide_mode
-            if wide_mode in ('noslice', 'slice'):
-                if wide_mode == 'slice' and W < 3:
-                    continue
-                os.environ['OSA_DP_SLICE'] = '1' if wide_mode == 'slice' else '0'
             ac = ConstraintActorCritic(Box(-np.inf, np.inf, (d_o,)), Box(-1, 1, (d_a,)), mc, 4, device=dev)
             data_all = make_data(W * M, d_o, d_a)
             up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False,
@@ -112,10 +108,9 @@ def main():
                                                      else 'rank-major, uncached exchange') + ')'
             else:
                 up.check_dp_sync()
-                path = ('osa_ppo_dp_chunked_pass' if up._dp.get('chunked') else
-                        ('osa_ppo_dp_slice_pass' if up._dp.get('sliced') else 'osa_ppo_dp_pass_placed')) + \
+                path = ('osa_ppo_dp_chunked_pass' if up._dp.get('chunked') else 'osa_ppo_dp_pass_placed') + \
                        (' (one XCC per network)' if up._dp.get('local') else ' (spread, uncached exchange)')
-            key = str(W) if wide_mode in ('', 'place', 'noslice') else f'{W} ({wide_mode})'
+            key = str(W) if wide_mode in ('', 'place') else f'{W} ({wide_mode})'
             rec['us_per_step'][key] = round(ms * 1e3 / nmb, 2)
             rec.setdefault('dp_path', {})[key] = path
             print(f'{name}: W={W} {path}: {ms * 1e3 / nmb:7.2f} us per optimiser step '

@@ -63,29 +63,9 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / reps
         chunks = B // 64
         cus = torch.cuda.get_device_properties(0).multi_processor_count
-        pb = min(cus // 3, chunks)
-        per = (chunks + pb - 1) // pb
-        pb = (chunks + per - 1) // per
-        rec = {'B': B, 'us_per_step_in_graph': round(us, 2), 'workgroups_per_network': pb,
-               'chunks_per_workgroup': per}
-        # the cooperative pass (osa_ppo_large_batch_pass): all steps of a pass in one launch
-        if B * 4 <= M and up._big_ok():
-            Mp = 4 * B
-            sub = {k: v[:Mp] for k, v in data.items()}
-            st = torch.zeros(4, 16, device=dev)
-            pp = torch.randperm(Mp, device=dev)
-            up._pass_fn = ('osa_ppo_pass_kernel', None)
-            for _ in range(3):
-                up.run_pass(sub, pp, lam, st)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                up.run_pass(sub, pp, lam, st)
-            e1.record()
-            torch.cuda.synchronize()
-            up.check_big_sync()
-            rec['us_per_step_cooperative_pass'] = round(e0.elapsed_time(e1) * 1e3 / 80, 2)
-            rec['peers'] = up._big['peers']
+        wgs = min(cus, 3 * chunks)  # balanced partial gradients: the 3 x chunks tasks shared by one workgroup per CU
+        rec = {'B': B, 'us_per_step_in_graph': round(us, 2), 'workgroups': wgs,
+               'chunk_tasks_per_workgroup': round(3 * chunks / wgs, 2)}
         rows.append(rec)
         print(rows[-1], flush=True)
         del up, ac, g
