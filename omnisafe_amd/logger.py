@@ -228,6 +228,13 @@ class Logger:  # pylint: disable=too-many-instance-attributes
             params[k] = {n: t.detach().cpu() for n, t in sd.items()} if isinstance(sd, dict) else sd
         torch.save(params, path)
 
+    def __del__(self) -> None:
+        try:  # a logger dropped without close(): the pending row still reaches the csv
+            if getattr(self, '_pending', None) is not None and not self._output_file.closed:
+                self.flush()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
     def close(self) -> None:
         self.flush()
         if self._maste_proc:

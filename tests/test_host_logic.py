@@ -571,3 +571,33 @@ def test_plugin_cpu_parallel_goes_through_the_reference_fork(tmp_path):
         for k in a:
             if not k.startswith('Time/'):
                 assert a[k] == b[k], (k, a[k], b[k])
+
+
+def test_logger_deferred_rows_equal_in_place_rows(tmp_path, monkeypatch):
+    """Logger.dump_tabular() snapshots the epoch and the csv row is written by flush() (behind the next rollout's launch,
+    close() at the latest): the same rows in the same order as with OSA_LOG_DEFER=0, at most one epoch later on disk."""
+    import csv as _csv
+
+    from omnisafe_amd.logger import Logger
+
+    files = {}
+    for defer in ('1', '0'):
+        monkeypatch.setenv('OSA_LOG_DEFER', defer)
+        lg = Logger(str(tmp_path / defer), 'x', verbose=False)
+        lg.register_key('Loss')
+        lg.register_key('Metrics/EpRet', window_length=3, min_and_max=True, delta=True)
+        path = os.path.join(lg.log_dir, 'progress.csv')
+        for e in range(4):
+            lg.store({'Loss': 0.5 * e}, **{'Metrics/EpRet': float(e * e)})
+            lg.store({'Loss': 0.25 * e})
+            lg.dump_tabular()
+            on_disk = len(open(path).read().splitlines())
+            assert on_disk == (e + 1 if defer == '1' and e > 0 else (0 if defer == '1' else e + 2))
+            assert lg.current_epoch == e + 1
+            if e == 1:
+                lg.flush()  # (what the adapter does once the next rollout is enqueued)
+                assert len(open(path).read().splitlines()) == e + 2
+        lg.close()
+        files[defer] = list(_csv.reader(open(path)))
+    assert files['1'] == files['0'] and len(files['1']) == 5
+
