@@ -201,16 +201,6 @@ __device__ __forceinline__ f32x4 gm_load4(const float* __restrict__ row, int c0,
   return v;
 }
 
-// Unit u of a TRANSPOSED operand tile (the operand is contiguous along the tile's row index, not along k): a wave's 64
-// lanes cover 16 consecutive k x 4 consecutive 16-byte pieces -- 64-byte row segments on the global side, and the
-// transposed LDS stores of 32 lanes hit 32 distinct banks (16 consecutive k per piece, pieces 4 LD = 16 banks apart).
-template <int BK>
-__device__ __forceinline__ void gm_tunit(int u, int& kq, int& c) {
-  const int hi = u >> 6;
-  kq = (u & 15) + 16 * (hi % (BK / 16));
-  c = ((u >> 4) & 3) + 4 * (hi / (BK / 16));
-}
-
 // C[m][n] = epi(sum_k A(m, k) B(k, n)).   AT: A(m, k) = A[k lda + m] (else A[m lda + k]);
 //                                          BT: B(k, n) = B[k ldb + n] (else B[n ldb + k]).
 // BK: K step per LDS stage.  16 when the launch has enough workgroups to hide memory latency behind each other; 64
@@ -220,9 +210,17 @@ __device__ __forceinline__ void gm_tunit(int u, int& kq, int& c) {
 template <int TM, int TN, int BK, bool AT, bool BT>
 __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
   constexpr int LD = BK + 4, MI = TM / 64, NJ = TN / 64, UA = TM * BK / 1024, UB = TN * BK / 1024;
+  // An operand that is contiguous along its tile-row index (AT / BT: the activations of the weight-gradient GEMM, the
+  // weights of the backward-data GEMM) stays K-MAJOR in LDS -- [k][row], leading dimension rows + 8 -- instead of being
+  // transposed on the way in: 16-byte global loads with a wave on 1 KB of consecutive bytes and 16-byte LDS stores, where
+  // the transposing stores were four scalar writes per piece from 64-byte row segments; the MFMA fragments then are four
+  // scalar LDS reads of 32 consecutive floats per lane group (the two lane groups 4 rows = 32 banks apart) instead of
+  // one 16-byte read.  Same values into the same MFMAs: same bits.
+  constexpr int LDTA = TM + 8, LDTB = TN + 8;
+  constexpr int SZA = AT ? BK * LDTA : TM * LD, SZB = BT ? BK * LDTB : TN * LD;
   extern __shared__ __attribute__((aligned(16))) float gm_smem[];
-  float(*sA)[TM * LD] = reinterpret_cast<float(*)[TM * LD]>(gm_smem);
-  float(*sB)[TN * LD] = reinterpret_cast<float(*)[TN * LD]>(gm_smem + 2 * TM * LD);
+  float(*sA)[SZA] = reinterpret_cast<float(*)[SZA]>(gm_smem);
+  float(*sB)[SZB] = reinterpret_cast<float(*)[SZB]>(gm_smem + 2 * SZA);
   const int pi = blockIdx.z / g.splits, sp = blockIdx.z - pi * g.splits;
   // (selected with scalar moves: a run-time index into the by-value argument would go through scratch memory)
   const GProb p = pi == 0 ? g.p[0] : (pi == 1 ? g.p[1] : g.p[2]);
@@ -249,9 +247,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
         const int r = u / (BK / 4), c = u % (BK / 4), m = m0 + r;
         ra[q] = gm_load4(A + (long)m * p.lda, k0 + 4 * c, kend, m < M);
       } else {
-        int kq, c;
-        gm_tunit<BK>(u, kq, c);
-        const int k = k0 + kq;
+        const int kq = u / (TM / 4), c = u % (TM / 4), k = k0 + kq;
         ra[q] = gm_load4(A + (long)k * p.lda, m0 + 4 * c, M, k < kend);
       }
     }
@@ -262,8 +258,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
         const int r = u / (BK / 4), c = u % (BK / 4), n = n0 + r;
         rb[q] = gm_load4(B + (long)n * p.ldb, k0 + 4 * c, kend, n < N);
       } else {
-        int kq, c;
-        gm_tunit<BK>(u, kq, c);
+        const int kq = u / (TN / 4), c = u % (TN / 4);
         const int k = k0 + kq, nn = n0 + 4 * c;
         f32x4 v = gm_load4(B + (long)k * p.ldb, nn, N, k < kend);
         if (p.ones_n >= 0 && k < kend) {  // the column of ones that turns the bias gradient into one more output column
@@ -282,10 +277,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
       if constexpr (!AT) {
         *reinterpret_cast<f32x4*>(&sA[st][(u / (BK / 4)) * LD + 4 * (u % (BK / 4))]) = ra[q];
       } else {
-        int kq, c;
-        gm_tunit<BK>(u, kq, c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sA[st][(4 * c + i) * LD + kq] = ra[q][i];
+        *reinterpret_cast<f32x4*>(&sA[st][(u / (TM / 4)) * LDTA + 4 * (u % (TM / 4))]) = ra[q];
       }
     }
 #pragma unroll
@@ -294,10 +286,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
       if constexpr (!BT) {
         *reinterpret_cast<f32x4*>(&sB[st][(u / (BK / 4)) * LD + 4 * (u % (BK / 4))]) = rb[q];
       } else {
-        int kq, c;
-        gm_tunit<BK>(u, kq, c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sB[st][(4 * c + i) * LD + kq] = rb[q][i];
+        *reinterpret_cast<f32x4*>(&sB[st][(u / (TN / 4)) * LDTB + 4 * (u % (TN / 4))]) = rb[q];
       }
     }
   };
@@ -322,11 +311,23 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
       // alike -- each fragment is ONE 16-byte LDS read per lane and feeds four MFMAs
       f32x4 af[MI], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&sA[st][(wm + 32 * i + l31) * LD + 8 * s + 4 * kk]);
+      for (int i = 0; i < MI; ++i) {
+        if constexpr (!AT) {
+          af[i] = *reinterpret_cast<const f32x4*>(&sA[st][(wm + 32 * i + l31) * LD + 8 * s + 4 * kk]);
+        } else {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(&sB[st][(wn + 32 * j + l31) * LD + 8 * s + 4 * kk]);
+          for (int q = 0; q < 4; ++q) af[i][q] = sA[st][(8 * s + 4 * kk + q) * LDTA + wm + 32 * i + l31];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if constexpr (!BT) {
+          bf[j] = *reinterpret_cast<const f32x4*>(&sB[st][(wn + 32 * j + l31) * LD + 8 * s + 4 * kk]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bf[j][q] = sB[st][(8 * s + 4 * kk + q) * LDTB + wn + 32 * j + l31];
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
 
 template <int TM, int TN, int BK, bool AT, bool BT>
 int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (TM + TN) * (BK + 4) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * ((AT ? BK * (TM + 8) : TM * (BK + 4)) + (BT ? BK * (TN + 8) : TN * (BK + 4))) * sizeof(float);
   if constexpr (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
