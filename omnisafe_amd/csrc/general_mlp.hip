@@ -387,6 +387,9 @@ int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
+#ifndef GM_BK
+#define GM_BK 16  // K step of the launches with enough workgroups (A/B: -DGM_BK=32)
+#endif
 // one grouped launch; the tile follows the largest problem (64-wide tiles for skinny ones), the K step the number of
 // workgroups the launch will have
 template <bool AT, bool BT>
@@ -408,7 +411,7 @@ int gm_gemm(const GArgs& g, hipStream_t st) {
   const long wgs = count(bigM ? 128 : 64, bigN ? 128 : 64);
   const bool deep = wgs < 256;  // few workgroups: latency-bound -> K step 64
 #define GM_GO(TM_, TN_)                                                              \
-  return deep ? gm_launch<TM_, TN_, 64, AT, BT>(g, maxM, maxN, st) : gm_launch<TM_, TN_, 16, AT, BT>(g, maxM, maxN, st)
+  return deep ? gm_launch<TM_, TN_, 64, AT, BT>(g, maxM, maxN, st) : gm_launch<TM_, TN_, GM_BK, AT, BT>(g, maxM, maxN, st)
   if (bigM && bigN) GM_GO(128, 128);
   if (bigM) GM_GO(128, 64);
   if (bigN) GM_GO(64, 128);
