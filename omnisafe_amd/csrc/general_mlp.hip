@@ -19,6 +19,8 @@
 // What bounds it: at hidden 1024 and batch 16 384 a step is 3 networks x 6 W rows = 2 x 10^11 FLOP: MFMA-bound
 // (roofline in bench.py --hidden 1024); at the YAML batch of 64 rows it streams 3 x 13 MB of weights, moments and
 // gradients per step: HBM / L2-bound.
+#include <stdlib.h>
+
 #include "mlp_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -85,6 +87,8 @@ int gm_make_layout(const osa_gmlp_desc* d, GLayout* lo) {
 }
 
 // ---- workspace carve-up (floats; every offset a multiple of 4 -> 16-byte aligned rows)
+#define GM_ROW_SPLIT_ROWS 256  // minibatches up to this many rows split the K of their forward / backward-data GEMMs
+#define GM_ROW_SPLITS 8
 struct GWs {
   size_t xg, actg, scal;          // gathered observations [R][ldx], actions [R][lda], scalars [6][R]
   size_t h[3][GM_MAXL];           // layer outputs of every network [R][ldh]
@@ -95,6 +99,7 @@ struct GWs {
   int S[3][GM_MAXL];              // splits of the row (= reduction) dimension of layer l's weight-gradient GEMM
   size_t npart, fin;              // norm partials [3][nb][2]; finals [3][8]
   size_t dws;                     // double scratch of the KL / evaluation reductions (4 x 1024 doubles)
+  size_t rsl, rsl_floats;         // K-slice slabs of the small-row forward / backward-data GEMMs (gm_gemm_rows)
   size_t total;
   int nblk, nb;
 };
@@ -147,6 +152,14 @@ GWs gm_ws(const GLayout& lo, long R) {
   w.npart = take((size_t)3 * w.nb * 2);
   w.fin = take(3 * 8);
   w.dws = take(2 * 4 * 1024);
+  {  // small minibatches: [3 networks][GM_ROW_SPLITS][R][widest layer]
+    int maxld = lo.ldx;
+    for (int net = 0; net < 3; ++net)
+      for (int l = 0; l < lo.n[net].L; ++l)
+        if (lo.n[net].ldh[l] > maxld) maxld = lo.n[net].ldh[l];
+    w.rsl_floats = R <= GM_ROW_SPLIT_ROWS ? (size_t)3 * GM_ROW_SPLITS * R * maxld : 0;
+    w.rsl = take(w.rsl_floats);
+  }
   w.total = off;
   return w;
 }
@@ -409,7 +422,11 @@ int gm_gemm(const GArgs& g, hipStream_t st) {
   if (bigN && count(bigM ? 128 : 64, 128) < 128) bigN = false;
   if (bigM && count(128, bigN ? 128 : 64) < 128) bigM = false;
   const long wgs = count(bigM ? 128 : 64, bigN ? 128 : 64);
-  const bool deep = wgs < 256;  // few workgroups: latency-bound -> K step 64
+  static const int deep_sw = [] {  // (A/B switch: OSA_GMLP_DEEP=0 / 1 forces the K step 16 / 64)
+    const char* v = getenv("OSA_GMLP_DEEP");
+    return v == nullptr ? -1 : (v[0] == '1' ? 1 : 0);
+  }();
+  const bool deep = deep_sw >= 0 ? deep_sw == 1 : wgs < 256;  // few workgroups: latency-bound -> K step 64
 #define GM_GO(TM_, TN_)                                                              \
   return deep ? gm_launch<TM_, TN_, 64, AT, BT>(g, maxM, maxN, st) : gm_launch<TM_, TN_, GM_BK, AT, BT>(g, maxM, maxN, st)
   if (bigM && bigN) GM_GO(128, 128);
@@ -417,6 +434,82 @@ int gm_gemm(const GArgs& g, hipStream_t st) {
   if (bigN) GM_GO(64, 128);
   GM_GO(64, 64);
 #undef GM_GO
+}
+
+// ---- small minibatches: the forward / backward-data GEMMs of a 64-row step are [64 x K] x [K x N] products whose K
+// loop streams megabytes of weights through a few dozen workgroups -- 16 dependent K steps with one tile of lookahead
+// and 48 workgroups' worth of bytes in flight: 25 us per layer at hidden 1024, whatever the arithmetic.  Here the K
+// range is cut into up to 8 slices (one workgroup each: 8 x the bytes in flight), the slices' raw products go to slabs
+// and ONE small launch adds them in slice order and applies the epilogue (bias, activation, activation' x aux).
+struct GEpi {
+  const float* slab;
+  float* C;
+  const float* bias;
+  const float* aux;
+  int M, N, ldc, ldaux, act, dact, S;
+  long slab_stride;
+};
+struct GEpiArgs {
+  GEpi e[3];
+  int n;
+};
+__global__ __launch_bounds__(256) void gm_rows_epilogue_kernel(GEpiArgs a) {
+  const GEpi e = blockIdx.y == 0 ? a.e[0] : (blockIdx.y == 1 ? a.e[1] : a.e[2]);
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)e.M * e.N) return;
+  const int m = (int)(idx / e.N), n = (int)(idx - (long)m * e.N);
+  const float* s = e.slab + (long)m * e.ldc + n;
+  float t[GM_ROW_SPLITS];
+#pragma unroll
+  for (int k = 0; k < GM_ROW_SPLITS; ++k) t[k] = k < e.S ? s[(long)k * e.slab_stride] : 0.f;
+  float v = t[0];
+#pragma unroll
+  for (int k = 1; k < GM_ROW_SPLITS; ++k)
+    if (k < e.S) v += t[k];
+  if (e.bias) v += e.bias[n];
+  if (e.act >= 0) v = gm_act(v, e.act);
+  if (e.dact >= 0) v *= gm_dact(e.aux[(long)m * e.ldaux + n], e.dact);
+  e.C[(long)m * e.ldc + n] = v;
+}
+
+template <bool AT, bool BT>
+int gm_gemm_rows(GArgs g, float* scratch, size_t scratch_floats, hipStream_t st) {
+  int maxM = 0, maxN = 0, maxK = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    if (g.p[i].M > maxM) maxM = g.p[i].M;
+    if (g.p[i].N > maxN) maxN = g.p[i].N;
+    if (g.p[i].K > maxK) maxK = g.p[i].K;
+  }
+  static const bool off = [] {
+    const char* v = getenv("OSA_GMLP_ROW_SPLIT");
+    return v != nullptr && v[0] == '0' && v[1] == 0;
+  }();
+  if (off || g.nprob == 0 || maxM > GM_ROW_SPLIT_ROWS || maxK < 512 || scratch == nullptr) return gm_gemm<AT, BT>(g, st);
+  const long tiles = (long)((maxM + 63) / 64) * ((maxN + 63) / 64) * g.nprob;
+  long S = 1;  // a power of two: equal slices, whole K steps
+  while (S < GM_ROW_SPLITS && tiles * S < 320 && maxK / (2 * S) >= 128) S *= 2;
+  if (S < 2) return gm_gemm<AT, BT>(g, st);
+  GEpiArgs ea = {};
+  size_t off_f = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    GProb& p = g.p[i];
+    if (p.accumulate || p.ones_n >= 0 || p.cb) return OSA_EINVAL;  // (weight-gradient problems never come here)
+    int Si = (int)S;
+    while (Si > 1 && p.K / Si < 128) Si /= 2;
+    const size_t need = (size_t)Si * p.M * p.ldc;
+    if (off_f + need > scratch_floats) return gm_gemm<AT, BT>(g, st);
+    GEpi& e = ea.e[ea.n++];
+    e.slab = scratch + off_f; e.C = p.C; e.bias = p.bias; e.aux = p.aux; e.M = p.M; e.N = p.N; e.ldc = p.ldc;
+    e.ldaux = p.ldaux; e.act = p.act; e.dact = p.dact; e.S = Si; e.slab_stride = (long)p.M * p.ldc;
+    p.C = scratch + off_f; p.slab_stride = e.slab_stride; p.splits = Si;
+    p.bias = nullptr; p.aux = nullptr; p.act = -1; p.dact = -1;
+    off_f += (need + 3) / 4 * 4;
+  }
+  g.splits = (int)S;
+  const int rc = gm_gemm<AT, BT>(g, st);
+  if (rc != OSA_OK) return rc;
+  hipLaunchKernelGGL(gm_rows_epilogue_kernel, dim3((unsigned)(((long)maxM * maxN + 255) / 256), ea.n), dim3(256), 0, st, ea);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
 }
 
 GProb gm_prob() {
@@ -855,7 +948,7 @@ int gm_forward(const GLayout& lo, const GWs& w, float* ws, const float* params, 
       p.act = l + 1 < n.L ? n.act : -1;
       g.p[g.nprob++] = p;
     }
-    const int rc = gm_gemm<false, false>(g, st);
+    const int rc = gm_gemm_rows<false, false>(g, w.rsl_floats ? ws + w.rsl : nullptr, w.rsl_floats, st);
     if (rc != OSA_OK) return rc;
   }
   return OSA_OK;
@@ -1033,7 +1126,8 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
       }
     }
     if ((rc = gm_gemm<true, true>(gw, st)) != OSA_OK) return rc;
-    if (gd.nprob > 0 && (rc = gm_gemm<false, true>(gd, st)) != OSA_OK) return rc;
+    if (gd.nprob > 0 && (rc = gm_gemm_rows<false, true>(gd, w.rsl_floats ? ws + w.rsl : nullptr, w.rsl_floats, st)) != OSA_OK)
+      return rc;
     for (int net = 0; net < 3; ++net)
       if (((mask >> net) & 1) && lo.n[net].L - 1 - step > 0) cur[net] ^= 1;
   }
