@@ -407,7 +407,12 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         out['roofline_fvp'] = {
             'bound': 'mfma', 'achieved': round(ach, 4), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None, 'kernel': fvp_events[0][0],
+            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+            # (HBM-side bytes of one product from the committed PMC passes of `bench.py --algo <algo>`, digest-checked;
+            # algorithmic: rows x 4 D_o bytes of observations + the gradient slabs)
+            'traffic': (pmc_traffic(['osa_fvp_kernel', 'osa_fvp_reduce_kernel'], args.algo)
+                        if fvp_events[0][0].startswith('osa_fvp_kernel') else None),
+            'kernel': fvp_events[0][0],
             'launches_timed': len(fvp_events), 'us_per_launch': round(ms * 1e3 / len(fvp_events), 2),
             'rows_per_launch': rows // len(fvp_events), 'flops_per_launch': fl // len(fvp_events),
             'fvp_per_epoch': len(fvp_events) // max(args.steps, 1),

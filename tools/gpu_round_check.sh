@@ -46,6 +46,11 @@ for A in CPO TRPOLag; do
   f=$(find $O/${T}_prof_$A -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_$A.csv; rm -rf $O/${T}_prof_$A
   timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_$A -- python $R/bench.py --algo $A --batch-size 128 --update-iters 10 --steps 1 --warmup 2 --no-cpu-baseline > $O/${T}_pmc_sq_$A.log 2>&1
   python $R/tools/pmc_sq_summary.py $O/${T}_pmc_sq_$A $O/${T}_pmc_sq_mfma_busy_$A | head -16; rm -rf $O/${T}_pmc_sq_$A
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${T}_pmc_${A}_$c -- python $R/bench.py --algo $A --batch-size 128 --update-iters 2 --steps 1 --warmup 2 --no-cpu-baseline > $O/${T}_pmc_${A}_$c.log 2>&1
+  done
+  python $R/tools/pmc_summary.py $O/${T}_pmc_${A}_FETCH_SIZE $O/${T}_pmc_${A}_WRITE_SIZE $O/${T}_pmc_traffic_$A | grep -E "fvp|kernel \|" | head -6
+  rm -rf $O/${T}_pmc_${A}_FETCH_SIZE $O/${T}_pmc_${A}_WRITE_SIZE
 done
 fi
 if [[ $STAGES == *4* ]]; then
