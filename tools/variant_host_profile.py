@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-args = types.SimpleNamespace(envs=4096, steps_per_env=16, kl_early_stop=False, algo='PPOLag')
+args = types.SimpleNamespace(envs=4096, steps_per_env=16, kl_early_stop=False, algo='PPOLag', hidden_sizes=[64, 64])
 with tempfile.TemporaryDirectory() as d:
     algo = bench.make_algo(args, 1, 16384, 8, 64, d)
     sync = lambda: torch.cuda.synchronize()  # noqa: E731
