@@ -10,7 +10,7 @@ from omnisafe_amd import config
 ALGOS = (sys.argv[1].split(',') if len(sys.argv) > 1 else None) or ['PolicyGradient', 'PPO', 'PPOLag', 'PDO', 'IPO', 'CPPOPID', 'P3O', 'FOCOPS', 'CUP', 'PPOSaute',
          'PPOSimmerPID', 'NaturalPG', 'TRPO', 'TRPOLag', 'RCPO', 'TRPOPID', 'OnCRPO', 'CPO', 'PCPO', 'TRPOSaute',
          'TRPOSimmerPID']
-N, T, EPOCHS, WARM = 4096, 16, 3, 1
+N, T, EPOCHS, WARM = 4096, 16, 3, 3
 rows = []
 for algo in ALGOS:
     d = config.get_default_kwargs(algo)
