@@ -692,6 +692,125 @@ def trpo_search_step(actor, obs, act, logp, adv, step_direction, grads, loss_bef
     return step_frac * step_direction, acceptance_step, float(expected_improve), final_kl
 
 
+def _fvp_raw(actor: Actor, fvp_obs: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """natural_pg.py:91-111 up to (not including) the averaging across ranks and the damping term."""
+    actor.zero_grad()
+    q = actor.dist(fvp_obs)
+    with torch.no_grad():
+        p = actor.dist(fvp_obs)
+    kl = torch.distributions.kl.kl_divergence(p, q).mean()
+    params = tuple(actor.parameters())
+    grads = torch.autograd.grad(kl, params, create_graph=True)
+    flat_grad_kl = torch.cat([g.view(-1) for g in grads])
+    kl_p = (flat_grad_kl * v).sum()
+    grads = torch.autograd.grad(kl_p, params, retain_graph=False)
+    return torch.cat([g.contiguous().view(-1) for g in grads])
+
+
+def trpolag_update_dp(ac: ActorCritic, datas: list, lam: float, perms: list, batch_size=128, update_iters=10,
+                      target_kl=0.01, cg_iters=15, cg_damping=0.1, fvp_sample_freq=1, critic_norm_coef=0.001,
+                      max_grad_norm=40.0, use_critic_norm=True, use_max_grad_norm=True, use_cost=True,
+                      total_steps=15, decay=0.8):
+    """One TRPOLag `_update()` as the reference runs it on `world` ranks (natural_pg.py:185-240 -> base/trpo.py:150-222
+    with utils/distributed.py:167-198, 259-275): the actor first, on every rank's FULL batch -- policy gradient
+    averaged over the ranks (avg_grads), every Fisher-vector product averaged over the ranks before the damping term
+    (natural_pg.py:113-117), the line search on the rank averages of loss improvement and KL (trpo.py:118-124) with the
+    finiteness test on the rank's OWN loss -- then `update_iters` passes of critic steps, each clipped per rank and
+    averaged (`_dp_step`).  The replicas are identical, so one copy of every network stands for all ranks; the
+    decisions that use rank-local values are taken as rank 0 takes them (ranks only differ there if a loss is not
+    finite).  `perms[r][i]`: rank r's minibatch order of critic pass i."""
+    world = len(datas)
+    actor = ac.actor
+    w32 = np.float32(world)
+    theta_old = flat_params(actor)
+    advs = [lag_adv_surrogate(d['adv_r'], d['adv_c'], lam) for d in datas]
+    # ---- policy gradient, averaged (dist_sum / world per parameter tensor)
+    losses, gsum = [], None
+    olds = []
+    for r, d in enumerate(datas):
+        actor.zero_grad()
+        loss = pg_loss_pi(actor, d['obs'], d['act'], d['logp'], advs[r])[0]
+        with torch.no_grad():
+            o = actor.dist(d['obs'])
+            olds.append((o.mean.clone(), o.stddev.clone()))
+        loss.backward()
+        g = flat_grads(actor)
+        gsum = g.clone() if gsum is None else gsum + g
+        losses.append(loss.detach().clone())
+    grads = -(gsum / world)
+    loss_before = sum(losses[1:], losses[0].clone()) / world  # dist_avg(loss): a 0-dim float32 tensor
+
+    def fvp_avg(v):
+        acc = None
+        for d in datas:
+            f = _fvp_raw(actor, d['obs'][::fvp_sample_freq], v)
+            acc = f.clone() if acc is None else acc + f
+        return acc / world + v * cg_damping
+
+    x = conjugate_gradients(fvp_avg, grads, cg_iters)
+    xHx = torch.dot(x, fvp_avg(x))
+    alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+    step_direction = x * alpha
+    # ---- line search on the rank averages (trpo.py:93-148)
+    step_frac, acceptance_step, final_kl = 1.0, 0, 0.0
+    expected_improve = grads.dot(step_direction)
+    for step in range(total_steps):
+        set_flat_params(actor, theta_old + step_frac * step_direction)
+        with torch.no_grad():
+            ls, kls = [], []
+            for r, d in enumerate(datas):
+                ls.append(pg_loss_pi(actor, d['obs'], d['act'], d['logp'], advs[r])[0])
+                qd = actor.dist(d['obs'])
+                pd = torch.distributions.Normal(*olds[r])
+                kls.append(torch.distributions.kl.kl_divergence(pd, qd).mean())
+            kl = float((sum(kls[1:], kls[0].clone()) / world).mean())
+            imps = [loss_before - l for l in ls]
+            loss_improve = sum(imps[1:], imps[0].clone()) / world
+        if not torch.isfinite(ls[0]):
+            pass
+        elif loss_improve.item() < 0:
+            pass
+        elif kl > target_kl:
+            pass
+        else:
+            acceptance_step, final_kl = step + 1, kl
+            break
+        step_frac *= decay
+    else:
+        step_direction = torch.zeros_like(step_direction)
+    final_step = step_frac * step_direction
+    set_flat_params(actor, theta_old + final_step)
+    stats = {'xHx': float(xHx), 'alpha': float(alpha), 'acceptance_step': acceptance_step, 'kl': final_kl,
+             'final_step_norm': float(torch.norm(final_step)), 'gradient_norm': float(torch.norm(grads)),
+             'expected_improve': float(expected_improve), 'loss_r': [], 'loss_c': []}
+    # ---- critics (natural_pg.py:205-223): every step clipped per rank, then averaged
+    M = datas[0]['obs'].shape[0]
+    for i in range(update_iters):
+        pm = [torch.as_tensor(perms[r][i], dtype=torch.long) for r in range(world)]
+        for s in range(0, M, batch_size):
+            idx = [pm[r][s:s + batch_size] for r in range(world)]
+
+            def critic_loss(critic, key, r):
+                def fn():
+                    d = datas[r]
+                    loss = torch.nn.functional.mse_loss(critic(d['obs'][idx[r]]), d[key][idx[r]])
+                    if use_critic_norm:
+                        for p in critic.parameters():
+                            loss = loss + p.pow(2).sum() * critic_norm_coef
+                    return loss
+                return fn
+
+            stats['loss_r'].append(_dp_step(ac.reward_critic, ac.reward_critic_optimizer,
+                                            [critic_loss(ac.reward_critic, 'target_value_r', r) for r in range(world)],
+                                            max_grad_norm, use_max_grad_norm))
+            if use_cost:
+                stats['loss_c'].append(_dp_step(ac.cost_critic, ac.cost_critic_optimizer,
+                                                [critic_loss(ac.cost_critic, 'target_value_c', r) for r in range(world)],
+                                                max_grad_norm, use_max_grad_norm))
+    del w32
+    return stats
+
+
 def cpo_determine_case(b_grads, ep_costs, q, r, s, target_kl=0.01):
     """second_order/cpo.py:237-268.  Returns (optim_case, A, B)."""
     if b_grads.dot(b_grads) <= 1e-6 and ep_costs < 0:

@@ -247,6 +247,37 @@ def test_dp2_ppolag_update_vs_reference(golden, tag, obs_dim, act_dim, bs):
     assert np.float32(stats['kl']) == g['r0/log/Train/KL'][-1] == g['r1/log/Train/KL'][-1]
 
 
+def test_dp2_trpolag_update_vs_reference(golden):
+    """BASELINE config 5's algorithm under two ranks: one `_update()` of the UNMODIFIED reference (TRPOLag, SynthAnt 27 / 8,
+    gloo) against the oracle's data-parallel restatement -- policy gradient and every Fisher-vector product averaged over
+    the ranks, the line search on the rank averages, then batch-128 critic steps clipped per rank and averaged
+    (natural_pg.py:91-119, 185-240; base/trpo.py:93-222; utils/distributed.py:167-198).  Everything is float32 tensor
+    arithmetic in the reference's order (a two-operand float sum is commutative): the post-update parameters of all
+    three networks, the trust-region step's logged scalars and every rank's critic losses BIT FOR BIT."""
+    g = golden('dp2_trpolag_ant.npz')
+    world = int(g['world'])
+    assert world == 2 and str(g['algo']) == 'TRPOLag'
+    torch.set_num_threads(1)
+    ac = load_ac(g, 'init/', 27, 8, actor_lr=None, critic_lr=1e-3)  # (TRPOLag.yaml: no actor optimiser, critic lr 0.001)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    perms = [g[f'r{r}/perms'] for r in range(world)]
+    stats = O.trpolag_update_dp(ac, _dp2_datas(g, world), lag.lagrangian_multiplier.item(), perms, batch_size=128,
+                                update_iters=perms[0].shape[0])
+    assert stats['acceptance_step'] == int(g['r0/log/Misc/AcceptanceStep'][0]) == int(g['r1/log/Misc/AcceptanceStep'][0])
+    for key, name in (('xHx', 'Misc/xHx'), ('alpha', 'Misc/Alpha'), ('final_step_norm', 'Misc/FinalStepNorm'),
+                      ('gradient_norm', 'Misc/gradient_norm')):
+        assert np.float32(stats[key]) == g[f'r0/log/{name}'][0] == g[f'r1/log/{name}'][0], key
+    assert np.float32(stats['kl']) == g['r0/log/Train/KL'][-1] == g['r1/log/Train/KL'][-1]
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'post/{net}/{k}']), (net, k, float(np.abs(v.numpy() - g[f'post/{net}/{k}']).max()))
+    for r in range(world):
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_r']]), g[f'r{r}/log/Loss/Loss_reward_critic'])
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_c']]), g[f'r{r}/log/Loss/Loss_cost_critic'])
+
+
 @pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant'])
 def test_dp2_advantage_statistics_vs_reference(golden, tag):
     """VectorOnPolicyBuffer.get() on two ranks: the advantages every rank hands to `_update()` are standardised with
