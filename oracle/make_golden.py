@@ -452,7 +452,7 @@ def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, u
     for k, v in captured.items():
         out[f'data/{k}'] = _np(v)
     if hasattr(algo, '_lagrange'):
-        out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+        out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
     # RandomSampler draws two permutations per pass (see gen_rollout_and_ppolag_update)
     out['perms'] = np.stack([_np(p) for p in rec.perms[::2]]) if rec.perms else np.zeros((0, N * T), np.int64)
     for net in ('actor', 'reward_critic', 'cost_critic'):
@@ -533,6 +533,10 @@ DP2_CONFIGS = [
     # 2 passes x 2 steps of 2048 rows per rank
     ('dp2_ppolag_point_largebatch', 'PPOLag', 'SynthPointGoal1-v0', 16, 256, {'batch_size': 2048},
      {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+    # BASELINE config 3 (8-rank config: CPO on 72 / 2): reward AND cost gradients, both conjugate-gradient solves and
+    # the two-constraint line search on rank averages (second_order/cpo.py:57-462); cost_limit below the synthetic
+    # env's episode cost so that the constraint is active (c > 0: not the trivial TRPO case)
+    ('dp2_cpo_car', 'CPO', 'SynthCarGoal1-v0', 16, 128, {'cost_limit': 0.5}, None),
 ]
 
 
@@ -557,8 +561,9 @@ def _dp2_worker(rank, world, port, spec, tmp):
            'train_cfgs': {'total_steps': spe * 4, 'vector_env_nums': N, 'torch_threads': 2, 'device': 'cpu',
                           'parallel': world},
            'algo_cfgs': dict({'steps_per_epoch': spe}, **ea),
-           'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': os.path.join(tmp, f'log{rank}')},
-           'lagrange_cfgs': lag}
+           'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': os.path.join(tmp, f'log{rank}')}}
+    if lag is not None:
+        cfg['lagrange_cfgs'] = lag
     algo = omnisafe.Agent(algo_name, env_id, custom_cfgs=cfg).agent  # (fork() joins the gloo group)
     assert rdist.world_size() == world and rdist.get_rank() == rank
     assert algo._steps_per_epoch == T and algo._seed == 1000 * rank
@@ -582,13 +587,14 @@ def _dp2_worker(rank, world, port, spec, tmp):
         return r
 
     algo._buf.get = spy_get
-    out['lambda_before'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    has_lag = hasattr(algo, '_lagrange')
+    out['lambda_before'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
     with _Recorder() as rec:
         torch.manual_seed(33 + 1000 * rank)
         algo._update()
     for k, v in captured.items():
         out[f'data/{k}'] = _np(v)
-    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
     out['perms'] = np.stack([_np(p) for p in rec.perms[::2]])  # RandomSampler draws two permutations per pass
     for net in ('actor', 'reward_critic', 'cost_critic'):
         for k, v in _state(getattr(ac, net)).items():
@@ -628,7 +634,7 @@ def gen_dp2_updates(only=None, world=2):
         for k, v in parts[0].items():
             if k.startswith(('init/', 'post/')) or k in ('N', 'T', 'world', 'seed', 'Jc', 'lambda_before', 'lambda_after'):
                 for r in range(1, world):
-                    assert np.array_equal(v, parts[r][k]), (tag, k, 'differs between ranks')
+                    assert np.array_equal(v, parts[r][k], equal_nan=True), (tag, k, 'differs between ranks')
                 out[k] = v
         for r in range(world):
             for k, v in parts[r].items():

@@ -9,7 +9,8 @@ path of world_size > 1: Lagrange step on the cross-rank mean cost, then
 
   replicated            all-gathered rollout + cooperative persistent pass (osa_ppo_dp_pass_placed), 60 / 2
   replicated-wide-split osa_ppo_split_dp_pass, 376 / 17 (BASELINE config 4)
-  replicated + chunked  osa_ppo_dp_chunked_pass for TRPOLag's batch-128 critics, 27 / 8 (BASELINE config 5), behind the
+  replicated + chunked  osa_ppo_dp_chunked_pass for TRPOLag's / CPO's batch-128 critics, 27 / 8 and 72 / 2 (BASELINE
+                        configs 5 and 3), behind the
                         FVP / CG / line search whose products and losses are rank-averaged (natural_pg.py:112,
                         trpo.py:114-118, 181-185)
   replicated-steps      two launches per step from a hipGraph
@@ -55,12 +56,16 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     g = dict(np.load(os.path.join(GOLDEN, f'{tag}.npz'), allow_pickle=False))
     N, T, algo_name, env_id = int(g['N']), int(g['T']), str(g['algo']), str(g['env_id'])
     assert int(g['world']) == world
-    trust_region = algo_name == 'TRPOLag'
+    trust_region = algo_name in ('TRPOLag', 'CPO')
     M = N * T
     bs = 128 if trust_region else (2048 if tag.endswith('largebatch') else 64)
     cfg = {'seed': 0, 'train_cfgs': {'device': 'cuda:0', 'total_steps': 4 * world * M, 'vector_env_nums': N},
            'algo_cfgs': {'steps_per_epoch': world * M, 'update_iters': 2, 'kl_early_stop': False, 'batch_size': bs},
-           'logger_cfgs': {'log_dir': os.path.join(tmpdir, f'r{rank}'), 'verbose': False}, 'lagrange_cfgs': LAG}
+           'logger_cfgs': {'log_dir': os.path.join(tmpdir, f'r{rank}'), 'verbose': False}}
+    if algo_name == 'CPO':
+        cfg['algo_cfgs']['cost_limit'] = 0.5  # (as the golden: the constraint is violated -> the recovery case)
+    else:
+        cfg['lagrange_cfgs'] = LAG
     algo = omnisafe_amd.Agent(algo_name, env_id, custom_cfgs=cfg).agent
     assert dist.world_size() == world and algo._steps_per_epoch == T and algo._seed == 1000 * rank
     ac = algo._actor_critic
@@ -86,7 +91,8 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     assert up.last_path == want_path, (up.last_path, want_path)
     for k, v in (want or {}).items():
         assert up._dp.get(k) == v, (k, up._dp.get(k), v)
-    np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    if hasattr(algo, '_lagrange'):
+        np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
 
     def max_err(net):
         return max(float(np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']).max())
@@ -100,6 +106,10 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     if trust_region:
         lg = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
         assert int(lg('Misc/AcceptanceStep')[-1]) == int(g['r0/log/Misc/AcceptanceStep'][-1])
+        if algo_name == 'CPO':  # the same case of the two-constraint problem (cpo.py:291-330), the same multipliers
+            assert int(lg('Misc/OptimCase')[-1]) == int(g['r0/log/Misc/OptimCase'][-1])
+            for key in ('Misc/q', 'Misc/r', 'Misc/s', 'Misc/Nu_star', 'Misc/cost_gradient_norm'):
+                np.testing.assert_allclose(lg(key)[-1], g['r0/log/' + key][-1], rtol=2e-2, err_msg=key)
         for key, rtol in (('Misc/Alpha', 1e-2), ('Misc/xHx', 1e-2), ('Misc/gradient_norm', 1e-3),
                           ('Misc/FinalStepNorm', 2e-2)):
             np.testing.assert_allclose(lg(key)[-1], g['r0/log/' + key][-1], rtol=rtol, err_msg=key)
@@ -134,6 +144,9 @@ CASES = [
     ('dp2_ppolag_humanoid', 'allreduce', 'per-step', None),
     ('dp2_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
     ('dp2_trpolag_ant', 'allreduce', 'per-step', None),
+    # BASELINE config 3: CPO, 72 / 2 -- reward and cost gradients, two CG solves, the recovery case, all on rank averages
+    ('dp2_cpo_car', 'replicated', 'replicated', {'chunked': True}),
+    ('dp2_cpo_car', 'allreduce', 'per-step', None),
     ('dp2_ppolag_point_largebatch', 'replicated', 'dp-large-batch', None),
     ('dp2_ppolag_point_largebatch', 'allreduce', 'dp-large-batch', None),
     # general networks (csrc/general_mlp.hip) under data parallelism: gradient GEMMs -> local clip -> flat all-reduce
