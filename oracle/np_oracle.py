@@ -870,6 +870,125 @@ def cpo_step_direction(optim_case, xHx, x, A, B, q, p, r, s, ep_costs, target_kl
     return step_direction, lambda_star, nu_star
 
 
+def cpo_update_dp(ac: ActorCritic, datas: list, ep_costs: float, perms: list, batch_size=128, update_iters=10,
+                  target_kl=0.01, cg_iters=15, cg_damping=0.1, fvp_sample_freq=1, critic_norm_coef=0.001,
+                  max_grad_norm=40.0, use_critic_norm=True, use_max_grad_norm=True, total_steps=20, decay=0.8):
+    """One CPO `_update()` as the reference runs it on `world` ranks (second_order/cpo.py:57-462 under
+    utils/distributed.py:167-198, 259-275): reward AND cost policy gradients averaged over the ranks, every
+    Fisher-vector product of both conjugate-gradient solves averaged before the damping term, the case analysis on the
+    averaged quantities with `ep_costs` = cross-rank mean episode cost - cost limit, the two-constraint line search on
+    the rank averages of reward improvement, cost difference and KL (cpo.py:106-178), then the critic passes of
+    `trpolag_update_dp`.  One copy of every network stands for all (identical) replicas."""
+    world = len(datas)
+    actor = ac.actor
+    theta_old = flat_params(actor)
+
+    def avg(ts):
+        return sum(ts[1:], ts[0].clone()) / world
+
+    def loss_cost_of(d):
+        dist = actor.dist(d['obs'])
+        ratio = torch.exp(dist.log_prob(d['act']).sum(axis=-1) - d['logp'])
+        return (ratio * d['adv_c']).mean()
+
+    def averaged_gradient(loss_fn):
+        ls, gsum = [], None
+        for d in datas:
+            actor.zero_grad()
+            loss = loss_fn(d)
+            loss.backward()
+            g = flat_grads(actor)
+            gsum = g.clone() if gsum is None else gsum + g
+            ls.append(loss.detach().clone())
+        return avg(ls), gsum / world
+
+    olds = []
+    with torch.no_grad():
+        for d in datas:
+            o = actor.dist(d['obs'])
+            olds.append((o.mean.clone(), o.stddev.clone()))
+    loss_reward_before, g_r = averaged_gradient(lambda d: pg_loss_pi(actor, d['obs'], d['act'], d['logp'], d['adv_r'])[0])
+    grads = -g_r
+
+    def fvp_avg(v):
+        acc = None
+        for d in datas:
+            f = _fvp_raw(actor, d['obs'][::fvp_sample_freq], v)
+            acc = f.clone() if acc is None else acc + f
+        return acc / world + v * cg_damping
+
+    x = conjugate_gradients(fvp_avg, grads, cg_iters)
+    xHx = x.dot(fvp_avg(x))
+    alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+    loss_cost_before, b_grads = averaged_gradient(loss_cost_of)
+    p = conjugate_gradients(fvp_avg, b_grads, cg_iters)
+    q = xHx
+    r = grads.dot(p)
+    s = b_grads.dot(p)
+    optim_case, A, B = cpo_determine_case(b_grads, ep_costs, q, r, s, target_kl)
+    step_direction, lambda_star, nu_star = cpo_step_direction(optim_case, xHx, x, A, B, q, p, r, s, ep_costs, target_kl)
+    # ---- line search (cpo.py:106-178)
+    step_frac, acceptance_step = 1.0, 0
+    kl = torch.zeros(1)
+    for step in range(total_steps):
+        set_flat_params(actor, theta_old + step_frac * step_direction)
+        acceptance_step = step + 1
+        with torch.no_grad():
+            lr_, lc_, kls = [], [], []
+            for i, d in enumerate(datas):
+                lr_.append(pg_loss_pi(actor, d['obs'], d['act'], d['logp'], d['adv_r'])[0])
+                lc_.append(loss_cost_of(d))
+                kls.append(torch.distributions.kl.kl_divergence(torch.distributions.Normal(*olds[i]),
+                                                                actor.dist(d['obs'])).mean())
+            kl = avg(kls)
+            loss_reward_improve = avg([loss_reward_before - l for l in lr_])
+            loss_cost_diff = avg([l - loss_cost_before for l in lc_])
+        if not torch.isfinite(kl):
+            continue
+        if loss_reward_improve < 0 if optim_case > 1 else False:
+            pass
+        elif loss_cost_diff > max(-ep_costs, 0):
+            pass
+        elif kl > target_kl:
+            pass
+        else:
+            break
+        step_frac *= decay
+    else:
+        step_direction = torch.zeros_like(step_direction)
+        acceptance_step = 0
+    final_step = step_frac * step_direction
+    set_flat_params(actor, theta_old + final_step)
+    stats = {'optim_case': int(optim_case), 'xHx': float(xHx), 'alpha': float(alpha), 'q': float(q), 'r': float(r),
+             's': float(s), 'A': float(A), 'B': float(B), 'lambda_star': float(lambda_star), 'nu_star': float(nu_star),
+             'acceptance_step': acceptance_step, 'kl': float(kl), 'final_step_norm': float(final_step.norm()),
+             'gradient_norm': float(torch.norm(grads)), 'cost_gradient_norm': float(torch.norm(b_grads)),
+             'loss_r': [], 'loss_c': []}
+    M = datas[0]['obs'].shape[0]
+    for i in range(update_iters):
+        pm = [torch.as_tensor(perms[k][i], dtype=torch.long) for k in range(world)]
+        for s0 in range(0, M, batch_size):
+            idx = [pm[k][s0:s0 + batch_size] for k in range(world)]
+
+            def critic_loss(critic, key, k):
+                def fn():
+                    d = datas[k]
+                    loss = torch.nn.functional.mse_loss(critic(d['obs'][idx[k]]), d[key][idx[k]])
+                    if use_critic_norm:
+                        for w in critic.parameters():
+                            loss = loss + w.pow(2).sum() * critic_norm_coef
+                    return loss
+                return fn
+
+            stats['loss_r'].append(_dp_step(ac.reward_critic, ac.reward_critic_optimizer,
+                                            [critic_loss(ac.reward_critic, 'target_value_r', k) for k in range(world)],
+                                            max_grad_norm, use_max_grad_norm))
+            stats['loss_c'].append(_dp_step(ac.cost_critic, ac.cost_critic_optimizer,
+                                            [critic_loss(ac.cost_critic, 'target_value_c', k) for k in range(world)],
+                                            max_grad_norm, use_max_grad_norm))
+    return stats
+
+
 # --------------------------------------------------------------------------------------------------
 # a1: OnPolicyAdapter.rollout (omnisafe/adapter/onpolicy_adapter.py:58-136) on a *recorded* env trace
 # --------------------------------------------------------------------------------------------------

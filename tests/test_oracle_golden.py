@@ -278,6 +278,36 @@ def test_dp2_trpolag_update_vs_reference(golden):
         np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_c']]), g[f'r{r}/log/Loss/Loss_cost_critic'])
 
 
+def test_dp2_cpo_update_vs_reference(golden):
+    """BASELINE config 3's algorithm under two ranks: one `_update()` of the UNMODIFIED reference (CPO, SynthCarGoal 72 / 2,
+    cost limit below the episode cost: the infeasible-recovery case) against `cpo_update_dp` -- both policy gradients and
+    every Fisher-vector product of both conjugate-gradient solves averaged over the ranks, the case analysis and the
+    two-constraint line search on rank averages (second_order/cpo.py:57-462), clip-then-average critic steps: the
+    optimisation case, every logged scalar of the step and the post-update parameters of all three networks BIT FOR
+    BIT."""
+    g = golden('dp2_cpo_car.npz')
+    world = int(g['world'])
+    assert world == 2 and str(g['algo']) == 'CPO'
+    torch.set_num_threads(1)
+    ac = load_ac(g, 'init/', 72, 2, actor_lr=None, critic_lr=1e-3)
+    perms = [g[f'r{r}/perms'] for r in range(world)]
+    ep_costs = float(g['Jc']) - 0.5
+    stats = O.cpo_update_dp(ac, _dp2_datas(g, world), ep_costs, perms, batch_size=128, update_iters=perms[0].shape[0])
+    assert stats['optim_case'] == int(g['r0/log/Misc/OptimCase'][0]) == 0  # c^2 / s - 2 delta > 0 and c > 0: recovery
+    assert stats['acceptance_step'] == int(g['r0/log/Misc/AcceptanceStep'][0])
+    for key, name in (('xHx', 'xHx'), ('alpha', 'Alpha'), ('q', 'q'), ('r', 'r'), ('s', 's'), ('A', 'A'), ('B', 'B'),
+                      ('lambda_star', 'Lambda_star'), ('nu_star', 'Nu_star'), ('final_step_norm', 'FinalStepNorm'),
+                      ('gradient_norm', 'gradient_norm'), ('cost_gradient_norm', 'cost_gradient_norm')):
+        assert np.float32(stats[key]) == g[f'r0/log/Misc/{name}'][0] == g[f'r1/log/Misc/{name}'][0], key
+    assert np.float32(stats['kl']) == g['r0/log/Train/KL'][-1]
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'post/{net}/{k}']), (net, k, float(np.abs(v.numpy() - g[f'post/{net}/{k}']).max()))
+    for r in range(world):
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_r']]), g[f'r{r}/log/Loss/Loss_reward_critic'])
+        np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_c']]), g[f'r{r}/log/Loss/Loss_cost_critic'])
+
+
 @pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant'])
 def test_dp2_advantage_statistics_vs_reference(golden, tag):
     """VectorOnPolicyBuffer.get() on two ranks: the advantages every rank hands to `_update()` are standardised with
