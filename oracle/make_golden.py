@@ -641,6 +641,7 @@ def gen_dp2_updates(only=None, world=2):
                 if k.startswith(('data/', 'raw/', 'log/')) or k in ('perms', 'ep_cost_window'):
                     out[f'r{r}/{k}'] = v
         out['algo'], out['env_id'] = spec[1], spec[2]
+        tag = tag.replace('dp2_', f'dp{world}_')
         np.savez_compressed(os.path.join(OUT, f'{tag}.npz'), **out)
         moved = max(float(np.abs(out[k] - out['init/' + k[5:]]).max()) for k in out if k.startswith('post/actor/'))
         print(tag, 'Jc', out['Jc'], 'lambda', out['lambda_before'], '->', out['lambda_after'], 'perms',
@@ -912,6 +913,8 @@ if __name__ == '__main__':
         gen_config_shape_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp2':
         gen_dp2_updates(only=sys.argv[2:] or None)
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'dp4':  # the same recordings with FOUR ranks -> tests/golden/dp4_<...>.npz
+        gen_dp2_updates(only=sys.argv[2:] or ['dp2_ppolag_point', 'dp2_trpolag_ant'], world=4)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
         if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there
             os.replace(os.path.join(OUT, 'learning_reach.json'), os.path.join(OUT, '_learning_part_0prev.json'))

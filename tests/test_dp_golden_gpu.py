@@ -101,7 +101,7 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     errs = {n: max_err(n) for n in ('actor', 'reward_critic', 'cost_critic')}
     moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
     if rank == 0:
-        print(tag, dp_mode, up.last_path, 'max |param - 2-rank reference|:', errs, 'actor moved', moved, flush=True)
+        print(tag, dp_mode, up.last_path, f'max |param - {world}-rank reference|:', errs, 'actor moved', moved, flush=True)
     assert moved > 1e-3
     if trust_region:
         lg = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
@@ -160,3 +160,16 @@ CASES = [
 @pytest.mark.parametrize('tag,dp_mode,want_path,want', CASES)
 def test_two_ranks_reproduce_the_two_rank_reference(tmp_path, tag, dp_mode, want_path, want):
     mp.spawn(_worker, args=(2, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize('tag,dp_mode,want_path,want', [
+    ('dp4_ppolag_point', 'replicated', 'replicated', {'chunked': False}),
+    ('dp4_ppolag_point', 'allreduce', 'per-step', None),
+    ('dp4_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+])
+def test_four_ranks_reproduce_the_four_rank_reference(tmp_path, tag, dp_mode, want_path, want):
+    """The same recordings from a FOUR-rank run of the unmodified reference (`oracle/make_golden.py dp4`): a sum of four
+    rank gradients is no longer order-free -- the cooperative pass adds them in rank order, gloo's ring in its own -- so
+    this pins the rank-ordered reduction, the 1 / W scaling and the rank indexing beyond the two-rank case, at the same
+    tolerances."""
+    mp.spawn(_worker, args=(4, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=4, join=True)

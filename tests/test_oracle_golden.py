@@ -308,6 +308,35 @@ def test_dp2_cpo_update_vs_reference(golden):
         np.testing.assert_array_equal(np.float32([s[r] for s in stats['loss_c']]), g[f'r{r}/log/Loss/Loss_cost_critic'])
 
 
+def test_dp4_updates_vs_four_rank_reference(golden):
+    """FOUR ranks of the unmodified reference (`oracle/make_golden.py dp4`): a sum over four ranks is no longer order-free
+    (gloo's ring adds in its own order, the restatement in rank order), so the post-update parameters agree to float32
+    round-off (measured 3e-8) instead of bit for bit; the line-search decision and the multiplier are identical."""
+    torch.set_num_threads(1)
+    g = golden('dp4_ppolag_point.npz')
+    assert int(g['world']) == 4
+    ac = load_ac(g, 'init/', 60, 2)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    O.ppolag_update_dp(ac, _dp2_datas(g, 4), lag.lagrangian_multiplier.item(), [g[f'r{r}/perms'] for r in range(4)],
+                       batch_size=64, update_iters=2, kl_early_stop=False)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=2e-7, err_msg=f'{net}/{k}')
+    g = golden('dp4_trpolag_ant.npz')
+    ac = load_ac(g, 'init/', 27, 8, actor_lr=None, critic_lr=1e-3)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    stats = O.trpolag_update_dp(ac, _dp2_datas(g, 4), lag.lagrangian_multiplier.item(),
+                                [g[f'r{r}/perms'] for r in range(4)], batch_size=128, update_iters=2)
+    assert stats['acceptance_step'] == int(g['r0/log/Misc/AcceptanceStep'][0])
+    np.testing.assert_allclose(stats['xHx'], g['r0/log/Misc/xHx'][0], rtol=1e-5)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=2e-7, err_msg=f'{net}/{k}')
+
+
 @pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant'])
 def test_dp2_advantage_statistics_vs_reference(golden, tag):
     """VectorOnPolicyBuffer.get() on two ranks: the advantages every rank hands to `_update()` are standardised with
