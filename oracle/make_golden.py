@@ -915,6 +915,8 @@ if __name__ == '__main__':
         gen_dp2_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp4':  # the same recordings with FOUR ranks -> tests/golden/dp4_<...>.npz
         gen_dp2_updates(only=sys.argv[2:] or ['dp2_ppolag_point', 'dp2_trpolag_ant'], world=4)
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'dp8':  # EIGHT ranks (the world size BASELINE.json quotes): dp8_<...>.npz
+        gen_dp2_updates(only=sys.argv[2:] or ['dp2_ppolag_point'], world=8)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
         if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there
             os.replace(os.path.join(OUT, 'learning_reach.json'), os.path.join(OUT, '_learning_part_0prev.json'))

@@ -124,7 +124,15 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
                   for net in ('actor', 'reward_critic', 'cost_critic') for k, v in getattr(ac, net).state_dict().items())
         assert big <= 8 and max(errs.values()) < 1.5e-5, (big, errs)
     else:
-        assert max(errs.values()) < 2e-6, errs
+        if world >= 8:
+            # eight-term rank sums in MFMA / rank order v gloo's ring order, through 64 chained Adam steps: all but a
+            # handful of the 22 k parameters inside the single-process tolerance, the rest within a hundredth of ONE
+            # learning-rate step (measured: 1 element at 2.2e-6)
+            big = sum(int((np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']) > 2e-6).sum())
+                      for net in ('actor', 'reward_critic', 'cost_critic') for k, v in getattr(ac, net).state_dict().items())
+            assert big <= 4 and max(errs.values()) < 5e-6, (big, errs)
+        else:
+            assert max(errs.values()) < 2e-6, errs
         np.testing.assert_allclose(float(algo._logger._data['Train/KL'][-1]), g['r0/log/Train/KL'][-1], rtol=1e-2,
                                    atol=1e-7)
     # replicas identical
@@ -173,3 +181,13 @@ def test_four_ranks_reproduce_the_four_rank_reference(tmp_path, tag, dp_mode, wa
     this pins the rank-ordered reduction, the 1 / W scaling and the rank indexing beyond the two-rank case, at the same
     tolerances."""
     mp.spawn(_worker, args=(4, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=4, join=True)
+
+
+@pytest.mark.parametrize('dp_mode,want_path', [('replicated', 'replicated'), ('allreduce', 'per-step')])
+def test_eight_ranks_reproduce_the_eight_rank_reference(tmp_path, dp_mode, want_path):
+    """BASELINE.json quotes its 8-GPU configs at world size 8: the unmodified reference run with EIGHT ranks
+    (`oracle/make_golden.py dp8`, PPOLag 60 / 2, 2 x 32 optimiser steps of 8 x 64 rows) against eight real ranks sharing
+    the test box's GPU -- the cooperative pass with 24 resident workgroups, and the per-step all-reduce path."""
+    mp.spawn(_worker, args=(8, _free_port(), 'dp8_ppolag_point', dp_mode, want_path, None, str(tmp_path)), nprocs=8,
+             join=True)
+

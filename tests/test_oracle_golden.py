@@ -309,7 +309,7 @@ def test_dp2_cpo_update_vs_reference(golden):
 
 
 def test_dp4_updates_vs_four_rank_reference(golden):
-    """FOUR ranks of the unmodified reference (`oracle/make_golden.py dp4`): a sum over four ranks is no longer order-free
+    """FOUR (and, for PPOLag, EIGHT) ranks of the unmodified reference (`oracle/make_golden.py dp4` / `dp8`): a sum over four ranks is no longer order-free
     (gloo's ring adds in its own order, the restatement in rank order), so the post-update parameters agree to float32
     round-off (measured 3e-8) instead of bit for bit; the line-search decision and the multiplier are identical."""
     torch.set_num_threads(1)
@@ -320,6 +320,17 @@ def test_dp4_updates_vs_four_rank_reference(golden):
     lag.update_lagrange_multiplier(float(g['Jc']))
     assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
     O.ppolag_update_dp(ac, _dp2_datas(g, 4), lag.lagrangian_multiplier.item(), [g[f'r{r}/perms'] for r in range(4)],
+                       batch_size=64, update_iters=2, kl_early_stop=False)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=2e-7, err_msg=f'{net}/{k}')
+    g = golden('dp8_ppolag_point.npz')  # (EIGHT ranks: the world size BASELINE.json quotes)
+    assert int(g['world']) == 8
+    ac = load_ac(g, 'init/', 60, 2)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    O.ppolag_update_dp(ac, _dp2_datas(g, 8), lag.lagrangian_multiplier.item(), [g[f'r{r}/perms'] for r in range(8)],
                        batch_size=64, update_iters=2, kl_early_stop=False)
     for net in ('actor', 'reward_critic', 'cost_critic'):
         for k, v in getattr(ac, net).state_dict().items():
