@@ -348,9 +348,10 @@ def test_dp4_updates_vs_four_rank_reference(golden):
             np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=2e-7, err_msg=f'{net}/{k}')
 
 
-@pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant'])
+@pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant', 'dp2_cpo_car', 'dp4_ppolag_point',
+                                 'dp8_ppolag_point'])
 def test_dp2_advantage_statistics_vs_reference(golden, tag):
-    """VectorOnPolicyBuffer.get() on two ranks: the advantages every rank hands to `_update()` are standardised with
+    """VectorOnPolicyBuffer.get() on two (four, eight) ranks: the advantages every rank hands to `_update()` are standardised with
     the GLOBAL mean / population std (utils/distributed.py:382-392)."""
     g = golden(f'{tag}.npz')
     world = int(g['world'])
