@@ -2,8 +2,10 @@
 """Headline benchmark: env-steps/sec (rollout + update), PPO-Lag on SafetyPointGoal1 shapes.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W      # launches its own N ranks (one per GPU, RCCL), like the
+                                                       # reference's fork(): omnisafe/utils/distributed.py:121-137
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # (same thing, ranks started by torchrun)
 
 A "step" is ONE EPOCH of the hot path on one batch of synthetic input: rollout of T = 16 vector steps
 over 4096 device-resident envs per GPU (65 536 env-steps per GPU), dual GAE + standardisation, then the
@@ -80,7 +82,45 @@ def parse():
     # passes of the reference's update actually executed by the cpu_baseline leg (of --update-iters): 4 passes
     # + the rollout are ~13 s on the GPU box's host (2.7 s rollout + 2.55 s per pass at 16 threads)
     ap.add_argument('--ref-sample-iters', type=int, default=4)
+    # data-parallel update mode of the headline line under --gpus N > 1 (omnisafe_amd/update.py): 'replicated' (default:
+    # rollouts all-gathered once per epoch, every GPU runs the whole global optimiser chain, no per-step collective),
+    # 'replicated-steps', 'allreduce' (per optimiser step: gradient kernel -> ONE flat RCCL all-reduce -> Adam: the
+    # reference's structure, policy_gradient.py:437-443).  With N > 1 the line also carries an `allreduce_mode` object
+    # (the same workload in the per-step all-reduce mode, --allreduce-steps epochs) unless --no-allreduce-leg, and the
+    # large-batch `throughput_variant` (one flat RCCL all-reduce per step inside the captured update graph).
+    ap.add_argument('--dp-mode', default=None, choices=['replicated', 'replicated-steps', 'allreduce'])
+    ap.add_argument('--allreduce-steps', type=int, default=2)
+    ap.add_argument('--no-allreduce-leg', action='store_true')
+    # the N = 1 value of the same command (env-steps/s): adds efficiency_vs_n1 = value / (N x n1) to the line
+    ap.add_argument('--n1-value', type=float, default=None)
+    ap.add_argument('--n1-variant-value', type=float, default=None)
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) WITHOUT torchrun's environment: start the N ranks ourselves, as the reference's
+    `fork` does (omnisafe/utils/distributed.py:121-137 re-executes the script under `torchrun --nproc_per_node N`).
+    One process per GPU over `nccl` (= RCCL); when the box has fewer than N devices the launch is refused unless the
+    test hook OSA_SINGLE_DEVICE_RANKS=1 is set (all ranks on cuda:0 over gloo: a code-path check, not a measurement --
+    the printed line then says rccl_ranks 0)."""
+    import socket
+    import subprocess
+
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not env.get('OSA_SINGLE_DEVICE_RANKS'):
+        print(f'bench.py: --gpus {args.gpus} but this box exposes {ndev} GPU(s) (set OSA_SINGLE_DEVICE_RANKS=1 to run '
+              f'{args.gpus} ranks on one device over gloo as a code-path check)', file=sys.stderr)
+        return 2
+    if env.get('OSA_SINGLE_DEVICE_RANKS'):
+        env.setdefault('OSA_DIST_BACKEND', 'gloo')  # RCCL refuses two ranks on one device
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def make_algo(args, world, batch_size, update_iters, epochs, log_dir):
@@ -344,6 +384,10 @@ def cpu_baseline_reference(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        sys.exit(self_launch(args))  # the driver's `python bench.py --gpus N`: launch the ranks ourselves
+    if args.dp_mode:
+        os.environ['OSA_DP_MODE'] = args.dp_mode
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -382,6 +426,11 @@ def main():
                                 f'update_iters={args.update_iters}, kl_early_stop='
                                 f'{bool(args.kl_early_stop)}; 1 step = 1 epoch (rollout+GAE+update)'),
                    'env_steps_per_step': world * per_gpu_steps, 'parallelism': f'dp{world}',
+                   # (explicit keys: the driver's record truncates `workload`)
+                   'algo': args.algo, 'obs_dim': OBS_DIM, 'act_dim': ACT_DIM, 'hidden_sizes': list(args.hidden_sizes),
+                   'envs_per_gpu': args.envs, 'steps_per_env': args.steps_per_env,
+                   'steps_per_epoch_per_gpu': per_gpu_steps, 'batch_size': args.batch_size,
+                   'update_iters': args.update_iters, 'kl_early_stop': bool(args.kl_early_stop),
                    'dp_mode': (os.environ.get('OSA_DP_MODE', 'replicated') if world > 1 else None),
                    'update_path': algo._updater.last_path,
                    'rollout_path': ('graph of launches' if getattr(algo._env, 'last_rollout_graphed', False)
@@ -389,6 +438,15 @@ def main():
     }
     if args.algo != 'PPOLag':
         out['metric'] = f'env-steps/sec (rollout+update), {args.algo} SafetyPointGoal1 shapes'
+    import torch.distributed as tdist
+
+    backend = tdist.get_backend() if tdist.is_initialized() else None
+    # ranks that talk over RCCL (`nccl` backend, one device each); 0 = single process, or the one-device gloo test hook
+    out['dist_backend'] = backend
+    out['rccl_ranks'] = tdist.get_world_size() if backend == 'nccl' else 0
+    out['devices_visible'] = torch.cuda.device_count()
+    if args.n1_value:
+        out['efficiency_vs_n1'] = round(value / (world * args.n1_value), 4)
     # (the trust-region family updates critics only in the minibatch loop: its events carry 2 of the 3 networks)
     out['roofline'] = roofline_from_events(events, int(algo._updater.batch_size))
     if hasattr(algo, '_solver') and not algo._updater.update_actor:
@@ -422,6 +480,30 @@ def main():
     # (without early stop only the last pass's KL is evaluated; with it, one per pass: update.py)
     out['whole_path'] = whole_path(args, value, world, args.update_iters,
                                    args.update_iters if args.kl_early_stop else 1)
+    headline_mode = os.environ.get('OSA_DP_MODE', 'replicated')
+    if world > 1 and not args.no_allreduce_leg and headline_mode != 'allreduce' and args.algo == 'PPOLag':
+        # the same workload in the reference's own structure: per optimiser step gradient kernel -> ONE flat RCCL
+        # all-reduce of the three networks' clipped gradients -> Adam (policy_gradient.py:437-443 with 1 message for 19);
+        # every rank runs only its own 64-row minibatch.  A few epochs: a step waits for the collective's latency.
+        del algo
+        torch.cuda.empty_cache()
+        os.environ['OSA_DP_MODE'] = 'allreduce'
+        a_algo = make_algo(args, world, args.batch_size, args.update_iters, args.allreduce_steps + 3, log_dir)
+        run_epochs(a_algo, 2, lambda: torch.cuda.synchronize(dev))
+        a_dt = timed(a_algo, args.allreduce_steps, 0, world, dev)  # (no per-step events: 40 960 steps per epoch)
+        a_val = world * per_gpu_steps * args.allreduce_steps / a_dt
+        n_steps = args.update_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
+        out['allreduce_mode'] = {
+            'workload': 'same workload, dp_mode=allreduce (gradient kernel -> flat all-reduce -> Adam per optimiser step)',
+            'value': round(a_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+            'ms_per_step': round(a_dt / args.allreduce_steps * 1e3, 3), 'steps': args.allreduce_steps, 'warmup': 2,
+            'update_path': a_algo._updater.last_path,
+            'us_per_optimiser_step_incl_collective': round(a_dt / args.allreduce_steps * 1e6 / n_steps, 3),
+            'message_bytes': 3 * 8448 * 4 if not general else None}
+        if args.n1_value:
+            out['allreduce_mode']['efficiency_vs_n1'] = round(a_val / (world * args.n1_value), 4)
+        os.environ['OSA_DP_MODE'] = headline_mode
+        algo = a_algo
     if not args.no_variant and args.algo == 'PPOLag':
         # the large-batch setting on EVERY rank (round 4): under world_size > 1 the update is the data-parallel
         # large-batch pass -- partial gradients, local clip, ONE flat RCCL all-reduce, Adam per step, the whole pass
@@ -447,6 +529,8 @@ def main():
             'update_path': v_algo._updater.last_path,
             'roofline': roofline_from_events(v_events, vb),
             'whole_path': whole_path(args, v_val, world, 8, 1)}
+        if args.n1_variant_value:
+            out['throughput_variant']['efficiency_vs_n1'] = round(v_val / (world * args.n1_variant_value), 4)
         if world > 1:
             # per-step exchange time = what a step costs beyond the single-GPU step measured on the same kernels
             # (profiles/r4_dp_large_batch_world1_rccl.json: +8.9 us at world 1, no wire time)

@@ -197,8 +197,12 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         st = self.__dict__.setdefault('_rollout_graph', {})
         # every by-value launch argument that can change between epochs is part of the key (a changed seed
         # re-captures instead of silently replaying the old stream)
+        # (general networks: the layer-wise path's scratch block, whose address the captured launches bake in --
+        # gmlp_ws() grows by reallocation, so a larger request after capture must re-capture, never replay)
+        gws = getattr(agent, '_gws', None)
         key = (T, buffer.data['obs'].data_ptr(), agent.params.data_ptr(), self._num_envs,
-               getattr(self._env, '_seed', None), getattr(agent, 'seed', None))
+               getattr(self._env, '_seed', None), getattr(agent, 'seed', None),
+               int(gws.data_ptr()) if gws is not None else 0)
         if st.get('key') != key:  # first epoch (also sets kernel attributes, which must not happen under capture)
             st.clear()
             st.update(key=key, graph=None, failed=False)
@@ -388,7 +392,10 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
             # Host env (HostEnvBridge): the bootstrap values and the episode accounting of this step are not needed
             # for the next action -- they are handed to the bridge, which enqueues them behind the next action's
             # device-to-host copy: the device does them while the host steps the env (round 4; device envs: in line)
-            if getattr(self._env, 'host_resident', False) and not epoch_end and os.environ.get('OSA_HOST_DEFER', '1') != '0':
+            # (`defer` is a METHOD of the bridge: it resolves through the `__getattr__` forwarding of env wrappers such
+            # as _EarlyTerminatedEnv, where an attribute ASSIGNMENT would land on the wrapper and never be seen)
+            defer = getattr(self._env, 'defer', None) if getattr(self._env, 'host_resident', False) else None
+            if callable(defer) and not epoch_end and os.environ.get('OSA_HOST_DEFER', '1') != '0':
                 # (self._final_norm is rewritten by the NEXT step's normalisation, which is enqueued behind this work)
                 final_src = self._final_norm if have_final else None
 
@@ -403,7 +410,7 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
                         _lib.ptr(ep['cost'][t]), _lib.ptr(ep['len'][t]), _lib.ptr(reward_row), _lib.ptr(cost_row),
                         _lib.stream_ptr()), 'osa_rollout_post_step')
 
-                self._env.deferred_device_work = post_step
+                defer(post_step)
                 buffer.advance()
                 continue
             vfinal = agent.values(self._final_norm) if have_final else (None, None)

@@ -118,6 +118,18 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
         c = self._cfgs
         start_time = time.time()
         self._logger.log('INFO: Start training')
+        try:
+            self._learn_epochs(c, start_time)
+        finally:
+            self._logger.flush()  # a deferred csv row (logger.py) reaches the disk even when an epoch raises
+        ep_ret = self._logger.get_stats('Metrics/EpRet')[0]
+        ep_cost = self._logger.get_stats('Metrics/EpCost')[0]
+        ep_len = self._logger.get_stats('Metrics/EpLen')[0]
+        self._logger.close()
+        self._env.close()
+        return ep_ret, ep_cost, ep_len
+
+    def _learn_epochs(self, c, start_time: float) -> None:
         for epoch in range(c.train_cfgs.epochs):
             epoch_time = time.time()
             rollout_time = time.time()
@@ -145,12 +157,6 @@ class PolicyGradient(BaseAlgo):  # pylint: disable=too-many-instance-attributes
             self._logger.dump_tabular()
             if (epoch + 1) % c.logger_cfgs.save_model_freq == 0 or (epoch + 1) == c.train_cfgs.epochs:
                 self._logger.torch_save()
-        ep_ret = self._logger.get_stats('Metrics/EpRet')[0]
-        ep_cost = self._logger.get_stats('Metrics/EpCost')[0]
-        ep_len = self._logger.get_stats('Metrics/EpLen')[0]
-        self._logger.close()
-        self._env.close()
-        return ep_ret, ep_cost, ep_len
 
     # ------------------------------------------------------------------ update
     def _lagrange_tensor(self) -> torch.Tensor:

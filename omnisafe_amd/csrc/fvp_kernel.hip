@@ -490,12 +490,12 @@ int osa_launch_fvp_fast(const OsaNet& nd, const float* params, float* grads, con
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
 #define OFV_GO(OT, KBT)                                                                                          \
   do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
+    static OsaPerDeviceOnce attr_set;                                                                               \
+    if (attr_set.need()) {                                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_fvp_kernel<OT, KBT>),                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)            \
         return OSA_EHIP;                                                                                        \
-      attr_set = true;                                                                                          \
+      attr_set.set();                                                                                          \
     }                                                                                                           \
     hipLaunchKernelGGL((osa_fvp_kernel<OT, KBT>), dim3(nblk), dim3(256), lds, st, a);                           \
   } while (0)

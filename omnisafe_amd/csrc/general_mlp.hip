@@ -387,12 +387,12 @@ template <int TM, int TN, int BK, bool AT, bool BT>
 int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * ((AT ? BK * (TM + 8) : TM * (BK + 4)) + (BT ? BK * (TN + 8) : TN * (BK + 4))) * sizeof(float);
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OsaPerDeviceOnce attr_set;
+    if (attr_set.need()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gm_gemm_kernel<TM, TN, BK, AT, BT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OSA_EHIP;
-      attr_set = true;
+      attr_set.set();
     }
   }
   dim3 grid((maxN + TN - 1) / TN, (maxM + TM - 1) / TM, g.nprob * g.splits);

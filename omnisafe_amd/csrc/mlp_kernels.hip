@@ -1338,13 +1338,13 @@ int osa_ppo_minibatch_ext(int obs_dim, int act_dim, int hidden, float* params, f
   const size_t lds = osa_mb_lds_bytes(a.nd);
 #define OSA_CALL(HT, OT, NSB)                                                                          \
   do {                                                                                            \
-    static bool attr_set = false;                                                                 \
-    if (!attr_set) {                                                                              \
+    static OsaPerDeviceOnce attr_set;                                                                 \
+    if (attr_set.need()) {                                                                              \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_mb_grad_kernel<HT, OT, NSB>),         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=    \
           hipSuccess)                                                                             \
         return OSA_EHIP;                                                                          \
-      attr_set = true;                                                                            \
+      attr_set.set();                                                                            \
     }                                                                                             \
     hipLaunchKernelGGL((osa_mb_grad_kernel<HT, OT, NSB>), dim3(nblk, 3), dim3(256), lds,               \
                        osa_stream(stream), a);                                                    \

@@ -20,6 +20,22 @@
 
 static inline hipStream_t osa_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// "done once PER DEVICE": hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and a
+// process may drive more than one (the launch of a > 64 KB LDS kernel on a second device would otherwise fail)
+struct OsaPerDeviceOnce {
+  unsigned long long done = 0;  // bit d = device d (one node: <= 64 devices)
+  bool need() const {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return !((done >> (d & 63)) & 1ull);
+  }
+  void set() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    done |= 1ull << (d & 63);
+  }
+};
+
 // ActionScale.step (omnisafe/envs/wrapper.py:510-514), one element; no contraction so that every kernel that applies
 // it (osa_action_scale_kernel, the policy step's fused epilogue) produces the same bits
 __device__ __forceinline__ float osa_action_scale1(float a, float lo, float hi, float min_a, float max_a) {

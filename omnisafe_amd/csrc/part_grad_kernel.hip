@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_part_kernel(OsaPassArgs a) {
 
 template <int KB, int OT, bool SO>
 static int osa_launch_part(const OsaPassArgs& a, hipStream_t stream, int G) {
-  static bool attr_set = false;
+  static OsaPerDeviceOnce attr_set;
   const size_t lds = osa_part_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
-  if (!attr_set) {
+  if (attr_set.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_part_kernel<KB, OT, SO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((osa_ppo_part_kernel<KB, OT, SO>), dim3(G), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;

@@ -36,14 +36,14 @@ template <int KB, int OT, bool MULTI, bool COOP = false, bool EXT = false, bool 
           bool SO = false>
 static int osa_launch_pass(const OsaPassArgs& a, hipStream_t stream, int grid_y = 1) {
   const dim3 grid = (COOP && a.dp_local == 1) ? dim3(8 * grid_y) : ((!COOP && a.one_xcc) ? dim3(17) : dim3(3, grid_y));
-  static bool attr_set = false;
+  static OsaPerDeviceOnce attr_set;
   const size_t lds = osa_pass_lds_bytes(KB, OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
-  if (!attr_set) {
+  if (attr_set.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_ppo_pass_kernel<KB, OT, MULTI, COOP, EXT, HIER, DPS, SO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
-    attr_set = true;
+    attr_set.set();
   }
   if constexpr (COOP) {
     // the 3 x world workgroups meet at an arrival counter every step, so they MUST be co-resident: a

@@ -818,14 +818,14 @@ static size_t osa_wide_lds_bytes(int OT) {
 
 template <int OT>
 static int osa_launch_wide(const OsaWideArgs& a, hipStream_t stream) {
-  static bool attr_set = false;
+  static OsaPerDeviceOnce attr_set;
   const size_t lds = osa_wide_lds_bytes(OT);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
-  if (!attr_set) {
+  if (attr_set.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_pass_kernel<OT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((osa_wide_pass_kernel<OT>), dim3(3), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;

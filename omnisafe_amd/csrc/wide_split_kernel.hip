@@ -1272,14 +1272,14 @@ extern "C" bool osa_is_exchange_ptr(const void* p);  // ppo_pass_kernel.hip
 
 template <int OT, bool DP = false>
 static int osa_launch_split(const OsaSplitArgs& a, hipStream_t stream) {
-  static bool attr_set = false;
+  static OsaPerDeviceOnce attr_set;
   const size_t lds = osa_split_lds_bytes(OT, a.nmb);
   if (lds > 160 * 1024) return OSA_EUNSUPPORTED;
-  if (!attr_set) {
+  if (attr_set.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&osa_wide_split_kernel<OT, DP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OSA_EHIP;
-    attr_set = true;
+    attr_set.set();
   }
   // the workgroups of a network wait for each other every step, so they MUST be co-resident: a cooperative
   // launch makes the runtime verify that and refuses otherwise (the caller then takes the one-CU kernel)

@@ -89,7 +89,11 @@ def all_reduce_avg_(t: torch.Tensor) -> torch.Tensor:
     exact for powers of two, so the bits equal sum / world) instead of a separate elementwise launch behind it."""
     if collectives_active():
         ws = world_size()
-        if ws > 1 and (ws & (ws - 1)) == 0 and t.is_contiguous() and dist.get_backend() == 'nccl':
+        # (float device tensors only; RCCL's AVG pre-scales every operand by 1 / world: exact for a power-of-two world
+        # except where a gradient element is so small that the pre-scaled value is subnormal -- |g| < 2^-126 x world,
+        # far below Adam's eps -- where sum / world would round once instead of per operand)
+        if (ws > 1 and (ws & (ws - 1)) == 0 and t.is_contiguous() and t.is_cuda and t.is_floating_point()
+                and dist.get_backend() == 'nccl'):
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
             return t
         all_reduce_sum_(t)

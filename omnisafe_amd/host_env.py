@@ -172,6 +172,15 @@ class HostEnvBridge:  # pylint: disable=too-many-instance-attributes
     def host_env(self):
         return self._env
 
+    def defer(self, work) -> None:
+        """Hand over device work of the step just taken that the next action does not depend on; it is enqueued behind
+        the next action's device-to-host copy (step) or in front of a reset.  A method, so that env wrappers which
+        forward attribute READS to the bridge (adapter._EarlyTerminatedEnv) reach it."""
+        if self.deferred_device_work is not None:  # (never dropped: run what is still pending first, in order)
+            pending, self.deferred_device_work = self.deferred_device_work, None
+            pending()
+        self.deferred_device_work = work
+
     def set_seed(self, seed: int) -> None:
         self._env.set_seed(seed)
 

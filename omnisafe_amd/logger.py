@@ -37,6 +37,22 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         self._current_row: dict[str, float] = {}
         self._csv = None
         self._pending = None  # (snapshot of the epoch's values, epoch) of a deferred dump_tabular
+        # a deferred row must reach the csv whatever ends the process (sys.exit, an uncaught exception elsewhere):
+        # flushed at interpreter exit through a weak reference (learn() also flushes in its `finally`)
+        import atexit
+        import weakref
+
+        ref = weakref.ref(self)
+
+        def _flush_at_exit() -> None:
+            lg = ref()
+            try:
+                if lg is not None and lg._pending is not None and not lg._output_file.closed:  # noqa: SLF001
+                    lg.flush()
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+        atexit.register(_flush_at_exit)
         # Optional sinks of the reference (logger.py:130-150, 312-318): the epoch row goes to TensorBoard
         # (`<log_dir>/tb`) and / or Weights & Biases when their packages are importable; when one is asked for and
         # missing, the run continues on csv alone and SAYS so (a drop-in must not silently ignore a config key).
@@ -147,9 +163,12 @@ class Logger:  # pylint: disable=too-many-instance-attributes
         the large-batch setting).  Without cross-rank statistics the epoch's values are therefore only SNAPSHOT here
         and the row is written by `flush()` -- which the adapter calls right after it has enqueued the next epoch's
         rollout, `close()` / `torch_save()` / the next `dump_tabular()` at the latest: same rows, same order, one
-        epoch later on disk at most.  OSA_LOG_DEFER=0 writes in place."""
+        epoch later on disk at most; an exception out of `learn()` and interpreter exit flush it too.  OSA_LOG_DEFER=0
+        writes in place, and so does a logger with `verbose` output or an external sink (TensorBoard / wandb): whoever
+        watches those sees every epoch when the reference would show it."""
         self.flush()
-        if not dist.collectives_active() and os.environ.get('OSA_LOG_DEFER', '1') != '0':
+        live_sinks = self._verbose or self._tb_writer is not None or self._wandb is not None
+        if not dist.collectives_active() and not live_sinks and os.environ.get('OSA_LOG_DEFER', '1') != '0':
             snap = {key: np.asarray(self._data[key], dtype=np.float32) for key in self._data}
             for key in self._data:
                 if self._headers_windows[key] is None:

@@ -43,10 +43,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
+def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir, real_devices=False):
     os.environ.update(OSA_DP_MODE=dp_mode, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OSA_DIST_BACKEND='gloo',
-                      OSA_SINGLE_DEVICE_RANKS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if real_devices:  # one rank per GPU over `nccl` (= RCCL over xGMI): the production configuration
+        os.environ.pop('OSA_DIST_BACKEND', None)
+        os.environ.pop('OSA_SINGLE_DEVICE_RANKS', None)
+    else:  # all ranks on the test box's one GPU: RCCL refuses duplicate devices, so gloo (staged through the host)
+        os.environ.update(OSA_DIST_BACKEND='gloo', OSA_SINGLE_DEVICE_RANKS='1')
+    DEV = f'cuda:{rank}' if real_devices else 'cuda:0'
     if want_path.startswith('general-'):  # the layer-wise path for general networks, on the YAML-default shapes
         os.environ['OSA_FORCE_GENERAL_MLP'] = '1'
     sys.path.insert(0, ROOT)
@@ -59,7 +64,7 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
     trust_region = algo_name in ('TRPOLag', 'CPO')
     M = N * T
     bs = 128 if trust_region else (2048 if tag.endswith('largebatch') else 64)
-    cfg = {'seed': 0, 'train_cfgs': {'device': 'cuda:0', 'total_steps': 4 * world * M, 'vector_env_nums': N},
+    cfg = {'seed': 0, 'train_cfgs': {'device': DEV, 'total_steps': 4 * world * M, 'vector_env_nums': N},
            'algo_cfgs': {'steps_per_epoch': world * M, 'update_iters': 2, 'kl_early_stop': False, 'batch_size': bs},
            'logger_cfgs': {'log_dir': os.path.join(tmpdir, f'r{rank}'), 'verbose': False}}
     if algo_name == 'CPO':
@@ -68,12 +73,14 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir):
         cfg['lagrange_cfgs'] = LAG
     algo = omnisafe_amd.Agent(algo_name, env_id, custom_cfgs=cfg).agent
     assert dist.world_size() == world and algo._steps_per_epoch == T and algo._seed == 1000 * rank
+    if real_devices:
+        assert torch.distributed.get_backend() == 'nccl' and str(algo._actor_critic.device) == DEV
     ac = algo._actor_critic
     for net in ('actor', 'reward_critic', 'cost_critic'):
         sd = {k[len('init/') + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
               if k.startswith(f'init/{net}/')}
         getattr(ac, net).load_state_dict(sd)
-    data = {k[len(f'r{rank}/data/'):]: torch.from_numpy(np.ascontiguousarray(v)).to('cuda:0')
+    data = {k[len(f'r{rank}/data/'):]: torch.from_numpy(np.ascontiguousarray(v)).to(DEV)
             for k, v in g.items() if k.startswith(f'r{rank}/data/')}
     assert data['obs'].shape[0] == M
     algo._buf.get = lambda: dict(data)
@@ -191,3 +198,30 @@ def test_eight_ranks_reproduce_the_eight_rank_reference(tmp_path, dp_mode, want_
     mp.spawn(_worker, args=(8, _free_port(), 'dp8_ppolag_point', dp_mode, want_path, None, str(tmp_path)), nprocs=8,
              join=True)
 
+
+
+# ---- the same recordings on DISTINCT devices over `nccl` (= RCCL): runs wherever the box has the GPUs (the driver's
+# 8-GPU node), skips on the 1-GPU test box.  Over RCCL the large-batch pass is a captured graph incl. its all-reduces.
+REAL = [
+    (2, 'dp2_ppolag_point', 'replicated', 'replicated', {'chunked': False}),
+    (2, 'dp2_ppolag_point', 'allreduce', 'per-step', None),
+    (2, 'dp2_ppolag_humanoid', 'replicated', 'replicated-wide-split', None),
+    (2, 'dp2_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+    (2, 'dp2_cpo_car', 'allreduce', 'per-step', None),
+    (2, 'dp2_ppolag_point_largebatch', 'allreduce', 'dp-large-batch-graph', None),
+    (4, 'dp4_ppolag_point', 'replicated', 'replicated', {'chunked': False}),
+    (4, 'dp4_ppolag_point', 'allreduce', 'per-step', None),
+    (8, 'dp8_ppolag_point', 'replicated', 'replicated', None),
+    (8, 'dp8_ppolag_point', 'allreduce', 'per-step', None),
+]
+
+
+@pytest.mark.parametrize('world,tag,dp_mode,want_path,want', REAL)
+def test_ranks_on_distinct_devices_over_rccl_reproduce_the_reference(tmp_path, world, tag, dp_mode, want_path, want):
+    """One rank per GPU, `nccl` backend (omnisafe/utils/distributed.py:75-80,100): the reference's multi-rank
+    recordings through the real RCCL collectives -- flat gradient all-reduce (ReduceOp.AVG), the rollout all-gather of
+    the replicated mode, the fp64 statistics, the captured large-batch pass."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    mp.spawn(_worker, args=(world, _free_port(), tag, dp_mode, want_path, want, str(tmp_path), True), nprocs=world,
+             join=True)

@@ -249,3 +249,81 @@ def test_large_batch_dp_pass_is_one_graph_with_its_rccl_allreduces(tmp_path):
     dst = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(dst, exist_ok=True)
     json.dump(res, open(os.path.join(dst, 'r4_dp_large_batch_world1.json'), 'w'), indent=1)
+
+
+def _multi_device_worker(rank, world, port, algo, dp_mode, tmpdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OSA_DP_MODE=dp_mode, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('OSA_DIST_BACKEND', 'OSA_SINGLE_DEVICE_RANKS', 'OSA_DIST_FORCE_COLLECTIVES'):
+        os.environ.pop(k, None)
+    sys.path.insert(0, ROOT)
+    import omnisafe_amd
+    from omnisafe_amd import distributed as dist
+
+    cfg = {'seed': 4, 'train_cfgs': {'device': f'cuda:{rank}', 'total_steps': 2 * world * 128 * 16, 'vector_env_nums': 128},
+           'algo_cfgs': {'steps_per_epoch': world * 128 * 16, 'update_iters': 2},
+           'logger_cfgs': {'log_dir': os.path.join(tmpdir, f'r{rank}'), 'verbose': False},
+           'env_cfgs': {'horizon': 8, 'cost_p': 0.3}}
+    agent = omnisafe_amd.Agent(algo, 'SynthPointGoal1-v0', custom_cfgs=cfg)
+    assert torch.distributed.get_backend() == 'nccl' and dist.world_size() == world
+    p = agent.agent._actor_critic.params
+    assert p.device.index == rank
+    p0 = p.clone()
+    ep_ret, ep_cost, ep_len = agent.learn()
+    assert bool(torch.isfinite(p).all()) and not torch.equal(p, p0)
+    assert ep_len == 8.0 and 1.0 < ep_cost < 4.0
+    lo, hi = p.clone(), p.clone()  # every replica took the same optimiser steps
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(lo, hi), 'replicas diverged'
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+@pytest.mark.parametrize('algo,dp_mode', [('PPOLag', 'replicated'), ('PPOLag', 'allreduce'), ('TRPOLag', 'replicated'),
+                                          ('CPO', 'allreduce')])
+def test_agents_on_distinct_devices_over_rccl(tmp_path, world, algo, dp_mode):
+    """Whole `Agent.learn()` runs with one rank per GPU over RCCL (skipped unless the box has `world` GPUs): rollouts
+    sharded over the ranks' envs (policy_gradient.py:73-77), Lagrange / advantage statistics and gradients exchanged
+    over the real xGMI collectives, replicas bit-identical afterwards."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    mp.spawn(_multi_device_worker, args=(world, _free_port(), algo, dp_mode, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """The driver's scaling command is `python bench.py --gpus N ...` WITHOUT torchrun's environment: bench.py must start
+    the N ranks itself (as the reference's fork(), omnisafe/utils/distributed.py:121-137) and rank 0 must print ONE
+    JSON line for the whole job.  With N GPUs on the box: over RCCL.  On the 1-GPU test box: the documented hook
+    (all ranks on cuda:0 over gloo) -- a check of the launch path and the line, not a measurement."""
+    import subprocess
+
+    n = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'OSA_DIST_BACKEND', 'OSA_DP_MODE',
+              'OSA_DIST_FORCE_COLLECTIVES'):
+        env.pop(k, None)
+    real = torch.cuda.device_count() >= n
+    if not real:
+        env['OSA_SINGLE_DEVICE_RANKS'] = '1'
+    else:
+        env.pop('OSA_SINGLE_DEVICE_RANKS', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '2', '--envs',
+           '256', '--update-iters', '2', '--allreduce-steps', '1', '--variant-batch', '2048', '--n1-value', '50000']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == n and out['config']['parallelism'] == f'dp{n}' and out['config']['batch_size'] == 64
+    assert out['config']['envs_per_gpu'] == 256 and out['config']['update_iters'] == 2
+    assert out['config']['dp_mode'] == 'replicated' and out['config']['update_path'].startswith('replicated')
+    assert out['rccl_ranks'] == (n if real else 0) and out['dist_backend'] == ('nccl' if real else 'gloo')
+    assert out['value'] > 0 and 'efficiency_vs_n1' in out
+    assert out['allreduce_mode']['update_path'] == 'per-step' and out['allreduce_mode']['value'] > 0
+    assert out['throughput_variant']['update_path'].startswith('dp-large-batch')
+    # refused, loudly, when the box has fewer GPUs and the hook is not set
+    if not real:
+        env.pop('OSA_SINGLE_DEVICE_RANKS')
+        q = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert q.returncode == 2 and 'OSA_SINGLE_DEVICE_RANKS' in q.stderr

@@ -405,28 +405,38 @@ class _TraceEnvWithResets(TraceEnv):
     """TraceEnv whose reset() serves the reference's recorded resets in call order (the early-terminated
     adapter resets the env in the middle of an epoch) and does not rewind the trace."""
 
-    def __init__(self, g):
-        super().__init__(g)
+    def __init__(self, g, dev=None):
+        super().__init__(g, dev=dev)
         self.n_resets = 0
 
     def reset(self, seed=None, options=None):
-        obs = torch.from_numpy(self.g['rollout/resets'][self.n_resets]).to(DEV)
+        obs = torch.from_numpy(self.g['rollout/resets'][self.n_resets]).to(self.dev)
         self.n_resets += 1
         return obs, {}
 
 
-def test_early_terminated_rollout_on_reference_trace(golden):
+@pytest.mark.parametrize('host_env', [False, True], ids=['device-env', 'host-env-bridge'])
+def test_early_terminated_rollout_on_reference_trace(golden, host_env):
     """EarlyTerminatedAdapter (early_terminated_adapter.py:50-88) replayed on the raw env trace of a
     reference PPOEarlyTerminated rollout: 14 early terminations (zero reward, terminated, mid-epoch
-    reset, no bootstrap) interleaved with 18 time-limit truncations."""
-    from omnisafe_amd.adapter import EarlyTerminatedAdapter
+    reset, no bootstrap) interleaved with 18 time-limit truncations.  `host-env-bridge`: the same trace served by a
+    HOST env through HostEnvBridge UNDER the early-termination wrapper -- the bootstrap values / episode accounting of
+    a step are handed to the bridge (`defer`, reached through the wrapper's attribute forwarding) and must still be
+    written for every step (round-4 advisor finding: an attribute assignment landed on the wrapper and was lost)."""
+    from omnisafe_amd.adapter import EarlyTerminatedAdapter, HostEnvBridge
     from omnisafe_amd.buffer import VectorOnPolicyBuffer
     from test_mlp_gpu import make_ac
 
     g = golden('early_terminated_rollout.npz')
     N, T = int(g['N']), int(g['T'])
-    env = _TraceEnvWithResets(g)
-    adapter = EarlyTerminatedAdapter('trace', N, 0, _cfgs(cost_limit=float(g['cost_limit'])), env=env)
+    env = _TraceEnvWithResets(g, dev='cpu' if host_env else None)
+    bridge = HostEnvBridge(env, DEV) if host_env else None
+    adapter = EarlyTerminatedAdapter('trace', N, 0, _cfgs(cost_limit=float(g['cost_limit'])),
+                                     env=bridge if host_env else env)
+    if host_env:
+        deferred = []
+        plain_defer = bridge.defer
+        bridge.defer = lambda work: (deferred.append(1), plain_defer(work))[1]
     ac = make_ac(60, 2, g, 'init/')
     eps_iter = iter(g['rollout/eps'])
     plain_step = ac.step
@@ -442,6 +452,8 @@ def test_early_terminated_rollout_on_reference_trace(golden):
     logger = _LoggerStub()
     adapter.rollout(T, ac, buf, logger)
     assert env.n_resets == g['rollout/resets'].shape[0] == 15  # epoch start + 14 early terminations
+    if host_env:  # every step but the epoch's last handed its post-step work to the bridge, and none is left over
+        assert len(deferred) == T - 1 and bridge.deferred_device_work is None
     buf.compute_advantages()
     b = {k: v.cpu().numpy() for k, v in buf.data.items()}
     assert np.array_equal(b['reward'], g['buffer/reward']) and np.array_equal(b['cost'], g['buffer/cost'])
