@@ -485,7 +485,8 @@ int osa_debug_set_part_clock_buffer(long long* dev_ptr);
  * osa_gmlp_layout fills out[0] = P, out[1] = offset of log_std, then {oW, ob, ld} for network 0..2 x layer
  * 0..OSA_GMLP_MAX_LAYERS-1 (-1 / 0 for absent layers): 2 + 72 ints.
  * ws: osa_gmlp_ws_floats(desc, rows) floats of scratch for a call over `rows` rows (layer outputs, dL/dz, partial
- * gradient slabs); contents irrelevant between calls. */
+ * gradient slabs), ZERO-INITIALISED ONCE by the caller: it holds the arrival tickets of the small-minibatch kernels,
+ * which every call leaves at zero; everything else is irrelevant between calls. */
 #define OSA_GMLP_MAX_LAYERS 8
 typedef struct osa_gmlp_desc {
   int obs_dim, act_dim;
@@ -512,6 +513,20 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
                        const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
                        int loss_kind, int mode, int nets_mask, const float* vec, float fvp_scale, float* ws,
                        size_t ws_floats, float* step_stats, void* stream);
+/* osa_gmlp_minibatch with the extended actor surrogates of osa_ppo_minibatch_ext (FOCOPS first_order/focops.py:83-92,
+ * CUP's second stage first_order/cup.py:96-103, P3O penalty_function/p3o.py:62-68,112-114) on general networks -- the
+ * reference builds any hidden_sizes for them as for every other algorithm (utils/model.py:73-111).  ext == NULL:
+ * osa_gmlp_minibatch.  The trust-mask mean and the penalty are minibatch-level quantities: with kl_mask_eta >= 0 or
+ * cost_kappa > 0 at most 256 rows (OSA_EUNSUPPORTED otherwise); step_stats[10] receives the penalty value.
+ * Minibatches of at most 64 rows (the YAML batch_size) run on the skinny kernels (weights streamed once per pass,
+ * clip + Adam from recomputed gradient tiles; OSA_GMLP_SKINNY=0: the tiled GEMM path). */
+int osa_gmlp_minibatch_ext(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                           float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
+                           const float* target_value_r, const float* target_value_c, const float* adv_r,
+                           const float* adv_c, const long* idx, long B, const float* lagrange,
+                           const osa_ppo_hparams* hp, int loss_kind, int mode, int nets_mask, const float* vec,
+                           float fvp_scale, float* ws, size_t ws_floats, float* step_stats,
+                           const osa_surrogate_ext* ext, void* stream);
 /* osa_adam_apply for general networks; fin8x3: 24 floats of device scratch. */
 int osa_gmlp_adam_apply(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
                         float* grads, const osa_ppo_hparams* hp, int nets_mask, float* fin8x3, void* stream);
@@ -624,57 +639,6 @@ int osa_synth_env_step(unsigned long long seed, unsigned long long step,
                        int horizon, float cost_p, int* steps, float* obs, int ld_obs, float* reward,
                        float* cost, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                        int ld_final, int reset_only, void* stream);
-
-/* The device part of OnPolicyAdapter.rollout (omnisafe/adapter/onpolicy_adapter.py:58-136) for one epoch as ONE
- * persistent launch: env reset, then per vector step the policy step (constraint_actor_critic.py:84-109 + ActionScale),
- * the synthetic env's step, ObsNormalize (final observations of truncated envs first, then the next observations:
- * envs/wrapper.py:231-241), the bootstrap values and the episode accounting -- the sequence osa_policy_step_scaled /
- * osa_synth_env_step / osa_normalizer_push / osa_normalizer_apply / osa_rollout_post_step performs with five launches
- * per step, with the same arithmetic (same bits: a workgroup owns 128 envs = one partial-sum block of
- * osa_normalizer_push; the workgroups meet at a grid barrier once per normaliser push).
- * Supported (osa_rollout_persistent_supported != 0): the synthetic env above, fused [64, 64] tanh networks,
- * num_envs a multiple of 128 and at most 128 x the device's compute units, obs_dim <= 96; OSA_EUNSUPPORTED otherwise.
- * Stream positions: the env consumes positions env_step .. env_step + steps (reset + steps), the policy noise
- * noise_offset + 1 .. noise_offset + steps + steps / horizon + 1 (one per policy step or value evaluation, as the
- * host-side counters of the launch-per-step path advance) -- the caller advances its counters accordingly.
- * ws: osa_rollout_persistent_ws_doubles(num_envs, obs_dim) doubles, zero-initialised once; osa_rollout_persistent_timed_out
- * reads its sticky flag (a workgroup did not arrive at a barrier within the spin bound: results invalid). */
-typedef struct osa_rollout_desc {
-  int obs_dim, act_dim, hidden;   /* network shape, as osa_policy_step */
-  int num_envs, steps;            /* N, T (rows of the time-major rollout buffer) */
-  const float* params;            /* [3][P] */
-  /* rollout buffer rows [T][N](xD): obs, act, value_r, value_c, logp, reward, cost, path_end, boot_r, boot_c */
-  float* obs; float* act; float* value_r; float* value_c; float* logp; float* reward; float* cost;
-  uint8_t* path_end; float* boot_r; float* boot_c;
-  /* episode rows [T][N] and running episode sums [N] (osa_rollout_post_step) */
-  uint8_t* ep_done; float* ep_ret_out; float* ep_cost_out; float* ep_len_out;
-  float* ep_ret; float* ep_cost; float* ep_len;
-  float* last_obs;                /* [N][obs_dim] normalised observation after the last step */
-  float* final_norm;              /* [N][obs_dim] normalised final observations (scratch) */
-  float* act_env;                 /* [N][act_dim] ActionScale output of the last step */
-  const float* old_min; const float* old_max; /* env action bounds (ActionScale maps [-1, 1] onto them) */
-  float* vscratch;                /* [4][N] bootstrap values (scratch) */
-  /* ObsNormalize running state (osa_normalizer_push) */
-  float* norm_mean; float* norm_sumsq; float* norm_var; float* norm_std; long* norm_count; float norm_clip;
-  double* ws;
-  /* synthetic env (osa_synth_env_step): state and last outputs */
-  unsigned long long env_seed, env_step; const unsigned long long* env_step_base;
-  int horizon; float cost_p; int* env_steps;
-  float* env_obs; float* env_final; float* env_reward; float* env_cost;
-  uint8_t* env_terminated; uint8_t* env_truncated;
-  /* policy noise stream (osa_policy_step: seed, offset, offset_base) */
-  unsigned long long noise_seed, noise_offset; const unsigned long long* noise_offset_base;
-  /* != 0: the value rows value_r / value_c are NOT written here -- nothing inside the rollout reads them -- and the
-   * caller evaluates them afterwards with one osa_policy_step (nets_mask 6, deterministic) over the T N buffer rows */
-  int defer_critics;
-} osa_rollout_desc;
-int osa_rollout_persistent_supported(int obs_dim, int act_dim, int hidden, int num_envs);
-size_t osa_rollout_persistent_ws_doubles(int num_envs, int obs_dim);
-int osa_rollout_persistent(const osa_rollout_desc* desc, void* stream);
-int osa_rollout_persistent_timed_out(const double* ws, int num_envs, int obs_dim, int* out);
-/* debug: 8 x int64 of device memory receiving workgroup 0's phase clocks (100 MHz ticks summed over the epoch: policy
- * step, env step, partial moments, grid barrier, merge, normalise, bootstrap values, episode accounting); NULL = off */
-int osa_debug_set_rollout_clock_buffer(long long* dev_ptr);
 
 /* Learnable synthetic vector CMDP "SynthReach-v0" (obs_dim >= 6, 2 actions; stand-in for a
  * Safety-Gymnasium goal task, which is third-party CPU physics outside the reference repo; plays the

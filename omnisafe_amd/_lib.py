@@ -49,6 +49,8 @@ SIGNATURES: dict[str, tuple] = {
                                   _P, _F, _F, _P, C.c_size_t, _P]),
     'osa_gmlp_minibatch': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I,
                                 _I, _P, _F, _P, C.c_size_t, _P, _P]),
+    'osa_gmlp_minibatch_ext': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I,
+                                    _I, _P, _F, _P, C.c_size_t, _P, _P, _P]),
     'osa_gmlp_adam_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'osa_gmlp_actor_stats': (_I, [_P, _P, _P, _I, _L, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P,
                                   C.c_size_t, _P, _P]),
@@ -114,28 +116,8 @@ SIGNATURES: dict[str, tuple] = {
     'osa_action_scale': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _P]),
     'osa_rollout_post_step': (_I, [_I, _I] + [_P] * 21),
     'osa_synth_env_step': (_I, [_U, _U, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
-    'osa_rollout_persistent_supported': (_I, [_I, _I, _I, _I]),
-    'osa_rollout_persistent_ws_doubles': (C.c_size_t, [_I, _I]),
-    'osa_rollout_persistent': (_I, [_P, _P]),
-    'osa_rollout_persistent_timed_out': (_I, [_P, _I, _I, _P]),
-    'osa_debug_set_rollout_clock_buffer': (_I, [_P]),
     'osa_reach_env_step': (_I, [_U, _U, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
-
-
-class RolloutDesc(C.Structure):
-    """ctypes mirror of ``osa_rollout_desc`` (include/omnisafe_amd.h): one epoch's rollout as one launch."""
-
-    _fields_ = ([(k, _I) for k in ('obs_dim', 'act_dim', 'hidden', 'num_envs', 'steps')] + [('params', _P)]
-                + [(k, _P) for k in ('obs', 'act', 'value_r', 'value_c', 'logp', 'reward', 'cost', 'path_end', 'boot_r',
-                                     'boot_c', 'ep_done', 'ep_ret_out', 'ep_cost_out', 'ep_len_out', 'ep_ret', 'ep_cost',
-                                     'ep_len', 'last_obs', 'final_norm', 'act_env', 'old_min', 'old_max', 'vscratch',
-                                     'norm_mean', 'norm_sumsq', 'norm_var', 'norm_std', 'norm_count')]
-                + [('norm_clip', _F), ('ws', _P), ('env_seed', _U), ('env_step', _U), ('env_step_base', _P),
-                   ('horizon', _I), ('cost_p', _F), ('env_steps', _P)]
-                + [(k, _P) for k in ('env_obs', 'env_final', 'env_reward', 'env_cost', 'env_terminated',
-                                     'env_truncated')]
-                + [('noise_seed', _U), ('noise_offset', _U), ('noise_offset_base', _P), ('defer_critics', _I)])
 
 
 class OsaError(RuntimeError):

@@ -180,13 +180,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
 
         T = int(steps_per_epoch)
         self.last_rollout_path = 'launches'
-        if self._persistent_rollout_ok(T, agent, buffer):
-            self._rollout_persistent(T, agent, buffer)
-            self.last_rollout_path, self.last_rollout_graphed = 'persistent', False
-            buffer.prefetch()
-            self._flush_logs(logger, buffer)
-            self._check_persistent_rollout()
-            return
         use_graph = (os.environ.get('OSA_ROLLOUT_GRAPH', '1') != '0' and self._graph_safe_hooks
                      and getattr(self._env, 'graph_safe', False) and hasattr(agent, 'commit_rng'))
         if not use_graph:
@@ -234,98 +227,6 @@ class OnPolicyAdapter:  # pylint: disable=too-many-instance-attributes
         # get()'s device work goes out before the host synchronises on the episode metrics (buffer.py:prefetch)
         buffer.prefetch()
         self._flush_logs(logger, buffer)
-
-    # ------------------------------------------------------------------ one launch per epoch
-    def _persistent_rollout_ok(self, T: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer) -> bool:
-        """The epoch's device work as ONE persistent launch (csrc/rollout_persistent.hip): opt-in with
-        OSA_ROLLOUT_PERSISTENT=1, for the plain adapter on the synthetic env with the observation normaliser only and
-        fused [64, 64] tanh networks.  Same bits as the launch-per-step sequence below (tests/test_rollout_gpu.py), but
-        not faster than its captured graph on the benchmark's 4096 envs (0.76 vs 0.71 ms per 16-step epoch, profiles/
-        r4_rollout_timing.json): one workgroup per 128 envs -- the blocking of the normaliser's partial sums, which
-        fixes the bits -- keeps 32 of the 256 compute units busy, and the env's Philox draws and the forward passes
-        then cost what the graph's chip-wide launches spend on launch gaps."""
-        import os
-
-        if os.environ.get('OSA_ROLLOUT_PERSISTENT', '0') != '1':
-            return False
-        cls = type(self)
-        plain = (cls._after_env_step is OnPolicyAdapter._after_env_step and cls._after_reset is OnPolicyAdapter._after_reset
-                 and cls._flush_extra is OnPolicyAdapter._flush_extra and self._obs_dim == self._raw_obs_dim)
-        if not (plain and type(self._env) is envs_mod.SynthVectorEnv and self._obs_normalizer is not None
-                and self._reward_normalizer is None and self._cost_normalizer is None):
-            return False
-        if (getattr(agent, 'general', True) or not hasattr(agent, '_rng_base')
-                or getattr(agent.step, '__func__', None) is not getattr(type(agent), 'step', None)):
-            return False
-        N, D = self._num_envs, self._obs_dim
-        if not self._lib.osa_rollout_persistent_supported(D, self._act_dim, agent.hidden, N):
-            return False
-        if N // 128 > torch.cuda.get_device_properties(self._device).multi_processor_count:
-            return False  # the workgroups (128 envs each) meet at a grid barrier: all of them must be resident
-        b = buffer.data
-        return (buffer.size == T and buffer.num_buffers == N and all(b[k].is_contiguous() for k in (
-            'obs', 'act', 'value_r', 'value_c', 'logp', 'reward', 'cost', 'path_end', 'boot_r', 'boot_c')))
-
-    def _rollout_persistent(self, T: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer) -> None:
-        import ctypes as C
-        import os
-
-        lib, N, env, nz = self._lib, self._num_envs, self._env, self._obs_normalizer
-        assert buffer.ptr == 0
-        self._ensure_episode_rows(T)
-        ep, b = self._ep_rows, buffer.data
-        st = self.__dict__.setdefault('_persistent_state', {})
-        if st.get('N') != N:
-            st.update(N=N, vscratch=torch.empty(4, N, dtype=torch.float32, device=self._device),
-                      ws=torch.zeros(lib.osa_rollout_persistent_ws_doubles(N, self._obs_dim), dtype=torch.float64,
-                                     device=self._device))
-        flip = env._flip ^ ((T + 1) & 1)  # reset + T steps alternate the env's two observation buffers
-        d = _lib.RolloutDesc()
-        d.obs_dim, d.act_dim, d.hidden, d.num_envs, d.steps = self._obs_dim, self._act_dim, agent.hidden, N, T
-        d.params = _lib.ptr(agent.params)
-        for k in ('obs', 'act', 'value_r', 'value_c', 'logp', 'reward', 'cost', 'path_end', 'boot_r', 'boot_c'):
-            setattr(d, k, _lib.ptr(b[k]))
-        d.ep_done, d.ep_ret_out = _lib.ptr(ep['done']), _lib.ptr(ep['ret'])
-        d.ep_cost_out, d.ep_len_out = _lib.ptr(ep['cost']), _lib.ptr(ep['len'])
-        d.ep_ret, d.ep_cost, d.ep_len = _lib.ptr(self._ep_ret), _lib.ptr(self._ep_cost), _lib.ptr(self._ep_len)
-        d.last_obs, d.final_norm, d.act_env = _lib.ptr(self._last_obs), _lib.ptr(self._final_norm), _lib.ptr(self._act_env)
-        d.old_min, d.old_max, d.vscratch = _lib.ptr(self._old_min), _lib.ptr(self._old_max), _lib.ptr(st['vscratch'])
-        d.norm_mean, d.norm_sumsq, d.norm_var = _lib.ptr(nz._mean), _lib.ptr(nz._sumsq), _lib.ptr(nz._var)
-        d.norm_std, d.norm_count, d.norm_clip = _lib.ptr(nz._std), _lib.ptr(nz._count), nz._clip_value
-        d.ws = _lib.ptr(st['ws'])
-        d.env_seed, d.env_step, d.env_step_base = env._seed & 0xFFFFFFFFFFFFFFFF, env._t, _lib.ptr(env._t_base)
-        d.horizon, d.cost_p, d.env_steps = env._horizon, env._cost_p, _lib.ptr(env._steps)
-        d.env_obs, d.env_final = _lib.ptr(env._obs[flip]), _lib.ptr(env._final)
-        d.env_reward, d.env_cost = _lib.ptr(env._reward), _lib.ptr(env._cost)
-        d.env_terminated, d.env_truncated = _lib.ptr(env._term), _lib.ptr(env._trunc)
-        d.noise_seed, d.noise_offset, d.noise_offset_base = agent.seed, agent._rng_offset, _lib.ptr(agent._rng_base)
-        # the critics' outputs of the buffer rows are read by nobody before GAE: one launch over all T N rows afterwards
-        # instead of 2 of the 3 forward passes inside every step of the persistent kernel's critical path
-        d.defer_critics = int(os.environ.get('OSA_ROLLOUT_DEFER_CRITICS', '1') != '0')
-        _lib.check(lib.osa_rollout_persistent(C.byref(d), _lib.stream_ptr()), 'osa_rollout_persistent')
-        if d.defer_critics:
-            _lib.check(lib.osa_policy_step_scaled(
-                self._obs_dim, self._act_dim, agent.hidden, _lib.ptr(agent.params), _lib.ptr(b['obs']), self._obs_dim,
-                T * N, None, 0, 0, None, 1, 6, None, self._act_dim, _lib.ptr(b['value_r']), _lib.ptr(b['value_c']),
-                None, None, 0, None, 0, None, None, 0.0, 1.0, _lib.stream_ptr()), 'osa_policy_step_scaled')
-        # the host-side counters, as reset() + T x step() / agent.step() / agent.values() leave them
-        env._flip, env._t, env._since_reset = flip, env._t + T + 1, T
-        agent._rng_offset += T + T // env._horizon + 1
-        env.commit()
-        agent.commit_rng()
-        buffer.ptr = T
-
-    def _check_persistent_rollout(self) -> None:
-        """After the epoch's host synchronisation: did every workgroup arrive at every grid barrier?"""
-        import ctypes as C
-
-        st = self._persistent_state
-        flag = C.c_int(0)
-        _lib.check(self._lib.osa_rollout_persistent_timed_out(_lib.ptr(st['ws']), self._num_envs, self._obs_dim,
-                                                              C.byref(flag)), 'osa_rollout_persistent_timed_out')
-        if flag.value != 0:
-            raise _lib.OsaError('osa_rollout_persistent: a workgroup did not reach a grid barrier (the rows of this '
-                                'epoch are invalid); set OSA_ROLLOUT_PERSISTENT=0')
 
     def _rollout_device(self, T: int, agent: ConstraintActorCritic, buffer: VectorOnPolicyBuffer) -> None:
         """Everything of the rollout that runs on the device (no host synchronisation inside)."""

@@ -21,10 +21,9 @@
 // gradients per step: HBM / L2-bound.
 #include <stdlib.h>
 
-#include "mlp_device.h"
+#include "skinny_mlp.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define GM_MAXL OSA_GMLP_MAX_LAYERS
 #define GM_NSTAT 16
 
 namespace {
@@ -100,9 +99,15 @@ struct GWs {
   size_t npart, fin;              // norm partials [3][nb][2]; finals [3][8]
   size_t dws;                     // double scratch of the KL / evaluation reductions (4 x 1024 doubles)
   size_t rsl, rsl_floats;         // K-slice slabs of the small-row forward / backward-data GEMMs (gm_gemm_rows)
+  // skinny path (R <= GS_MAX_ROWS): dL/d(pre-activation) of EVERY layer stays alive until the weight-gradient launch;
+  // its 64 x 64 tiles, network by network and layer by layer (+ one tail workgroup per network)
+  size_t zs[3][GM_MAXL];
+  int sk_tile0[3][GM_MAXL], sk_tk[3][GM_MAXL], sk_ntile[3], sk_maxT1;
+  size_t bslab, tick;             // partial tiles and tickets of gs_big_kernel (the tickets are ZERO between launches)
   size_t total;
   int nblk, nb;
 };
+#define GS_MAX_ROWS 64
 
 // Splits of the row (= reduction) dimension of ONE layer's weight-gradient GEMM: the launch (three networks) should
 // fill the chip -- output tiles x networks x splits >= ~512 workgroups -- with at least 128 rows per split and at most
@@ -149,7 +154,43 @@ GWs gm_ws(const GLayout& lo, long R) {
       w.slab[net][l] = take((size_t)w.S[net][l] * (n.out[l] * n.ld[l] + r4(n.out[l])));
     }
   w.nb = (lo.P + 1023) / 1024;
-  w.npart = take((size_t)3 * w.nb * 2);
+  w.sk_maxT1 = 0;
+  for (int net = 0; net < 3; ++net) {
+    int t = 0;
+    for (int l = 0; l < GM_MAXL; ++l) {
+      w.zs[net][l] = 0;
+      w.sk_tile0[net][l] = t;
+      w.sk_tk[net][l] = 1;
+      if (l >= lo.n[net].L || R > GS_MAX_ROWS) continue;
+      const GNet& n = lo.n[net];
+      w.zs[net][l] = take((size_t)R * n.ldh[l]);
+      w.sk_tk[net][l] = (n.ld[l] + 63) / 64;
+      t += ((n.out[l] + 63) / 64) * w.sk_tk[net][l];
+    }
+    w.sk_ntile[net] = t;
+    if (t + 1 > w.sk_maxT1) w.sk_maxT1 = t + 1;
+  }
+  w.npart = take((size_t)3 * (w.nb > w.sk_maxT1 ? w.nb : w.sk_maxT1) * 2);
+  {  // gs_big_kernel: per launch (one layer, forward or backward) sum over the networks of tiles x slices x 4096 floats
+    size_t need = 0, tiles = 0;
+    if (R <= GS_MAX_ROWS)
+      for (int net = 0; net < 3; ++net) {
+        size_t mx = 0, mt = 0;
+        for (int l = 0; l < lo.n[net].L; ++l) {
+          const GNet& n = lo.n[net];
+          const size_t f = (size_t)((n.out[l] + 63) / 64) * ((n.in[l] + GSB_CL - 1) / GSB_CL);   // forward: tiles over out
+          const size_t bw = (size_t)((n.in[l] + 63) / 64) * ((n.out[l] + GSB_CL - 1) / GSB_CL);  // backward: tiles over in
+          if (f > mx) mx = f;
+          if (bw > mx) mx = bw;
+          const size_t t = (size_t)((n.out[l] > n.in[l] ? n.out[l] : n.in[l]) + 63) / 64;
+          if (t > mt) mt = t;
+        }
+        need += mx * 4096;
+        tiles += mt;
+      }
+    w.bslab = take(need);
+    w.tick = take(tiles + 4);
+  }
   w.fin = take(3 * 8);
   w.dws = take(2 * 4 * 1024);
   {  // small minibatches: [3 networks][GM_ROW_SPLITS][R][widest layer]
@@ -162,22 +203,6 @@ GWs gm_ws(const GLayout& lo, long R) {
   }
   w.total = off;
   return w;
-}
-
-// ---- activations (scalar forms of mlp_device.h's)
-__device__ __forceinline__ float gm_act(float v, int act) {
-  if (act == OSA_ACT_TANH) return osa_tanhf(v);
-  if (act == OSA_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == OSA_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-  if (act == OSA_ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
-  return v;
-}
-__device__ __forceinline__ float gm_dact(float h, int act) {  // derivative through the OUTPUT h
-  if (act == OSA_ACT_TANH) return 1.f - h * h;
-  if (act == OSA_ACT_RELU) return h > 0.f ? 1.f : 0.f;
-  if (act == OSA_ACT_SIGMOID) return h * (1.f - h);
-  if (act == OSA_ACT_SOFTPLUS) return 1.f - expf(-h);
-  return 1.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,16 +228,6 @@ struct GArgs {
   GProb p[3];
   int nprob, splits;
 };
-
-__device__ __forceinline__ f32x4 gm_load4(const float* __restrict__ row, int c0, int limit, bool ok) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (!ok || c0 >= limit) return v;
-  if (c0 + 3 < limit) return *reinterpret_cast<const f32x4*>(row + c0);
-  v.x = row[c0];
-  if (c0 + 1 < limit) v.y = row[c0 + 1];
-  if (c0 + 2 < limit) v.z = row[c0 + 2];
-  return v;
-}
 
 // C[m][n] = epi(sum_k A(m, k) B(k, n)).   AT: A(m, k) = A[k lda + m] (else A[m lda + k]);
 //                                          BT: B(k, n) = B[k ldb + n] (else B[n ldb + k]).
@@ -546,16 +561,6 @@ __global__ __launch_bounds__(256) void gm_gather_kernel(
   }
 }
 
-__device__ __forceinline__ float gm_block_sum(float v, float* red) {  // deterministic; result to all; 256 threads
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v = osa_wave_sum(v);
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  const float s = (red[0] + red[1]) + (red[2] + red[3]);
-  return s;
-}
-
 struct GLossArgs {
   long R;
   int act_dim, lda, ldo[3];          // row strides of the action rows and of the three output layers
@@ -574,6 +579,14 @@ struct GLossArgs {
   const float* tmean;
   int ldt;
   float fvp_scale;
+  // extended actor surrogates (osa_surrogate_ext: FOCOPS, CUP's second stage, P3O); ext_on = 0: none
+  int ext_on;
+  const long* idx;           // minibatch rows (old_mean is indexed like obs), or nullptr
+  const float* old_mean;
+  int ld_old_mean;
+  const float* old_log_std;
+  float ext_kl_coef, ext_mask_eta, ext_ratio_scale, ext_cost_kappa, ext_cost_excess;
+  float* stats;              // stats[10] receives P3O's penalty value
 };
 
 // grid (nblk, 3): one thread per row.  Actor (policy_gradient.py:514-524 with PPOLag's surrogate, ppo.py:66-87 /
@@ -592,6 +605,7 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
       const float diff = a.out[net][b * a.ldo[net]] - a.scal[(net == 1 ? 3 : 4) * a.R + b];
       loss = diff * diff;
       a.dz[net][b * a.ldz[net]] = 2.f * diff * invB;
+      for (int d = 1; d < a.ldz[net]; ++d) a.dz[net][b * a.ldz[net] + d] = 0.f;  // (row padding: the skinny kernels' 16-byte loads)
     }
   } else if (a.loss_kind == 2) {
     if (valid)
@@ -599,6 +613,8 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
         const float sd = expf(a.log_std[d]);
         a.dz[0][b * a.ldz[0] + d] = a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale;
       }
+    if (valid)
+      for (int d = a.act_dim; d < a.ldz[0]; ++d) a.dz[0][b * a.ldz[0] + d] = 0.f;
   } else {
     const float lam = a.lagrange ? *a.lagrange : 0.f;
     float lp = 0.f;
@@ -608,9 +624,35 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
         const float z = a.actg[b * a.lda + d] - a.out[0][b * a.ldo[0] + d];
         lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
       }
-    float dlogp = 0.f;
+    const float ratio = valid ? expf(lp - a.scal[0 * a.R + b]) : 0.f;
+    // ---- extended surrogates: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
+    // trust mask with the reference's broadcast semantics (focops.py:84-88: the surrogate term sees the minibatch MEAN
+    // of the mask), P3O's kappa * relu(mean(ratio * A_c) + excess) -- the arithmetic of osa_mb_grad_kernel's EXT form.
+    // The mask mean and the penalty are minibatch-level: ONE block (the entry point refuses more than 256 rows).
+    float kl = 0.f, mask = 1.f, mask_mean = 1.f, cost_w = 0.f;
+    const long orow = a.ext_on ? (a.idx ? a.idx[valid ? b : 0] : (valid ? b : 0)) : 0;
+    if (a.ext_on) {
+      if (valid)
+        for (int d = 0; d < a.act_dim; ++d) {
+          const float ls = a.log_std[d], ls0 = a.old_log_std[d], dl = ls - ls0;
+          const float q = expf(dl), isd0 = expf(-ls0);
+          const float u = (a.out[0][b * a.ldo[0] + d] - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
+          kl += 0.5f * (q * q + u * u - 1.f - 2.f * dl);
+        }
+      if (a.ext_mask_eta >= 0.f || a.ext_cost_kappa > 0.f) {  // block-uniform
+        mask = (a.ext_mask_eta < 0.f || (valid && kl <= a.ext_mask_eta)) ? 1.f : 0.f;
+        const float tm = gm_block_sum(valid ? mask : 0.f, red);
+        const float tc = gm_block_sum(valid ? ratio * a.scal[2 * a.R + b] : 0.f, red);
+        if (a.ext_mask_eta >= 0.f) mask_mean = tm * invB;
+        if (a.ext_cost_kappa > 0.f) {
+          const float pen = tc * invB + a.ext_cost_excess;
+          if (pen > 0.f) cost_w = a.ext_cost_kappa;
+          if (threadIdx.x == 0 && a.stats) a.stats[10] = a.ext_cost_kappa * fmaxf(pen, 0.f);
+        }
+      }
+    }
+    float dlogp = 0.f, dklw = 0.f;
     if (valid) {
-      const float ratio = expf(lp - a.scal[0 * a.R + b]);
       const float adv = (a.scal[1 * a.R + b] - lam * a.scal[2 * a.R + b]) / (1.f + lam);
       float dratio;
       if (a.loss_kind == 0) {
@@ -624,6 +666,12 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
         loss = -(ratio * adv);
         dratio = -adv;
       }
+      if (a.ext_on) {
+        const float rs = a.ext_ratio_scale * mask_mean;
+        loss = loss * rs + a.ext_kl_coef * kl * mask;
+        dratio = dratio * rs + cost_w * a.scal[2 * a.R + b];
+        dklw = a.ext_kl_coef * mask * invB;
+      }
       ratio_s = ratio;
       dlogp = dratio * ratio * invB;
     }
@@ -633,13 +681,23 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
       if (valid) {
         const float sd = expf(a.log_std[d]);
         const float iv = 1.f / (sd * sd);
-        const float z = a.actg[b * a.lda + d] - a.out[0][b * a.ldo[0] + d];
-        a.dz[0][b * a.ldz[0] + d] = dlogp * z * iv;
+        const float mu = a.out[0][b * a.ldo[0] + d];
+        const float z = a.actg[b * a.lda + d] - mu;
+        float dmu = dlogp * z * iv;
         dl = dlogp * (z * z * iv - 1.f);
+        if (a.ext_on) {  // d KL / d mu = (mu - mu0) / var0;  d KL / d log_std = var / var0 - 1
+          const float ls0 = a.old_log_std[d], q = expf(a.log_std[d] - ls0), isd0 = expf(-ls0);
+          const float u = (mu - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
+          dmu += dklw * (u * isd0);
+          dl += dklw * (q * q - 1.f);
+        }
+        a.dz[0][b * a.ldz[0] + d] = dmu;
       }
       dl = gm_block_sum(dl, red);
       if (threadIdx.x == 0) a.dls[(long)blockIdx.x * a.lda + d] = dl;
     }
+    if (valid)
+      for (int d = a.act_dim; d < a.ldz[0]; ++d) a.dz[0][b * a.ldz[0] + d] = 0.f;  // (row padding)
   }
   loss = gm_block_sum(loss, red);
   ratio_s = gm_block_sum(ratio_s, red);
@@ -919,6 +977,7 @@ __global__ __launch_bounds__(256) void gm_rowstat_final_kernel(const double* __r
   }
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -961,6 +1020,186 @@ int gm_gather(const GLayout& lo, const GWs& w, float* ws, long R, const long* id
                      act, ld_act, lo.act_dim, s0, s1, s2, s3, s4, ws + w.xg, lo.ldx, act ? ws + w.actg : nullptr,
                      lo.lda, ws + w.scal);
   return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+
+void gm_fill_ext(GLossArgs& la, const osa_surrogate_ext* ext, const long* idx, float* stats) {
+  la.ext_on = 0;
+  if (!ext) return;
+  la.ext_on = 1; la.idx = idx; la.old_mean = ext->old_mean; la.ld_old_mean = ext->ld_old_mean;
+  la.old_log_std = ext->old_log_std; la.ext_kl_coef = ext->kl_coef; la.ext_mask_eta = ext->kl_mask_eta;
+  la.ext_ratio_scale = ext->ratio_scale; la.ext_cost_kappa = ext->cost_kappa; la.ext_cost_excess = ext->cost_excess;
+  la.stats = stats;
+}
+
+// A launch goes to gs_big_kernel (contraction split over workgroups, operands through LDS) when its largest problem
+// is large in BOTH dimensions: below that the simple kernels sit at the launch-latency floor anyway.
+template <bool BWD>
+bool gs_big_ok(const GSArgs& g) {
+  static const int sw = [] {  // (A/B switch: OSA_GMLP_BIG=0 keeps every layer on gs_fwd / gs_bwd)
+    const char* v = getenv("OSA_GMLP_BIG");
+    return (v != nullptr && v[0] == '0' && v[1] == 0) ? 0 : 1;
+  }();
+  if (!sw) return false;
+  int maxC = 0, maxO = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const int C = BWD ? g.p[i].N : g.p[i].K, O = BWD ? g.p[i].K : g.p[i].N;
+    if (C > maxC) maxC = C;
+    if (O > maxO) maxO = O;
+  }
+  return maxC >= 512 && maxO >= 256;
+}
+
+template <bool BWD>
+int gs_big_launch(const GSArgs& g, float* slab, int* ticket, hipStream_t st) {
+  constexpr size_t lds = (size_t)((BWD ? GSB_CL * GSB_LDT : 64 * GSB_LD) + 64 * GSB_LD) * sizeof(float);
+  static OsaPerDeviceOnce attr_set;
+  if (attr_set.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_big_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return OSA_EHIP;
+    attr_set.set();
+  }
+  GSBArgs a = {};
+  a.nprob = g.nprob; a.R = g.R; a.slab = slab; a.ticket = ticket;
+  int total = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    a.p[i] = g.p[i];
+    const int C = BWD ? g.p[i].N : g.p[i].K, O = BWD ? g.p[i].K : g.p[i].N;
+    a.tiles[i] = (O + 63) / 64;
+    a.S[i] = (C + GSB_CL - 1) / GSB_CL;
+    total += a.tiles[i] * a.S[i];
+  }
+  hipLaunchKernelGGL(gs_big_kernel<BWD>, dim3(total), dim3(512), lds, st, a);
+  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+}
+
+bool gs_enabled() {  // (A/B and test switch: OSA_GMLP_SKINNY=0 keeps small minibatches on the tiled GEMM)
+  const char* v = getenv("OSA_GMLP_SKINNY");
+  return !(v != nullptr && v[0] == '0' && v[1] == 0);
+}
+
+// One optimiser step (or its gradient: mode 1 / 2) of a minibatch of B <= 64 rows on the skinny kernels:
+// gather, L forward launches, loss, L - 1 backward-data launches, ONE weight-gradient launch over all layers
+// (norm partials), gm_final_kernel, then clip + Adam from recomputed tiles (mode 0) or the scaling of the written
+// gradient (mode 1).
+int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* adam_m, float* adam_v, int* adam_step,
+                        float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
+                        const float* target_value_r, const float* target_value_c, const float* adv_r,
+                        const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
+                        int loss_kind, int mode, int mask, float* ws, float* step_stats, const osa_surrogate_ext* ext,
+                        hipStream_t st) {
+  int rc;
+  if ((rc = gm_gather(lo, w, ws, B, idx, obs, ld_obs, act, ld_act, logp, adv_r, adv_c, target_value_r, target_value_c,
+                      st)) != OSA_OK)
+    return rc;
+  int maxL = 0;
+  for (int net = 0; net < 3; ++net)
+    if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
+  // ---- forward, layer by layer (the networks of a layer in one launch)
+  for (int l = 0; l < maxL; ++l) {
+    GSArgs g = {};
+    g.R = (int)B;
+    int maxN = 0;
+    for (int net = 0; net < 3; ++net) {
+      const GNet& n = lo.n[net];
+      if (!((mask >> net) & 1) || l >= n.L) continue;
+      GSProb& p = g.p[g.nprob++];
+      const float* pn = params + (long)net * lo.P;
+      p.X = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
+      p.ldx = l == 0 ? lo.ldx : n.ldh[l - 1];
+      p.W = pn + n.oW[l]; p.ldw = n.ld[l];
+      p.bias = pn + n.ob[l];
+      p.Y = ws + w.h[net][l]; p.ldy = n.ldh[l];
+      p.N = n.out[l]; p.K = n.in[l];
+      p.act = l + 1 < n.L ? n.act : -1;
+      if (p.N > maxN) maxN = p.N;
+    }
+    if (gs_big_ok<false>(g))
+      gs_big_launch<false>(g, ws + w.bslab, reinterpret_cast<int*>(ws + w.tick), st);
+    else
+      hipLaunchKernelGGL(gs_fwd_kernel, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+  }
+  // ---- loss and dL/d(output)
+  const GNet& an = lo.n[0];
+  GLossArgs la = {};
+  la.R = B; la.act_dim = lo.act_dim; la.lda = lo.lda;
+  for (int net = 0; net < 3; ++net) {
+    const GNet& n = lo.n[net];
+    la.out[net] = ws + w.h[net][n.L - 1];
+    la.ldo[net] = n.ldh[n.L - 1];
+    la.dz[net] = ws + w.zs[net][n.L - 1];
+    la.ldz[net] = n.ldh[n.L - 1];
+  }
+  la.actg = ws + w.actg; la.scal = ws + w.scal; la.log_std = params + an.oLS; la.lagrange = lagrange;
+  la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
+  la.dls = ws + w.dls; la.lpart = ws + w.lpart;
+  gm_fill_ext(la, ext, idx, step_stats);
+  hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
+  // ---- backward-data, from the top of EACH network
+  for (int step = 0; step + 1 < maxL; ++step) {
+    GSArgs g = {};
+    g.R = (int)B;
+    int maxK = 0;
+    for (int net = 0; net < 3; ++net) {
+      const GNet& n = lo.n[net];
+      const int l = n.L - 1 - step;
+      if (!((mask >> net) & 1) || l < 1) continue;
+      GSProb& p = g.p[g.nprob++];
+      p.X = ws + w.zs[net][l]; p.ldx = n.ldh[l];
+      p.W = params + (long)net * lo.P + n.oW[l]; p.ldw = n.ld[l];
+      p.Y = ws + w.zs[net][l - 1]; p.ldy = n.ldh[l - 1];
+      p.aux = ws + w.h[net][l - 1]; p.ldaux = n.ldh[l - 1];
+      p.N = n.out[l]; p.K = n.in[l];
+      p.act = n.act;
+      if (p.K > maxK) maxK = p.K;
+    }
+    if (g.nprob > 0) {
+      if (gs_big_ok<true>(g))
+        gs_big_launch<true>(g, ws + w.bslab, reinterpret_cast<int*>(ws + w.tick), st);
+      else
+        hipLaunchKernelGGL(gs_bwd_kernel, dim3((maxK + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+    }
+  }
+  // ---- weight gradients of all layers: norm partials (+ the gradient itself for modes 1 / 2)
+  GSWArgs wa = {};
+  for (int net = 0; net < 3; ++net) {
+    const GNet& n = lo.n[net];
+    wa.L[net] = n.L; wa.ntile[net] = w.sk_ntile[net]; wa.oLS[net] = n.oLS;
+    for (int l = 0; l < n.L; ++l) {
+      GSWLayer& y = wa.l[net][l];
+      y.dZ = ws + w.zs[net][l]; y.ldz = n.ldh[l];
+      y.H = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
+      y.ldh = l == 0 ? lo.ldx : n.ldh[l - 1];
+      y.out = n.out[l]; y.in = n.in[l]; y.ldw = n.ld[l]; y.oW = n.oW[l]; y.ob = n.ob[l];
+      y.tile0 = w.sk_tile0[net][l]; y.tk = w.sk_tk[net][l];
+    }
+  }
+  wa.R = (int)B; wa.P = lo.P; wa.maxT1 = w.sk_maxT1; wa.act_dim = lo.act_dim; wa.lda = lo.lda; wa.nblk = w.nblk;
+  wa.nets_mask = mask; wa.loss_kind = loss_kind; wa.write_grads = mode != 0; wa.use_critic_norm = hp->use_critic_norm;
+  wa.params = params; wa.adam_m = adam_m; wa.adam_v = adam_v; wa.grads = grads; wa.npart = ws + w.npart;
+  wa.fin = ws + w.fin; wa.dls = ws + w.dls; wa.lpart = ws + w.lpart; wa.stats = step_stats;
+  wa.entropy_coef = hp->entropy_coef; wa.critic_norm_coef = hp->critic_norm_coef; wa.beta1 = hp->beta1;
+  wa.beta2 = hp->beta2; wa.eps = hp->adam_eps;
+  wa.fold = mode == 0; wa.use_max_grad_norm = hp->use_max_grad_norm; wa.max_grad_norm = hp->max_grad_norm;
+  wa.adam_step = adam_step; wa.lr_dev = hp->lr_device; wa.lr_actor = hp->lr_actor; wa.lr_critic = hp->lr_critic;
+  hipLaunchKernelGGL(gs_wgrad_kernel<0>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
+  if (mode == 0) {
+    hipLaunchKernelGGL(gs_wgrad_kernel<1>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
+    OSA_CHECK_LAUNCH();
+    return OSA_OK;
+  }
+  GFinArgs fa = {};
+  fa.nb = w.sk_maxT1; fa.nets_mask = mask; fa.mode = mode; fa.npart = ws + w.npart; fa.fin = ws + w.fin;
+  fa.adam_step = adam_step; fa.stats = step_stats; fa.max_grad_norm = hp->max_grad_norm;
+  fa.lr_actor = hp->lr_actor; fa.lr_critic = hp->lr_critic; fa.beta1 = hp->beta1; fa.beta2 = hp->beta2;
+  fa.use_max_grad_norm = hp->use_max_grad_norm; fa.lr_dev = hp->lr_device;
+  hipLaunchKernelGGL(gm_final_kernel, dim3(3), dim3(256), 0, st, fa);
+  if (mode == 1)
+    hipLaunchKernelGGL(gm_apply_kernel, dim3((lo.P / 4 + 255) / 256, 3), dim3(256), 0, st, lo.P, mask, mode,
+                       ws + w.fin, params, adam_m, adam_v, grads, hp->beta1, hp->beta2, hp->adam_eps);
+  OSA_CHECK_LAUNCH();
+  return OSA_OK;
 }
 
 }  // namespace
@@ -1024,7 +1263,24 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
                        const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
                        int loss_kind, int mode, int nets_mask, const float* vec, float fvp_scale, float* ws,
                        size_t ws_floats, float* step_stats, void* stream) {
+  return osa_gmlp_minibatch_ext(desc, params, adam_m, adam_v, adam_step, grads, obs, ld_obs, act, ld_act, logp,
+                                target_value_r, target_value_c, adv_r, adv_c, idx, B, lagrange, hp, loss_kind, mode,
+                                nets_mask, vec, fvp_scale, ws, ws_floats, step_stats, nullptr, stream);
+}
+
+int osa_gmlp_minibatch_ext(const osa_gmlp_desc* desc, float* params, float* adam_m, float* adam_v, int* adam_step,
+                           float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
+                           const float* target_value_r, const float* target_value_c, const float* adv_r,
+                           const float* adv_c, const long* idx, long B, const float* lagrange,
+                           const osa_ppo_hparams* hp, int loss_kind, int mode, int nets_mask, const float* vec,
+                           float fvp_scale, float* ws, size_t ws_floats, float* step_stats,
+                           const osa_surrogate_ext* ext, void* stream) {
   OSA_REQUIRE(desc && params && adam_m && adam_v && adam_step && grads && obs && hp && ws && B > 0);
+  if (ext) {
+    OSA_REQUIRE(loss_kind != 2 && ext->old_mean && ext->old_log_std && ext->ld_old_mean >= desc->act_dim);
+    // the trust-mask mean and the penalty are minibatch-level quantities of ONE 256-row block of the loss kernel
+    if ((ext->kl_mask_eta >= 0.f || ext->cost_kappa > 0.f) && B > 256) return OSA_EUNSUPPORTED;
+  }
   OSA_REQUIRE(mode >= 0 && mode <= 2 && loss_kind >= 0 && loss_kind <= 2);
   OSA_REQUIRE(loss_kind == 2 ? vec != nullptr : (act && logp && target_value_r && target_value_c && adv_r && adv_c));
   GLayout lo;
@@ -1035,6 +1291,10 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
   hipStream_t st = osa_stream(stream);
   int mask = nets_mask & (hp->use_cost ? 7 : 3);
   if (loss_kind == 2) mask = 1;
+  if (B <= GS_MAX_ROWS && loss_kind != 2 && gs_enabled())
+    return gm_minibatch_skinny(lo, w, params, adam_m, adam_v, adam_step, grads, obs, ld_obs, act, ld_act, logp,
+                               target_value_r, target_value_c, adv_r, adv_c, idx, B, lagrange, hp, loss_kind, mode, mask,
+                               ws, step_stats, ext, st);
   if ((rc = gm_gather(lo, w, ws, B, idx, obs, ld_obs, loss_kind == 2 ? nullptr : act, ld_act, logp, adv_r, adv_c,
                       target_value_r, target_value_c, st)) != OSA_OK)
     return rc;
@@ -1088,6 +1348,7 @@ int osa_gmlp_minibatch(const osa_gmlp_desc* desc, float* params, float* adam_m, 
   la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
   la.dls = ws + w.dls; la.lpart = ws + w.lpart;
   la.tmean = ws + w.t[an.L - 1]; la.ldt = an.ldh[an.L - 1]; la.fvp_scale = fvp_scale;
+  gm_fill_ext(la, ext, idx, step_stats);
   hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
   OSA_CHECK_LAUNCH();
   // ---- backward: weight (+ bias) gradients into the slabs, then dZ of the layer below

@@ -1,9 +1,8 @@
 // ConstraintActorCritic.step (omnisafe/models/actor_critic/constraint_actor_critic.py:84-109) for the 16 rows of one
 // wave and ONE network: forward pass (mlp_device.h), then -- actor -- sample a = mu + eps sigma (injected noise or
 // Philox4x32-10 + Box-Muller, one counter block per (row, dimension)), log-probability, ActionScale (envs/wrapper.py:
-// 510-514) and -- critics -- the value.  Shared by osa_policy_step_kernel (mlp_kernels.hip: one launch per vector
-// step) and the persistent rollout kernel (rollout_persistent.hip: the whole epoch in one launch), so that both
-// produce the same bits.
+// 510-514) and -- critics -- the value.  The body of osa_policy_step_kernel (mlp_kernels.hip: one launch per vector
+// step).
 #pragma once
 #include "mlp_device.h"
 

@@ -54,9 +54,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # general networks (hidden_sizes outside the fused family: csrc/general_mlp.hip) run every optimiser step on
         # the layer-wise GEMM path -- no persistent pass, data parallelism by per-step all-reduce
         self.general = bool(getattr(ac, 'general', False))
-        if self.general and ext is not None:
-            raise NotImplementedError('FOCOPS / CUP / P3O surrogates are implemented for the fused network family '
-                                      '([H, H], H in 32 .. 256) only')
+        if self.general and ext is not None and int(batch_size) > 256 and (ext.kl_mask_eta >= 0 or ext.cost_kappa > 0):
+            # (FOCOPS' trust-mask mean and P3O's penalty are minibatch-level quantities of one block of the loss kernel)
+            raise NotImplementedError('FOCOPS / P3O on general networks: batch_size <= 256')
         self.update_critics = update_critics
         self.lib = _lib.load(require_gpu=True)
         self.batch_size, self.update_iters = int(batch_size), int(update_iters)
@@ -199,9 +199,15 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         """The per-step launches of a pass go through a captured hipGraph: large minibatches (the launches, not the
         rows, are what a step waits for), plain surrogate, single process.  OSA_UPDATE_GRAPH=0 keeps eager launches."""
         nmb = (M + self.batch_size - 1) // self.batch_size
-        # (general networks: a step is ~13 launches of the layer-wise path -- captured whenever the pass stays below a
+        # (general networks: a step is ~10 launches of the layer-wise path -- captured whenever the pass stays below a
         # few thousand graph nodes, whatever the batch size)
-        return ((self.batch_size >= 2048 or (self.general and nmb <= 256)) and self.ext is None
+        # `allreduce` data parallelism at ANY batch size over RCCL (round 5): per step gradient kernel -> ONE flat
+        # all-reduce -> osa_adam_apply (policy_gradient.py:437-443's order with 1 message for 19), the pass's ~1000
+        # steps incl. their collectives one captured hipGraph -- eager, a 64-row step costs 58 us of launches against
+        # 9 us of kernel time at world 1 (profiles/r4_rccl_world1_timing.json)
+        dp_graph = (dist.collectives_active() and self.dp_mode == 'allreduce' and not self.general and nmb <= 1100
+                    and dist.graph_capturable())
+        return ((self.batch_size >= 2048 or (self.general and nmb <= 256) or dp_graph) and self.ext is None
                 and (not dist.collectives_active() or dist.graph_capturable())
                 and os.environ.get('OSA_UPDATE_GRAPH', '1') != '0' and not self._ug.get('failed', False))
 
@@ -306,13 +312,20 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev[0].record()
         if self.general:
             ws, nws = ac.gmlp_ws(B)
-            _lib.check(lib.osa_gmlp_minibatch(
+            gext = None
+            if self.ext is not None:  # FOCOPS / CUP / P3O on general networks (utils/model.py:73-111 builds any width)
+                self.ext.old_mean = self._old_mean.data_ptr()
+                self.ext.ld_old_mean = self._old_mean.stride(0)
+                self.ext.old_log_std = self._old_log_std.data_ptr()
+                gext = C.byref(self.ext)
+            _lib.check(lib.osa_gmlp_minibatch_ext(
                 C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
                 _lib.ptr(ac.adam_step), _lib.ptr(ac.grads), _lib.ptr(data['obs']), data['obs'].stride(0),
                 _lib.ptr(data['act']), data['act'].stride(0), _lib.ptr(data['logp']),
                 _lib.ptr(data['target_value_r']), _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']),
                 _lib.ptr(data['adv_c']), _lib.ptr(idx), B, _lib.ptr(lagrange), C.byref(self.hp), self.loss_kind,
-                mode, self._nets_mask(), None, 0.0, _lib.ptr(ws), nws, _lib.ptr(stats_row), st), 'osa_gmlp_minibatch')
+                mode, self._nets_mask(), None, 0.0, _lib.ptr(ws), nws, _lib.ptr(stats_row), gext, st),
+                'osa_gmlp_minibatch_ext')
             if ev is not None:
                 ev[1].record()
                 self.profile_events.append(('gm_gemm_kernel', B, ev))
@@ -925,6 +938,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         if not use_repl and not use_pass and B >= 2048 and dist.collectives_active() and self.ext is None:
             # (what ran, for the tests and the bench line: the captured pass incl. its RCCL all-reduces, or eager steps)
             self.last_path = 'dp-large-batch-graph' if getattr(self, '_graphed_pass', False) else 'dp-large-batch'
+        elif (not use_repl and not use_pass and dist.collectives_active() and self.dp_mode == 'allreduce'
+              and getattr(self, '_graphed_pass', False)):
+            self.last_path = 'allreduce-graph'  # (eager steps -- gloo, or before the capture -- stay 'per-step')
         if self.general:
             self.last_path = 'general-' + self.last_path  # (layer-wise GEMM path, csrc/general_mlp.hip)
         if self._use_wide:

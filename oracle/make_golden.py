@@ -403,7 +403,7 @@ SIBLINGS = [
 ]
 
 
-def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, update_iters=2):
+def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, update_iters=2, model=None):
     """One reference `_update()` of `algo_name` on a reference-collected buffer of N x T transitions of
     `env_id`: inputs (initial parameters, `buf.get()` output, EpCost window, recorded permutations) and
     outputs (parameters of all three networks, multiplier, logged statistics) -> tests/golden/<out_name>."""
@@ -423,6 +423,8 @@ def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, u
            'logger_cfgs': {'use_wandb': False, 'use_tensorboard': False, 'log_dir': d}}
     if lag:
         cfg['lagrange_cfgs'] = lag
+    if model:  # network shapes other than the YAML's [64, 64] (utils/model.py:73-111 builds any hidden_sizes)
+        cfg['model_cfgs'] = model
     algo = omnisafe.Agent(algo_name, env_id, custom_cfgs=cfg).agent
     ac = algo._actor_critic
     out = {'N': N, 'T': T, 'algo': algo_name, 'env_id': env_id}
@@ -452,7 +454,7 @@ def _gen_update_golden(algo_name, env_id, out_name, N, T, horizon, extra, lag, u
     for k, v in captured.items():
         out[f'data/{k}'] = _np(v)
     if hasattr(algo, '_lagrange'):
-        out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
+        out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
     # RandomSampler draws two permutations per pass (see gen_rollout_and_ppolag_update)
     out['perms'] = np.stack([_np(p) for p in rec.perms[::2]]) if rec.perms else np.zeros((0, N * T), np.int64)
     for net in ('actor', 'reward_critic', 'cost_critic'):
@@ -495,6 +497,30 @@ CONFIG_SHAPES = [
      {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
     ('config5_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
 ]
+
+
+# One whole reference `_update()` on networks OUTSIDE the YAML's [64, 64] family (the layer-wise path of
+# csrc/general_mlp.hip incl. its skinny kernels for 64-row minibatches): unequal widths, actor != critics.
+_M256 = {'actor': {'hidden_sizes': [256, 128]}, 'critic': {'hidden_sizes': [256, 128]}}
+HIDDEN_SHAPES = [
+    ('hidden256x128_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}, _M256),
+    ('hidden256x128_trpolag_ant', 'TRPOLag', 'SynthAnt-v0', {}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5},
+     _M256),
+    ('hidden256x128_focops_point', 'FOCOPS', 'SynthPointGoal1-v0', {'focops_eta': 0.02}, {'cost_limit': 1.0}, _M256),
+    ('hidden96x40x24_p3o_point', 'P3O', 'SynthPointGoal1-v0', {'cost_limit': 0.5, 'kappa': 2.0}, None,
+     {'actor': {'hidden_sizes': [96, 40, 24]}, 'critic': {'hidden_sizes': [80, 48]}}),
+]
+
+
+def gen_hidden_shape_updates(only=None):
+    N, T, horizon = 16, 64, 16
+    for tag, algo_name, env_id, extra, lag, model in HIDDEN_SHAPES:
+        if only and tag not in only:
+            continue
+        out = _gen_update_golden(algo_name, env_id, f'{tag}.npz', N, T, horizon, extra, lag, model=model)
+        print(tag, {k: out[k] for k in ('Jc', 'lambda_before', 'lambda_after') if k in out}, 'perms',
+              out['perms'].shape, out['init/actor/mean.0.weight'].shape)
 
 
 def gen_config_shape_updates(only=None):
@@ -594,7 +620,7 @@ def _dp2_worker(rank, world, port, spec, tmp):
         algo._update()
     for k, v in captured.items():
         out[f'data/{k}'] = _np(v)
-    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
+    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
     out['perms'] = np.stack([_np(p) for p in rec.perms[::2]])  # RandomSampler draws two permutations per pass
     for net in ('actor', 'reward_critic', 'cost_critic'):
         for k, v in _state(getattr(ac, net)).items():
@@ -887,6 +913,7 @@ def main():
     gen_trust_region_updates()
     gen_sibling_updates()
     gen_config_shape_updates()
+    gen_hidden_shape_updates()
     gen_dp2_updates()
     gen_saute_simmer()
     gen_early_terminated()
@@ -911,6 +938,10 @@ if __name__ == '__main__':
         ref_harness.import_reference()
         torch.set_num_threads(1)
         gen_config_shape_updates(only=sys.argv[2:] or None)
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'hidden-shapes':
+        ref_harness.import_reference()
+        torch.set_num_threads(1)
+        gen_hidden_shape_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp2':
         gen_dp2_updates(only=sys.argv[2:] or None)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp4':  # the same recordings with FOUR ranks -> tests/golden/dp4_<...>.npz

@@ -74,15 +74,16 @@ def test_models_accept_what_the_reference_builds(monkeypatch):
     assert ac.general
 
 
+@pytest.mark.parametrize('B', [300, 64])  # (64: the YAML batch_size -- the skinny kernels; 300: the tiled GEMM)
 @pytest.mark.parametrize('obs_dim,act_dim,a_h,c_h,a_act,c_act', SHAPES)
-def test_policy_step_kl_and_one_update_vs_oracle(monkeypatch, obs_dim, act_dim, a_h, c_h, a_act, c_act):
+def test_policy_step_kl_and_one_update_vs_oracle(monkeypatch, obs_dim, act_dim, a_h, c_h, a_act, c_act, B):
     from omnisafe_amd.update import PPOUpdater
 
     monkeypatch.setenv('OSA_FORCE_GENERAL_MLP', '1')
     torch.manual_seed(2)
     ac, ref = make(obs_dim, act_dim, a_h, c_h, a_act, c_act)
     assert ac.general
-    M, B = 700, 300  # ragged: not a multiple of any tile
+    M = 700  # ragged: not a multiple of any tile
     obs = torch.randn(M, obs_dim)
     eps = torch.randn(M, act_dim)
     # ---- ConstraintActorCritic.step (constraint_actor_critic.py:84-109)
@@ -133,7 +134,7 @@ def test_policy_step_kl_and_one_update_vs_oracle(monkeypatch, obs_dim, act_dim, 
             # (Adam's first steps are lr g / (|g| + eps): elements whose gradient is of the order of eps amplify
             # summation-order differences -- all but a handful agree to float32 rounding)
             bad = np.abs(got - want) > 2e-6 + 1e-4 * np.abs(want)
-            assert bad.mean() < 2e-3 and np.abs(got - want).max() < 3e-3, (net, key, bad.mean(), np.abs(got - want).max())
+            assert bad.mean() < 2e-3 and np.abs(got - want).max() < 1e-3, (net, key, bad.mean(), np.abs(got - want).max())
     # ---- KL(old || new) after the two steps (policy_gradient.py:383-390)
     kl = float(up.kl(dev['obs']))
     np.testing.assert_allclose(kl, O.kl_old_new(ref.actor, obs, om, osd), rtol=5e-3, atol=1e-7)
@@ -249,3 +250,171 @@ def test_agents_with_general_networks_end_to_end(tmp_path, algo_name, a_h, c_h):
     assert bool(torch.isfinite(p).all()) and not torch.equal(p, p0)
     sd = a._actor_critic.actor.state_dict()
     assert tuple(sd['mean.0.weight'].shape) == (a_h[0], 72)
+
+
+def _mb_call(up, dev, idx, B, lam, stats_row, mode):
+    """osa_gmlp_minibatch with an explicit mode (0 clip + Adam, 1 clipped gradient only, 2 raw gradient)."""
+    import ctypes as C
+
+    from omnisafe_amd import _lib
+
+    ac, lib = up.ac, up.lib
+    ws, nws = ac.gmlp_ws(B)
+    _lib.check(lib.osa_gmlp_minibatch(
+        C.byref(ac.desc), _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step),
+        _lib.ptr(ac.grads), _lib.ptr(dev['obs']), dev['obs'].stride(0), _lib.ptr(dev['act']), dev['act'].stride(0),
+        _lib.ptr(dev['logp']), _lib.ptr(dev['target_value_r']), _lib.ptr(dev['target_value_c']), _lib.ptr(dev['adv_r']),
+        _lib.ptr(dev['adv_c']), _lib.ptr(idx), B, _lib.ptr(lam), C.byref(up.hp), up.loss_kind, mode, up._nets_mask(),
+        None, 0.0, _lib.ptr(ws), nws, _lib.ptr(stats_row), _lib.stream_ptr()), 'osa_gmlp_minibatch')
+
+
+@pytest.mark.parametrize('B', [64, 37, 3])
+@pytest.mark.parametrize('obs_dim,act_dim,a_h,c_h,a_act,c_act', SHAPES + [
+    (60, 2, [100, 100, 100, 100, 100, 100, 100], [20], 'sigmoid', 'softplus'),  # seven hidden layers / one
+    (33, 5, [], [], 'tanh', 'tanh')])                                           # no hidden layer at all
+def test_skinny_step_equals_the_tiled_step(monkeypatch, obs_dim, act_dim, a_h, c_h, a_act, c_act, B):
+    """Minibatches of <= 64 rows (the YAML batch_size) take the skinny kernels (general_mlp.hip: gs_fwd / gs_bwd /
+    gs_wgrad -- weights streamed once per pass, clip + Adam from recomputed gradient tiles); OSA_GMLP_SKINNY=0 keeps
+    them on the tiled GEMM path that the tests above pin to the oracle and to the reference's goldens.  Same inputs,
+    three chained optimiser steps, then one clipped and one raw gradient: parameters, moments, statistics and
+    gradients agree to the summation order of float32 MFMA chains."""
+    from omnisafe_amd.update import PPOUpdater
+
+    monkeypatch.setenv('OSA_FORCE_GENERAL_MLP', '1')
+    M = 500
+    g = torch.Generator().manual_seed(5)
+    cpu = {'obs': torch.randn(M, obs_dim, generator=g), 'act': torch.randn(M, act_dim, generator=g),
+           'logp': -1.0 + 0.3 * torch.randn(M, generator=g), 'target_value_r': torch.randn(M, generator=g),
+           'target_value_c': torch.randn(M, generator=g), 'adv_r': torch.randn(M, generator=g),
+           'adv_c': torch.randn(M, generator=g)}
+    dev = {k: v.to(DEV).contiguous() for k, v in cpu.items()}
+    idxs = [torch.randperm(M, generator=g)[:B].to(DEV) for _ in range(5)]
+    lam = torch.tensor([0.7], device=DEV)
+    out = {}
+    for skinny in ('1', '0'):
+        monkeypatch.setenv('OSA_GMLP_SKINNY', skinny)
+        torch.manual_seed(3)
+        ac, _ = make(obs_dim, act_dim, a_h, c_h, a_act, c_act)
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, entropy_coef=0.02)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        stats = torch.zeros(5, 16, device=DEV)
+        for k in range(3):
+            up.minibatch(dev, idxs[k], B, lam, stats[k])
+        res = {'params': ac.params.clone(), 'm': ac.adam_m.clone(), 'v': ac.adam_v.clone(),
+               'step': ac.adam_step.clone()}
+        _mb_call(up, dev, idxs[3], B, lam, stats[3], 1)
+        res['g_clipped'] = ac.grads.clone()
+        _mb_call(up, dev, idxs[4], B, lam, stats[4], 2)
+        res['g_raw'] = ac.grads.clone()
+        assert torch.equal(ac.params, res['params']) and torch.equal(ac.adam_step, res['step'])  # modes 1 / 2: no update
+        res['stats'] = stats.clone()
+        out[skinny] = res
+    a, b = out['1'], out['0']
+    assert a['step'].tolist() == [3, 3, 3] == b['step'].tolist()
+    for key in ('g_raw', 'g_clipped', 'm', 'v'):
+        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
+        scale = np.abs(y).max() + 1e-30
+        assert np.abs(x - y).max() <= 1e-4 * scale, (key, np.abs(x - y).max(), scale)
+    x, y = a['params'].cpu().numpy(), b['params'].cpu().numpy()
+    # (three Adam steps of lr <= 1e-3: elements whose gradient is of the order of eps amplify summation-order noise)
+    bad = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
+    assert bad.mean() < 2e-3 and np.abs(x - y).max() < 1e-3, (bad.mean(), np.abs(x - y).max())
+    sa, sb = a['stats'].cpu().numpy(), b['stats'].cpu().numpy()
+    np.testing.assert_allclose(sa[:, :10], sb[:, :10], rtol=2e-4, atol=1e-6)
+    # zero padding of the blocks stays zero on the skinny path as well
+    real = torch.zeros_like(ac.params, dtype=torch.bool)
+    for i, net in enumerate((ac.actor, ac.reward_critic, ac.cost_critic)):
+        real[i, net._flat_index] = True
+    for key in ('params', 'm', 'v', 'g_raw', 'g_clipped'):
+        assert float(a[key][~real].abs().max()) == 0.0, key
+
+
+HIDDEN = [  # tests/golden/<tag>.npz = one `_update()` of the UNMODIFIED reference with these model_cfgs
+    ('hidden256x128_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', ({}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+     {'actor': {'hidden_sizes': [256, 128]}, 'critic': {'hidden_sizes': [256, 128]}}),
+    ('hidden256x128_focops_point', 'FOCOPS', 'SynthPointGoal1-v0', ({'focops_eta': 0.02}, {'cost_limit': 1.0}),
+     {'actor': {'hidden_sizes': [256, 128]}, 'critic': {'hidden_sizes': [256, 128]}}),
+    ('hidden96x40x24_p3o_point', 'P3O', 'SynthPointGoal1-v0', ({'cost_limit': 0.5, 'kappa': 2.0}, None),
+     {'actor': {'hidden_sizes': [96, 40, 24]}, 'critic': {'hidden_sizes': [80, 48]}}),
+]
+
+
+def _run_hidden(name, g, tmp_path, env_id, extra, model, batch_size):
+    import omnisafe_amd
+
+    N, T = int(g['N']), int(g['T'])
+    extra_algo, lag = extra
+    cfg = {'seed': 0, 'train_cfgs': {'device': DEV, 'total_steps': 4 * N * T, 'vector_env_nums': N},
+           'algo_cfgs': dict({'steps_per_epoch': N * T, 'update_iters': 2, 'kl_early_stop': False,
+                              'batch_size': batch_size}, **extra_algo),
+           'model_cfgs': model, 'logger_cfgs': {'log_dir': str(tmp_path), 'verbose': False}}
+    if lag:
+        cfg['lagrange_cfgs'] = lag
+    algo = omnisafe_amd.Agent(name, env_id, custom_cfgs=cfg).agent
+    ac = algo._actor_critic
+    assert ac.general
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        sd = {k[len('init/') + len(net) + 1:]: torch.from_numpy(v.copy()) for k, v in g.items()
+              if k.startswith(f'init/{net}/')}
+        getattr(ac, net).load_state_dict(sd)
+    data = {k[5:]: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in g.items() if k.startswith('data/')}
+    algo._buf.get = lambda: dict(data)
+    algo._logger.extend('Metrics/EpCost', [float(v) for v in g['ep_cost_window']])
+    algo._perms_override = [torch.from_numpy(p.copy()) for p in g['perms']]
+    algo._update()
+    return algo, ac
+
+
+def _hidden_check(ac, g, nets, atol):
+    for net in nets:
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{net}/{k}'], rtol=0, atol=atol, err_msg=f'{net}/{k}')
+
+
+@pytest.mark.parametrize('skinny', ['1', '0'])
+@pytest.mark.parametrize('tag,name,env_id,extra,model', HIDDEN)
+def test_first_order_update_of_the_reference_at_general_widths(golden, tmp_path, monkeypatch, tag, name, env_id, extra,
+                                                              model, skinny):
+    """One whole `_update()` of the unmodified reference built with `hidden_sizes` OUTSIDE the fused family
+    (oracle/make_golden.py::gen_hidden_shape_updates: [256, 128] for PPOLag and FOCOPS, actor [96, 40, 24] / critics
+    [80, 48] for P3O with its penalty active): 32 chained 64-row Adam steps per network on the layer-wise path -- skinny
+    kernels and tiled GEMM -- against the reference's post-update parameters, at the tolerance of the fused kernels'
+    config-shape tests (atol 2e-6; the parameters move by > 5e-3)."""
+    monkeypatch.setenv('OSA_GMLP_SKINNY', skinny)
+    g = golden(f'{tag}.npz')
+    algo, ac = _run_hidden(name, g, tmp_path, env_id, extra, model, 64)
+    assert algo._last_update_steps == 2 * 16
+    err = {n: max(float(np.abs(v.cpu().numpy() - g[f'post/{n}/{k}']).max()) for k, v in getattr(ac, n).state_dict().items())
+           for n in ('actor', 'reward_critic', 'cost_critic')}
+    print(tag, 'skinny', skinny, 'max |param - reference|:', err)
+    _hidden_check(ac, g, ('actor', 'reward_critic', 'cost_critic'), 2e-6)
+    moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
+    assert moved > 5e-3
+    log = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
+    np.testing.assert_allclose(log('Train/KL')[-1], g['log/Train/KL'][-1], rtol=1e-2, atol=1e-7)
+    np.testing.assert_allclose(log('Loss/Loss_pi').mean(), g['log/Loss/Loss_pi'].mean(), rtol=2e-3, atol=2e-6)
+    for key in ('Loss/Loss_reward_critic', 'Loss/Loss_cost_critic'):
+        np.testing.assert_allclose(log(key).mean(), g['log/' + key].mean(), rtol=2e-4)
+    if name == 'P3O':
+        assert float(g['log/Loss/Loss_pi_cost'].mean()) > 0.1  # the penalty is active in this recording
+        np.testing.assert_allclose(log('Loss/Loss_pi_cost')[-1], g['log/Loss/Loss_pi_cost'].mean(), rtol=1e-3)
+    if 'lambda_after' in g:
+        np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+
+
+def test_trpolag_update_of_the_reference_at_general_widths(golden, tmp_path):
+    """TRPOLag with hidden_sizes [256, 128] on 27 / 8 (tests/golden/hidden256x128_trpolag_ant.npz): Fisher-vector
+    products, CG, line search and the 128-row critic passes of the unmodified reference on the layer-wise path --
+    accepted line-search index identical, tolerances of tests/test_config_shapes_gpu.py's trust-region family."""
+    g = golden('hidden256x128_trpolag_ant.npz')
+    model = {'actor': {'hidden_sizes': [256, 128]}, 'critic': {'hidden_sizes': [256, 128]}}
+    algo, ac = _run_hidden('TRPOLag', g, tmp_path, 'SynthAnt-v0', ({}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}),
+                           model, 128)
+    log = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
+    assert int(log('Misc/AcceptanceStep')[-1]) == int(g['log/Misc/AcceptanceStep'][-1])
+    for key, rtol in (('Misc/Alpha', 1e-2), ('Misc/xHx', 1e-2), ('Misc/gradient_norm', 1e-3), ('Misc/H_inv_g', 1e-2),
+                      ('Misc/FinalStepNorm', 2e-2)):
+        np.testing.assert_allclose(log(key)[-1], g['log/' + key][-1], rtol=rtol, err_msg=key)
+    np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+    _hidden_check(ac, g, ('actor',), 5e-5)
+    _hidden_check(ac, g, ('reward_critic', 'cost_critic'), 2e-5)

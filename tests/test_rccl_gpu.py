@@ -108,18 +108,39 @@ def _collectives_worker(_rank, port, out_path):
             'target_value_c': torch.randn(M, device=dev), 'adv_r': torch.randn(M, device=dev),
             'adv_c': torch.randn(M, device=dev)}
     lam = torch.tensor([0.2], device=dev)
-    for mode in ('allreduce', 'replicated', 'replicated-steps'):
-        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, dp_mode=mode)
-        up.run(data, lam, actor_lr=3e-4, critic_lr=3e-4)  # warm-up (graph capture, LDS attributes)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out_ = up.run(data, lam, actor_lr=3e-4, critic_lr=3e-4)
-        b.record()
-        torch.cuda.synchronize()
+    p_init, g = ac.params.clone(), torch.Generator().manual_seed(11)
+    perms = [[torch.randperm(M, generator=g)] for _ in range(3)]
+
+    def reset():
+        ac.params.copy_(p_init)
+        ac.adam_m.zero_()
+        ac.adam_v.zero_()
+        ac.adam_step.zero_()
+
+    after = {}
+    for mode in ('allreduce-eager', 'allreduce', 'replicated', 'replicated-steps'):
+        reset()
+        if mode == 'allreduce-eager':
+            os.environ['OSA_UPDATE_GRAPH'] = '0'
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False,
+                        dp_mode='allreduce' if mode == 'allreduce-eager' else mode)
+        for k in range(3):  # eager warm-up pass (LDS attributes) / capture / replay: the third one is timed
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out_ = up.run(data, lam, perms=perms[k] if mode.startswith('allreduce') else None, actor_lr=3e-4,
+                          critic_lr=3e-4)
+            b.record()
+            torch.cuda.synchronize()
+        os.environ.pop('OSA_UPDATE_GRAPH', None)
         assert out_['steps'] == M // B and bool(torch.isfinite(ac.params).all())
-        assert up.last_path == ('per-step' if mode == 'allreduce' else 'replicated')
+        # round 5: the per-step all-reduce mode is ONE captured hipGraph per pass incl. its 1024 RCCL all-reduces
+        assert up.last_path == {'allreduce-eager': 'per-step', 'allreduce': 'allreduce-graph'}.get(mode, 'replicated')
+        after[mode] = ac.params.clone()
         res[f'dp_mode_{mode}_us_per_step_world1'] = a.elapsed_time(b) * 1e3 / out_['steps']
+    # the captured pass performs the eager launches' arithmetic: same bits after three updates
+    assert torch.equal(after['allreduce'], after['allreduce-eager'])
+    assert float((after['allreduce'] - p_init).abs().max()) > 1e-3
     torch.distributed.destroy_process_group()
     with open(out_path, 'w') as f:
         json.dump(res, f, indent=1)
@@ -152,7 +173,8 @@ def _agent_worker(_rank, port, algo, dp_mode, tmpdir):
     assert bool(torch.isfinite(p).all()) and not torch.equal(p, p0)
     assert ep_len == 8.0 and 1.0 < ep_cost < 4.0
     if algo == 'PPOLag':
-        assert agent.agent._updater.last_path == ('per-step' if dp_mode == 'allreduce' else 'replicated')
+        # (2 passes per epoch: the first pass of the first epoch is eager, every later one a replayed graph)
+        assert agent.agent._updater.last_path == ('allreduce-graph' if dp_mode == 'allreduce' else 'replicated')
     torch.distributed.destroy_process_group()
 
 
@@ -320,7 +342,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out['config']['dp_mode'] == 'replicated' and out['config']['update_path'].startswith('replicated')
     assert out['rccl_ranks'] == (n if real else 0) and out['dist_backend'] == ('nccl' if real else 'gloo')
     assert out['value'] > 0 and 'efficiency_vs_n1' in out
-    assert out['allreduce_mode']['update_path'] == 'per-step' and out['allreduce_mode']['value'] > 0
+    assert out['allreduce_mode']['update_path'] == ('allreduce-graph' if real else 'per-step')
+    assert out['allreduce_mode']['value'] > 0
     assert out['throughput_variant']['update_path'].startswith('dp-large-batch')
     # refused, loudly, when the box has fewer GPUs and the hook is not set
     if not real:

@@ -586,66 +586,6 @@ def test_rollout_graph_replay_equals_eager_launches(tmp_path, monkeypatch, algo_
     assert not torch.equal(s_g[2]['act'], s_g[3]['act']) and not torch.equal(s_g[3]['reward'], s_g[4]['reward'])
 
 
-@pytest.mark.parametrize('env_id,N,T,horizon', [('SynthPointGoal1-v0', 256, 24, 10), ('SynthAnt-v0', 384, 16, 8),
-                                                ('SynthTiny-v0', 128, 12, 1000), ('SynthCarGoal1-v0', 1024, 9, 3)])
-@pytest.mark.parametrize('defer', [1, 0])
-def test_persistent_rollout_equals_the_launch_per_step_rollout(tmp_path, monkeypatch, env_id, N, T, horizon, defer):
-    """One persistent launch per epoch (csrc/rollout_persistent.hip) against the launch-per-step sequence of the same
-    agent: bit-identical buffer rows, normaliser state, episode rows and metrics, env state and stream positions after
-    every one of 4 epochs (rollout + update) -- truncation steps inside the epoch, on its last step (horizon divides T)
-    and none at all; obs_dim with and without the 16-byte row alignment."""
-    import omnisafe_amd
-
-    def run(persistent):
-        monkeypatch.setenv('OSA_ROLLOUT_PERSISTENT', '1' if persistent else '0')
-        monkeypatch.setenv('OSA_ROLLOUT_DEFER_CRITICS', str(defer))  # critics' rows after the kernel / inside it
-        cfg = {'seed': 11, 'train_cfgs': {'device': DEV, 'total_steps': 4 * N * T, 'vector_env_nums': N},
-               'algo_cfgs': {'steps_per_epoch': N * T, 'update_iters': 1, 'batch_size': N * T // 2},
-               'logger_cfgs': {'log_dir': str(tmp_path / ('p' if persistent else 'l')), 'verbose': False},
-               'env_cfgs': {'horizon': horizon, 'cost_p': 0.2}}
-        algo = omnisafe_amd.Agent('PPOLag', env_id, custom_cfgs=cfg).agent
-        ad, snaps = algo._env, []
-        for _ in range(4):
-            ad.rollout(steps_per_epoch=algo._steps_per_epoch, agent=algo._actor_critic, buffer=algo._buf,
-                       logger=algo._logger)
-            snap = {k: v.clone() for k, v in algo._buf.data.items()}
-            nz, env = ad._obs_normalizer, ad._env
-            for k in ('_mean', '_sumsq', '_var', '_std', '_count'):
-                snap['norm' + k] = getattr(nz, k).clone()
-            for k in ('done', 'ret', 'cost', 'len'):
-                # (the out rows are written where an episode ended only)
-                snap['ep_' + k] = ad._ep_rows[k].clone() if k == 'done' else ad._ep_rows[k] * ad._ep_rows['done']
-            snap.update(last_obs=ad._last_obs.clone(), act_env=ad._act_env.clone(), ep_ret=ad._ep_ret.clone(),
-                        ep_cost=ad._ep_cost.clone(), ep_len=ad._ep_len.clone(), env_obs=env._obs[env._flip].clone(),
-                        env_steps=env._steps.clone(), env_reward=env._reward.clone(), env_cost=env._cost.clone(),
-                        env_trunc=env._trunc.clone(), env_t=env._t_base.clone(),
-                        rng=algo._actor_critic._rng_base.clone())
-            if T >= horizon:
-                snap.update(env_final=env._final.clone(), final_norm=ad._final_norm.clone())
-            for k in ('Metrics/EpRet', 'Metrics/EpCost', 'Metrics/EpLen', 'Value/reward', 'Value/cost'):
-                snap[k] = torch.tensor([float(x) for x in algo._logger._data[k]])
-            assert env._t == 0 and algo._actor_critic._rng_offset == 0 and env._since_reset == T
-            if T >= horizon:
-                algo._update()
-            else:  # (no finished episode, no update: ppo_lag.py:74 asserts on the empty EpCost window)
-                algo._buf.ptr = 0
-            snap['params'] = algo._actor_critic.params.clone()
-            snaps.append(snap)
-            algo._logger.dump_tabular()
-        return algo, snaps
-
-    a_p, s_p = run(True)
-    a_l, s_l = run(False)
-    assert a_p._env.last_rollout_path == 'persistent' and a_l._env.last_rollout_path == 'launches'
-    for ep, (g, e) in enumerate(zip(s_p, s_l)):
-        assert set(g) == set(e)
-        for k in g:
-            assert torch.equal(g[k].cpu(), e[k].cpu()), (ep, k)
-    assert not torch.equal(s_p[2]['act'], s_p[3]['act']) and not torch.equal(s_p[2]['reward'], s_p[3]['reward'])
-    if T >= horizon:
-        assert int(s_p[0]['ep_done'].sum()) == N * (T // horizon)
-
-
 class _CountEnv:
     """Single, NON-auto-resetting env that asks for the TimeLimit and AutoReset wrappers (the shape of a
     caller-side Safety-Gymnasium shim, envs/safety_gymnasium_env.py:160-210, single-env case): obs = [steps since

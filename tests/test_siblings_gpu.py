@@ -110,6 +110,29 @@ def test_first_order_sibling_update_vs_reference(golden, tmp_path, name, tag):
             assert np.array_equal(v.cpu().numpy(), g[f'init/cost_critic/{k}'])
 
 
+@pytest.mark.parametrize('skinny', ['1', '0'])
+@pytest.mark.parametrize('name,tag', [('FOCOPS', 'focops'), ('FOCOPS', 'focops_masked'), ('CUP', 'cup'), ('P3O', 'p3o')])
+def test_extended_surrogates_on_general_networks_vs_reference(golden, tmp_path, monkeypatch, name, tag, skinny):
+    """FOCOPS / CUP / P3O on the layer-wise path for general networks (osa_gmlp_minibatch_ext; the reference builds any
+    hidden_sizes for them, utils/model.py:73-111): OSA_FORCE_GENERAL_MLP=1 sends the [64, 64] networks of the
+    reference's `_update()` goldens through it -- on the skinny kernels (64-row minibatches) and on the tiled GEMM --
+    at the tolerances of the fused kernels."""
+    monkeypatch.setenv('OSA_FORCE_GENERAL_MLP', '1')
+    monkeypatch.setenv('OSA_GMLP_SKINNY', skinny)
+    g = golden(f'sibling_{tag}.npz')
+    algo, ac = _run_update(name, tag, g, tmp_path, trust_region=False)
+    assert ac.general
+    _check_params(ac, g, ('actor', 'reward_critic', 'cost_critic'), 5e-6)
+    np.testing.assert_allclose(_log(algo, 'Train/KL')[-1], g['log/Train/KL'][-1], rtol=5e-3, atol=1e-7)
+    np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi').mean(), g['log/Loss/Loss_pi'].mean(), rtol=2e-3, atol=2e-6)
+    if tag == 'p3o':
+        np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi_cost')[-1], g['log/Loss/Loss_pi_cost'].mean(), rtol=1e-3)
+    if tag == 'cup':
+        np.testing.assert_allclose(_log(algo, 'Loss/Loss_pi_c')[-1], g['log/Loss/Loss_pi_c'].mean(), rtol=2e-3,
+                                   atol=2e-6)
+        assert int(_log(algo, 'Train/SecondStepStopIter')[-1]) == int(g['log/Train/SecondStepStopIter'][-1])
+
+
 @pytest.mark.parametrize('name,tag', TRUST_REGION)
 def test_trust_region_sibling_update_vs_reference(golden, tmp_path, name, tag):
     g = golden(f'sibling_{tag}.npz')
