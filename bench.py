@@ -14,7 +14,7 @@ optimiser steps x 3 networks) with kl_early_stop OFF so that every epoch does th
 reference would usually stop earlier).  This is BASELINE.json configs[1] ("PPOLag on
 SafetyPointGoal1-v0, 1xMI355X, 4096 vectorized envs, steps_per_epoch=65536"); weak scaling: each rank
 owns 4096 envs, steps_per_epoch = 65 536 x world_size; under data parallelism the rollouts are all-gathered
-once per epoch and every rank runs the whole global optimiser chain (no per-step collective).
+once per epoch and every rank runs the whole global optimiser chain (no per-step collective, profiles/HISTORY.md §5).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     dominant kernel (osa_ppo_pass_kernel: one persistent launch = one whole pass of 1024 dependent
@@ -460,7 +460,7 @@ def main():
         r['flops_per_launch'] = int(r['flops_per_launch'] * scale)
         r['note'] = 'critic passes of the trust-region family (actor excluded from the FLOP count); ' + r.get('note', '')
     if fvp_events:
-        # Fisher-vector product (natural_pg.py:91-119 as JVP -> VJP): forward 2 W, tangent forward 2 x 2 W
+        # Fisher-vector product (natural_pg.py:91-119 as JVP -> VJP, profiles/HISTORY.md §3.1): forward 2 W, tangent forward 2 x 2 W
         # (two products per layer), backward 4 W = 8 W_pi FLOP... per row the count the round-3 verdict prescribes
         ms = sum(e[2][0].elapsed_time(e[2][1]) for e in fvp_events)
         rows = sum(e[1] for e in fvp_events)

@@ -387,6 +387,23 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
                     const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
                     float* step_stats, void* stream);
 int osa_ppo_dp_end_pass(int* adam_step, int nets_mask, int nsteps, void* stream);
+/* The two halves of osa_ppo_dp_step for the PER-STEP ALL-REDUCE mode over real ranks (round 5) -- the reference's own
+ * structure, policy_gradient.py:437-443 with distributed.py:167-198: clip_grad_norm_, avg_grads, optimizer.step -- on
+ * the persistent pass kernel's gradient-only form instead of the per-step kernels (weights staged in LDS once per
+ * launch, gradients from registers: 13 us against 48 per 64-row step).
+ *   phase 1: the locally clipped gradients and statistics of THIS rank's minibatch (world = 1, perm = its row indices,
+ *            M rows of them, step_index = 0) into slabs[3][P + 16]; nothing else is touched;
+ *   [caller: ONE flat all-reduce (average) of the slabs]
+ *   phase 2: Adam from the slabs (step count adam_step[net] + step_index + 1: pass the step's index within the pass
+ *            and call osa_ppo_dp_end_pass after its last step); only the parameter / moment / slab / hp arguments are used.
+ *   phase 0: osa_ppo_dp_step. */
+int osa_ppo_dp_step_phase(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                          const float* logp, const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                          int step_index, const float* lagrange, const osa_ppo_hparams* hp,
+                          const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
+                          float* step_stats, int phase, void* stream);
 
 /* The same replicated-data optimiser chain as ONE cooperative persistent launch per pass: 3 x world
  * workgroups stay resident for all ceil(M/B) steps; workgroup (net, r) keeps its own LDS/register copy
@@ -485,8 +502,7 @@ int osa_debug_set_part_clock_buffer(long long* dev_ptr);
  * osa_gmlp_layout fills out[0] = P, out[1] = offset of log_std, then {oW, ob, ld} for network 0..2 x layer
  * 0..OSA_GMLP_MAX_LAYERS-1 (-1 / 0 for absent layers): 2 + 72 ints.
  * ws: osa_gmlp_ws_floats(desc, rows) floats of scratch for a call over `rows` rows (layer outputs, dL/dz, partial
- * gradient slabs), ZERO-INITIALISED ONCE by the caller: it holds the arrival tickets of the small-minibatch kernels,
- * which every call leaves at zero; everything else is irrelevant between calls. */
+ * gradient slabs); contents irrelevant between calls. */
 #define OSA_GMLP_MAX_LAYERS 8
 typedef struct osa_gmlp_desc {
   int obs_dim, act_dim;

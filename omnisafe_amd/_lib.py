@@ -83,6 +83,7 @@ SIGNATURES: dict[str, tuple] = {
                                      _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     'osa_ppo_dp_step': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'osa_ppo_dp_step_phase': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
     'osa_ppo_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I,
                           _P, _P, _I, _I, _P, _P]),
     'osa_ppo_wide_pass_supported': (_I, [_I, _I, _I]),

@@ -1,7 +1,7 @@
 // Fisher-vector product of the actor over the whole rollout, throughput-shaped (round 4).
 //
 // NaturalPG._fvp (omnisafe/algorithms/on_policy/naive/natural_pg.py:91-119) = J^T diag(1 / sigma^2) J v / (M D_a) on the
-// mean network (a JVP through the network, then the ordinary backward pass; no double backward).  The
+// mean network (profiles/HISTORY.md §3.1: a JVP through the network, then the ordinary backward pass; no double backward).  The
 // general gradient kernel (osa_mb_grad_kernel, mlp_kernels.hip) served it so far: every wave fetched the weights AND
 // the vector from L2 for each of its 16 rows' three passes (0.5 MB per 64-row chunk and workgroup) and every chunk
 // read-modified-wrote the 33 KB gradient block in global memory -- 163 us per product at 65 536 rows = 16 % of the

@@ -103,7 +103,6 @@ struct GWs {
   // its 64 x 64 tiles, network by network and layer by layer (+ one tail workgroup per network)
   size_t zs[3][GM_MAXL];
   int sk_tile0[3][GM_MAXL], sk_tk[3][GM_MAXL], sk_ntile[3], sk_maxT1;
-  size_t bslab, tick;             // partial tiles and tickets of gs_big_kernel (the tickets are ZERO between launches)
   size_t total;
   int nblk, nb;
 };
@@ -171,26 +170,6 @@ GWs gm_ws(const GLayout& lo, long R) {
     if (t + 1 > w.sk_maxT1) w.sk_maxT1 = t + 1;
   }
   w.npart = take((size_t)3 * (w.nb > w.sk_maxT1 ? w.nb : w.sk_maxT1) * 2);
-  {  // gs_big_kernel: per launch (one layer, forward or backward) sum over the networks of tiles x slices x 4096 floats
-    size_t need = 0, tiles = 0;
-    if (R <= GS_MAX_ROWS)
-      for (int net = 0; net < 3; ++net) {
-        size_t mx = 0, mt = 0;
-        for (int l = 0; l < lo.n[net].L; ++l) {
-          const GNet& n = lo.n[net];
-          const size_t f = (size_t)((n.out[l] + 63) / 64) * ((n.in[l] + GSB_CL - 1) / GSB_CL);   // forward: tiles over out
-          const size_t bw = (size_t)((n.in[l] + 63) / 64) * ((n.out[l] + GSB_CL - 1) / GSB_CL);  // backward: tiles over in
-          if (f > mx) mx = f;
-          if (bw > mx) mx = bw;
-          const size_t t = (size_t)((n.out[l] > n.in[l] ? n.out[l] : n.in[l]) + 63) / 64;
-          if (t > mt) mt = t;
-        }
-        need += mx * 4096;
-        tiles += mt;
-      }
-    w.bslab = take(need);
-    w.tick = take(tiles + 4);
-  }
   w.fin = take(3 * 8);
   w.dws = take(2 * 4 * 1024);
   {  // small minibatches: [3 networks][GM_ROW_SPLITS][R][widest layer]
@@ -561,151 +540,11 @@ __global__ __launch_bounds__(256) void gm_gather_kernel(
   }
 }
 
-struct GLossArgs {
-  long R;
-  int act_dim, lda, ldo[3];          // row strides of the action rows and of the three output layers
-  const float* out[3];               // output-layer rows of the three networks [R][ldo]
-  float* dz[3];                      // dL/d(output) [R][ldz]
-  int ldz[3];
-  const float* actg;
-  const float* scal;                 // [0] logp [1] adv_r [2] adv_c [3] target_value_r [4] target_value_c
-  const float* log_std;              // actor's log_std [act_dim]
-  const float* lagrange;
-  float clip;
-  int loss_kind, nets_mask;
-  float* dls;                        // [nblk][lda] per-block sums of dL/d(log_std)
-  float* lpart;                      // [3][nblk][4] per-block {loss, ratio} sums
-  // Fisher-vector product (loss_kind 2): dL/d(out) = tangent of the mean / sigma^2 * fvp_scale
-  const float* tmean;
-  int ldt;
-  float fvp_scale;
-  // extended actor surrogates (osa_surrogate_ext: FOCOPS, CUP's second stage, P3O); ext_on = 0: none
-  int ext_on;
-  const long* idx;           // minibatch rows (old_mean is indexed like obs), or nullptr
-  const float* old_mean;
-  int ld_old_mean;
-  const float* old_log_std;
-  float ext_kl_coef, ext_mask_eta, ext_ratio_scale, ext_cost_kappa, ext_cost_excess;
-  float* stats;              // stats[10] receives P3O's penalty value
-};
-
-// grid (nblk, 3): one thread per row.  Actor (policy_gradient.py:514-524 with PPOLag's surrogate, ppo.py:66-87 /
-// policy_gradient.py:574-578) and critics (policy_gradient.py:428-433: mean squared error; the L2 term joins in
-// gm_reduce_kernel).
 __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
   __shared__ float red[4];
   const int net = blockIdx.y;
   if (!((a.nets_mask >> net) & 1)) return;
-  const long b = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = b < a.R;
-  const float invB = 1.f / (float)a.R;
-  float loss = 0.f, ratio_s = 0.f;
-  if (net != 0) {
-    if (valid) {
-      const float diff = a.out[net][b * a.ldo[net]] - a.scal[(net == 1 ? 3 : 4) * a.R + b];
-      loss = diff * diff;
-      a.dz[net][b * a.ldz[net]] = 2.f * diff * invB;
-      for (int d = 1; d < a.ldz[net]; ++d) a.dz[net][b * a.ldz[net] + d] = 0.f;  // (row padding: the skinny kernels' 16-byte loads)
-    }
-  } else if (a.loss_kind == 2) {
-    if (valid)
-      for (int d = 0; d < a.act_dim; ++d) {
-        const float sd = expf(a.log_std[d]);
-        a.dz[0][b * a.ldz[0] + d] = a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale;
-      }
-    if (valid)
-      for (int d = a.act_dim; d < a.ldz[0]; ++d) a.dz[0][b * a.ldz[0] + d] = 0.f;
-  } else {
-    const float lam = a.lagrange ? *a.lagrange : 0.f;
-    float lp = 0.f;
-    if (valid)
-      for (int d = 0; d < a.act_dim; ++d) {
-        const float sd = expf(a.log_std[d]);
-        const float z = a.actg[b * a.lda + d] - a.out[0][b * a.ldo[0] + d];
-        lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
-      }
-    const float ratio = valid ? expf(lp - a.scal[0 * a.R + b]) : 0.f;
-    // ---- extended surrogates: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
-    // trust mask with the reference's broadcast semantics (focops.py:84-88: the surrogate term sees the minibatch MEAN
-    // of the mask), P3O's kappa * relu(mean(ratio * A_c) + excess) -- the arithmetic of osa_mb_grad_kernel's EXT form.
-    // The mask mean and the penalty are minibatch-level: ONE block (the entry point refuses more than 256 rows).
-    float kl = 0.f, mask = 1.f, mask_mean = 1.f, cost_w = 0.f;
-    const long orow = a.ext_on ? (a.idx ? a.idx[valid ? b : 0] : (valid ? b : 0)) : 0;
-    if (a.ext_on) {
-      if (valid)
-        for (int d = 0; d < a.act_dim; ++d) {
-          const float ls = a.log_std[d], ls0 = a.old_log_std[d], dl = ls - ls0;
-          const float q = expf(dl), isd0 = expf(-ls0);
-          const float u = (a.out[0][b * a.ldo[0] + d] - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
-          kl += 0.5f * (q * q + u * u - 1.f - 2.f * dl);
-        }
-      if (a.ext_mask_eta >= 0.f || a.ext_cost_kappa > 0.f) {  // block-uniform
-        mask = (a.ext_mask_eta < 0.f || (valid && kl <= a.ext_mask_eta)) ? 1.f : 0.f;
-        const float tm = gm_block_sum(valid ? mask : 0.f, red);
-        const float tc = gm_block_sum(valid ? ratio * a.scal[2 * a.R + b] : 0.f, red);
-        if (a.ext_mask_eta >= 0.f) mask_mean = tm * invB;
-        if (a.ext_cost_kappa > 0.f) {
-          const float pen = tc * invB + a.ext_cost_excess;
-          if (pen > 0.f) cost_w = a.ext_cost_kappa;
-          if (threadIdx.x == 0 && a.stats) a.stats[10] = a.ext_cost_kappa * fmaxf(pen, 0.f);
-        }
-      }
-    }
-    float dlogp = 0.f, dklw = 0.f;
-    if (valid) {
-      const float adv = (a.scal[1 * a.R + b] - lam * a.scal[2 * a.R + b]) / (1.f + lam);
-      float dratio;
-      if (a.loss_kind == 0) {
-        const float lo = 1.f - a.clip, hi = 1.f + a.clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = ratio * adv, s2 = rc * adv;
-        const bool inrange = ratio >= lo && ratio <= hi;
-        loss = -fminf(s1, s2);
-        dratio = (s1 < s2 || inrange) ? -adv : 0.f;
-      } else {
-        loss = -(ratio * adv);
-        dratio = -adv;
-      }
-      if (a.ext_on) {
-        const float rs = a.ext_ratio_scale * mask_mean;
-        loss = loss * rs + a.ext_kl_coef * kl * mask;
-        dratio = dratio * rs + cost_w * a.scal[2 * a.R + b];
-        dklw = a.ext_kl_coef * mask * invB;
-      }
-      ratio_s = ratio;
-      dlogp = dratio * ratio * invB;
-    }
-    // d logp / d mu = z / var;  d logp / d log_std = z^2 / var - 1; block sums of the latter, dimension by dimension
-    for (int d = 0; d < a.act_dim; ++d) {
-      float dl = 0.f;
-      if (valid) {
-        const float sd = expf(a.log_std[d]);
-        const float iv = 1.f / (sd * sd);
-        const float mu = a.out[0][b * a.ldo[0] + d];
-        const float z = a.actg[b * a.lda + d] - mu;
-        float dmu = dlogp * z * iv;
-        dl = dlogp * (z * z * iv - 1.f);
-        if (a.ext_on) {  // d KL / d mu = (mu - mu0) / var0;  d KL / d log_std = var / var0 - 1
-          const float ls0 = a.old_log_std[d], q = expf(a.log_std[d] - ls0), isd0 = expf(-ls0);
-          const float u = (mu - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
-          dmu += dklw * (u * isd0);
-          dl += dklw * (q * q - 1.f);
-        }
-        a.dz[0][b * a.ldz[0] + d] = dmu;
-      }
-      dl = gm_block_sum(dl, red);
-      if (threadIdx.x == 0) a.dls[(long)blockIdx.x * a.lda + d] = dl;
-    }
-    if (valid)
-      for (int d = a.act_dim; d < a.ldz[0]; ++d) a.dz[0][b * a.ldz[0] + d] = 0.f;  // (row padding)
-  }
-  loss = gm_block_sum(loss, red);
-  ratio_s = gm_block_sum(ratio_s, red);
-  if (threadIdx.x == 0) {
-    float* lp_ = a.lpart + ((long)net * gridDim.x + blockIdx.x) * 4;
-    lp_[0] = loss;
-    lp_[1] = ratio_s;
-  }
+  gm_loss_body(a, net, (long)blockIdx.x * 256 + threadIdx.x, blockIdx.x, red, a.dz[net], a.ldz[net], true);
 }
 
 struct GRedArgs {
@@ -1032,56 +871,15 @@ void gm_fill_ext(GLossArgs& la, const osa_surrogate_ext* ext, const long* idx, f
   la.stats = stats;
 }
 
-// A launch goes to gs_big_kernel (contraction split over workgroups, operands through LDS) when its largest problem
-// is large in BOTH dimensions: below that the simple kernels sit at the launch-latency floor anyway.
-template <bool BWD>
-bool gs_big_ok(const GSArgs& g) {
-  static const int sw = [] {  // (A/B switch: OSA_GMLP_BIG=0 keeps every layer on gs_fwd / gs_bwd)
-    const char* v = getenv("OSA_GMLP_BIG");
-    return (v != nullptr && v[0] == '0' && v[1] == 0) ? 0 : 1;
-  }();
-  if (!sw) return false;
-  int maxC = 0, maxO = 0;
-  for (int i = 0; i < g.nprob; ++i) {
-    const int C = BWD ? g.p[i].N : g.p[i].K, O = BWD ? g.p[i].K : g.p[i].N;
-    if (C > maxC) maxC = C;
-    if (O > maxO) maxO = O;
-  }
-  return maxC >= 512 && maxO >= 256;
-}
-
-template <bool BWD>
-int gs_big_launch(const GSArgs& g, float* slab, int* ticket, hipStream_t st) {
-  constexpr size_t lds = (size_t)((BWD ? GSB_CL * GSB_LDT : 64 * GSB_LD) + 64 * GSB_LD) * sizeof(float);
-  static OsaPerDeviceOnce attr_set;
-  if (attr_set.need()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_big_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return OSA_EHIP;
-    attr_set.set();
-  }
-  GSBArgs a = {};
-  a.nprob = g.nprob; a.R = g.R; a.slab = slab; a.ticket = ticket;
-  int total = 0;
-  for (int i = 0; i < g.nprob; ++i) {
-    a.p[i] = g.p[i];
-    const int C = BWD ? g.p[i].N : g.p[i].K, O = BWD ? g.p[i].K : g.p[i].N;
-    a.tiles[i] = (O + 63) / 64;
-    a.S[i] = (C + GSB_CL - 1) / GSB_CL;
-    total += a.tiles[i] * a.S[i];
-  }
-  hipLaunchKernelGGL(gs_big_kernel<BWD>, dim3(total), dim3(512), lds, st, a);
-  return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
-}
-
 bool gs_enabled() {  // (A/B and test switch: OSA_GMLP_SKINNY=0 keeps small minibatches on the tiled GEMM)
   const char* v = getenv("OSA_GMLP_SKINNY");
   return !(v != nullptr && v[0] == '0' && v[1] == 0);
 }
 
-// One optimiser step (or its gradient: mode 1 / 2) of a minibatch of B <= 64 rows on the skinny kernels:
-// gather, L forward launches, loss, L - 1 backward-data launches, ONE weight-gradient launch over all layers
-// (norm partials), gm_final_kernel, then clip + Adam from recomputed tiles (mode 0) or the scaling of the written
+// One optimiser step (or its gradient: mode 1 / 2) of a minibatch of B <= 64 rows on the skinny kernels: L forward
+// launches (layer 0 reads the minibatch's rows in place: no gather), loss + top layer's backward in one launch, L - 2
+// more backward-data launches, ONE weight-gradient launch over all layers (norm partials), then clip + Adam from
+// recomputed tiles (mode 0: 2 L + 1 launches, 7 for two hidden layers) or gm_final_kernel + the scaling of the written
 // gradient (mode 1).
 int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* adam_m, float* adam_v, int* adam_step,
                         float* grads, const float* obs, int ld_obs, const float* act, int ld_act, const float* logp,
@@ -1089,55 +887,88 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
                         const float* adv_c, const long* idx, long B, const float* lagrange, const osa_ppo_hparams* hp,
                         int loss_kind, int mode, int mask, float* ws, float* step_stats, const osa_surrogate_ext* ext,
                         hipStream_t st) {
-  int rc;
-  if ((rc = gm_gather(lo, w, ws, B, idx, obs, ld_obs, act, ld_act, logp, adv_r, adv_c, target_value_r, target_value_c,
-                      st)) != OSA_OK)
-    return rc;
   int maxL = 0;
   for (int net = 0; net < 3; ++net)
     if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
-  // ---- forward, layer by layer (the networks of a layer in one launch)
+  // ---- forward, layer by layer (the networks of a layer in one launch).  No gather launch: layer 0 reads the caller's
+  // observation rows through the minibatch's indices, the loss its scalars and action rows likewise
   for (int l = 0; l < maxL; ++l) {
     GSArgs g = {};
     g.R = (int)B;
+    g.xrows = l == 0;
+    g.xidx = idx;
     int maxN = 0;
     for (int net = 0; net < 3; ++net) {
       const GNet& n = lo.n[net];
       if (!((mask >> net) & 1) || l >= n.L) continue;
       GSProb& p = g.p[g.nprob++];
       const float* pn = params + (long)net * lo.P;
-      p.X = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
-      p.ldx = l == 0 ? lo.ldx : n.ldh[l - 1];
+      p.X = l == 0 ? obs : ws + w.h[net][l - 1];
+      p.ldx = l == 0 ? ld_obs : n.ldh[l - 1];
       p.W = pn + n.oW[l]; p.ldw = n.ld[l];
       p.bias = pn + n.ob[l];
       p.Y = ws + w.h[net][l]; p.ldy = n.ldh[l];
       p.N = n.out[l]; p.K = n.in[l];
       p.act = l + 1 < n.L ? n.act : -1;
+      p.net = net;
       if (p.N > maxN) maxN = p.N;
     }
-    if (gs_big_ok<false>(g))
-      gs_big_launch<false>(g, ws + w.bslab, reinterpret_cast<int*>(ws + w.tick), st);
+    if (l == 0)
+      hipLaunchKernelGGL(gs_fwd_kernel<true>, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
     else
-      hipLaunchKernelGGL(gs_fwd_kernel, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+      hipLaunchKernelGGL(gs_fwd_kernel<false>, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
   }
   // ---- loss and dL/d(output)
   const GNet& an = lo.n[0];
   GLossArgs la = {};
   la.R = B; la.act_dim = lo.act_dim; la.lda = lo.lda;
+  bool fuse = true;  // loss inside the top layer's backward launch: top layers up to 32 wide
   for (int net = 0; net < 3; ++net) {
     const GNet& n = lo.n[net];
     la.out[net] = ws + w.h[net][n.L - 1];
     la.ldo[net] = n.ldh[n.L - 1];
     la.dz[net] = ws + w.zs[net][n.L - 1];
     la.ldz[net] = n.ldh[n.L - 1];
+    if (((mask >> net) & 1) && n.ldh[n.L - 1] > 32) fuse = false;
   }
-  la.actg = ws + w.actg; la.scal = ws + w.scal; la.log_std = params + an.oLS; la.lagrange = lagrange;
+  la.log_std = params + an.oLS; la.lagrange = lagrange;
   la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
-  la.dls = ws + w.dls; la.lpart = ws + w.lpart;
+  la.dls = ws + w.dls; la.lpart = ws + w.lpart; la.nblk = w.nblk;
+  la.direct = 1; la.ld_act = ld_act; la.act = act; la.idx = idx;
+  la.sp[0] = logp; la.sp[1] = adv_r; la.sp[2] = adv_c; la.sp[3] = target_value_r; la.sp[4] = target_value_c;
   gm_fill_ext(la, ext, idx, step_stats);
-  hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
+  static const bool fuse_on = [] {  // (A/B switch: OSA_GMLP_TOP_FUSE=0 keeps the loss a launch of its own)
+    const char* v = getenv("OSA_GMLP_TOP_FUSE");
+    return !(v != nullptr && v[0] == '0' && v[1] == 0);
+  }();
+  fuse = fuse && fuse_on;
+  if (fuse) {
+    GSArgs g = {};
+    g.R = (int)B;
+    int maxld = 0;
+    for (int net = 0; net < 3; ++net) {
+      const GNet& n = lo.n[net];
+      if (!((mask >> net) & 1)) continue;
+      const int l = n.L - 1;
+      GSProb& p = g.p[g.nprob++];
+      p.net = net;
+      p.W = params + (long)net * lo.P + n.oW[l]; p.ldw = n.ld[l];
+      p.N = n.out[l];
+      if (l >= 1) {  // (a network without a hidden layer takes part with zero output columns: loss only)
+        p.Y = ws + w.zs[net][l - 1]; p.ldy = n.ldh[l - 1];
+        p.aux = ws + w.h[net][l - 1]; p.ldaux = n.ldh[l - 1];
+        p.K = n.in[l];
+        p.act = n.act;
+        if (p.ldy > maxld) maxld = p.ldy;
+      }
+    }
+    if (g.nprob > 0)
+      hipLaunchKernelGGL(gs_top_kernel, dim3(maxld > 0 ? (maxld + 15) / 16 : 1, g.nprob), dim3(256), 0, st, g, la);
+  } else {
+    hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
+  }
   // ---- backward-data, from the top of EACH network
-  for (int step = 0; step + 1 < maxL; ++step) {
+  for (int step = fuse ? 1 : 0; step + 1 < maxL; ++step) {
     GSArgs g = {};
     g.R = (int)B;
     int maxK = 0;
@@ -1152,14 +983,10 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
       p.aux = ws + w.h[net][l - 1]; p.ldaux = n.ldh[l - 1];
       p.N = n.out[l]; p.K = n.in[l];
       p.act = n.act;
+      p.net = net;
       if (p.K > maxK) maxK = p.K;
     }
-    if (g.nprob > 0) {
-      if (gs_big_ok<true>(g))
-        gs_big_launch<true>(g, ws + w.bslab, reinterpret_cast<int*>(ws + w.tick), st);
-      else
-        hipLaunchKernelGGL(gs_bwd_kernel, dim3((maxK + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
-    }
+    if (g.nprob > 0) hipLaunchKernelGGL(gs_bwd_kernel, dim3((maxK + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
   }
   // ---- weight gradients of all layers: norm partials (+ the gradient itself for modes 1 / 2)
   GSWArgs wa = {};
@@ -1169,8 +996,9 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
     for (int l = 0; l < n.L; ++l) {
       GSWLayer& y = wa.l[net][l];
       y.dZ = ws + w.zs[net][l]; y.ldz = n.ldh[l];
-      y.H = l == 0 ? ws + w.xg : ws + w.h[net][l - 1];
-      y.ldh = l == 0 ? lo.ldx : n.ldh[l - 1];
+      y.H = l == 0 ? obs : ws + w.h[net][l - 1];
+      y.ldh = l == 0 ? ld_obs : n.ldh[l - 1];
+      y.hrows = l == 0; y.hidx = idx;
       y.out = n.out[l]; y.in = n.in[l]; y.ldw = n.ld[l]; y.oW = n.oW[l]; y.ob = n.ob[l];
       y.tile0 = w.sk_tile0[net][l]; y.tk = w.sk_tk[net][l];
     }
@@ -1183,6 +1011,8 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
   wa.beta2 = hp->beta2; wa.eps = hp->adam_eps;
   wa.fold = mode == 0; wa.use_max_grad_norm = hp->use_max_grad_norm; wa.max_grad_norm = hp->max_grad_norm;
   wa.adam_step = adam_step; wa.lr_dev = hp->lr_device; wa.lr_actor = hp->lr_actor; wa.lr_critic = hp->lr_critic;
+  // (four workgroups per compute unit -- 35 KB of LDS each -- is the best occupancy measured: capped at 3 / 2 / 1 the
+  // two launches take 41 / 43 / 62 us instead of 33 at 1024 x 1024, profiles/HISTORY.md)
   hipLaunchKernelGGL(gs_wgrad_kernel<0>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
   if (mode == 0) {
     hipLaunchKernelGGL(gs_wgrad_kernel<1>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
@@ -1303,7 +1133,7 @@ int osa_gmlp_minibatch_ext(const osa_gmlp_desc* desc, float* params, float* adam
   if (loss_kind == 2) {
     // forward-mode tangent of the mean network along `vec` (natural_pg.py:91-119 without a double backward: for a
     // Gaussian policy with state-independent log_std the Hessian of mean KL at theta_old is J^T diag(1/sigma^2) J /
-    // (M D_a)):  T_l = (H_{l-1} Vw_l^T + vb_l + T_{l-1} W_l^T) * act'(H_l)
+    // (M D_a), profiles/HISTORY.md §3.1):  T_l = (H_{l-1} Vw_l^T + vb_l + T_{l-1} W_l^T) * act'(H_l)
     for (int l = 0; l < an.L; ++l) {
       GArgs g = {};
       g.splits = 1;
@@ -1346,7 +1176,7 @@ int osa_gmlp_minibatch_ext(const osa_gmlp_desc* desc, float* params, float* adam
   }
   la.actg = ws + w.actg; la.scal = ws + w.scal; la.log_std = params + an.oLS; la.lagrange = lagrange;
   la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
-  la.dls = ws + w.dls; la.lpart = ws + w.lpart;
+  la.dls = ws + w.dls; la.lpart = ws + w.lpart; la.nblk = w.nblk;
   la.tmean = ws + w.t[an.L - 1]; la.ldt = an.ldh[an.L - 1]; la.fvp_scale = fvp_scale;
   gm_fill_ext(la, ext, idx, step_stats);
   hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);

@@ -18,7 +18,7 @@
 // run on the VALU here: summation-order differences of ~1e-7); tests compare both against the reference's
 // golden vectors.
 //
-// What bounds the step on gfx950 (measured): float32 MFMAs and VALU instructions do
+// What bounds the step on gfx950 (measured, profiles/HISTORY.md §6): float32 MFMAs and VALU instructions do
 // not overlap (in-wave or across waves), so the step costs MFMA cycles + VALU cycles + waits; the kernel is
 // register-bound (256 VGPRs + ~200 AGPRs), and every runtime branch between phases is a scheduling barrier.
 // Modes of the same kernel: plain pass (grid 3), data-parallel gradient step (grid 3 x world, writes
@@ -89,7 +89,7 @@ struct OsaPassArgs {
   // chunk) and cut into G contiguous ranges of part_tpw tasks: workgroup w owns tasks [w part_tpw, (w + 1) part_tpw).
   // A range that crosses a network boundary is processed in two segments (weights reloaded, one slab per segment).
   // 16 384 rows x 3 networks = 768 tasks on 256 compute units: 3 tasks each, where the strided mode above ran
-  // 64 workgroups x 4 chunks per network on 192 units (44.7 -> 26 us per launch).  Slab index of a
+  // 64 workgroups x 4 chunks per network on 192 units (44.7 -> 26 us per launch, profiles/HISTORY.md §7.4).  Slab index of a
   // segment = w - (first workgroup of that network); dp_world = slab stride per network.
   int part_tpw;
   // extended actor surrogates (EXT instantiations; osa_surrogate_ext of the public header): per-sample
@@ -177,7 +177,7 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // the 8 output-layer groups of the unrolled forward loop and in the backward / weight-gradient phases -- 16 scheduling
 // barriers in the hottest code (same-box A/B: 9.11 -> 8.87 us per step)
 // (Round 3's sliced data-parallel reduction, the two-stage large-batch pass and the per-network body split were
-// measured slower and removed in round 4: DESIGN.md 7.)
+// measured slower and removed in round 4: profiles/HISTORY.md §7.)
 template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool DPS, bool SO>
 __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const int net, const int rk, const int pc0 = 0,
                                                   const int pn = 0) {

@@ -252,7 +252,31 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
                     int step_index, const float* lagrange, const osa_ppo_hparams* hp,
                     const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
                     float* step_stats, void* stream) {
+  return osa_ppo_dp_step_phase(obs_dim, act_dim, hidden, params, adam_m, adam_v, adam_step, obs, ld_obs, act, ld_act,
+                               logp, target_value_r, target_value_c, adv_r, adv_c, perm, M, B, world, step_index,
+                               lagrange, hp, lr_dev, loss_kind, nets_mask, slabs, step_stats, 0, stream);
+}
+
+int osa_ppo_dp_step_phase(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                          int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                          const float* logp, const float* target_value_r, const float* target_value_c,
+                          const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world,
+                          int step_index, const float* lagrange, const osa_ppo_hparams* hp,
+                          const float* lr_dev, int loss_kind, int nets_mask, float* slabs,
+                          float* step_stats, int phase, void* stream) {
   if (!osa_ppo_pass_supported(obs_dim, act_dim, hidden)) return OSA_EUNSUPPORTED;
+  OSA_REQUIRE(phase >= 0 && phase <= 2);
+  if (phase == 2) {  // Adam from the (all-reduced) slabs only
+    OSA_REQUIRE(params && adam_m && adam_v && adam_step && hp && step_stats && slabs && world >= 1 && step_index >= 0);
+    const OsaNet nd = osa_make_net(obs_dim, act_dim, hidden);
+    OsaPassHp h = {};
+    h.lr_actor = hp->lr_actor; h.lr_critic = hp->lr_critic; h.beta1 = hp->beta1; h.beta2 = hp->beta2;
+    h.adam_eps = hp->adam_eps;
+    hipLaunchKernelGGL(osa_dp_apply_kernel, dim3((nd.P + 255) / 256, 3), dim3(256), 0, osa_stream(stream), nd, params,
+                       adam_m, adam_v, adam_step, slabs, world, h, lr_dev, nets_mask & (hp->use_cost ? 7 : 3), step_stats,
+                       step_index);
+    return hipGetLastError() == hipSuccess ? OSA_OK : OSA_EHIP;
+  }
   OSA_REQUIRE(params && adam_m && adam_v && adam_step && obs && act && logp && hp && step_stats && slabs);
   OSA_REQUIRE(target_value_r && target_value_c && adv_r && adv_c && M > 0 && B > 0 && world >= 1);
   OSA_REQUIRE(ld_obs >= obs_dim && ld_act >= act_dim && step_index >= 0 && (long)step_index * B < M);
@@ -283,7 +307,7 @@ int osa_ppo_dp_step(int obs_dim, int act_dim, int hidden, float* params, float* 
   OSA_DP_CASE(6, 1); OSA_DP_CASE(1, 2); OSA_DP_CASE(2, 2); OSA_DP_CASE(3, 2); OSA_DP_CASE(4, 2);
   OSA_DP_CASE(5, 2); OSA_DP_CASE(6, 2);
 #undef OSA_DP_CASE
-  if (rc != OSA_OK) return rc;
+  if (rc != OSA_OK || phase == 1) return rc;  // (phase 1: the gradients only -- the caller's all-reduce comes next)
   hipLaunchKernelGGL(osa_dp_apply_kernel, dim3((a.nd.P + 255) / 256, 3), dim3(256), 0, st, a.nd, params,
                      adam_m, adam_v, adam_step, slabs, world, a.hp, lr_dev, a.nets_mask, step_stats,
                      step_index);

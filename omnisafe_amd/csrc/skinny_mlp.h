@@ -46,6 +46,166 @@ __device__ __forceinline__ float gm_block_sum(float v, float* red) {  // determi
 }
 
 // ------------------------------------------------------------------------------------------------
+// loss and dL/d(output) of the layer-wise path
+// ------------------------------------------------------------------------------------------------
+struct GLossArgs {
+  long R;
+  int act_dim, lda, ldo[3];          // row strides of the action rows and of the three output layers
+  const float* out[3];               // output-layer rows of the three networks [R][ldo]
+  float* dz[3];                      // dL/d(output) [R][ldz]
+  int ldz[3];
+  const float* actg;
+  const float* scal;                 // [0] logp [1] adv_r [2] adv_c [3] target_value_r [4] target_value_c
+  const float* log_std;              // actor's log_std [act_dim]
+  const float* lagrange;
+  float clip;
+  int loss_kind, nets_mask;
+  float* dls;                        // [nblk][lda] per-block sums of dL/d(log_std)
+  float* lpart;                      // [3][nblk][4] per-block {loss, ratio} sums
+  int nblk;
+  // Fisher-vector product (loss_kind 2): dL/d(out) = tangent of the mean / sigma^2 * fvp_scale
+  const float* tmean;
+  int ldt;
+  float fvp_scale;
+  // extended actor surrogates (osa_surrogate_ext: FOCOPS, CUP's second stage, P3O); ext_on = 0: none
+  int ext_on;
+  const long* idx;           // minibatch rows (old_mean is indexed like obs), or nullptr
+  const float* old_mean;
+  int ld_old_mean;
+  const float* old_log_std;
+  float ext_kl_coef, ext_mask_eta, ext_ratio_scale, ext_cost_kappa, ext_cost_excess;
+  float* stats;              // stats[10] receives P3O's penalty value
+  // direct != 0 (skinny path: no gather launch): the per-sample scalars and the action rows are read from the caller's
+  // arrays through the minibatch's row indices -- sp[k][row], act[row * ld_act + d], row = idx ? idx[b] : b
+  int direct, ld_act;
+  const float* sp[5];
+  const float* act;
+};
+
+// grid (nblk, 3): one thread per row.  Actor (policy_gradient.py:514-524 with PPOLag's surrogate, ppo.py:66-87 /
+// policy_gradient.py:574-578) and critics (policy_gradient.py:428-433: mean squared error; the L2 term joins in
+// gm_reduce_kernel).
+// (a device function of 256 threads: gm_loss_kernel = one block per 256 rows and network; gs_top_kernel calls it for the
+// <= 64 rows of a skinny step in EVERY workgroup of the top layer's backward launch -- dzp / ldzp then is an LDS image and
+// only the `writer` workgroup leaves the block partials and statistics)
+__device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, const long b, const int blk, float* red,
+                                             float* __restrict__ dzp, const int ldzp, const bool writer) {
+  const bool valid = b < a.R;
+  const long row = valid ? (a.idx ? a.idx[b] : b) : 0;  // the sample's row in the caller's arrays
+  auto SC = [&](int k) -> float { return a.direct ? a.sp[k][row] : a.scal[(long)k * a.R + b]; };
+  auto ACT = [&](int d) -> float { return a.direct ? a.act[row * a.ld_act + d] : a.actg[b * a.lda + d]; };
+  const float invB = 1.f / (float)a.R;
+  float loss = 0.f, ratio_s = 0.f;
+  if (net != 0) {
+    if (valid) {
+      const float diff = a.out[net][b * a.ldo[net]] - SC(net == 1 ? 3 : 4);
+      loss = diff * diff;
+      dzp[b * ldzp] = 2.f * diff * invB;
+      for (int d = 1; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;  // (row padding: the skinny kernels' 16-byte loads)
+    }
+  } else if (a.loss_kind == 2) {
+    if (valid)
+      for (int d = 0; d < a.act_dim; ++d) {
+        const float sd = expf(a.log_std[d]);
+        dzp[b * ldzp + d] = a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale;
+      }
+    if (valid)
+      for (int d = a.act_dim; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;
+  } else {
+    const float lam = a.lagrange ? *a.lagrange : 0.f;
+    float lp = 0.f;
+    if (valid)
+      for (int d = 0; d < a.act_dim; ++d) {
+        const float sd = expf(a.log_std[d]);
+        const float z = ACT(d) - a.out[0][b * a.ldo[0] + d];
+        lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+      }
+    const float ratio = valid ? expf(lp - SC(0)) : 0.f;
+    // ---- extended surrogates: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
+    // trust mask with the reference's broadcast semantics (focops.py:84-88: the surrogate term sees the minibatch MEAN
+    // of the mask), P3O's kappa * relu(mean(ratio * A_c) + excess) -- the arithmetic of osa_mb_grad_kernel's EXT form.
+    // The mask mean and the penalty are minibatch-level: ONE block (the entry point refuses more than 256 rows).
+    float kl = 0.f, mask = 1.f, mask_mean = 1.f, cost_w = 0.f;
+    const long orow = row;
+    if (a.ext_on) {
+      if (valid)
+        for (int d = 0; d < a.act_dim; ++d) {
+          const float ls = a.log_std[d], ls0 = a.old_log_std[d], dl = ls - ls0;
+          const float q = expf(dl), isd0 = expf(-ls0);
+          const float u = (a.out[0][b * a.ldo[0] + d] - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
+          kl += 0.5f * (q * q + u * u - 1.f - 2.f * dl);
+        }
+      if (a.ext_mask_eta >= 0.f || a.ext_cost_kappa > 0.f) {  // block-uniform
+        mask = (a.ext_mask_eta < 0.f || (valid && kl <= a.ext_mask_eta)) ? 1.f : 0.f;
+        const float tm = gm_block_sum(valid ? mask : 0.f, red);
+        const float tc = gm_block_sum(valid ? ratio * SC(2) : 0.f, red);
+        if (a.ext_mask_eta >= 0.f) mask_mean = tm * invB;
+        if (a.ext_cost_kappa > 0.f) {
+          const float pen = tc * invB + a.ext_cost_excess;
+          if (pen > 0.f) cost_w = a.ext_cost_kappa;
+          if (threadIdx.x == 0 && a.stats && writer) a.stats[10] = a.ext_cost_kappa * fmaxf(pen, 0.f);
+        }
+      }
+    }
+    float dlogp = 0.f, dklw = 0.f;
+    if (valid) {
+      const float adv = (SC(1) - lam * SC(2)) / (1.f + lam);
+      float dratio;
+      if (a.loss_kind == 0) {
+        const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * adv, s2 = rc * adv;
+        const bool inrange = ratio >= lo && ratio <= hi;
+        loss = -fminf(s1, s2);
+        dratio = (s1 < s2 || inrange) ? -adv : 0.f;
+      } else {
+        loss = -(ratio * adv);
+        dratio = -adv;
+      }
+      if (a.ext_on) {
+        const float rs = a.ext_ratio_scale * mask_mean;
+        loss = loss * rs + a.ext_kl_coef * kl * mask;
+        dratio = dratio * rs + cost_w * SC(2);
+        dklw = a.ext_kl_coef * mask * invB;
+      }
+      ratio_s = ratio;
+      dlogp = dratio * ratio * invB;
+    }
+    // d logp / d mu = z / var;  d logp / d log_std = z^2 / var - 1; block sums of the latter, dimension by dimension
+    for (int d = 0; d < a.act_dim; ++d) {
+      float dl = 0.f;
+      if (valid) {
+        const float sd = expf(a.log_std[d]);
+        const float iv = 1.f / (sd * sd);
+        const float mu = a.out[0][b * a.ldo[0] + d];
+        const float z = ACT(d) - mu;
+        float dmu = dlogp * z * iv;
+        dl = dlogp * (z * z * iv - 1.f);
+        if (a.ext_on) {  // d KL / d mu = (mu - mu0) / var0;  d KL / d log_std = var / var0 - 1
+          const float ls0 = a.old_log_std[d], q = expf(a.log_std[d] - ls0), isd0 = expf(-ls0);
+          const float u = (mu - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
+          dmu += dklw * (u * isd0);
+          dl += dklw * (q * q - 1.f);
+        }
+        dzp[b * ldzp + d] = dmu;
+      }
+      dl = gm_block_sum(dl, red);
+      if (threadIdx.x == 0 && writer) a.dls[(long)blk * a.lda + d] = dl;
+    }
+    if (valid)
+      for (int d = a.act_dim; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;  // (row padding)
+  }
+  loss = gm_block_sum(loss, red);
+  ratio_s = gm_block_sum(ratio_s, red);
+  if (threadIdx.x == 0 && writer) {
+    float* lp_ = a.lpart + ((long)net * a.nblk + blk) * 4;
+    lp_[0] = loss;
+    lp_[1] = ratio_s;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // small minibatches (rows <= 64: the reference's YAML batch_size): the skinny path
 // ------------------------------------------------------------------------------------------------
 // A 64-row optimiser step at hidden 1024 is bandwidth work -- 13 MB of weights per network pass, 2 x 64 flops per weight
@@ -70,10 +230,15 @@ struct GSProb {
   int ldx, ldw, ldy, ldaux;
   int N, K;           // W is N x K
   int act;            // fwd: activation, or -1;  bwd: activation whose derivative multiplies, or -1
+  int net;            // the network this problem belongs to (gs_top_kernel)
 };
 struct GSArgs {
   GSProb p[3];
   int nprob, R;
+  // != 0 (forward of layer 0, round 5: no gather launch): X is the CALLER's observation array -- any row stride, any
+  // alignment -- and row r of the minibatch is X[(xidx ? xidx[r] : r) * ldx ..]: four-byte loads, K = obs_dim is small
+  int xrows;
+  const long* xidx;
 };
 
 #ifndef GS_WAVES
@@ -97,6 +262,18 @@ __device__ __forceinline__ f32x4 gs_load4(const float* __restrict__ row, int c0,
   return ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// the same four columns from a row of ANY alignment (four-byte loads; columns beyond `lim` are zero)
+__device__ __forceinline__ f32x4 gs_load4u(const float* __restrict__ row, int c0, int lim, bool ok) {
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool okq = ok && c0 + q < lim;
+    const float t = row[okq ? c0 + q : 0];
+    v[q] = okq ? t : 0.f;
+  }
+  return v;
+}
+
 // the cross-wave sum of the 4 row tiles' accumulators, in wave order; returns tile `t`'s sum for lane `ln`
 __device__ __forceinline__ f32x4 gs_sum_waves(const float* red, int t, int ln) {
   f32x4 v = *reinterpret_cast<const f32x4*>(red + ((0 * 4 + t) * 64 + ln) * 4);
@@ -105,7 +282,8 @@ __device__ __forceinline__ f32x4 gs_sum_waves(const float* red, int t, int ln) {
   return v;
 }
 
-// grid (ceil(maxN / 16), nprob), 64 GS_WAVES threads
+// grid (ceil(maxN / 16), nprob), 64 GS_WAVES threads.   XI: the rows come from the caller's array (GSArgs.xrows)
+template <bool XI>
 __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
   __shared__ __attribute__((aligned(16))) float red[GS_WAVES * 4 * 64 * 4];
   const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
@@ -127,48 +305,37 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     xok[t] = 16 * t + j < R;
-    xrow[t] = p.X + (long)(xok[t] ? 16 * t + j : 0) * p.ldx;
+    long r = xok[t] ? 16 * t + j : 0;
+    if (XI && a.xidx) r = a.xidx[r];
+    xrow[t] = p.X + r * p.ldx;
   }
-  for (int bb = b0; bb < b1; bb += GS_PF) {
+  // (XI: layer 0 -- obs_dim columns, a block or two per wave: no window of clamped loads)
+  constexpr int PFW = XI ? 1 : GS_PF;
+  for (int bb = b0; bb < b1; bb += PFW) {
     // every load of the window is issued before the first MFMA: the weights come from HBM, the rows from L2
-    f32x4 wf[GS_PF][GS_NQ], xf[GS_PF][GS_NQ][4];
+    f32x4 wf[PFW][GS_NQ], xf[PFW][GS_NQ][4];
 #pragma unroll
-    for (int u = 0; u < GS_PF; ++u)
+    for (int u = 0; u < PFW; ++u)
 #pragma unroll
       for (int q = 0; q < GS_NQ; ++q)
-#ifdef GS_PROBE_NOW  // (tools/skinny_probe.hip: ablations)
-        wf[u][q] = (f32x4){1.f, 2.f, 3.f, 4.f};
-#else
         wf[u][q] = gs_load4(wrow, GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q, p.ldw, wok && bb + u < b1);
-#endif
 #pragma unroll
-    for (int u = 0; u < GS_PF; ++u)
+    for (int u = 0; u < PFW; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int q = 0; q < GS_NQ; ++q)
-#ifdef GS_PROBE_NOX
-          xf[u][q][t] = (f32x4){1.f, 2.f, 3.f, (float)t};
-#elif defined(GS_PROBE_XCOAL)  // same bytes, GS_PROBE_XCOAL rows x (1024 / GS_PROBE_XCOAL) contiguous bytes per wave instruction
-          xf[u][q][t] = *reinterpret_cast<const f32x4*>(
-              p.X + (long)((lane / (64 / GS_PROBE_XCOAL)) + GS_PROBE_XCOAL * ((4 * (bb + u) + t) % (64 / GS_PROBE_XCOAL))) * p.ldx +
-              (256 / GS_PROBE_XCOAL) * ((4 * (bb + u) + t) / (64 / GS_PROBE_XCOAL)) + 4 * (lane % (64 / GS_PROBE_XCOAL)));
-#else
-          xf[u][q][t] = gs_load4(xrow[t], GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q, p.ldx, xok[t] && bb + u < b1);
-#endif
+          xf[u][q][t] = XI ? gs_load4u(xrow[t], GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q, K, xok[t] && bb + u < b1)
+                           : gs_load4(xrow[t], GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q, p.ldx, xok[t] && bb + u < b1);
 #pragma unroll
-    for (int u = 0; u < GS_PF; ++u) {
+    for (int u = 0; u < PFW; ++u) {
       if (bb + u < b1) {  // wave-uniform
 #pragma unroll
         for (int q = 0; q < GS_NQ; ++q)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-#ifdef GS_PROBE_NOMFMA
-            for (int t = 0; t < 4; ++t) acc[t][s] += wf[u][q][s] * xf[u][q][t][s];
-#else
             for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[u][q][s], xf[u][q][t][s], acc[t]);
-#endif
       }
     }
   }
@@ -268,175 +435,64 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
   }
 }
 
-// ---- the large layers of a skinny step: contraction split over WORKGROUPS, operands through LDS -----------------------
-// gs_fwd / gs_bwd above give every workgroup 16 output columns and the WHOLE contraction: every workgroup then reads all
-// 64 rows of the layer's input -- 256 KB at width 1024, 61 MB per launch over 192 workgroups, and that L2 -> L1 traffic
-// (not the 12.6 MB of weights, not the MFMAs) is what a launch costs (tools/skinny_probe.hip: 14.3 us back to back, 7.7
-// without the row loads).  Here a workgroup owns 64 output columns x a 256-wide SLICE of the contraction: 64 KB of weights
-// + 64 KB of rows, both staged once in LDS with fully coalesced 16-byte loads and read from there as MFMA fragments (5 x
-// less traffic at the same number of workgroups).  The slices' partial tiles meet in memory: every workgroup publishes
-// its 64 x 64 tile (device-coherent 4-byte stores), takes a ticket, and the LAST arriver of a tile adds the slices in slice
-// order -- deterministic, whatever the arrival order -- and applies the epilogue.  Tickets return to zero.
-#define GSB_CL 256             // contraction columns per slice
-#define GSB_LD (GSB_CL + 4)    // leading dimension of the [64][256] operand images in LDS
-#define GSB_LDT 68             // leading dimension of the [256][64] image (backward: W rows are contiguous along the output)
-struct GSBArgs {
-  GSProb p[3];
-  int nprob, R;
-  int tiles[3], S[3];          // 64-column output tiles and contraction slices of every problem
-  float* slab;                 // [sum tiles x S][64 rows][64 columns] partial tiles
-  int* ticket;                 // [sum tiles], zero between launches
-};
-
-template <bool BWD>
-__global__ __launch_bounds__(512) void gs_big_kernel(GSBArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float gsb_smem[];
-  float* sA = gsb_smem;                                  // FWD: W slice [64 cols][GSB_LD]; BWD: W slice [256 n][GSB_LDT]
-  float* sB = gsb_smem + (BWD ? GSB_CL * GSB_LDT : 64 * GSB_LD);  // rows [64][GSB_LD]
-  __shared__ int s_last;
-  // ---- which (problem, tile, slice)
-  int b = blockIdx.x, pi = 0, tbase = 0;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-    if (pi == q && q + 1 < a.nprob && b >= a.tiles[q] * a.S[q]) {
-      b -= a.tiles[q] * a.S[q];
-      tbase += a.tiles[q] * a.S[q];
-      pi = q + 1;
-    }
-  const GSProb p = pi == 0 ? a.p[0] : (pi == 1 ? a.p[1] : a.p[2]);
-  const int S = pi == 0 ? a.S[0] : (pi == 1 ? a.S[1] : a.S[2]);
-  const int tile = b / S, sl = b - tile * S;
-  const int tkidx = tile + (pi == 0 ? 0 : (pi == 1 ? a.tiles[0] : a.tiles[0] + a.tiles[1]));  // the tile's ticket
-  const int c0 = 64 * tile;      // first output column
-  const int q0 = GSB_CL * sl;    // first contraction index
-  const int C = BWD ? p.N : p.K; // contraction length;  outputs: FWD p.N columns, BWD p.K columns
-  const int NO = BWD ? p.K : p.N;
+// ---- loss + backward through the TOP layer in one launch (round 5) -----------------------------------------------------
+// The top layer's backward-data product contracts over act_dim (or 1) outputs: every workgroup of that launch can afford
+// to compute the loss of all <= 64 rows itself (dL/d(output) into LDS) instead of waiting for a 5 us launch that does it
+// once.  Workgroup 0 of a network is the writer: dL/d(output) rows for the weight-gradient launch, block partials of
+// dL/d(log_std), loss statistics.  Networks without a hidden layer take part with zero output columns (loss only).
+#define GS_TOP_LDZ 36  // leading dimension of the dL/d(output) image in LDS (top layers up to 32 wide)
+// grid (max(1, ceil(maxK / 16)), nprob), 256 threads (wave = row tile)
+__global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la) {
+  __shared__ __attribute__((aligned(16))) float sDZ[64 * GS_TOP_LDZ];
+  __shared__ float red[4];
+  const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
+  const int k0 = blockIdx.x * 16;
+  const bool writer = blockIdx.x == 0;
+  if (!writer && k0 >= p.ldy) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  const int R = a.R;
-  // ---- stage the operands (16-byte loads, a wave on whole rows)
-  if (!BWD) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {  // 64 rows x 64 pieces
-      const int u = tid + 512 * q, r = u >> 6, c4 = 4 * (u & 63);
-      const bool okw = c0 + r < p.N;
-      *reinterpret_cast<f32x4*>(sA + r * GSB_LD + c4) =
-          gs_load4(p.W + (long)(okw ? c0 + r : 0) * p.ldw, q0 + c4, p.ldw, okw);
-      *reinterpret_cast<f32x4*>(sB + r * GSB_LD + c4) = gs_load4(p.X + (long)(r < R ? r : 0) * p.ldx, q0 + c4, p.ldx, r < R);
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {  // W: 256 rows n x 16 pieces;  dZ: 64 rows x 64 pieces
-      const int u = tid + 512 * q;
-      const int n = u >> 4, c4 = 4 * (u & 15);
-      const bool okw = q0 + n < p.N;
-      *reinterpret_cast<f32x4*>(sA + n * GSB_LDT + c4) =
-          gs_load4(p.W + (long)(okw ? q0 + n : 0) * p.ldw, c0 + c4, p.ldw, okw);
-      const int r = u >> 6, d4 = 4 * (u & 63);
-      *reinterpret_cast<f32x4*>(sB + r * GSB_LD + d4) = gs_load4(p.X + (long)(r < R ? r : 0) * p.ldx, q0 + d4, p.ldx, r < R);
-    }
-  }
+  const int net = p.net, R = a.R, ldz = la.ldz[net];
+  for (int e = tid; e < 64 * GS_TOP_LDZ; e += 256) sDZ[e] = 0.f;
   __syncthreads();
-  // ---- MFMA: wave = (column tile cw of 16, half hw of the slice); D[m = column][n = row] as in gs_fwd / gs_bwd
-  const int cw = wave & 3, hw = wave >> 2;
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int bb = 0; bb < GSB_CL / 32; ++bb) {
-    const int k = (GSB_CL / 2) * hw + 16 * bb + 4 * g;
-    f32x4 af, bf[4];
-    if (!BWD) {
-      af = *reinterpret_cast<const f32x4*>(sA + (16 * cw + j) * GSB_LD + k);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) af[s] = sA[(k + s) * GSB_LDT + 16 * cw + j];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const f32x4*>(sB + (16 * t + j) * GSB_LD + k);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(af[s], bf[t][s], acc[t]);
-  }
-  __syncthreads();  // operand images consumed: sB becomes the [row][64] output tile
-  // ---- the two halves of the slice, added in LDS; tile element (row, column) at sB[row * GSB_LDT + column]
-  float* sT = sB;
-  if (hw == 1) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(sT + (16 * t + j) * GSB_LDT + 16 * cw + 4 * g) = acc[t];
-  }
+  gm_loss_body(la, net, tid, 0, red, sDZ, GS_TOP_LDZ, writer);  // (rows beyond R: nothing written, the image stays zero)
   __syncthreads();
-  if (hw == 0) {
+  if (writer)
+    for (int e = tid; e < R * ldz; e += 256) la.dz[net][e] = sDZ[(e / ldz) * GS_TOP_LDZ + e % ldz];
+  if (k0 >= p.ldy) return;
+  // ---- dZ'[r][k] = (sum_n dZ[r][n] W[n][k]) act'(H[r][k]) for the 16 columns k0 .., row tile = wave
+  const int N = p.N;
+  const bool kok = k0 + j < p.K;
+  const float* __restrict__ wcol = p.W + (kok ? k0 + j : 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4* d = reinterpret_cast<f32x4*>(sT + (16 * t + j) * GSB_LDT + 16 * cw + 4 * g);
-      *d = acc[t] + *d;
-    }
-  }
-  __syncthreads();
-  // ---- publish / combine.  Thread -> (row, 4 columns): 64 rows x 16 pieces = 1024 pieces, two per thread
-  float* __restrict__ myslab = a.slab + ((long)(tbase + tile * S + sl)) * 4096;
-  if (S > 1) {
+  for (int bb = 0; bb < 2; ++bb) {
+    if (16 * bb < N) {  // block-uniform
+      float wf[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int u = tid + 512 * q, r = u >> 4, c4 = 4 * (u & 15);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sT + r * GSB_LDT + c4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        __hip_atomic_store(myslab + r * 64 + c4 + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the tile's stores have been performed at the device-coherent level before the ticket is taken
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) {
-      const int seen = __hip_atomic_fetch_add(a.ticket + tkidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = seen == S - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int u = tid + 512 * q, r = u >> 4, c4 = 4 * (u & 15);
-    f32x4 v;
-    if (S > 1) {
-      const float* __restrict__ s0 = a.slab + ((long)(tbase + tile * S)) * 4096 + r * 64 + c4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = __hip_atomic_load(s0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int k = 1; k < S; ++k)
-          t += __hip_atomic_load(s0 + (long)k * 4096 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[e] = t;
+      for (int s = 0; s < 4; ++s) {
+        const int n = 16 * bb + 4 * g + s;
+        const bool ok = kok && n < N;
+        const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
+        wf[s] = ok ? wv : 0.f;
       }
-    } else {
-      v = *reinterpret_cast<const f32x4*>(sT + r * GSB_LDT + c4);
-    }
-    const int col = c0 + c4;
-    if (r < R && col < p.ldy) {
-      f32x4 h = {0.f, 0.f, 0.f, 0.f};
-      if (BWD && p.act >= 0) h = *reinterpret_cast<const f32x4*>(p.aux + (long)r * p.ldaux + col);
+      const f32x4 xf = *reinterpret_cast<const f32x4*>(sDZ + (16 * wave + j) * GS_TOP_LDZ + 16 * bb + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float y = 0.f;  // (padding columns of the row: zero)
-        if (col + e < NO) {
-          y = v[e];
-          if (!BWD) {
-            if (p.bias) y += p.bias[col + e];
-            if (p.act >= 0) y = gm_act(y, p.act);
-          } else if (p.act >= 0) {
-            y *= gm_dact(h[e], p.act);
-          }
-        }
-        v[e] = y;
-      }
-      *reinterpret_cast<f32x4*>(p.Y + (long)r * p.ldy + col) = v;
+      for (int s = 0; s < 4; ++s) acc = OSA_MFMA(wf[s], xf[s], acc);
     }
   }
-  (void)C;
-  if (S > 1 && tid == 0) {
-    __hip_atomic_store(a.ticket + tkidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  const int row = 16 * wave + j, k = k0 + 4 * g;
+  if (row < R && k < p.ldy) {
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    if (p.act >= 0) h = *reinterpret_cast<const f32x4*>(p.aux + (long)row * p.ldaux + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = 0.f;
+      if (k + r < p.K) {
+        y = acc[r];
+        if (p.act >= 0) y *= gm_dact(h[r], p.act);
+      }
+      acc[r] = y;
+    }
+    *reinterpret_cast<f32x4*>(p.Y + (long)row * p.ldy + k) = acc;
   }
 }
 
@@ -444,6 +500,10 @@ struct GSWLayer {
   const float* dZ;  // [R][ldz]   dL/d(pre-activation) of this layer
   const float* H;   // [R][ldh]   the layer's input rows
   int ldz, ldh, out, in, ldw, oW, ob, tile0, tk;
+  // != 0 (layer 0 without a gather launch): H is the caller's observation array, row r = H[(hidx ? hidx[r] : r) * ldh ..],
+  // any alignment (four-byte loads)
+  int hrows;
+  const long* hidx;
 };
 struct GSWArgs {
   GSWLayer l[3][GM_MAXL];
@@ -610,7 +670,13 @@ __global__ __launch_bounds__(256) void gs_wgrad_kernel(GSWArgs a) {
   for (int q = 0; q < 4; ++q) {
     const int u = tid + 256 * q, r = u >> 4, c4 = 4 * (u & 15);
     *reinterpret_cast<f32x4*>(sZ + r * GS_LDT + c4) = gs_load4(ly.dZ + (long)(r < R ? r : 0) * ly.ldz, n0 + c4, ly.ldz, r < R);
-    *reinterpret_cast<f32x4*>(sH + r * GS_LDT + c4) = gs_load4(ly.H + (long)(r < R ? r : 0) * ly.ldh, k0 + c4, ly.ldh, r < R);
+    if (ly.hrows) {  // block-uniform
+      long hr = r < R ? r : 0;
+      if (ly.hidx) hr = ly.hidx[hr];
+      *reinterpret_cast<f32x4*>(sH + r * GS_LDT + c4) = gs_load4u(ly.H + hr * ly.ldh, k0 + c4, ly.in, r < R);
+    } else {
+      *reinterpret_cast<f32x4*>(sH + r * GS_LDT + c4) = gs_load4(ly.H + (long)(r < R ? r : 0) * ly.ldh, k0 + c4, ly.ldh, r < R);
+    }
   }
   __syncthreads();
   // column tile c of the 64 columns holds the columns k0 + 4 j + c: the four accumulators of a lane then are four

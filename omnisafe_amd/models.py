@@ -334,8 +334,7 @@ class ConstraintActorCritic:  # pylint: disable=too-many-instance-attributes
         need = int(self._lib.osa_gmlp_ws_floats(C.byref(self.desc), int(rows)))
         assert need > 0
         if self._gws is None or self._gws.numel() < need:
-            # (zeros: the workspace holds arrival tickets that every launch leaves at zero -- osa_gmlp_ws_floats)
-            self._gws = torch.zeros(need, dtype=torch.float32, device=self.device)
+            self._gws = torch.empty(need, dtype=torch.float32, device=self.device)
         return self._gws, int(self._gws.numel())
 
     # ------------------------------------------------------------------ rollout step

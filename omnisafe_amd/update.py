@@ -72,6 +72,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         self.dp_mode = dp_mode
         self.seed = int(seed)
         self._dp: dict = {}
+        self._ar_k = 0  # steps of the current pass taken by the fast all-reduce mode (minibatch / _ar_end_pass)
         self.hp = HParams(clip=clip, entropy_coef=entropy_coef, critic_norm_coef=critic_norm_coef,
                           max_grad_norm=max_grad_norm, lr_actor=0.0, lr_critic=0.0, beta1=0.9,
                           beta2=0.999, adam_eps=1e-8, use_critic_norm=int(use_critic_norm),
@@ -265,6 +266,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     s0 = k * B
                     nb = min(B, M - s0)
                     self.minibatch(data, st['perm'][ip * M + s0:ip * M + s0 + nb], nb, lagrange, st['stats'][ip * nmb + k])
+                self._ar_end_pass()
 
         hp.lr_device = st['lr'].data_ptr()
         pe, self.profile_events = self.profile_events, None  # (one event pair around the pass, none inside a capture)
@@ -301,6 +303,30 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         stats_rows.copy_(st['stats'])
         self._graphed_pass = st['graph'] is not None
 
+    def _allreduce_fast_ok(self, data: dict, B: int) -> bool:
+        """The `allreduce` mode's steps on osa_ppo_dp_step_phase: fused network family, plain surrogates, minibatches the
+        persistent kernels take, 16-byte aligned rows (run() pads them once per update).  OSA_ALLREDUCE_FAST=0: the
+        per-step kernels (osa_ppo_minibatch mode 1 -> all-reduce -> osa_adam_apply)."""
+        obs = data['obs']
+        return (self.dp_mode == 'allreduce' and not self.general and self.ext is None and self.loss_kind in (0, 1)
+                and self.batch_size <= self.persistent_max_batch and obs.stride(0) % 4 == 0 and obs.data_ptr() % 16 == 0
+                and os.environ.get('OSA_ALLREDUCE_FAST', '1') != '0'
+                and bool(self.lib.osa_ppo_pass_supported(self.ac.obs_dim, self.ac.act_dim, self.ac.hidden)))
+
+    def _ar_slab(self) -> torch.Tensor:
+        if getattr(self, '_ar_slab_t', None) is None:
+            n = self.lib.osa_ppo_dp_ws_floats(self.ac.obs_dim, self.ac.act_dim, self.ac.hidden, 1)
+            self._ar_slab_t = torch.zeros(n, dtype=torch.float32, device=self.ac.device)
+        return self._ar_slab_t
+
+    def _ar_end_pass(self) -> None:
+        """After the last step of a pass of the fast all-reduce mode: the Adam step counters advance by its steps."""
+        if self._ar_k:
+            _lib.check(self.lib.osa_ppo_dp_end_pass(_lib.ptr(self.ac.adam_step),
+                                                    self._nets_mask() & (7 if self.hp.use_cost else 3), self._ar_k,
+                                                    _lib.stream_ptr()), 'osa_ppo_dp_end_pass')
+            self._ar_k = 0
+
     def minibatch(self, data: dict, idx: torch.Tensor | None, B: int, lagrange: torch.Tensor,
                   stats_row: torch.Tensor) -> None:
         ac, lib, st = self.ac, self.lib, _lib.stream_ptr()
@@ -335,6 +361,25 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                                                    _lib.ptr(ac.adam_v), _lib.ptr(ac.adam_step), _lib.ptr(ac.grads),
                                                    C.byref(self.hp), self._nets_mask(), _lib.ptr(ac._gfin), st),
                            'osa_gmlp_adam_apply')
+            return
+        if dp and self._allreduce_fast_ok(data, B):
+            # per-step all-reduce mode on the pass kernel's gradient-only form (round 5): clipped gradients of THIS rank's
+            # minibatch -> ONE flat all-reduce (average) of the slab -> Adam (policy_gradient.py:437-443 order)
+            slab = self._ar_slab()
+            args = (ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+                    _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0), _lib.ptr(data['act']),
+                    data['act'].stride(0), _lib.ptr(data['logp']), _lib.ptr(data['target_value_r']),
+                    _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']), _lib.ptr(data['adv_c']), _lib.ptr(idx),
+                    B, self.batch_size, 1)
+            tail = (_lib.ptr(lagrange), C.byref(self.hp), self.hp.lr_device, self.loss_kind, self._nets_mask(),
+                    _lib.ptr(slab), _lib.ptr(stats_row))
+            _lib.check(lib.osa_ppo_dp_step_phase(*args, 0, *tail, 1, st), 'osa_ppo_dp_step_phase(grad)')
+            if ev is not None:
+                ev[1].record()
+                self.profile_events.append(('osa_ppo_pass_kernel', B, ev))
+            dist.all_reduce_avg_(slab)
+            _lib.check(lib.osa_ppo_dp_step_phase(*args, self._ar_k, *tail, 2, st), 'osa_ppo_dp_step_phase(apply)')
+            self._ar_k += 1
             return
         ext = None
         if self.ext is not None:
@@ -637,7 +682,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # (the reduction sliced over the ranks + Adam on the slice + parameters exchanged -- round 3's
         # osa_ppo_dp_slice_pass -- measured 17.9 us per step at 8 virtual ranks against 15.7 for the direct sum, 15.9 v
         # 13.2 at 4: the second hand-off costs more than the W - 2 slab reads and the 7/8 of Adam it saves; removed in
-        # round 4, DESIGN.md 5.2, profiles/r3_dp_shapes_timing.md)
+        # round 4, profiles/HISTORY.md §5.2, profiles/r3_dp_shapes_timing.md)
         st['sliced'] = False
         fn = lib.osa_ppo_dp_chunked_pass if chunked else lib.osa_ppo_dp_pass_placed
         rc = fn(
@@ -917,6 +962,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     nb = min(B, M - s)
                     self.minibatch(data, perm[s:s + nb], nb, lagrange, stats[step])
                     step += 1
+                self._ar_end_pass()
             update_counts += 1
             last_perm = self._dp['perm'][dist.rank()] if use_repl else perm
             # the KL pass feeds the early-stop test; without early stop only the last pass's value is

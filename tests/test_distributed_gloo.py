@@ -170,7 +170,7 @@ def test_seed_and_step_sharding(tmp_path):
 
 # ---------------------------------------------------------------------------------------------
 def _case_replicated_protocol(rank, world, tmpdir):
-    """The replicated-data update: one all-gather of the epoch's rows, then every rank runs the
+    """The replicated-data update (profiles/HISTORY.md §5): one all-gather of the epoch's rows, then every rank runs the
     WHOLE global optimiser chain on the same data -- rank r's minibatches drawn from a stream every rank can
     regenerate -- so the replicas agree without gradient traffic.  Here: the all-gather layout, the
     regenerated permutation streams and, with the oracle as the local step, bit-equal replicas that match

@@ -124,7 +124,7 @@ def _worker(rank, world, port, tag, dp_mode, want_path, want, tmpdir, real_devic
     elif env_id == 'SynthHumanoid-v0':
         # 376 inputs: the first layer is a 376-term float32 sum in MFMA-tile order (the split wide pass: over
         # cooperating workgroups) where the reference's CPU sgemm has its own order (~1e-7 relative in every gradient); through Adam's first steps lr g / (|g| + eps) the handful of elements whose
-        # early gradients lie within ~1e-8 of zero move by a visible fraction of lr (the single-GPU
+        # early gradients lie within ~1e-8 of zero move by a visible fraction of lr (profiles/HISTORY.md §3.3; the single-GPU
         # test_wide_split_* asserts the same shape): all but a few of the 86 k parameters inside the single-process
         # tolerance, the stragglers inside a twentieth of ONE learning-rate step
         big = sum(int((np.abs(v.cpu().numpy() - g[f'post/{net}/{k}']) > 2e-6).sum())

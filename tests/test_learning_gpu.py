@@ -13,7 +13,7 @@ Tolerance: the seed-mean of the tail metric (average of the last 3 epochs) must 
 deviation (ddof=1, over the reference's seeds) of the reference's seed-mean, for both return and cost;
 a difference larger than that only fails if it is also larger than four standard errors of the
 difference (episode cost is heavy-tailed: a per-episode standard deviation of 8 at a mean of 2.8, so
-3-seed means scatter by more than the reference's sigma on their own -- DESIGN.md section 6 lists the
+3-seed means scatter by more than the reference's sigma on their own -- profiles/HISTORY.md §6 lists the
 3-, 12- and 20-seed numbers).  The two sides do not share random streams (torch CPU generator vs device Philox), so
 this is a statistical statement, not a trace comparison; trace-level parity of the same update is
 covered by tests/test_mlp_gpu.py and tests/test_rollout_gpu.py."""

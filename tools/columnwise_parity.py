@@ -9,7 +9,7 @@ With ~ 35 columns x 10 epochs x 2 tests, about 7 cells below p = 0.01 are expect
 shows as a column that is significant over several consecutive epochs (the table lists every column with two or
 more cells below 0.01, or any below 0.001).  /Min and /Max columns are skipped: the reference logs the MEAN in
 both (distributed.py:388-391 reduces the vector element-wise, logger.py:366 averages it), omnisafe_amd logs the
-extremes."""
+extremes (profiles/HISTORY.md §8)."""
 import json
 import sys
 

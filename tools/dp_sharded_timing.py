@@ -1,5 +1,5 @@
 """GPU tool: the cooperative replicated-data pass with the three networks' chains SHARDED over the ranks
-("network-sharded" variant): a real rank of a W-GPU job then keeps only W workgroups
+(profiles/HISTORY.md §5, "network-sharded" variant): a real rank of a W-GPU job then keeps only W workgroups
 resident (one network, W virtual ranks) instead of 3 W, and the updated networks are broadcast once per pass.
 Times one pass for W virtual ranks with nets_mask = all three networks / one network."""
 import os, sys, types, json

@@ -39,45 +39,13 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 2; ++it) {
       CK(hipEventRecord(e0));
       for (int r = 0; r < reps; ++r) {
-        if (which == 0) hipLaunchKernelGGL(gs_fwd_kernel, dim3((H + 15) / 16, 3), dim3(64 * GS_WAVES), 0, 0, g);
+        if (which == 0) hipLaunchKernelGGL(gs_fwd_kernel<false>, dim3((H + 15) / 16, 3), dim3(64 * GS_WAVES), 0, 0, g);
         else hipLaunchKernelGGL(gs_bwd_kernel, dim3((H + 15) / 16, 3), dim3(64 * GS_WAVES), 0, 0, g);
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     printf("%s H=%d R=%d ld=%d waves=%d kb=%d pf=%d : %.2f us per launch (back to back)\n", which ? "bwd" : "fwd", H, R, ld,
            GS_WAVES, GS_KB, GS_PF, ms * 1e3 / reps);
-  }
-  // ---- gs_big_kernel: contraction split over workgroups, operands through LDS
-  {
-    float* slab; int* tick;
-    const int tiles = (H + 63) / 64, S = (H + GSB_CL - 1) / GSB_CL;
-    CK(hipMalloc(&slab, (size_t)3 * tiles * S * 4096 * 4));
-    CK(hipMalloc(&tick, 3 * tiles * 4));
-    CK(hipMemset(tick, 0, 3 * tiles * 4));
-    GSBArgs ba = {};
-    ba.nprob = 3; ba.R = R; ba.slab = slab; ba.ticket = tick;
-    for (int i = 0; i < 3; ++i) { ba.p[i] = g.p[i]; ba.tiles[i] = tiles; ba.S[i] = S; }
-    for (int which = 0; which < 2; ++which) {
-      const size_t lds = (size_t)((which ? GSB_CL * GSB_LDT : 64 * GSB_LD) + 64 * GSB_LD) * 4;
-      if (which) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      else CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      for (int it = 0; it < 2; ++it) {
-        CK(hipEventRecord(e0));
-        for (int r = 0; r < reps; ++r) {
-          if (which == 0) hipLaunchKernelGGL(gs_big_kernel<false>, dim3(3 * tiles * S), dim3(512), lds, 0, ba);
-          else hipLaunchKernelGGL(gs_big_kernel<true>, dim3(3 * tiles * S), dim3(512), lds, 0, ba);
-        }
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-      }
-      CK(hipGetLastError());
-      printf("big %s H=%d R=%d tiles=%d S=%d : %.2f us per launch (back to back)\n", which ? "bwd" : "fwd", H, R, tiles, S,
-             ms * 1e3 / reps);
-    }
-    std::vector<int> th(3 * tiles);
-    CK(hipMemcpy(th.data(), tick, 3 * tiles * 4, hipMemcpyDeviceToHost));
-    int bad = 0;
-    for (int v : th) bad += v != 0;
-    printf("tickets left non-zero: %d\n", bad);
   }
   return 0;
 }
