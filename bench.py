@@ -185,22 +185,27 @@ def timed(algo, steps, warmup, world, dev):
 
 def pmc_traffic(kernel_prefixes, tag):
     """HBM-side bytes per launch of the dominant kernel(s) from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r4_pmc_traffic_<tag>.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction --
+    (profiles/r<N>_pmc_traffic_<tag>.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction --
     tools/gpu_round_check.sh + tools/pmc_summary.py); PMC counters cannot be read from inside the process, so this is
     the offline measurement of the same command.  The file records the digest of the kernel sources it was measured on
     (`_abi_digest` = osa_abi_digest()); a file measured on OTHER kernels is stale and yields None (round-3 verdict:
     the traffic of a previous build must not ride along with a new kernel's time).  Several prefixes = a step made of
     several launches: their sum."""
-    path = os.path.join(ROOT, 'profiles', f'r4_pmc_traffic_{tag}.json')
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
+    import glob
+
     try:
         from omnisafe_amd import build as _b
 
-        if d.get('_abi_digest') != _b.source_digest():
-            return None
+        digest = _b.source_digest()
     except Exception:  # noqa: BLE001
+        return None
+    d = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_traffic_{tag}.json')), reverse=True):
+        cand = json.load(open(path))
+        if cand.get('_abi_digest') == digest:  # (the newest round's file measured on exactly these kernel sources)
+            d = cand
+            break
+    if d is None:
         return None
     total = 0
     for pre in kernel_prefixes:

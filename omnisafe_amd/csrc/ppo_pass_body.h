@@ -257,16 +257,23 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   const bool small_out = SO || ((OT == 1) && out_dim <= 2);  // (SO: a compile-time `true`)
 
   // ---- load parameters into the LDS master copy (coalesced)
-#ifdef OSA_BODY_PART_ONLY
   // 16-byte loads (the blocks of a network are 64-byte aligned, rows multiples of 16 floats) and 16-byte LDS stores:
   // KB + 4 + OT loads per thread instead of 16 KB + 32 + 4 OT four-byte ones -- the prologue of a segment is paid
-  // by every workgroup once per launch and twice by the two that straddle a network boundary
-  f32x4 w1v_[KB];
-#pragma unroll
-  for (int q = 0; q < KB; ++q) w1v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW1 + 4 * (tid + 256 * q));
+  // by every workgroup once per launch and twice by the two that straddle a network boundary.  Round 5: also in the
+  // gradient-only instantiations (DPS), whose launches are ONE optimiser step each (osa_ppo_dp_step_phase: the per-step
+  // all-reduce mode; `replicated-steps`) -- the prologue there is paid per step
+#ifdef OSA_BODY_PART_ONLY
+  constexpr bool VPRO = true;
 #else
-  for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
+  constexpr bool VPRO = DPS;
 #endif
+  f32x4 w1v_[VPRO ? KB : 1];
+  if constexpr (VPRO) {
+#pragma unroll
+    for (int q = 0; q < KB; ++q) w1v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW1 + 4 * (tid + 256 * q));
+  } else {
+    for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
+  }
   if (tid < H) {
     sB1[tid] = gp[nd.ob1 + tid];
     sB2[tid] = gp[nd.ob2 + tid];
@@ -447,8 +454,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   long row_nxt = row_of(cidx + 1);
   OSA_PART_MARK(11);
   // ... while the remaining weights stream into LDS (matters for the one-step-per-launch dp mode)
-#ifdef OSA_BODY_PART_ONLY
-  {
+  if constexpr (VPRO) {
     f32x4 w2v_[4], w3v_[OT];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w2v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW2 + 4 * (tid + 256 * q));
@@ -473,13 +479,12 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       const int e4 = tid + 256 * q;
       *reinterpret_cast<f32x4*>(sW3 + (e4 >> 4) * PSLD + 4 * (e4 & 15)) = w3v_[q];
     }
+  } else {
+    for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
+    if constexpr (W2T)
+      for (int e = tid; e < H * H; e += 256) sW2T[(e & 63) * PSLD + (e >> 6)] = gp[nd.oW2 + e];
+    for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
   }
-#else
-  for (int e = tid; e < H * H; e += 256) sW2[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW2 + e];
-  if constexpr (W2T)
-    for (int e = tid; e < H * H; e += 256) sW2T[(e & 63) * PSLD + (e >> 6)] = gp[nd.oW2 + e];
-  for (int e = tid; e < OUTP * H; e += 256) sW3[(e >> 6) * PSLD + (e & 63)] = gp[nd.oW3 + e];
-#endif
   OSA_PART_MARK(12);
   __syncthreads();  // LDS master copy complete
   OSA_PART_MARK(4);
