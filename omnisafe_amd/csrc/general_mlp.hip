@@ -206,6 +206,11 @@ struct GProb {
 struct GArgs {
   GProb p[3];
   int nprob, splits;
+  // != 0: XCD-aware tile order (+ 1 % at 1024 x 1024 / 16 384 rows: 3 960 v 3 998 us per step, same box).  Workgroup i of a launch lands on XCC i mod 8 (each with its own L2): in dispatch order
+  // (x fastest) the 8 column tiles of a 1024-wide layer go to 8 DIFFERENT L2s and every one of them streams the whole
+  // row operand.  Remapped, XCC c owns the row blocks c, c + 8, ... with ALL their column tiles: a row block is fetched
+  // into one L2 once, the (small) column operand into every L2.  Same tiles, same arithmetic.
+  int xcd;
 };
 
 // C[m][n] = epi(sum_k A(m, k) B(k, n)).   AT: A(m, k) = A[k lda + m] (else A[m lda + k]);
@@ -233,7 +238,13 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
   const GProb p = pi == 0 ? g.p[0] : (pi == 1 ? g.p[1] : g.p[2]);
   const int M = p.M, N = p.N, K = p.K;
   const int ncols = N + (p.ones_n >= 0 ? 1 : 0);
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd && (gridDim.y & 7) == 0) {
+    const int gx = gridDim.x, lid = bx + gx * by, xcd = lid & 7, slot = lid >> 3;
+    by = (slot / gx) * 8 + xcd;
+    bx = slot - (slot / gx) * gx;
+  }
+  const int m0 = by * TM, n0 = bx * TN;
   if (m0 >= M || n0 >= (ncols > p.ldc ? ncols : p.ldc) || sp >= p.splits) return;
   int kper = (K + p.splits - 1) / p.splits;
   kper = (kper + BK - 1) / BK * BK;
@@ -378,7 +389,13 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(GArgs g) {
 }
 
 template <int TM, int TN, int BK, bool AT, bool BT>
-int gm_launch(const GArgs& g, int maxM, int maxN, hipStream_t st) {
+int gm_launch(const GArgs& g_, int maxM, int maxN, hipStream_t st) {
+  static const int xcd_sw = [] {  // (A/B switch: OSA_GMLP_XCD_ORDER=0 keeps the dispatch order)
+    const char* v = getenv("OSA_GMLP_XCD_ORDER");
+    return (v != nullptr && v[0] == '0' && v[1] == 0) ? 0 : 1;
+  }();
+  GArgs g = g_;
+  g.xcd = xcd_sw;
   constexpr size_t lds = (size_t)2 * ((AT ? BK * (TM + 8) : TM * (BK + 4)) + (BT ? BK * (TN + 8) : TN * (BK + 4))) * sizeof(float);
   if constexpr (lds > 64 * 1024) {
     static OsaPerDeviceOnce attr_set;

@@ -213,6 +213,9 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
 //   gs_fwd_kernel    Y[r][n] = act(sum_k X[r][k] W[n][k] + b[n]): one workgroup per 16 output columns and ALL rows,
 //                    8 waves split the contraction; the weights are streamed ONCE, 16 bytes per lane with the whole
 //                    range of a wave in flight before its first MFMA, the activations come from L2;
+//                    layer 0 reads the minibatch's rows in place through the row indices (no gather launch);
+//   gs_top_kernel    loss + backward through the top layer in ONE launch: every workgroup computes dL/d(output) of all
+//                    <= 64 rows itself in LDS (gm_loss_body), workgroup 0 of a network writes what later launches need;
 //   gs_bwd_kernel    dZ'[r][k] = (sum_n dZ[r][n] W[n][k]) act'(H[r][k]): one workgroup per 16 columns k, the waves
 //                    split the contraction over n;
 //   gs_wgrad_kernel  dW = dZ^T H of ALL layers and networks in one launch, one 64 x 64 tile per workgroup (operands via
@@ -220,7 +223,10 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
 //                    partials (and the gradient itself only where the caller asks for it), phase 1 REcomputes the tile
 //                    -- 64 MFMAs per wave -- and applies clip + Adam straight from the accumulators: the 13 MB gradient
 //                    is never written or read, a step streams weights twice and the Adam state once.
-// Same arithmetic per element as the tiled path up to the summation order of the contraction (float32 MFMA chains).
+// 2 L + 1 launches per step for L linear layers.  Same arithmetic per element as the tiled path up to the summation order
+// of the contraction (float32 MFMA chains).  What a launch of gs_fwd / gs_bwd on a 1024 x 1024 layer costs is the L2 -> L1
+// traffic of the 64 input rows, which every one of its 192 workgroups reads (tools/skinny_probe.hip; a split-K form that
+// avoids it loses more to the exchange of partial tiles between workgroups: profiles/HISTORY.md, round-5 table).
 struct GSProb {
   const float* X;     // fwd: input rows [R][ldx];  bwd: dZ rows [R][ldx]
   const float* W;     // [N][ldw]
