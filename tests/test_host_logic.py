@@ -601,3 +601,23 @@ def test_logger_deferred_rows_equal_in_place_rows(tmp_path, monkeypatch):
         files[defer] = list(_csv.reader(open(path)))
     assert files['1'] == files['0'] and len(files['1']) == 5
 
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` without torchrun's environment launches its own ranks (as the reference's `fork`,
+    omnisafe/utils/distributed.py:121-137); on a box with fewer than N devices it refuses loudly (exit code 2, the test
+    hook named) instead of stacking ranks on one device silently.  Runs here without a GPU: device_count() == 0."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'OSA_SINGLE_DEVICE_RANKS')}
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('a multi-GPU box launches the ranks for real')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert 'OSA_SINGLE_DEVICE_RANKS' in p.stderr and '--gpus 2' in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]  # no bench line from a refused launch
