@@ -423,3 +423,46 @@ def test_trpolag_update_of_the_reference_at_general_widths(golden, tmp_path):
     np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
     _hidden_check(ac, g, ('actor',), 5e-5)
     _hidden_check(ac, g, ('reward_critic', 'cost_critic'), 2e-5)
+
+
+@pytest.mark.parametrize('mask_kind', ['critics-only', 'actor-only', 'no-cost'])
+def test_skinny_step_with_network_masks_equals_the_tiled_step(monkeypatch, mask_kind):
+    """The trust-region family updates the critics alone in its minibatch loop (natural_pg.py:205-223), PPO / PolicyGradient
+    leave the cost critic out (use_cost False): the skinny kernels under the same network masks as the tiled path --
+    untouched networks stay bit-for-bit untouched, the updated ones agree as in test_skinny_step_equals_the_tiled_step."""
+    from omnisafe_amd.update import PPOUpdater
+
+    monkeypatch.setenv('OSA_FORCE_GENERAL_MLP', '1')
+    M, B, obs_dim, act_dim = 300, 64, 27, 8
+    g = torch.Generator().manual_seed(8)
+    cpu = {'obs': torch.randn(M, obs_dim, generator=g), 'act': torch.randn(M, act_dim, generator=g),
+           'logp': -3.0 + 0.3 * torch.randn(M, generator=g), 'target_value_r': torch.randn(M, generator=g),
+           'target_value_c': torch.randn(M, generator=g), 'adv_r': torch.randn(M, generator=g),
+           'adv_c': torch.randn(M, generator=g)}
+    dev = {k: v.to(DEV).contiguous() for k, v in cpu.items()}
+    idxs = [torch.randperm(M, generator=g)[:B].to(DEV) for _ in range(2)]
+    lam = torch.tensor([0.3], device=DEV)
+    kw = {'critics-only': {'update_actor': False}, 'actor-only': {'update_critics': False}, 'no-cost': {'use_cost': False}}[mask_kind]
+    out = {}
+    for skinny in ('1', '0'):
+        monkeypatch.setenv('OSA_GMLP_SKINNY', skinny)
+        torch.manual_seed(4)
+        ac, _ = make(obs_dim, act_dim, [96, 48], [80], 'tanh', 'relu')
+        p0 = ac.params.clone()
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, **kw)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        stats = torch.zeros(2, 16, device=DEV)
+        for k in range(2):
+            up.minibatch(dev, idxs[k], B, lam, stats[k])
+        out[skinny] = (ac.params.clone(), ac.adam_step.clone(), p0)
+    (pa, sa, p0), (pb, sb, _) = out['1'], out['0']
+    assert sa.tolist() == sb.tolist()
+    untouched = {'critics-only': [0], 'actor-only': [1, 2], 'no-cost': [2]}[mask_kind]
+    for net in range(3):
+        if net in untouched:
+            assert torch.equal(pa[net], p0[net]) and sa[net].item() == 0, net
+        else:
+            assert sa[net].item() == 2 and not torch.equal(pa[net], p0[net])
+            x, y = pa[net].cpu().numpy(), pb[net].cpu().numpy()
+            bad = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
+            assert bad.mean() < 2e-3 and np.abs(x - y).max() < 1e-3, (net, bad.mean(), np.abs(x - y).max())
