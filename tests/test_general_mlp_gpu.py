@@ -271,7 +271,8 @@ def _mb_call(up, dev, idx, B, lam, stats_row, mode):
 @pytest.mark.parametrize('B', [64, 37, 3])
 @pytest.mark.parametrize('obs_dim,act_dim,a_h,c_h,a_act,c_act', SHAPES + [
     (60, 2, [100, 100, 100, 100, 100, 100, 100], [20], 'sigmoid', 'softplus'),  # seven hidden layers / one
-    (33, 5, [], [], 'tanh', 'tanh')])                                           # no hidden layer at all
+    (33, 5, [], [], 'tanh', 'tanh'),                                            # no hidden layer at all
+    (61, 3, [30, 7], [50, 1, 9], 'tanh', 'relu')])                              # widths that are not multiples of 4 (row padding)
 def test_skinny_step_equals_the_tiled_step(monkeypatch, obs_dim, act_dim, a_h, c_h, a_act, c_act, B):
     """Minibatches of <= 64 rows (the YAML batch_size) take the skinny kernels (general_mlp.hip: gs_fwd / gs_bwd /
     gs_wgrad -- weights streamed once per pass, clip + Adam from recomputed gradient tiles); OSA_GMLP_SKINNY=0 keeps
