@@ -82,6 +82,28 @@ __device__ __forceinline__ void ofv_stage(const OsaNet& nd, const OsaNet& nl, co
   }
 }
 
+// Software pipeline of N MFMA groups whose A fragments come from LDS (round 5): group idx + D is requested BEFORE the
+// MFMAs of group idx issue, and sched_barriers pin that order.  With one wave per SIMD nothing else hides an LDS round
+// trip: left to itself the compiler sinks every ds_read next to its consumer and drains lgkmcnt in front of each MFMA
+// group (197 s_waitcnt in the round-4 kernel; 36 % of a chunk's cycles were neither MFMA nor VALU).  The MFMA order is
+// untouched: same bits.
+#define OFV_SB() __builtin_amdgcn_sched_barrier(0)
+template <int N, int D, typename LD, typename MM>
+__device__ __forceinline__ void ofv_pipe(LD ld, MM mm) {
+  f32x4 buf[D + 1][2];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    if (k < N) ld(k, buf[k % (D + 1)]);
+#pragma unroll
+  for (int idx = 0; idx < N; ++idx) {
+    if (idx + D < N) ld(idx + D, buf[(idx + D) % (D + 1)]);
+    OFV_SB();
+    mm(idx, buf[idx % (D + 1)]);
+    OFV_SB();
+  }
+}
+#define OFV_D 2  // groups in flight ahead of the MFMAs (a group = 4 or 8 MFMAs = 128 / 256 cycles)
+
 // osa_mlp_forward (mlp_device.h) on x fragments that are already in registers: the same MFMA sequence (K blocks outer,
 // hidden tiles inner, the four k of a fragment in order), weights from the padded LDS block
 template <int OT, int KBT>
@@ -94,47 +116,56 @@ __device__ __forceinline__ void ofv_forward(const OsaNet& nl, const float* __res
   const float* __restrict__ W3 = p + nl.oW3;
 #pragma unroll
   for (int t = 0; t < HT; ++t) h1[t] = *reinterpret_cast<const f32x4*>(p + nl.ob1 + 16 * t + 4 * g);
+  // (two hidden tiles per group, their MFMAs alternating: no MFMA issues right behind the one whose result it accumulates
+  // onto; every accumulator still receives its products in the same order)
+  ofv_pipe<KBT * HT / 2, OFV_D>(
+      [&](int idx, f32x4 (&d)[2]) {
+        const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
+        d[0] = *reinterpret_cast<const f32x4*>(W1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
+        d[1] = *reinterpret_cast<const f32x4*>(W1 + (16 * (t + 1) + i) * nl.INP + 16 * kb + 4 * g);
+      },
+      [&](int idx, const f32x4 (&w)[2]) {
+        const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
 #pragma unroll
-  for (int kb = 0; kb < KBT; ++kb) {
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
-      h1[t] = OSA_MFMA(w.x, xf[kb].x, h1[t]);
-      h1[t] = OSA_MFMA(w.y, xf[kb].y, h1[t]);
-      h1[t] = OSA_MFMA(w.z, xf[kb].z, h1[t]);
-      h1[t] = OSA_MFMA(w.w, xf[kb].w, h1[t]);
-    }
-  }
+        for (int s = 0; s < 4; ++s) {
+          h1[t] = OSA_MFMA(w[0][s], xf[kb][s], h1[t]);
+          h1[t + 1] = OSA_MFMA(w[1][s], xf[kb][s], h1[t + 1]);
+        }
+      });
 #pragma unroll
   for (int t = 0; t < HT; ++t) h1[t] = osa_act4(h1[t], act);
 #pragma unroll
   for (int t = 0; t < HT; ++t) h2[t] = *reinterpret_cast<const f32x4*>(p + nl.ob2 + 16 * t + 4 * g);
+  ofv_pipe<HT * HT / 2, OFV_D>(
+      [&](int idx, f32x4 (&d)[2]) {
+        const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
+        d[0] = *reinterpret_cast<const f32x4*>(W2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
+        d[1] = *reinterpret_cast<const f32x4*>(W2 + (16 * (t + 1) + i) * nl.H + 16 * kb + 4 * g);
+      },
+      [&](int idx, const f32x4 (&w)[2]) {
+        const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
 #pragma unroll
-  for (int kb = 0; kb < HT; ++kb) {
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
-      h2[t] = OSA_MFMA(w.x, h1[kb].x, h2[t]);
-      h2[t] = OSA_MFMA(w.y, h1[kb].y, h2[t]);
-      h2[t] = OSA_MFMA(w.z, h1[kb].z, h2[t]);
-      h2[t] = OSA_MFMA(w.w, h1[kb].w, h2[t]);
-    }
-  }
+        for (int s = 0; s < 4; ++s) {
+          h2[t] = OSA_MFMA(w[0][s], h1[kb][s], h2[t]);
+          h2[t + 1] = OSA_MFMA(w[1][s], h1[kb][s], h2[t + 1]);
+        }
+      });
 #pragma unroll
   for (int t = 0; t < HT; ++t) h2[t] = osa_act4(h2[t], act);
 #pragma unroll
   for (int o = 0; o < OT; ++o) out[o] = *reinterpret_cast<const f32x4*>(p + nl.ob3 + 16 * o + 4 * g);
-#pragma unroll
-  for (int kb = 0; kb < HT; ++kb) {
-#pragma unroll
-    for (int o = 0; o < OT; ++o) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
-      out[o] = OSA_MFMA(w.x, h2[kb].x, out[o]);
-      out[o] = OSA_MFMA(w.y, h2[kb].y, out[o]);
-      out[o] = OSA_MFMA(w.z, h2[kb].z, out[o]);
-      out[o] = OSA_MFMA(w.w, h2[kb].w, out[o]);
-    }
-  }
+  ofv_pipe<HT * OT, OFV_D>(
+      [&](int idx, f32x4 (&d)[2]) {
+        const int kb = idx / OT, o = idx % OT;
+        d[0] = *reinterpret_cast<const f32x4*>(W3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
+      },
+      [&](int idx, const f32x4 (&w)[2]) {
+        const int kb = idx / OT, o = idx % OT;
+        out[o] = OSA_MFMA(w[0].x, h2[kb].x, out[o]);
+        out[o] = OSA_MFMA(w[0].y, h2[kb].y, out[o]);
+        out[o] = OSA_MFMA(w[0].z, h2[kb].z, out[o]);
+        out[o] = OSA_MFMA(w[0].w, h2[kb].w, out[o]);
+      });
 }
 
 template <int OT, int KBT>
@@ -200,58 +231,62 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       f32x4 t1[HT], t2[HT], tm[OT];
 #pragma unroll
       for (int t = 0; t < HT; ++t) t1[t] = *reinterpret_cast<const f32x4*>(v + nl.ob1 + 16 * t + 4 * g);
+      ofv_pipe<KBT * HT / 2, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {
+            const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
+            d[0] = *reinterpret_cast<const f32x4*>(v + nl.oW1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
+            d[1] = *reinterpret_cast<const f32x4*>(v + nl.oW1 + (16 * (t + 1) + i) * nl.INP + 16 * kb + 4 * g);
+          },
+          [&](int idx, const f32x4 (&w)[2]) {
+            const int kb = idx / (HT / 2), t = 2 * (idx % (HT / 2));
 #pragma unroll
-      for (int kb = 0; kb < KBT; ++kb) {
-        const f32x4 x = xf[kb];
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(v + nl.oW1 + (16 * t + i) * nl.INP + 16 * kb + 4 * g);
-          t1[t] = OSA_MFMA(w.x, x.x, t1[t]);
-          t1[t] = OSA_MFMA(w.y, x.y, t1[t]);
-          t1[t] = OSA_MFMA(w.z, x.z, t1[t]);
-          t1[t] = OSA_MFMA(w.w, x.w, t1[t]);
-        }
-      }
+            for (int s = 0; s < 4; ++s) {
+              t1[t] = OSA_MFMA(w[0][s], xf[kb][s], t1[t]);
+              t1[t + 1] = OSA_MFMA(w[1][s], xf[kb][s], t1[t + 1]);
+            }
+          });
 #pragma unroll
       for (int t = 0; t < HT; ++t) t1[t] = t1[t] * osa_dact4(h1[t], OSA_ACT_TANH);
 #pragma unroll
       for (int t = 0; t < HT; ++t) t2[t] = *reinterpret_cast<const f32x4*>(v + nl.ob2 + 16 * t + 4 * g);
-#pragma unroll
-      for (int kb = 0; kb < HT; ++kb) {
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(v + nl.oW2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
-          const f32x4 w = *reinterpret_cast<const f32x4*>(p + nl.oW2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
-          t2[t] = OSA_MFMA(wv.x, h1[kb].x, t2[t]);
-          t2[t] = OSA_MFMA(wv.y, h1[kb].y, t2[t]);
-          t2[t] = OSA_MFMA(wv.z, h1[kb].z, t2[t]);
-          t2[t] = OSA_MFMA(wv.w, h1[kb].w, t2[t]);
-          t2[t] = OSA_MFMA(w.x, t1[kb].x, t2[t]);
-          t2[t] = OSA_MFMA(w.y, t1[kb].y, t2[t]);
-          t2[t] = OSA_MFMA(w.z, t1[kb].z, t2[t]);
-          t2[t] = OSA_MFMA(w.w, t1[kb].w, t2[t]);
-        }
-      }
+      ofv_pipe<HT * HT, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {
+            const int kb = idx / HT, t = idx % HT;
+            d[0] = *reinterpret_cast<const f32x4*>(v + nl.oW2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
+            d[1] = *reinterpret_cast<const f32x4*>(p + nl.oW2 + (16 * t + i) * nl.H + 16 * kb + 4 * g);
+          },
+          [&](int idx, const f32x4 (&w)[2]) {
+            const int kb = idx / HT, t = idx % HT;
+            t2[t] = OSA_MFMA(w[0].x, h1[kb].x, t2[t]);
+            t2[t] = OSA_MFMA(w[0].y, h1[kb].y, t2[t]);
+            t2[t] = OSA_MFMA(w[0].z, h1[kb].z, t2[t]);
+            t2[t] = OSA_MFMA(w[0].w, h1[kb].w, t2[t]);
+            t2[t] = OSA_MFMA(w[1].x, t1[kb].x, t2[t]);
+            t2[t] = OSA_MFMA(w[1].y, t1[kb].y, t2[t]);
+            t2[t] = OSA_MFMA(w[1].z, t1[kb].z, t2[t]);
+            t2[t] = OSA_MFMA(w[1].w, t1[kb].w, t2[t]);
+          });
 #pragma unroll
       for (int t = 0; t < HT; ++t) t2[t] = t2[t] * osa_dact4(h2[t], OSA_ACT_TANH);
 #pragma unroll
       for (int o = 0; o < OT; ++o) tm[o] = *reinterpret_cast<const f32x4*>(v + nl.ob3 + 16 * o + 4 * g);
-#pragma unroll
-      for (int kb = 0; kb < HT; ++kb) {
-#pragma unroll
-        for (int o = 0; o < OT; ++o) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(v + nl.oW3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
-          const f32x4 w = *reinterpret_cast<const f32x4*>(p + nl.oW3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
-          tm[o] = OSA_MFMA(wv.x, h2[kb].x, tm[o]);
-          tm[o] = OSA_MFMA(wv.y, h2[kb].y, tm[o]);
-          tm[o] = OSA_MFMA(wv.z, h2[kb].z, tm[o]);
-          tm[o] = OSA_MFMA(wv.w, h2[kb].w, tm[o]);
-          tm[o] = OSA_MFMA(w.x, t2[kb].x, tm[o]);
-          tm[o] = OSA_MFMA(w.y, t2[kb].y, tm[o]);
-          tm[o] = OSA_MFMA(w.z, t2[kb].z, tm[o]);
-          tm[o] = OSA_MFMA(w.w, t2[kb].w, tm[o]);
-        }
-      }
+      ofv_pipe<HT * OT, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {
+            const int kb = idx / OT, o = idx % OT;
+            d[0] = *reinterpret_cast<const f32x4*>(v + nl.oW3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
+            d[1] = *reinterpret_cast<const f32x4*>(p + nl.oW3 + (16 * o + i) * nl.H + 16 * kb + 4 * g);
+          },
+          [&](int idx, const f32x4 (&w)[2]) {
+            const int kb = idx / OT, o = idx % OT;
+            tm[o] = OSA_MFMA(w[0].x, h2[kb].x, tm[o]);
+            tm[o] = OSA_MFMA(w[0].y, h2[kb].y, tm[o]);
+            tm[o] = OSA_MFMA(w[0].z, h2[kb].z, tm[o]);
+            tm[o] = OSA_MFMA(w[0].w, h2[kb].w, tm[o]);
+            tm[o] = OSA_MFMA(w[1].x, t2[kb].x, tm[o]);
+            tm[o] = OSA_MFMA(w[1].y, t2[kb].y, tm[o]);
+            tm[o] = OSA_MFMA(w[1].z, t2[kb].z, tm[o]);
+            tm[o] = OSA_MFMA(w[1].w, t2[kb].w, tm[o]);
+          });
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
 #pragma unroll
@@ -274,31 +309,37 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
     const float* __restrict__ W2 = p + nl.oW2;
     const float* __restrict__ W3 = p + nl.oW3;
     f32x4 z2[HT], z1[HT];
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
+    {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      ofv_pipe<HT * OT, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
+            const int t = idx / OT, o = idx % OT;
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
+            for (int s = 0; s < 4; ++s) d[0][s] = W3[(16 * o + 4 * g + s) * nl.H + 16 * t + i];
+          },
+          [&](int idx, const f32x4 (&w)[2]) {
+            const int t = idx / OT, o = idx % OT;
+            if (o == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // A[i][k] = W3^T[16t+i][16o+4g+s]
-          const float w = W3[(16 * o + 4 * g + s) * nl.H + 16 * t + i];
-          acc = OSA_MFMA(w, dO[o][s], acc);
-        }
-      }
-      z2[t] = acc * osa_dact4(h2[t], OSA_ACT_TANH);
+            for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[0][s], dO[o][s], acc);
+            if (o == OT - 1) z2[t] = acc * osa_dact4(h2[t], OSA_ACT_TANH);
+          });
     }
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
+    {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      ofv_pipe<HT * HT, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
+            const int t = idx / HT, kb = idx % HT;
 #pragma unroll
-      for (int kb = 0; kb < HT; ++kb) {
+            for (int s = 0; s < 4; ++s) d[0][s] = W2[(16 * kb + 4 * g + s) * nl.H + 16 * t + i];
+          },
+          [&](int idx, const f32x4 (&w)[2]) {
+            const int t = idx / HT, kb = idx % HT;
+            if (kb == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // A[i][k] = W2^T[16t+i][16kb+4g+s]
-          const float w = W2[(16 * kb + 4 * g + s) * nl.H + 16 * t + i];
-          acc = OSA_MFMA(w, z2[kb][s], acc);
-        }
-      }
-      z1[t] = acc * osa_dact4(h1[t], OSA_ACT_TANH);
+            for (int s = 0; s < 4; ++s) acc = OSA_MFMA(w[0][s], z2[kb][s], acc);
+            if (kb == HT - 1) z1[t] = acc * osa_dact4(h1[t], OSA_ACT_TANH);
+          });
     }
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f * SLD + c]
     const int c = 16 * wave + j;
@@ -330,35 +371,43 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
         a2[sb] = *reinterpret_cast<const f32x4*>(sZ2 + (16 * rt + i) * SLD + 16 * sb + 4 * g);
         a1[sb] = *reinterpret_cast<const f32x4*>(sZ1 + (16 * rt + i) * SLD + 16 * sb + 4 * g);
       }
-#pragma unroll
-      for (int ti = 0; ti < HT; ++ti) {
+      {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SLD + 16 * sb + 4 * g);
-          acc = OSA_MFMA(a2[sb].x, b.x, acc);
-          acc = OSA_MFMA(a2[sb].y, b.y, acc);
-          acc = OSA_MFMA(a2[sb].z, b.z, acc);
-          acc = OSA_MFMA(a2[sb].w, b.w, acc);
-        }
-        gW2[ti] = first ? acc : gW2[ti] + acc;
+        ofv_pipe<HT * NSB, OFV_D>(
+            [&](int idx, f32x4 (&d)[2]) {
+              const int ti = idx / NSB, sb = idx % NSB;
+              d[0] = *reinterpret_cast<const f32x4*>(sH1 + (16 * ti + i) * SLD + 16 * sb + 4 * g);
+            },
+            [&](int idx, const f32x4 (&b)[2]) {
+              const int ti = idx / NSB, sb = idx % NSB;
+              if (sb == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+              acc = OSA_MFMA(a2[sb].x, b[0].x, acc);
+              acc = OSA_MFMA(a2[sb].y, b[0].y, acc);
+              acc = OSA_MFMA(a2[sb].z, b[0].z, acc);
+              acc = OSA_MFMA(a2[sb].w, b[0].w, acc);
+              if (sb == NSB - 1) gW2[ti] = first ? acc : gW2[ti] + acc;
+            });
       }
     }
     {  // dW3: output tiles o x column tile `wave`
       const int ct = wave;
-#pragma unroll
-      for (int o = 0; o < OT; ++o) {
+      {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * SLD + 16 * sb + 4 * g);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(sH2 + (16 * ct + i) * SLD + 16 * sb + 4 * g);
-          acc = OSA_MFMA(av.x, b.x, acc);
-          acc = OSA_MFMA(av.y, b.y, acc);
-          acc = OSA_MFMA(av.z, b.z, acc);
-          acc = OSA_MFMA(av.w, b.w, acc);
-        }
-        gW3[o] = first ? acc : gW3[o] + acc;
+        ofv_pipe<OT * NSB, OFV_D>(
+            [&](int idx, f32x4 (&d)[2]) {
+              const int o = idx / NSB, sb = idx % NSB;
+              d[0] = *reinterpret_cast<const f32x4*>(sDO + (16 * o + i) * SLD + 16 * sb + 4 * g);
+              d[1] = *reinterpret_cast<const f32x4*>(sH2 + (16 * ct + i) * SLD + 16 * sb + 4 * g);
+            },
+            [&](int idx, const f32x4 (&q)[2]) {
+              const int o = idx / NSB, sb = idx % NSB;
+              if (sb == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+              acc = OSA_MFMA(q[0].x, q[1].x, acc);
+              acc = OSA_MFMA(q[0].y, q[1].y, acc);
+              acc = OSA_MFMA(q[0].z, q[1].z, acc);
+              acc = OSA_MFMA(q[0].w, q[1].w, acc);
+              if (sb == NSB - 1) gW3[o] = first ? acc : gW3[o] + acc;
+            });
       }
     }
     // bias gradients: one thread per feature sums its LDS row over the 64 samples
@@ -387,19 +436,22 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       for (int r = 0; r < 4; ++r) sX[(16 * kb + 4 * g + r) * SLD + c] = xf[kb][r];
     }
     __syncthreads();
-#pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) {
+    {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int sb = 0; sb < NSB; ++sb) {
-        // B[k = sample 16 sb + 4 g + s][j = input feature 16 kb + cc]
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * SLD + 16 * sb + 4 * g);
-        acc = OSA_MFMA(a1[sb].x, b.x, acc);
-        acc = OSA_MFMA(a1[sb].y, b.y, acc);
-        acc = OSA_MFMA(a1[sb].z, b.z, acc);
-        acc = OSA_MFMA(a1[sb].w, b.w, acc);
-      }
-      gW1[kb] = first ? acc : gW1[kb] + acc;
+      ofv_pipe<KBT * NSB, OFV_D>(
+          [&](int idx, f32x4 (&d)[2]) {  // B[k = sample 16 sb + 4 g + s][j = input feature 16 kb + cc]
+            const int kb = idx / NSB, sb = idx % NSB;
+            d[0] = *reinterpret_cast<const f32x4*>(sX + (16 * kb + i) * SLD + 16 * sb + 4 * g);
+          },
+          [&](int idx, const f32x4 (&b)[2]) {
+            const int kb = idx / NSB, sb = idx % NSB;
+            if (sb == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = OSA_MFMA(a1[sb].x, b[0].x, acc);
+            acc = OSA_MFMA(a1[sb].y, b[0].y, acc);
+            acc = OSA_MFMA(a1[sb].z, b[0].z, acc);
+            acc = OSA_MFMA(a1[sb].w, b[0].w, acc);
+            if (sb == NSB - 1) gW1[kb] = first ? acc : gW1[kb] + acc;
+          });
     }
   }  // chunks
   // ---- this workgroup's slab
