@@ -214,3 +214,24 @@ def test_logger_rows_live(ref, tmp_path, monkeypatch):
                                atol=1e-7)
     k = ref_rows[0].index('Train/PolicyRatio')
     assert ref_rows[1][k + 1] == ref_rows[1][k + 2]  # the reference's Min == Max (== mean)
+
+
+def test_hidden_shape_golden_is_what_the_generator_produces(ref, tmp_path, monkeypatch):
+    """tests/golden/hidden96x40x24_p3o_point.npz -- one whole `_update()` of the UNMODIFIED reference built with
+    hidden_sizes outside the [64, 64] family (oracle/make_golden.py::gen_hidden_shape_updates) -- regenerated here from
+    the reference checkout: every array of the committed fixture comes out again, bit for bit."""
+    import make_golden
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'hidden96x40x24_p3o_point.npz')
+    monkeypatch.setattr(make_golden, 'OUT', str(tmp_path))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)  # (as make_golden's entry points: deterministic reductions)
+    try:
+        make_golden.gen_hidden_shape_updates(only=['hidden96x40x24_p3o_point'])
+    finally:
+        torch.set_num_threads(threads)
+    new, old = np.load(tmp_path / 'hidden96x40x24_p3o_point.npz'), np.load(golden)
+    assert sorted(new.files) == sorted(old.files)
+    differing = [k for k in old.files if not (new[k].shape == old[k].shape and (
+        np.array_equal(new[k], old[k]) if new[k].dtype.kind in 'iufb' else str(new[k]) == str(old[k])))]
+    assert not differing, differing
