@@ -21,7 +21,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_harness  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+# (OSA_GOLDEN_OUT: another output directory -- tests/test_oracle_vs_reference.py regenerates a fixture next to the committed one)
+OUT = os.environ.get('OSA_GOLDEN_OUT') or os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 
 
 def _np(x):

@@ -216,20 +216,20 @@ def test_logger_rows_live(ref, tmp_path, monkeypatch):
     assert ref_rows[1][k + 1] == ref_rows[1][k + 2]  # the reference's Min == Max (== mean)
 
 
-def test_hidden_shape_golden_is_what_the_generator_produces(ref, tmp_path, monkeypatch):
+def test_hidden_shape_golden_is_what_the_generator_produces(ref, tmp_path):
     """tests/golden/hidden96x40x24_p3o_point.npz -- one whole `_update()` of the UNMODIFIED reference built with
-    hidden_sizes outside the [64, 64] family (oracle/make_golden.py::gen_hidden_shape_updates) -- regenerated here from
-    the reference checkout: every array of the committed fixture comes out again, bit for bit."""
-    import make_golden
+    hidden_sizes outside the [64, 64] family (oracle/make_golden.py::gen_hidden_shape_updates) -- regenerated from the
+    reference checkout by the committed script (own process: no plugin of this package installed in it): every array of
+    the committed fixture comes out again, bit for bit."""
+    import subprocess
+    import sys
 
-    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'hidden96x40x24_p3o_point.npz')
-    monkeypatch.setattr(make_golden, 'OUT', str(tmp_path))
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)  # (as make_golden's entry points: deterministic reductions)
-    try:
-        make_golden.gen_hidden_shape_updates(only=['hidden96x40x24_p3o_point'])
-    finally:
-        torch.set_num_threads(threads)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, 'tests', 'golden', 'hidden96x40x24_p3o_point.npz')
+    env = dict(os.environ, OSA_GOLDEN_OUT=str(tmp_path))
+    p = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'make_golden.py'), 'hidden-shapes',
+                        'hidden96x40x24_p3o_point'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
     new, old = np.load(tmp_path / 'hidden96x40x24_p3o_point.npz'), np.load(golden)
     assert sorted(new.files) == sorted(old.files)
     differing = [k for k in old.files if not (new[k].shape == old[k].shape and (
