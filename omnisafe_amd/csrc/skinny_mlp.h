@@ -372,7 +372,17 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
 __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
   __shared__ __attribute__((aligned(16))) float red[GS_WAVES * 4 * 64 * 4];
   const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
-  const int k0 = blockIdx.x * 16;
+  // Column tiles 2 m and 2 m + 1 read the two 64-byte halves of the SAME 128-byte lines of every weight row: in dispatch
+  // order they land on different XCCs (workgroup i -> XCC i mod 8) and both L2s fetch the line -- the launch then moves
+  // 34 MB instead of 21 (profiles/r5_pmc_traffic_general_1024_B64_table.md).  Remapped, the pair shares an XCC.
+  int bx = blockIdx.x;
+#ifndef GS_BWD_NO_PAIR
+  if ((gridDim.x & 15) == 0) {
+    const int xcd = bx & 7, slot = bx >> 3;
+    bx = 2 * ((slot >> 1) * 8 + xcd) + (slot & 1);
+  }
+#endif
+  const int k0 = bx * 16;
   if (k0 >= p.ldy) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int R = a.R, N = p.N;

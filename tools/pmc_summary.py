@@ -20,7 +20,7 @@ def load(d, counter):
             if r['Counter_Name'] != counter:
                 continue
             name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
-            if not name.startswith(('osa_', 'gm_')):
+            if not name.startswith(('osa_', 'gm_', 'gs_')):
                 continue
             e = out.setdefault(name, [0, 0.0])
             e[0] += 1
