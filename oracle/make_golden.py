@@ -621,7 +621,7 @@ def _dp2_worker(rank, world, port, spec, tmp):
         algo._update()
     for k, v in captured.items():
         out[f'data/{k}'] = _np(v)
-    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier))
+    out['lambda_after'] = np.float32(float(algo._lagrange.lagrangian_multiplier) if has_lag else np.nan)
     out['perms'] = np.stack([_np(p) for p in rec.perms[::2]])  # RandomSampler draws two permutations per pass
     for net in ('actor', 'reward_critic', 'cost_critic'):
         for k, v in _state(getattr(ac, net)).items():
@@ -647,10 +647,15 @@ def gen_dp2_updates(only=None, world=2):
 
     import torch.multiprocessing as mp
 
+    # `tag@T` in `only`: the same config with T vector steps per rank (the 376-wide recording at 8 ranks is 25 MB at T = 128)
+    t_of = {o.split('@')[0]: int(o.split('@')[1]) for o in (only or []) if '@' in o}
+    only = [o.split('@')[0] for o in only] if only else only
     for spec in DP2_CONFIGS:
         tag = spec[0]
         if only and tag not in only:
             continue
+        if tag in t_of:
+            spec = spec[:4] + (t_of[tag],) + spec[5:]
         tmp = tempfile.mkdtemp()
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
@@ -948,6 +953,8 @@ if __name__ == '__main__':
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp4':  # the same recordings with FOUR ranks -> tests/golden/dp4_<...>.npz
         gen_dp2_updates(only=sys.argv[2:] or ['dp2_ppolag_point', 'dp2_trpolag_ant'], world=4)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'dp8':  # EIGHT ranks (the world size BASELINE.json quotes): dp8_<...>.npz
+        # (committed set: `dp8` [= dp2_ppolag_point], `dp8 dp2_ppolag_humanoid@32 dp2_trpolag_ant dp2_cpo_car`:
+        # BASELINE configs 4, 5, 3 at the world size they are quoted on)
         gen_dp2_updates(only=sys.argv[2:] or ['dp2_ppolag_point'], world=8)
     elif len(sys.argv) >= 2 and sys.argv[1] == 'merge-learning':
         if os.path.exists(os.path.join(OUT, 'learning_reach.json')):  # keep what is already there

@@ -190,13 +190,28 @@ def test_four_ranks_reproduce_the_four_rank_reference(tmp_path, tag, dp_mode, wa
     mp.spawn(_worker, args=(4, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=4, join=True)
 
 
-@pytest.mark.parametrize('dp_mode,want_path', [('replicated', 'replicated'), ('allreduce', 'per-step')])
-def test_eight_ranks_reproduce_the_eight_rank_reference(tmp_path, dp_mode, want_path):
+EIGHT = [
+    ('dp8_ppolag_point', 'replicated', 'replicated', None),
+    ('dp8_ppolag_point', 'allreduce', 'per-step', None),
+    # BASELINE configs 4, 5, 3 at the world size BASELINE.json quotes them on (`make_golden.py dp8 dp2_ppolag_humanoid@32
+    # dp2_trpolag_ant dp2_cpo_car`): the wide split pass with 8 x 3 x 5 workgroups, the chunked passes with 8 x 2 peers
+    # per network behind rank-averaged Fisher-vector products / line searches, CPO's recovery case on 8-rank averages
+    ('dp8_ppolag_humanoid', 'replicated', 'replicated-wide-split', None),
+    ('dp8_ppolag_humanoid', 'allreduce', 'per-step', None),
+    ('dp8_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+    ('dp8_trpolag_ant', 'allreduce', 'per-step', None),
+    ('dp8_cpo_car', 'replicated', 'replicated', {'chunked': True}),
+    ('dp8_cpo_car', 'allreduce', 'per-step', None),
+]
+
+
+@pytest.mark.parametrize('tag,dp_mode,want_path,want', EIGHT)
+def test_eight_ranks_reproduce_the_eight_rank_reference(tmp_path, tag, dp_mode, want_path, want):
     """BASELINE.json quotes its 8-GPU configs at world size 8: the unmodified reference run with EIGHT ranks
-    (`oracle/make_golden.py dp8`, PPOLag 60 / 2, 2 x 32 optimiser steps of 8 x 64 rows) against eight real ranks sharing
-    the test box's GPU -- the cooperative pass with 24 resident workgroups, and the per-step all-reduce path."""
-    mp.spawn(_worker, args=(8, _free_port(), 'dp8_ppolag_point', dp_mode, want_path, None, str(tmp_path)), nprocs=8,
-             join=True)
+    (`oracle/make_golden.py dp8`: PPOLag 60 / 2 and 376 / 17, TRPOLag 27 / 8, CPO 72 / 2) against eight real ranks
+    sharing the test box's GPU -- the cooperative passes with 24 .. 120 resident workgroups, and the per-step
+    all-reduce path."""
+    mp.spawn(_worker, args=(8, _free_port(), tag, dp_mode, want_path, want, str(tmp_path)), nprocs=8, join=True)
 
 
 
@@ -213,6 +228,9 @@ REAL = [
     (4, 'dp4_ppolag_point', 'allreduce', 'per-step', None),
     (8, 'dp8_ppolag_point', 'replicated', 'replicated', None),
     (8, 'dp8_ppolag_point', 'allreduce', 'per-step', None),
+    (8, 'dp8_ppolag_humanoid', 'replicated', 'replicated-wide-split', None),
+    (8, 'dp8_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+    (8, 'dp8_cpo_car', 'allreduce', 'per-step', None),
 ]
 
 

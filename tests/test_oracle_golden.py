@@ -348,8 +348,51 @@ def test_dp4_updates_vs_four_rank_reference(golden):
             np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=2e-7, err_msg=f'{net}/{k}')
 
 
+def test_dp8_config_shapes_vs_eight_rank_reference(golden):
+    """BASELINE configs 4, 5 and 3 at the world size BASELINE.json quotes them on: EIGHT ranks of the unmodified reference
+    (`oracle/make_golden.py dp8 dp2_ppolag_humanoid@32 dp2_trpolag_ant dp2_cpo_car`) against the oracle's data-parallel
+    restatements -- rank-ordered eight-term sums v gloo's ring order: float32 round-off instead of bit for bit; the
+    accepted line-search index, CPO's case and the multiplier identical."""
+    torch.set_num_threads(1)
+    g = golden('dp8_ppolag_humanoid.npz')
+    assert int(g['world']) == 8 and int(g['T']) == 32
+    ac = load_ac(g, 'init/', 376, 17)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    O.ppolag_update_dp(ac, _dp2_datas(g, 8), lag.lagrangian_multiplier.item(), [g[f'r{r}/perms'] for r in range(8)],
+                       batch_size=64, update_iters=2, kl_early_stop=False)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=5e-7, err_msg=f'{net}/{k}')
+    g = golden('dp8_trpolag_ant.npz')
+    ac = load_ac(g, 'init/', 27, 8, actor_lr=None, critic_lr=1e-3)
+    lag = O.Lagrange(cost_limit=0.5, lagrangian_multiplier_init=0.5, lambda_lr=0.035)
+    lag.update_lagrange_multiplier(float(g['Jc']))
+    assert np.float32(lag.lagrangian_multiplier.item()) == g['lambda_after']
+    stats = O.trpolag_update_dp(ac, _dp2_datas(g, 8), lag.lagrangian_multiplier.item(),
+                                [g[f'r{r}/perms'] for r in range(8)], batch_size=128, update_iters=2)
+    assert stats['acceptance_step'] == int(g['r0/log/Misc/AcceptanceStep'][0])
+    np.testing.assert_allclose(stats['xHx'], g['r0/log/Misc/xHx'][0], rtol=1e-4)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=5e-7, err_msg=f'{net}/{k}')
+    g = golden('dp8_cpo_car.npz')
+    ac = load_ac(g, 'init/', 72, 2, actor_lr=None, critic_lr=1e-3)
+    perms = [g[f'r{r}/perms'] for r in range(8)]
+    stats = O.cpo_update_dp(ac, _dp2_datas(g, 8), float(g['Jc']) - 0.5, perms, batch_size=128,
+                            update_iters=perms[0].shape[0])
+    assert stats['optim_case'] == int(g['r0/log/Misc/OptimCase'][0])
+    assert stats['acceptance_step'] == int(g['r0/log/Misc/AcceptanceStep'][0])
+    for key, name in (('xHx', 'xHx'), ('q', 'q'), ('r', 'r'), ('s', 's'), ('nu_star', 'Nu_star')):
+        np.testing.assert_allclose(stats[key], g[f'r0/log/Misc/{name}'][0], rtol=1e-3, err_msg=key)
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f'post/{net}/{k}'], rtol=0, atol=1e-6, err_msg=f'{net}/{k}')
+
+
 @pytest.mark.parametrize('tag', ['dp2_ppolag_point', 'dp2_trpolag_ant', 'dp2_cpo_car', 'dp4_ppolag_point',
-                                 'dp8_ppolag_point'])
+                                 'dp8_ppolag_point', 'dp8_ppolag_humanoid', 'dp8_trpolag_ant', 'dp8_cpo_car'])
 def test_dp2_advantage_statistics_vs_reference(golden, tag):
     """VectorOnPolicyBuffer.get() on two (four, eight) ranks: the advantages every rank hands to `_update()` are standardised with
     the GLOBAL mean / population std (utils/distributed.py:382-392)."""
