@@ -448,6 +448,43 @@ int osa_ppo_dp_pass_placed(int obs_dim, int act_dim, int hidden, float* params, 
                     const float* lagrange, const osa_ppo_hparams* hp, int loss_kind, int nets_mask,
                     float* exchange, int* sync, int local, float* step_stats, void* stream);
 
+/* ONE-SHOT PEER EXCHANGE (round 6; csrc/p2p_pass_kernel.hip): the data-parallel minibatch loop with REAL ranks and no
+ * collective on the step path -- SURVEY.md 8(e) "xGMI mapping" (one-shot all-to-all write of the <= 336 KB clipped
+ * gradients + local reduce).  Replaces per optimiser step `clip_grad_norm_` -> `distributed.avg_grads` (19 blocking
+ * all-reduces) -> `optimizer.step()`: omnisafe/algorithms/on_policy/base/policy_gradient.py:437-443, 478-483, 519-524;
+ * omnisafe/utils/distributed.py:167-198.
+ *
+ * Every rank (one process per GPU) owns ONE exchange buffer of osa_p2p_exchange_floats(...) floats in UNCACHED device
+ * memory: osa_p2p_exchange_alloc allocates it zeroed and returns its 64-byte IPC handle (hipIpcGetMemHandle); the host
+ * side exchanges the handles (torch.distributed all_gather: a set-up step, once) and maps every peer's buffer with
+ * osa_p2p_exchange_open (hipIpcOpenMemHandle; peers may be other devices of the node or other processes on the same
+ * device).  osa_p2p_exchange_release unmaps a peer's buffer / frees an own one.  All ranks must have opened all
+ * buffers (a barrier) before the first pass.
+ *
+ * osa_ppo_p2p_pass = osa_ppo_pass on THIS rank's rows (arrays, perm, M, B as there: 3 workgroups, weights in LDS, Adam
+ * moments in registers, all ceil(M / B) steps in one launch), except that after the local clip each network's
+ * workgroup writes its gradient slab into the buffer of every rank (peers[q], q = 0 .. world - 1 as mapped into this
+ * process; peers[rank] = the own buffer), releases at system scope, stores the step's sequence number into its arrival
+ * word in every buffer, waits for the `world` arrival words of its own buffer, adds the slabs IN RANK ORDER, divides
+ * by world (clip-then-average) and applies Adam: identical arithmetic on every rank, bit-identical replicas, every
+ * rank writes its own parameters / moments back.  step_stats: rank-averaged (what Logger.get_stats averages).
+ * seq0: optimiser steps exchanged through these buffers before this call -- the SAME on every rank; the caller adds
+ * ceil(M / B) after each call (arrival words only grow: nothing is reset between launches).  timeout_s: how long a
+ * workgroup waits for a peer before it sets the sticky word read by osa_p2p_exchange_timed_out (the pass then
+ * finishes without waiting: results invalid, the device never hangs).  world <= 16; B <= 2048 (B > 64: the workgroup
+ * walks through the minibatch's 64-row chunks); shapes as osa_ppo_pass_supported (OSA_EUNSUPPORTED otherwise). */
+size_t osa_p2p_exchange_floats(int obs_dim, int act_dim, int hidden, int world);
+int osa_p2p_exchange_alloc(size_t floats, float** out, void* ipc_handle64);
+int osa_p2p_exchange_open(const void* ipc_handle64, float** out);
+int osa_p2p_exchange_release(float* p);
+int osa_p2p_exchange_timed_out(const float* own, int* flag);
+int osa_ppo_p2p_pass(int obs_dim, int act_dim, int hidden, float* params, float* adam_m, float* adam_v,
+                     int* adam_step, const float* obs, int ld_obs, const float* act, int ld_act,
+                     const float* logp, const float* target_value_r, const float* target_value_c,
+                     const float* adv_r, const float* adv_c, const long* perm, long M, int B, int world, int rank,
+                     float* const* peers, unsigned seq0, double timeout_s, const float* lagrange,
+                     const osa_ppo_hparams* hp, int loss_kind, int nets_mask, float* step_stats, void* stream);
+
 /* Single-process persistent pass for minibatches of 64 < B <= 2048 rows (the trust-region family's critic
  * updates: batch_size 128, natural_pg.py:205-223) with the ceil(B / 64) 64-row CHUNKS of a minibatch on cooperating
  * workgroups (one compute unit each, per network) instead of one workgroup walking through them: every workgroup

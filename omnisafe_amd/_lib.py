@@ -81,6 +81,14 @@ SIGNATURES: dict[str, tuple] = {
     'osa_ppo_dp_chunked_pass_ws_floats': (C.c_size_t, [_I, _I, _I, _I, _I]),
     'osa_ppo_dp_chunked_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                                      _P, _P, _I, _I, _P, _P, _I, _P, _P]),
+    # one-shot peer exchange (csrc/p2p_pass_kernel.hip)
+    'osa_p2p_exchange_floats': (C.c_size_t, [_I, _I, _I, _I]),
+    'osa_p2p_exchange_alloc': (_I, [C.c_size_t, C.POINTER(C.c_void_p), _P]),
+    'osa_p2p_exchange_open': (_I, [_P, C.POINTER(C.c_void_p)]),
+    'osa_p2p_exchange_release': (_I, [_P]),
+    'osa_p2p_exchange_timed_out': (_I, [_P, _P]),
+    'osa_ppo_p2p_pass': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I,
+                              _P, C.c_uint, _D, _P, _P, _I, _I, _P, _P]),
     'osa_ppo_dp_step': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I,
                              _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'osa_ppo_dp_step_phase': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P]),

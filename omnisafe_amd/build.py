@@ -21,7 +21,8 @@ ARCH = 'gfx950'
 # per-source compiler options.  Pass kernel: let MFMA results land in architectural VGPRs where they are
 # consumed by VALU code (tanh, norms, Adam) instead of AGPRs + v_accvgpr_read moves (-0.8 % step time)
 PER_FILE_FLAGS = {'ppo_pass_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
-                  'part_grad_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+                  'part_grad_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
+                  'p2p_pass_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _hipcc() -> str:

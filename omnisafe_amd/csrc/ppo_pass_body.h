@@ -123,7 +123,24 @@ struct OsaPassArgs {
   // bytes of a sample) are then fetched from HBM once instead of three times
   int one_xcc;
   long long* dbg;  // optional [3][16] accumulated phase cycles (s_memtime), or nullptr
+  // ONE-SHOT PEER EXCHANGE (osa_ppo_p2p_pass; the P2P instantiations, round 6): real data parallelism without a
+  // collective on the step path.  This process is rank p2p_rank of dp_world; it runs the single-GPU form of the pass
+  // (3 workgroups, its OWN rows) and after the local clip every network's workgroup WRITES its gradient slab into the
+  // exchange buffer of every rank (p2p_peer[q]: rank q's buffer as mapped into this process -- hipIpcOpenMemHandle;
+  // [p2p_rank] is the rank's own allocation), releases at system scope, stores the step's sequence number into its
+  // arrival word in every buffer, waits until all dp_world words of its OWN buffer carry the number, and sums the
+  // slabs of its own buffer in rank order: identical arithmetic on every rank => bit-identical replicas.  Buffer
+  // layout (floats): [0, 256) int words -- arrival word of (net, source rank) at 64 net + rank, sticky time-out word
+  // at 240 --, then slabs [2 parities][3 networks][dp_world][XS].  p2p_seq0: optimiser steps exchanged through these
+  // buffers before this launch (the same on every rank); arrival words only ever grow, so nothing is reset between
+  // launches and a fast rank may write step k + 1 while a slow one still reads step k (other parity).
+  float* p2p_peer[16];
+  int p2p_rank;
+  unsigned p2p_seq0;
+  long long p2p_timeout;  // wall-clock ticks (100 MHz) a workgroup waits for its peers before it flags a time-out
 };
+#define OSA_P2P_HDR 256      // floats in front of the slabs
+#define OSA_P2P_STICKY 240   // int index of the sticky time-out word
 
 // Phase clocks (s_memtime deltas per phase, tools/phase_clocks.py, tools/dp_timing.py) are a COMPILE-TIME
 // option: the runtime-checked version put a branch -- a scheduling barrier -- between all phases of the
@@ -178,9 +195,10 @@ __host__ __device__ constexpr bool osa_pass_has_w2t(int KB, int OT) {
 // barriers in the hottest code (same-box A/B: 9.11 -> 8.87 us per step)
 // (Round 3's sliced data-parallel reduction, the two-stage large-batch pass and the per-network body split were
 // measured slower and removed in round 4: profiles/HISTORY.md §7.)
-template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool DPS, bool SO>
+template <int KB, int OT, bool MULTI, bool COOP, bool EXT, bool HIER, bool DPS, bool SO, bool P2P = false>
 __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const int net, const int rk, const int pc0 = 0,
                                                   const int pn = 0) {
+  static_assert(!P2P || (COOP && !HIER && !DPS && !EXT), "P2P is a form of the cooperative pass");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const OsaNet& nd = a.nd;
   constexpr bool coop = COOP;
@@ -199,7 +217,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   const int nranks = (HIER && chunked && a.dp_ranks > 1) ? a.dp_ranks : 1;
   const int cw = chunked ? a.dp_world / nranks : 1;
   const int crank = chunked ? rk / cw : 0, cchunk = chunked ? rk - crank * cw : 0;
-  const long roff = part ? 0 : (chunked ? (long)crank * a.M : (long)rk * a.M);
+  const long roff = (part || P2P) ? 0 : (chunked ? (long)crank * a.M : (long)rk * a.M);  // (P2P: the rank's own arrays)
   const float* __restrict__ obs_p = a.obs + roff * a.ld_obs;
   const float* __restrict__ act_p = a.act + roff * a.ld_act;
   const float* __restrict__ logp_p = a.logp + roff;
@@ -1027,7 +1045,12 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     constexpr int NT = HT + KB + OT, XS = NT * 1024 + 256 + PNSTAT;
     float* __restrict__ xbase = nullptr;
     f32x4* __restrict__ xs4 = nullptr;
-    if constexpr (coop) {
+    // (P2P: offset of this step's slab set of this network inside EVERY rank's exchange buffer)
+    const long p2p_off = P2P ? (long)OSA_P2P_HDR + (((long)((a.p2p_seq0 + (unsigned)(mb - a.mb0)) & 1u) * 3 + net) * a.dp_world) * XS : 0;
+    if constexpr (P2P) {
+      xbase = a.p2p_peer[a.p2p_rank] + p2p_off;  // the rank's own buffer: where the sum is formed
+      xs4 = reinterpret_cast<f32x4*>(xbase + (long)rk * XS);
+    } else if constexpr (coop) {
       // (chunk mode: the slabs of THIS rank's chunk group; own slab = chunk index)
       xbase = a.dp_slabs + (((long)((mb - a.mb0) & 1) * 3 + net) * a.dp_world + (chunked ? crank * cw : 0)) * XS;
       xs4 = reinterpret_cast<f32x4*>(xbase + (long)(chunked ? cchunk : rk) * XS);
@@ -1065,6 +1088,22 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       gsq += gb * gb;
     }
     if constexpr (coop) reinterpret_cast<float*>(xs4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
+    if constexpr (P2P) {
+      // the same tiles into every OTHER rank's buffer (posted writes: over xGMI where the peer is another device);
+      // they drain while the norm is reduced, the clip factor and the arrival word follow below
+      for (int q = 1; q < a.dp_world; ++q) {
+        int pr = a.p2p_rank + q;
+        pr = pr >= a.dp_world ? pr - a.dp_world : pr;  // (every rank starts with its right-hand neighbour: the 7 links in parallel)
+        f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(a.p2p_peer[pr] + p2p_off + (long)rk * XS);
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) d4[ti * 256 + tid] = g2[ti];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) d4[(HT + kb) * 256 + tid] = g1[kb];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) d4[(HT + KB + o) * 256 + tid] = g3[o];
+        reinterpret_cast<float*>(d4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
+      }
+    }
     // ---- block reduction of (gsq, psq, loss, ratio): wave shuffles, then a fixed-order sum
     gsq = osa_wave_sum_dpp(gsq);
     psq = osa_wave_sum_dpp(psq);
@@ -1132,7 +1171,50 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       if (leader) {
         float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
         t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
+        if constexpr (P2P) {
+          for (int q = 0; q < a.dp_world; ++q) {
+            if (q == a.p2p_rank) continue;
+            float* tq = a.p2p_peer[q] + p2p_off + (long)rk * XS + NT * 1024 + 256;
+            tq[0] = st_loss; tq[1] = st_ratio; tq[2] = st_psq; tq[3] = st_norm; tq[4] = st_ent; tq[5] = gs;
+          }
+        }
       }
+      if constexpr (P2P) {
+        // ---- one-shot exchange: every thread's slab stores are performed at SYSTEM scope (release), then thread q
+        // stores the step's sequence number into this rank's arrival word in rank q's buffer and polls the word rank
+        // q stores into OUR buffer -- dp_world words polled in parallel by dp_world lanes of wave 0
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        PTICK(12);
+        const unsigned target = a.p2p_seq0 + (unsigned)(mb - a.mb0) + 1u;
+        if (tid < a.dp_world) {
+          unsigned* theirs = reinterpret_cast<unsigned*>(a.p2p_peer[tid]) + 64 * net + a.p2p_rank;
+          __hip_atomic_store(theirs, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          unsigned* own = reinterpret_cast<unsigned*>(a.p2p_peer[a.p2p_rank]);
+          unsigned* mine = own + 64 * net + tid;
+          if (!coop_dead) {
+            long long t0 = 0;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((++spins & 1023) == 0) {  // the wall clock only every ~1k polls
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > a.p2p_timeout ||
+                    __hip_atomic_load(own + OSA_P2P_STICKY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                  // a peer is gone (or another workgroup of this rank gave up): flag it, never hang the GPU
+                  __hip_atomic_store(own + OSA_P2P_STICKY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  break;
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (!coop_dead) coop_dead = __hip_atomic_load(reinterpret_cast<unsigned*>(a.p2p_peer[a.p2p_rank]) + OSA_P2P_STICKY,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      } else {
       if (a.dp_uncached || a.dp_local) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // the slab stores have been performed: at device scope (uncached memory) / in the XCC's L2 (local)
@@ -1166,6 +1248,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       // same address (observed in wide_split_kernel.hip with small working sets; the double-buffered 38 KB
       // slabs here never showed it, which is luck, not a guarantee)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
       PTICK(10);
       // ---- sum the W gradients in rank order (same order on every peer), average
       f32x4 s2[HT], s1[KB], s3[OT];
@@ -1258,7 +1341,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
           apply_clip = true;
         }
       }
-      if (leader && (chunked ? cchunk == 0 : rk == 0)) {  // what Logger.get_stats averages across ranks
+      if (leader && (P2P || (chunked ? cchunk == 0 : rk == 0))) {  // what Logger.get_stats averages across ranks
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < W; ++r) {
           const float* t = xbase + (long)r * XS + NT * 1024 + 256;
@@ -1427,7 +1510,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     }
     PTICK(8);
     // ---- statistics of this optimiser step
-    if (leader && rk == 0) {
+    if (leader && (P2P || rk == 0)) {
       float* st = a.stats + (long)(mb - a.mb0) * PNSTAT;
       if (is_actor) {
         st[2] = st_loss;
@@ -1447,10 +1530,10 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     PTICK(9);
   }
 #ifdef OSA_PASS_CLOCKS
-  if (a.dbg && tid == 0 && rk == 0)
+  if (a.dbg && tid == 0 && (P2P || rk == 0))
     for (int k = 0; k < 13; ++k) a.dbg[net * 16 + k] = dbg_acc[k];
 #endif
-  if (rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
+  if (!P2P && rk != 0) return;  // cooperative mode: the peers' copies are identical, rank 0's is written back
   // ---- write back parameters and Adam state
   for (int e = tid; e < H * INP; e += 256) gp[nd.oW1 + e] = sW1[(e / INP) * W1LD + (e % INP)];
   for (int e = tid; e < H * H; e += 256) gp[nd.oW2 + e] = sW2[(e >> 6) * PSLD + (e & 63)];

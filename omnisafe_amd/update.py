@@ -69,7 +69,13 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # global step on every rank (no per-step collective) -- as one cooperative persistent launch per
         # pass (osa_ppo_dp_pass) or, with 'replicated-steps', as two launches per step replayed from a
         # hipGraph (osa_ppo_dp_step); 'allreduce' = per-step flat RCCL all-reduce
+        #   'p2p' (round 6) = every rank runs the single-GPU persistent pass on its own rows and the ranks exchange
+        #   their clipped gradients by ONE-SHOT PEER WRITES into IPC-mapped exchange buffers (osa_ppo_p2p_pass): no
+        #   collective and no W-fold recomputation on the step path; falls back to 'allreduce' where the pass kernel
+        #   does not apply (general networks, wide observations, extended surrogates)
         self.dp_mode = dp_mode
+        self._mode = 'allreduce' if dp_mode == 'p2p' else dp_mode  # what the steps run as (run() decides per update)
+        self._p2p: dict = {}
         self.seed = int(seed)
         self._dp: dict = {}
         self._ar_k = 0  # steps of the current pass taken by the fast all-reduce mode (minibatch / _ar_end_pass)
@@ -206,7 +212,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         # all-reduce -> osa_adam_apply (policy_gradient.py:437-443's order with 1 message for 19), the pass's ~1000
         # steps incl. their collectives one captured hipGraph -- eager, a 64-row step costs 58 us of launches against
         # 9 us of kernel time at world 1 (profiles/r4_rccl_world1_timing.json)
-        dp_graph = (dist.collectives_active() and self.dp_mode == 'allreduce' and not self.general and nmb <= 1100
+        dp_graph = (dist.collectives_active() and self._mode == 'allreduce' and not self.general and nmb <= 1100
                     and dist.graph_capturable())
         return ((self.batch_size >= 2048 or (self.general and nmb <= 256) or dp_graph) and self.ext is None
                 and (not dist.collectives_active() or dist.graph_capturable())
@@ -235,6 +241,8 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         M = data['obs'].shape[0]
         nmb = (M + B - 1) // B
         hp = self.hp
+        if dist.collectives_active() and self._allreduce_fast_ok(data, B):
+            self._ar_slab()  # (allocated before the key is formed: its pointer is part of it)
         key = (M, B, passes, tuple(int(data[k].data_ptr()) for k in ('obs', 'act', 'logp', 'target_value_r',
                                                                      'target_value_c', 'adv_r', 'adv_c')),
                int(lagrange.data_ptr()),
@@ -242,6 +250,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                # every pointer / stride the captured launches bake in (as the rollout graph's key does for params)
                tuple(int(t.data_ptr()) for t in (ac.params, ac.adam_m, ac.adam_v, ac.adam_step, ac.grads, self._ws)),
                int(ac.gmlp_ws(B)[0].data_ptr()) if self.general else 0,
+               # what selects the fast all-reduce steps, and the slab their launches bake in
+               (self._mode, os.environ.get('OSA_ALLREDUCE_FAST', '1'),
+                int(self._ar_slab_t.data_ptr()) if getattr(self, '_ar_slab_t', None) is not None else 0),
                (data['obs'].stride(0), data['act'].stride(0)),
                (hp.clip, hp.entropy_coef, hp.critic_norm_coef, hp.max_grad_norm, hp.beta1, hp.beta2, hp.adam_eps,
                 hp.use_critic_norm, hp.use_max_grad_norm, hp.use_cost))
@@ -261,6 +272,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         st['lr'].copy_(st['lr_host'], non_blocking=True)
 
         def enqueue() -> None:
+            self._ar_k = 0  # (a capture that was refused mid-pass, or an exception inside a pass, leaves no stale step index)
             for ip in range(passes):
                 for k in range(nmb):
                     s0 = k * B
@@ -308,7 +320,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         persistent kernels take, 16-byte aligned rows (run() pads them once per update).  OSA_ALLREDUCE_FAST=0: the
         per-step kernels (osa_ppo_minibatch mode 1 -> all-reduce -> osa_adam_apply)."""
         obs = data['obs']
-        return (self.dp_mode == 'allreduce' and not self.general and self.ext is None and self.loss_kind in (0, 1)
+        return (self._mode == 'allreduce' and not self.general and self.ext is None and self.loss_kind in (0, 1)
                 and self.batch_size <= self.persistent_max_batch and obs.stride(0) % 4 == 0 and obs.data_ptr() % 16 == 0
                 and os.environ.get('OSA_ALLREDUCE_FAST', '1') != '0'
                 and bool(self.lib.osa_ppo_pass_supported(self.ac.obs_dim, self.ac.act_dim, self.ac.hidden)))
@@ -514,6 +526,113 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             ev[1].record()
             self.profile_events.append((name, M, ev))
 
+    # ------------------------------------------------------------------ one-shot peer exchange (dp_mode 'p2p')
+    def _p2p_ok(self, data: dict) -> bool:
+        """osa_ppo_p2p_pass applies: fused network family with narrow observations, plain surrogates, minibatches the
+        persistent kernels take, 16-byte aligned rows (run() pads them once per update), at most 16 ranks."""
+        obs = data['obs']
+        return (self.dp_mode == 'p2p' and not self.general and self.ext is None and self.loss_kind in (0, 1)
+                and self.persistent and self.batch_size <= self.persistent_max_batch and dist.world_size() <= 16
+                and obs.stride(0) % 4 == 0 and obs.data_ptr() % 16 == 0 and not self._p2p.get('off')
+                and bool(self.lib.osa_ppo_pass_supported(self.ac.obs_dim, self.ac.act_dim, self.ac.hidden)))
+
+    def _p2p_setup(self) -> bool:
+        """Allocate this rank's exchange buffer (uncached device memory), hand its IPC handle to every rank and map
+        theirs (a set-up step: one all-gather of 64 bytes + a barrier; the step path has no collective).  Returns False
+        -- on EVERY rank, the decision is all-reduced -- when any rank's runtime refuses the allocation or a mapping."""
+        import torch.distributed as tdist
+
+        ac, lib, st = self.ac, self.lib, self._p2p
+        W, rank = dist.world_size(), dist.rank()
+        if st.get('W') == W and st.get('peers') is not None:
+            return True
+        self._p2p_free()
+        n = lib.osa_p2p_exchange_floats(ac.obs_dim, ac.act_dim, ac.hidden, W)
+        own, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        ok = n > 0 and lib.osa_p2p_exchange_alloc(n, C.byref(own), handle) == _lib.OSA_OK and bool(own.value)
+        handles: list = [None] * W
+        if W > 1:
+            tdist.all_gather_object(handles, bytes(handle) if ok else None)
+        else:
+            handles[0] = bytes(handle) if ok else None
+        ok = all(h is not None for h in handles)
+        ptrs = [None] * W
+        opened = []
+        if ok:
+            for q in range(W):
+                if q == rank:
+                    ptrs[q] = own.value
+                    continue
+                pq = C.c_void_p()
+                buf = (C.c_ubyte * 64).from_buffer_copy(handles[q])
+                if lib.osa_p2p_exchange_open(buf, C.byref(pq)) != _lib.OSA_OK or not pq.value:
+                    ok = False
+                    break
+                ptrs[q] = pq.value
+                opened.append(pq.value)
+        # everybody proceeds, or nobody does (and nobody writes into a buffer that somebody is about to free)
+        flag = torch.tensor([1.0 if ok else 0.0], device=ac.device if dist.graph_capturable() else 'cpu')
+        if W > 1:
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        if float(flag) < 1.0:
+            for pq in opened:
+                lib.osa_p2p_exchange_release(C.c_void_p(pq))
+            if own.value:
+                lib.osa_p2p_exchange_release(own)
+            st['off'] = True
+            import warnings
+
+            warnings.warn('omnisafe_amd: the peer-exchange buffers could not be allocated / mapped on every rank '
+                          '(hipIpc refused); dp_mode falls back to the per-step all-reduce', RuntimeWarning)
+            return False
+        st.update(W=W, own=own.value, opened=opened, peers=(C.c_void_p * W)(*ptrs), seq=0,
+                  timeout=float(os.environ.get('OSA_P2P_TIMEOUT_S', '20')))
+        return True
+
+    def _p2p_free(self) -> None:
+        st = self._p2p
+        for pq in st.get('opened', []):
+            self.lib.osa_p2p_exchange_release(C.c_void_p(pq))
+        if st.get('own'):
+            self.lib.osa_p2p_exchange_release(C.c_void_p(st['own']))
+        for k in ('own', 'opened', 'peers', 'W'):
+            st.pop(k, None)
+
+    def check_p2p_sync(self) -> None:
+        """Sticky time-out word of the peer exchange: a rank that never arrived leaves every other rank with Adam steps
+        on incompletely averaged gradients -- an error, never a silent fallback."""
+        st = self._p2p
+        if st.get('own'):
+            flag = C.c_int(0)
+            _lib.check(self.lib.osa_p2p_exchange_timed_out(C.c_void_p(st['own']), C.byref(flag)),
+                       'osa_p2p_exchange_timed_out')
+            if flag.value:
+                raise _lib.OsaError('osa_ppo_p2p_pass: a peer rank never arrived at an optimiser step within '
+                                    f"{st['timeout']} s (results invalid); set OSA_DP_MODE=allreduce")
+
+    def run_pass_p2p(self, data: dict, perm: torch.Tensor, lagrange: torch.Tensor, stats_rows: torch.Tensor) -> None:
+        """osa_ppo_p2p_pass: one pass of THIS rank's minibatches in one persistent launch, gradients exchanged by peer
+        writes (policy_gradient.py:366-382 + 437-443 under torch.distributed)."""
+        ac, st = self.ac, self._p2p
+        M = data['obs'].shape[0]
+        nmb = (M + self.batch_size - 1) // self.batch_size
+        ev = None
+        if self.profile_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(self.lib.osa_ppo_p2p_pass(
+            ac.obs_dim, ac.act_dim, ac.hidden, _lib.ptr(ac.params), _lib.ptr(ac.adam_m), _lib.ptr(ac.adam_v),
+            _lib.ptr(ac.adam_step), _lib.ptr(data['obs']), data['obs'].stride(0), _lib.ptr(data['act']),
+            data['act'].stride(0), _lib.ptr(data['logp']), _lib.ptr(data['target_value_r']),
+            _lib.ptr(data['target_value_c']), _lib.ptr(data['adv_r']), _lib.ptr(data['adv_c']), _lib.ptr(perm), M,
+            self.batch_size, st['W'], dist.rank(), st['peers'], st['seq'] & 0xFFFFFFFF, st['timeout'],
+            _lib.ptr(lagrange), C.byref(self.hp), self.loss_kind, self._nets_mask(), _lib.ptr(stats_rows),
+            _lib.stream_ptr()), 'osa_ppo_p2p_pass')
+        st['seq'] += nmb
+        if ev is not None:
+            ev[1].record()
+            self.profile_events.append(('osa_ppo_p2p_pass_kernel', M, ev))
+
     # ------------------------------------------------------------------ replicated-data DP path
     _DP_KEYS = ('obs', 'act', 'logp', 'target_value_r', 'target_value_c', 'adv_r', 'adv_c')
 
@@ -639,6 +758,7 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
 
     def __del__(self):
         try:
+            self._p2p_free()
             self._dp_free()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
@@ -912,6 +1032,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
         W = dist.world_size()
         if not self.general:  # (the layer-wise path gathers its rows into aligned scratch itself)
             data = self._aligned_rows(data)
+        # one-shot peer exchange: the single-GPU pass on this rank's rows + peer writes of the clipped gradients
+        use_p2p = dist.collectives_active() and self._p2p_ok(data) and self._p2p_setup()
+        self._mode = 'allreduce' if self.dp_mode == 'p2p' else self.dp_mode  # (p2p not applicable: per-step all-reduce)
         use_repl = (dist.collectives_active() and not self.general and self.ext is None and self.update_critics
                     and self.dp_mode in ('replicated', 'replicated-steps') and B <= self.persistent_max_batch and bool(
             self.lib.osa_ppo_pass_supported(ac.obs_dim, ac.act_dim, ac.hidden)))
@@ -923,12 +1046,12 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             gathered = self._aligned_rows(self.gather_for_replicated(data, W))
         # which machinery ran (tests assert the timed path, not a fallback)
         self.last_path = ('replicated-wide-split' if self._repl_wide else 'replicated') if use_repl else (
-            ('persistent-wide' if self._use_wide else 'persistent') if use_pass else 'per-step')
+            ('persistent-wide' if self._use_wide else 'persistent') if use_pass else ('p2p' if use_p2p else 'per-step'))
         # all passes' permutations in one launch (one shuffle per row, DataLoader(shuffle=True) semantics) instead of
         # update_iters separate randperm launches
         all_perms = None
         # all passes as ONE captured graph when nothing on the host sits between them (see _graph_pass)
-        whole = (perms is None and not use_repl and not use_pass and self._graph_pass_ok(M)
+        whole = (perms is None and not use_repl and not use_pass and not use_p2p and self._graph_pass_ok(M)
                  and not (self.update_actor and self.kl_early_stop)
                  and self.update_iters * nmb * (16 if self.general else 1) <= 1024
                  and os.environ.get('OSA_UPDATE_GRAPH_WHOLE', '1') != '0')
@@ -954,6 +1077,9 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
             elif use_pass:  # one persistent launch for the whole pass
                 self.run_pass(data, perm, lagrange, stats[step:step + nmb])
                 step += nmb
+            elif use_p2p:  # the same launch per rank, gradients exchanged by peer writes
+                self.run_pass_p2p(data, perm, lagrange, stats[step:step + nmb])
+                step += nmb
             elif self._graph_pass_ok(M):  # large minibatches: the pass's steps (two launches each) as one hipGraph
                 self._graph_pass(data, perm, lagrange, stats[step:step + nmb])
                 step += nmb
@@ -974,17 +1100,23 @@ class PPOUpdater:  # pylint: disable=too-many-instance-attributes
                     if use_repl:  # the stream is drained anyway: see a lost peer before the KL decision
                         self.check_dp_sync()
                         self.check_wide_dp_sync()
+                    if use_p2p:
+                        self.check_p2p_sync()
                     if final_kl > self.target_kl:
                         break
         if use_repl:
             self.check_dp_sync()  # (run() ends in a host read of the statistics anyway)
             self.check_wide_dp_sync()
-        if not use_repl and not use_pass and B > 64 and not self.general:
+        if use_p2p:
+            self.check_p2p_sync()  # (a host read; run() ends in one of the statistics anyway)
+        if not use_repl and not use_pass and not use_p2p and B > 64 and not self.general:
             self.check_reduce_sync()
-        if not use_repl and not use_pass and B >= 2048 and dist.collectives_active() and self.ext is None:
+        if use_p2p:
+            pass
+        elif not use_repl and not use_pass and B >= 2048 and dist.collectives_active() and self.ext is None:
             # (what ran, for the tests and the bench line: the captured pass incl. its RCCL all-reduces, or eager steps)
             self.last_path = 'dp-large-batch-graph' if getattr(self, '_graphed_pass', False) else 'dp-large-batch'
-        elif (not use_repl and not use_pass and dist.collectives_active() and self.dp_mode == 'allreduce'
+        elif (not use_repl and not use_pass and dist.collectives_active() and self._mode == 'allreduce'
               and getattr(self, '_graphed_pass', False)):
             self.last_path = 'allreduce-graph'  # (eager steps -- gloo, or before the capture -- stay 'per-step')
         if self.general:

@@ -514,10 +514,20 @@ HIDDEN_SHAPES = [
 ]
 
 
+# Generated only when named (`make_golden.py hidden-shapes hidden1024x1024_ppolag_point`) and never committed (26 MB):
+# the network shape of the reference's one published timing table (docs/source/start/efficiency.rst:15-23), recorded
+# LIVE on the GPU box's host from the staged archive by tests/test_general_mlp_gpu.py::test_update_of_the_live_reference_at_1024x1024
+_M1024 = {'actor': {'hidden_sizes': [1024, 1024]}, 'critic': {'hidden_sizes': [1024, 1024]}}
+LIVE_HIDDEN_SHAPES = [
+    ('hidden1024x1024_ppolag_point', 'PPOLag', 'SynthPointGoal1-v0', {},
+     {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}, _M1024),
+]
+
+
 def gen_hidden_shape_updates(only=None):
     N, T, horizon = 16, 64, 16
-    for tag, algo_name, env_id, extra, lag, model in HIDDEN_SHAPES:
-        if only and tag not in only:
+    for tag, algo_name, env_id, extra, lag, model in HIDDEN_SHAPES + LIVE_HIDDEN_SHAPES:
+        if (only and tag not in only) or (not only and tag.startswith('hidden1024')):
             continue
         out = _gen_update_golden(algo_name, env_id, f'{tag}.npz', N, T, horizon, extra, lag, model=model)
         print(tag, {k: out[k] for k in ('Jc', 'lambda_before', 'lambda_after') if k in out}, 'perms',

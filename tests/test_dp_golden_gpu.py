@@ -15,6 +15,8 @@ path of world_size > 1: Lagrange step on the cross-rank mean cost, then
                         trpo.py:114-118, 181-185)
   replicated-steps      two launches per step from a hipGraph
   allreduce             gradient kernel -> ONE flat all-reduce -> Adam per optimiser step
+  p2p                   the single-GPU persistent pass per rank, clipped gradients exchanged by one-shot peer writes into
+                        hipIpc-mapped uncached buffers (osa_ppo_p2p_pass): no collective on the step path
   dp-large-batch        B = 2048: partial gradients -> local clip -> flat all-reduce -> Adam (graph-captured with RCCL;
                         eager over gloo)
   general-*             the same exchanges around the layer-wise GEMM path for general network shapes
@@ -164,6 +166,12 @@ CASES = [
     ('dp2_cpo_car', 'allreduce', 'per-step', None),
     ('dp2_ppolag_point_largebatch', 'replicated', 'dp-large-batch', None),
     ('dp2_ppolag_point_largebatch', 'allreduce', 'dp-large-batch', None),
+    # ONE-SHOT PEER EXCHANGE (round 6, osa_ppo_p2p_pass): every rank runs the single-GPU persistent pass on its own rows,
+    # the clipped gradients travel by peer writes into hipIpc-mapped uncached buffers (here: two processes on one GPU)
+    ('dp2_ppolag_point', 'p2p', 'p2p', None),
+    ('dp2_trpolag_ant', 'p2p', 'p2p', None),     # batch-128 critic passes: the workgroup walks through two chunks
+    ('dp2_cpo_car', 'p2p', 'p2p', None),
+    ('dp2_ppolag_humanoid', 'p2p', 'per-step', None),  # 376-wide rows: outside the pass kernel -> per-step all-reduce
     # general networks (csrc/general_mlp.hip) under data parallelism: gradient GEMMs -> local clip -> flat all-reduce
     # -> osa_gmlp_adam_apply per step; FVP / line-search averages of the trust-region family
     ('dp2_ppolag_point', 'allreduce', 'general-per-step', None),
@@ -181,6 +189,8 @@ def test_two_ranks_reproduce_the_two_rank_reference(tmp_path, tag, dp_mode, want
     ('dp4_ppolag_point', 'replicated', 'replicated', {'chunked': False}),
     ('dp4_ppolag_point', 'allreduce', 'per-step', None),
     ('dp4_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
+    ('dp4_ppolag_point', 'p2p', 'p2p', None),
+    ('dp4_trpolag_ant', 'p2p', 'p2p', None),
 ])
 def test_four_ranks_reproduce_the_four_rank_reference(tmp_path, tag, dp_mode, want_path, want):
     """The same recordings from a FOUR-rank run of the unmodified reference (`oracle/make_golden.py dp4`): a sum of four
@@ -202,6 +212,11 @@ EIGHT = [
     ('dp8_trpolag_ant', 'allreduce', 'per-step', None),
     ('dp8_cpo_car', 'replicated', 'replicated', {'chunked': True}),
     ('dp8_cpo_car', 'allreduce', 'per-step', None),
+    # the peer exchange at the world size BASELINE.json quotes: 8 processes x 3 workgroups, every workgroup writes its
+    # slab into 8 buffers and adds 8 slabs in rank order
+    ('dp8_ppolag_point', 'p2p', 'p2p', None),
+    ('dp8_trpolag_ant', 'p2p', 'p2p', None),
+    ('dp8_cpo_car', 'p2p', 'p2p', None),
 ]
 
 
@@ -231,6 +246,10 @@ REAL = [
     (8, 'dp8_ppolag_humanoid', 'replicated', 'replicated-wide-split', None),
     (8, 'dp8_trpolag_ant', 'replicated', 'replicated', {'chunked': True}),
     (8, 'dp8_cpo_car', 'allreduce', 'per-step', None),
+    (2, 'dp2_ppolag_point', 'p2p', 'p2p', None),
+    (4, 'dp4_ppolag_point', 'p2p', 'p2p', None),
+    (8, 'dp8_ppolag_point', 'p2p', 'p2p', None),
+    (8, 'dp8_trpolag_ant', 'p2p', 'p2p', None),
 ]
 
 

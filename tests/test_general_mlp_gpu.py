@@ -426,6 +426,65 @@ def test_trpolag_update_of_the_reference_at_general_widths(golden, tmp_path):
     _hidden_check(ac, g, ('reward_critic', 'cost_critic'), 2e-5)
 
 
+@pytest.fixture(scope='module')
+def live_1024(tmp_path_factory):
+    """One `_update()` of the UNMODIFIED reference with hidden_sizes [1024, 1024] on all three networks -- the shape of
+    the reference's one published timing table (docs/source/start/efficiency.rst:15-23; builder utils/model.py:73-111) --
+    recorded NOW on this box's host by the committed generator in its own process (`oracle/make_golden.py hidden-shapes
+    hidden1024x1024_ppolag_point`; from /root/reference in the build container, from the staged archive
+    oracle/_ref/omnisafe_ref.zip on the GPU box).  27 MB: a live recording instead of a committed fixture."""
+    import os
+    import subprocess
+    import sys
+
+    import ref_harness
+
+    if not ref_harness.reference_available():
+        pytest.skip('no reference: neither /root/reference nor oracle/_ref/omnisafe_ref.zip')
+    out = tmp_path_factory.mktemp('live1024')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OSA_GOLDEN_OUT=str(out), OMP_NUM_THREADS='8')
+    env.pop('OSA_FORCE_GENERAL_MLP', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'make_golden.py'), 'hidden-shapes',
+                        'hidden1024x1024_ppolag_point'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    g = dict(np.load(out / 'hidden1024x1024_ppolag_point.npz'))
+    assert g['init/actor/mean.2.weight'].shape == (1024, 1024) and g['init/reward_critic/critic_0.2.weight'].shape == (1024, 1024)
+    return g
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize('skinny', ['1', '0'])
+def test_update_of_the_live_reference_at_1024x1024(live_1024, tmp_path, monkeypatch, skinny):
+    """The skinny kernels (OSA_GMLP_SKINNY=1) and the tiled GEMM path (= 0) against the reference itself at
+    1024 x 1024: 32 chained 64-row Adam steps of three 1.1 M-parameter networks.  Tolerance as the committed
+    hidden-shape recordings (atol 2e-6), with stragglers in proportion: a 1024-term float32 contraction in MFMA-tile
+    order v the CPU's sgemm order moves a gradient element by ~1e-7 relative, and Adam's first steps turn an element
+    whose gradient is of the order of eps into a visible fraction of lr -- 2 of 32 768 elements per tensor in the
+    [256, 128] recordings, allowed here: 64 of 1 048 576, none beyond 1.5e-5 (a twentieth of one learning-rate step)."""
+    monkeypatch.setenv('OSA_GMLP_SKINNY', skinny)
+    g = live_1024
+    model = {'actor': {'hidden_sizes': [1024, 1024]}, 'critic': {'hidden_sizes': [1024, 1024]}}
+    algo, ac = _run_hidden('PPOLag', g, tmp_path, 'SynthPointGoal1-v0',
+                           ({}, {'lagrangian_multiplier_init': 0.5, 'cost_limit': 0.5}), model, 64)
+    assert algo._last_update_steps == 2 * 16
+    worst = {}
+    for net in ('actor', 'reward_critic', 'cost_critic'):
+        for k, v in getattr(ac, net).state_dict().items():
+            err = np.abs(v.cpu().numpy() - g[f'post/{net}/{k}'])
+            worst[f'{net}/{k}'] = (int((err > 2e-6).sum()), float(err.max()), err.size)
+    print('skinny', skinny, '(elements > 2e-6, max |param - live reference|, size):', worst)
+    for key, (n_big, mx, size) in worst.items():
+        assert n_big <= max(2, size // 16384) and mx <= 1.5e-5, (key, n_big, mx, size)
+    moved = max(float(np.abs(g[f'post/actor/{k}'] - g[f'init/actor/{k}']).max()) for k in ac.actor.state_dict())
+    assert moved > 5e-3
+    log = lambda key: np.asarray(list(algo._logger._data[key]), np.float64)  # noqa: E731
+    np.testing.assert_allclose(log('Train/KL')[-1], g['log/Train/KL'][-1], rtol=1e-2, atol=1e-7)
+    for key in ('Loss/Loss_reward_critic', 'Loss/Loss_cost_critic'):
+        np.testing.assert_allclose(log(key).mean(), g['log/' + key].mean(), rtol=2e-4)
+    np.testing.assert_allclose(algo._lagrange.lagrangian_multiplier, float(g['lambda_after']), rtol=1e-6)
+
+
 @pytest.mark.parametrize('mask_kind', ['critics-only', 'actor-only', 'no-cost'])
 def test_skinny_step_with_network_masks_equals_the_tiled_step(monkeypatch, mask_kind):
     """The trust-region family updates the critics alone in its minibatch loop (natural_pg.py:205-223), PPO / PolicyGradient
