@@ -20,8 +20,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   roofline     dominant kernel (osa_ppo_pass_kernel: one persistent launch = one whole pass of 1024 dependent
                64-row optimiser steps of all three networks), algorithmic FLOPs / mean launch time measured
                with HIP events in the timed region
-  cpu_baseline the oracle (oracle/np_oracle.py, a CPU restatement pinned bit-exact to the reference)
-               timed on this box's host cores on a bounded sample of the same workload
+  cpu_baseline the UNMODIFIED REFERENCE (kind "reference": omnisafe.Agent('PPOLag', device=cpu).learn() from the staged
+               archive oracle/_ref/omnisafe_ref.zip) timed on this box's host cores on a bounded sample of the same
+               workload (--ref-sample-iters of the 40 passes executed, the passes scaled; `full_epoch_value` = the
+               committed all-40-passes measurement); cpu_baseline_port = the oracle port (oracle/np_oracle.py) beside it
 and a "throughput_variant" object: the same workload shape with the large-batch setting the reference
 itself uses for GPU-resident envs (PPOLag.yaml ShadowHand* blocks: batch_size 8192 -> here 16 384,
 update_iters 8), which shows what the kernels do when the optimiser chain is not 64 rows wide.
@@ -88,7 +90,11 @@ def parse():
     # reference's structure, policy_gradient.py:437-443).  With N > 1 the line also carries an `allreduce_mode` object
     # (the same workload in the per-step all-reduce mode, --allreduce-steps epochs) unless --no-allreduce-leg, and the
     # large-batch `throughput_variant` (one flat RCCL all-reduce per step inside the captured update graph).
-    ap.add_argument('--dp-mode', default=None, choices=['replicated', 'replicated-steps', 'allreduce'])
+    # 'p2p' (round 6): every rank runs the single-GPU persistent pass on its own rows; clipped gradients exchanged by
+    # one-shot peer writes into hipIpc-mapped buffers (osa_ppo_p2p_pass), no collective on the step path
+    ap.add_argument('--dp-mode', default=None, choices=['replicated', 'replicated-steps', 'allreduce', 'p2p'])
+    ap.add_argument('--no-p2p-leg', action='store_true')
+    ap.add_argument('--no-early-stop-leg', action='store_true')
     ap.add_argument('--allreduce-steps', type=int, default=2)
     # passes per epoch of the all-reduce leg: a collective per 64-row optimiser step makes 40 passes (40 960 steps) a
     # minutes-long epoch on slow transports (the one-device gloo hook); its per-step time does not depend on the count
@@ -261,6 +267,9 @@ def roofline_from_events(events, batch_size):
             floor = MFMA_PER_STEP * MFMA_CYCLES / (ENGINE_GHZ * 1e3)
             out['chain_floor_us'] = round(floor, 3)  # serial MFMA issue cycles of one step (see the constants)
             out['chain_frac'] = round(floor / (us / steps), 4)  # the meaningful denominator of a B = 64 chain
+            # (why the step sits at ~2 x the floor: float32 MFMA and VALU work do not overlap on gfx950 -- raw probe
+            # output and the per-phase clocks of the current step)
+            out['chain_floor_evidence'] = ['profiles/r6_mfma_overlap_probe_raw.txt', 'profiles/r6_pass_phase_clocks.txt']
         out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
                        'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
                        'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
@@ -390,6 +399,44 @@ def cpu_baseline_reference(args):
         return {'error': f'{type(exc).__name__}: {exc}'}
 
 
+def full_epoch_reference(args):
+    """The unmodified reference's env-steps/s with ALL update passes executed, measured on a GPU box's host by this
+    script's own `--ref-sample-iters <update_iters>` leg and committed (profiles/r*_reference_full_epoch_config2.json);
+    only for the default workload the file was measured on."""
+    import glob
+
+    if (args.algo, args.envs, args.steps_per_env, args.batch_size, args.update_iters, list(args.hidden_sizes)) != (
+            'PPOLag', 4096, 16, 64, 40, [64, 64]):
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_reference_full_epoch_config2.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+            if int(d.get('sample_iters', 0)) == args.update_iters:
+                return {'value': d['value'], 'source': os.path.relpath(path, ROOT)}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
+def kl_pass_us(algo, dev, reps=20):
+    """HIP-event time of ONE full-batch KL(old || new) pass (policy_gradient.py:383-390) on this rank's rollout."""
+    up = algo._updater
+    try:
+        obs = algo._last_update_data['obs']  # the rows of the last epoch's update (env-major `buf.get()` output)
+        up.snapshot_old_distribution(obs)
+        up.kl(obs)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            up.kl(obs)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return round(e0.elapsed_time(e1) * 1e3 / reps, 2)
+    except Exception:  # noqa: BLE001 - a reported extra
+        return None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
@@ -488,6 +535,16 @@ def main():
     # (without early stop only the last pass's KL is evaluated; with it, one per pass: update.py)
     out['whole_path'] = whole_path(args, value, world, args.update_iters,
                                    args.update_iters if args.kl_early_stop else 1)
+    if not args.kl_early_stop and args.algo == 'PPOLag':
+        # Work NOT done in the timed region against the reference's loop: the reference evaluates the full-batch KL after
+        # EVERY pass (policy_gradient.py:383-390); with kl_early_stop off only the last value is observable (logged
+        # Train/KL), so the earlier update_iters - 1 passes are not computed.  Their cost, measured:
+        us = kl_pass_us(algo, dev)
+        out['config']['kl_passes_skipped'] = args.update_iters - 1
+        out['config']['kl_pass_us'] = us
+        if us is not None:
+            out['config']['kl_passes_skipped_frac_of_epoch'] = round((args.update_iters - 1) * us * 1e-3 /
+                                                                      (dt / args.steps * 1e3), 5)
     headline_mode = os.environ.get('OSA_DP_MODE', 'replicated')
     if world > 1 and not args.no_allreduce_leg and headline_mode != 'allreduce' and args.algo == 'PPOLag':
         # the same workload in the reference's own structure: per optimiser step gradient kernel -> ONE flat RCCL
@@ -510,16 +567,69 @@ def main():
             'ms_per_step': round(a_dt / args.allreduce_steps * 1e3, 3), 'steps': args.allreduce_steps, 'warmup': 2,
             'update_path': a_algo._updater.last_path,
             'us_per_optimiser_step_incl_collective': round(a_dt / args.allreduce_steps * 1e6 / n_steps, 3),
-            'message_bytes': 3 * 8448 * 4 if not general else None}
-        if args.n1_value:
+            'message_bytes': (4 * int(a_algo._updater.lib.osa_ppo_dp_ws_floats(OBS_DIM, ACT_DIM, HIDDEN, 1))
+                              if not general else None)}
+        if args.n1_value and a_iters == args.update_iters:
+            # (a ratio of throughputs is a scaling efficiency only at the SAME update_iters as the N = 1 headline)
             out['allreduce_mode']['efficiency_vs_n1'] = round(a_val / (world * args.n1_value), 4)
         os.environ['OSA_DP_MODE'] = headline_mode
         algo = a_algo
+    if world > 1 and not args.no_p2p_leg and headline_mode != 'p2p' and args.algo == 'PPOLag' and not general:
+        # the same workload with the one-shot peer exchange (round 6): each rank runs the single-GPU persistent pass on
+        # its own rows, the clipped gradients travel by peer writes into hipIpc-mapped buffers -- no collective and no
+        # W-fold recomputation on the step path; FULL update_iters (a pass is one launch per rank)
+        del algo
+        torch.cuda.empty_cache()
+        os.environ['OSA_DP_MODE'] = 'p2p'
+        p_algo = make_algo(args, world, args.batch_size, args.update_iters, args.steps + 3, log_dir)
+        run_epochs(p_algo, 2, lambda: torch.cuda.synchronize(dev))
+        p_dt = timed(p_algo, args.steps, 0, world, dev)
+        p_val = world * per_gpu_steps * args.steps / p_dt
+        n_steps = args.update_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
+        out['p2p_mode'] = {
+            'workload': 'same shapes and update_iters, dp_mode=p2p (osa_ppo_p2p_pass)',
+            'value': round(p_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+            'ms_per_step': round(p_dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': 2,
+            'update_path': p_algo._updater.last_path,
+            'us_per_optimiser_step_incl_rollout': round(p_dt / args.steps * 1e6 / n_steps, 3)}
+        if args.n1_value:
+            out['p2p_mode']['efficiency_vs_n1'] = round(p_val / (world * args.n1_value), 4)
+        os.environ['OSA_DP_MODE'] = headline_mode
+        algo = p_algo
+    if world == 1 and not args.no_early_stop_leg and args.algo == 'PPOLag' and not args.kl_early_stop and not general:
+        # the YAML default `kl_early_stop: true` (PPOLag.yaml; SURVEY 8d's parity variant): one full-batch KL pass AND
+        # one host synchronisation per pass.  (a) target_kl at the YAML's 0.02: the update stops where the reference's
+        # would (passes_executed < update_iters: less work per epoch, not comparable with the headline); (b) a target
+        # nothing reaches: all passes, i.e. the headline's work + update_iters - 1 KL passes + update_iters host syncs
+        del algo
+        torch.cuda.empty_cache()
+        es = {}
+        for tag, tkl in (('yaml_target_kl_0.02', None), ('never_stops', 1e30)):
+            args.kl_early_stop = True
+            e_algo = make_algo(args, world, args.batch_size, args.update_iters, 8, log_dir)
+            args.kl_early_stop = False
+            if tkl is not None:
+                e_algo._updater.target_kl = tkl
+            run_epochs(e_algo, 2, lambda: torch.cuda.synchronize(dev))
+            passes = []
+            t0 = time.perf_counter()
+            for _ in range(3):
+                run_epochs(e_algo, 1, lambda: torch.cuda.synchronize(dev))
+                passes.append(int(getattr(e_algo, '_last_update_steps', 0)) // ((per_gpu_steps + args.batch_size - 1) // args.batch_size))
+            e_dt = (time.perf_counter() - t0) / 3
+            es[tag] = {'value': round(per_gpu_steps / e_dt, 1), 'ms_per_step': round(e_dt * 1e3, 3),
+                       'passes_executed': passes, 'target_kl': float(e_algo._updater.target_kl)}
+            del e_algo
+            torch.cuda.empty_cache()
+        es['note'] = ('kl_early_stop on (PPOLag.yaml default): a KL pass + a host read per pass; `never_stops` = every pass '
+                      'executed = the headline workload + the 39 skipped KL passes + 40 syncs')
+        out['kl_early_stop_epoch'] = es
+        algo = None
     if not args.no_variant and args.algo == 'PPOLag':
         # the large-batch setting on EVERY rank (round 4): under world_size > 1 the update is the data-parallel
         # large-batch pass -- partial gradients, local clip, ONE flat RCCL all-reduce, Adam per step, the whole pass
         # incl. its collectives one captured hipGraph (`dp-large-batch-graph`)
-        del algo
+        algo = None
         torch.cuda.empty_cache()
         vb = args.variant_batch
         v_algo = make_algo(args, world, vb, 8, 14, log_dir)
@@ -552,6 +662,14 @@ def main():
         port = cpu_baseline(args)
         ref = cpu_baseline_reference(args)
         if ref is not None and 'error' not in ref:
+            if int(ref.get('sample_iters', 0)) < args.update_iters:
+                # the bounded sample extrapolates its passes; the same command with ALL passes executed (105 s on the
+                # box's host: `--ref-sample-iters 40`, tools/gpu_round_check.sh stage 6) is the committed measurement
+                full = full_epoch_reference(args)
+                if full is not None:
+                    ref['full_epoch_value'] = full['value']
+                    ref['full_epoch_source'] = full['source']
+                    ref['gpu_over_full_epoch_reference'] = round(value / full['value'], 1)
             out['cpu_baseline'] = ref           # the unmodified reference on this box's host cores
             out['cpu_baseline_port'] = port     # the oracle port (vectorised numpy rollout: flatters the CPU)
         else:

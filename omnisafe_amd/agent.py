@@ -3,9 +3,10 @@
 epochs = total_steps // steps_per_epoch, registry lookup, ``learn()``.
 
 Process model: the reference re-executes itself under torchrun when ``parallel > 1``
-(omnisafe/utils/distributed.py:83-139).  Here the launcher is external (``python -m
-torch.distributed.run --nproc-per-node N ...``, one process per GPU) and
-``omnisafe_amd.distributed.init_from_env`` joins the RCCL process group from torchrun's environment.
+(omnisafe/utils/distributed.py:83-139).  Here ``omnisafe_amd.distributed.init_from_env`` joins the RCCL process
+group from torchrun's environment (one process per GPU); the ranks are started either by the caller (``python -m
+torch.distributed.run --nproc-per-node N ...``) or by the script itself -- ``python bench.py --gpus N`` re-executes
+itself under ``torch.distributed.run`` exactly as the reference's ``fork`` does (distributed.py:121-137).
 """
 from __future__ import annotations
 

@@ -13,9 +13,12 @@
 //
 // The exchange buffers are UNCACHED device memory (hipExtMallocWithFlags(hipDeviceMallocUncached)): a peer's writes
 // arrive at the memory side and must not meet stale lines in the owner's per-XCC L2.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ppo_pass_body.h"
+
+long long* osa_pass_dbg_ptr();  // ppo_pass_kernel.hip (phase clocks: -DOSA_PASS_CLOCKS builds)
 
 template <int KB, int OT, bool MULTI, bool SO>
 __global__ __launch_bounds__(256, 1) void osa_ppo_p2p_pass_kernel(OsaPassArgs a) {
@@ -169,6 +172,10 @@ int osa_ppo_p2p_pass(int obs_dim, int act_dim, int hidden, float* params, float*
     OSA_REQUIRE(g_p2p_bytes[k] >= osa_p2p_exchange_floats(obs_dim, act_dim, hidden, world) * sizeof(float));
   }
   a.p2p_rank = rank; a.p2p_seq0 = seq0; a.p2p_timeout = (long long)(timeout_s * 1e8);
+  {  // OSA_P2P_FENCE=system: LLVM's system-scope fences instead of written-through stores (A/B switch)
+    static const bool sysf = getenv("OSA_P2P_FENCE") && !strcmp(getenv("OSA_P2P_FENCE"), "system");
+    a.p2p_fence = sysf ? 1 : 0;
+  }
   a.ext_ratio_scale = 1.f; a.ext_mask_eta = -1.f;
   a.nd = osa_make_net(obs_dim, act_dim, hidden);
   a.params = params; a.adam_m = adam_m; a.adam_v = adam_v; a.adam_step = adam_step;
@@ -181,7 +188,7 @@ int osa_ppo_p2p_pass(int obs_dim, int act_dim, int hidden, float* params, float*
   a.hp.beta2 = hp->beta2; a.hp.adam_eps = hp->adam_eps; a.hp.use_critic_norm = hp->use_critic_norm;
   a.hp.use_max_grad_norm = hp->use_max_grad_norm; a.hp.use_cost = hp->use_cost;
   a.loss_kind = loss_kind; a.nets_mask = nets_mask & (hp->use_cost ? 7 : 3); a.stats = step_stats;
-  a.dbg = nullptr; a.dp_slabs = nullptr; a.dp_world = world; a.mb0 = 0; a.dp_sync = nullptr; a.part_stride = 0;
+  a.dbg = osa_pass_dbg_ptr(); a.dp_slabs = nullptr; a.dp_world = world; a.mb0 = 0; a.dp_sync = nullptr; a.part_stride = 0;
   a.dp_uncached = 1; a.dp_local = 0; a.dp_chunk = 0; a.dp_ranks = 1; a.one_xcc = 1;
   const int KB = a.nd.KB, OT = a.nd.OUTP / 16;
   hipStream_t st = osa_stream(stream);

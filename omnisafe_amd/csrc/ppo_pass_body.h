@@ -138,6 +138,10 @@ struct OsaPassArgs {
   int p2p_rank;
   unsigned p2p_seq0;
   long long p2p_timeout;  // wall-clock ticks (100 MHz) a workgroup waits for its peers before it flags a time-out
+  // 0: every exchange store carries the system-scope bits (sc0 sc1: written through to the memory side) and the
+  // hand-off waits for the stores' acknowledgements only; 1: ordinary stores + LLVM's system-scope release / acquire
+  // fences (an L2 write-back and invalidate per step: A/B switch OSA_P2P_FENCE=system)
+  int p2p_fence;
 };
 #define OSA_P2P_HDR 256      // floats in front of the slabs
 #define OSA_P2P_STICKY 240   // int index of the sticky time-out word
@@ -172,6 +176,16 @@ __device__ __forceinline__ float osa_sym_sum1(float a, float sa, float b, float 
   const float pa = a * sa;
   const float pb = b * sb;
   return pa + pb;
+}
+
+// Exchange stores of the peer-exchange pass: global stores with sc0 sc1 (system scope: the data is written through to
+// the memory side -- the peer's HBM over xGMI, or this device's uncached buffer -- instead of waiting in this XCC's L2
+// for a write-back).  Their completion is what s_waitcnt vmcnt(0) waits for before the arrival word goes out.
+__device__ __forceinline__ void osa_store_sys(f32x4* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void osa_store_sys(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 // floats of dynamic LDS without the transposed W2 copy, and whether that copy still fits the 160 KB of a CU
@@ -1060,7 +1074,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     for (int ti = 0; ti < HT; ++ti) {
       const f32x4 w = w2r[ti];
       if (l2) g2[ti] = g2[ti] + w * c2;
-      if constexpr (coop) xs4[ti * 256 + tid] = g2[ti];
+      if constexpr (coop && !P2P) xs4[ti * 256 + tid] = g2[ti];  // (P2P: the own gradient stays in registers)
       acc_p = acc_p + w * w;
       acc_g = acc_g + g2[ti] * g2[ti];
     }
@@ -1068,7 +1082,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     for (int kb = 0; kb < KB; ++kb) {
       const f32x4 w = w1r[kb];
       if (l2) g1[kb] = g1[kb] + w * c2;
-      if constexpr (coop) xs4[(HT + kb) * 256 + tid] = g1[kb];
+      if constexpr (coop && !P2P) xs4[(HT + kb) * 256 + tid] = g1[kb];
       acc_p = acc_p + w * w;
       acc_g = acc_g + g1[kb] * g1[kb];
     }
@@ -1076,7 +1090,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     for (int o = 0; o < OT; ++o) {
       const f32x4 w = w3r[o];
       if (l2) g3[o] = g3[o] + w * c2;
-      if constexpr (coop) xs4[(HT + KB + o) * 256 + tid] = g3[o];
+      if constexpr (coop && !P2P) xs4[(HT + KB + o) * 256 + tid] = g3[o];
       acc_p = acc_p + w * w;
       acc_g = acc_g + g3[o] * g3[o];
     }
@@ -1087,7 +1101,7 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       psq += wb * wb;
       gsq += gb * gb;
     }
-    if constexpr (coop) reinterpret_cast<float*>(xs4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
+    if constexpr (coop && !P2P) reinterpret_cast<float*>(xs4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
     if constexpr (P2P) {
       // the same tiles into every OTHER rank's buffer (posted writes: over xGMI where the peer is another device);
       // they drain while the norm is reduced, the clip factor and the arrival word follow below
@@ -1096,12 +1110,12 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
         pr = pr >= a.dp_world ? pr - a.dp_world : pr;  // (every rank starts with its right-hand neighbour: the 7 links in parallel)
         f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(a.p2p_peer[pr] + p2p_off + (long)rk * XS);
 #pragma unroll
-        for (int ti = 0; ti < HT; ++ti) d4[ti * 256 + tid] = g2[ti];
+        for (int ti = 0; ti < HT; ++ti) osa_store_sys(d4 + ti * 256 + tid, g2[ti]);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) d4[(HT + kb) * 256 + tid] = g1[kb];
+        for (int kb = 0; kb < KB; ++kb) osa_store_sys(d4 + (HT + kb) * 256 + tid, g1[kb]);
 #pragma unroll
-        for (int o = 0; o < OT; ++o) d4[(HT + KB + o) * 256 + tid] = g3[o];
-        reinterpret_cast<float*>(d4)[NT * 1024 + tid] = (boff >= 0) ? gb : 0.f;
+        for (int o = 0; o < OT; ++o) osa_store_sys(d4 + (HT + KB + o) * 256 + tid, g3[o]);
+        osa_store_sys(reinterpret_cast<float*>(d4) + NT * 1024 + tid, (boff >= 0) ? gb : 0.f);
       }
     }
     // ---- block reduction of (gsq, psq, loss, ratio): wave shuffles, then a fixed-order sum
@@ -1168,22 +1182,33 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
       // contiguous per wave instruction); complete the slab with the clip factor and the statistics
       const int W = chunked ? cw : a.dp_world;  // peers of this hand-off
       const float gs = (apply_clip && !chunked) ? coef : 1.f;  // (chunk mode: the SUM is clipped, below)
-      if (leader) {
-        float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
-        t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
-        if constexpr (P2P) {
-          for (int q = 0; q < a.dp_world; ++q) {
-            if (q == a.p2p_rank) continue;
-            float* tq = a.p2p_peer[q] + p2p_off + (long)rk * XS + NT * 1024 + 256;
-            tq[0] = st_loss; tq[1] = st_ratio; tq[2] = st_psq; tq[3] = st_norm; tq[4] = st_ent; tq[5] = gs;
+      if constexpr (P2P) {
+        // the slab's tail (statistics, clip factor) into every rank's buffer: lane q of the leader's wave serves rank q
+        if (wave == 3) {  // (wave-uniform; the entropy terms live in the leader = lane 0 of this wave)
+          const float l_loss = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st_loss)));
+          const float l_ent = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st_ent)));
+          if (lane < a.dp_world) {
+            float* tq = a.p2p_peer[lane] + p2p_off + (long)rk * XS + NT * 1024 + 256;
+            osa_store_sys(reinterpret_cast<f32x4*>(tq), (f32x4){l_loss, st_ratio, st_psq, st_norm});
+            osa_store_sys(tq + 4, l_ent);
+            osa_store_sys(tq + 5, gs);
           }
         }
+      } else if (leader) {
+        float* t = reinterpret_cast<float*>(xs4) + NT * 1024 + 256;
+        t[0] = st_loss; t[1] = st_ratio; t[2] = st_psq; t[3] = st_norm; t[4] = st_ent; t[5] = gs;
       }
       if constexpr (P2P) {
         // ---- one-shot exchange: every thread's slab stores are performed at SYSTEM scope (release), then thread q
         // stores the step's sequence number into this rank's arrival word in rank q's buffer and polls the word rank
         // q stores into OUR buffer -- dp_world words polled in parallel by dp_world lanes of wave 0
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (a.p2p_fence) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        } else {
+          // (the stores were written through at system scope: their acknowledgements are all that is waited for)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_waitcnt(0);
+        }
         __syncthreads();
         PTICK(12);
         const unsigned target = a.p2p_seq0 + (unsigned)(mb - a.mb0) + 1u;
@@ -1213,7 +1238,9 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
         __syncthreads();
         if (!coop_dead) coop_dead = __hip_atomic_load(reinterpret_cast<unsigned*>(a.p2p_peer[a.p2p_rank]) + OSA_P2P_STICKY,
                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        // the own buffer is uncached (never in this XCC's L2): the vector L1 is what has to forget its lines
+        if (a.p2p_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       } else {
       if (a.dp_uncached || a.dp_local) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1287,12 +1314,31 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
         float tb[RU], tg[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-          const float* __restrict__ xr = xbase + (long)min(r0 + u, W - 1) * XS;
+          int src = min(r0 + u, W - 1);
+          // P2P: the own gradient never went to memory -- its slot of the rank-ordered sum is filled from the
+          // registers below; the load is pointed at a neighbour's slab (lines the trip requests anyway)
+          if (P2P && src == rk) src = (src > 0) ? src - 1 : (W > 1 ? 1 : 0);
+          const float* __restrict__ xr = xbase + (long)src * XS;
           const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(xr);
 #pragma unroll
           for (int q = 0; q < NT; ++q) t[u][q] = x4[q * 256 + tid];
           tb[u] = xr[NT * 1024 + tid];
           tg[u] = xr[NT * 1024 + 256 + 5];
+        }
+        if constexpr (P2P) {
+#pragma unroll
+          for (int u = 0; u < RU; ++u) {
+            if (r0 + u == rk) {  // workgroup-uniform: the same bits the peers read from this rank's slab
+#pragma unroll
+              for (int ti = 0; ti < HT; ++ti) t[u][ti] = g2[ti];
+#pragma unroll
+              for (int kb = 0; kb < KB; ++kb) t[u][HT + kb] = g1[kb];
+#pragma unroll
+              for (int o = 0; o < OT; ++o) t[u][HT + KB + o] = g3[o];
+              tb[u] = (boff >= 0) ? gb : 0.f;
+              tg[u] = gs;
+            }
+          }
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {

@@ -27,6 +27,9 @@ __global__ __launch_bounds__(256, 1) void osa_ppo_pass_kernel(OsaPassArgs a) {
 // ------------------------------------------------------------------------------------------------
 static long long* g_osa_pass_dbg = nullptr;
 
+// (library-internal: the phase-clock buffer for the other translation units that instantiate the pass body)
+long long* osa_pass_dbg_ptr() { return g_osa_pass_dbg; }
+
 static size_t osa_pass_lds_bytes(int KB, int OT) {
   const size_t fl = (size_t)osa_pass_lds_floats(KB, OT) + (osa_pass_has_w2t(KB, OT) ? 64 * PSLD : 0);
   return fl * sizeof(float);

@@ -11,7 +11,7 @@ SUF=$1; SRC=$2; shift; shift
 python -m omnisafe_amd.build >/dev/null
 L=omnisafe_amd/lib
 EXTRA=""
-[ "$SRC" = "ppo_pass_kernel.hip" -o "$SRC" = "part_grad_kernel.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$SRC" = "ppo_pass_kernel.hip" -o "$SRC" = "part_grad_kernel.hip" -o "$SRC" = "p2p_pass_kernel.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA "$@" -c omnisafe_amd/csrc/$SRC -o $L/${SRC}_$SUF.o -Wall -Wno-unused-function
 OBJS=""
 for o in $L/*.hip.o; do

@@ -82,6 +82,26 @@ def worker(rank, world, port, rows, reps, distinct, out_path):
             if it >= 2:
                 best = min(best, e0.elapsed_time(e1))
         up.check_p2p_sync()
+        if os.environ.get('OSA_LIB_PATH', '').endswith('p2pclocks.so') and rank == 0:
+            # per-phase cycles of one optimiser step (build: tools/build_variant_lib.sh p2pclocks p2p_pass_kernel.hip
+            # -DOSA_PASS_CLOCKS): the exchange = 'bias+norms .. publish' (stores issued while the norm is reduced),
+            # 'release+barrier', 'arrival wait+acquire', 'sum of the slabs'
+            dbg = torch.zeros(48, dtype=torch.int64, device=dev)
+            up.lib.osa_debug_set_pass_clock_buffer(dbg.data_ptr())
+        tdist.barrier()
+        if os.environ.get('OSA_LIB_PATH', '').endswith('p2pclocks.so'):
+            up.run_pass_p2p(data, perm, lam, st)
+            torch.cuda.synchronize()
+            if rank == 0:
+                up.lib.osa_debug_set_pass_clock_buffer(None)
+                d = dbg.cpu().numpy().reshape(3, 16)[:, :13] / float(nmb)
+                names = ['top(mask,sX)', 'fwd(+prefetch issue)', 'loss', 'bwd', 'barA wait', 'dW', 'bias+norms(+peer stores)',
+                         'barB', 'adam', 'stats+barC', 'arrival wait+acquire', 'sum of the slabs', 'release+barrier']
+                order = [0, 1, 2, 3, 4, 5, 6, 7, 12, 10, 11, 8, 9]
+                print(f'{name} W={world}: cycles per optimiser step   actor   V_r   V_c', flush=True)
+                for i in order:
+                    print(f'  {names[i]:30s}', *[f'{v:9.1f}' for v in d[:, i]], flush=True)
+                print(f'  {"total":30s}', *[f'{v:9.1f}' for v in d.sum(1)], flush=True)
         p = ac.params.clone()
         lo, hi = p.cpu().clone(), p.cpu().clone()
         if world > 1:
