@@ -103,6 +103,10 @@ struct GWs {
   // its 64 x 64 tiles, network by network and layer by layer (+ one tail workgroup per network)
   size_t zs[3][GM_MAXL];
   int sk_tile0[3][GM_MAXL], sk_tk[3][GM_MAXL], sk_ntile[3], sk_maxT1;
+  // (round 6) the clip norm from the forward / backward launches (skinny_mlp.h: gs_gram_norm): outputs before the bias,
+  // Gram matrices of the layers' input rows, partial outputs of the fused top layer, norm slots [3][slot_stride][4]
+  size_t ylin[3][GM_MAXL], gram[3][GM_MAXL], oslab[3], slots;
+  int fs[3][GM_MAXL], ds[3][GM_MAXL], ts[3], nslot[3], slot_stride;
   size_t total;
   int nblk, nb;
 };
@@ -169,6 +173,31 @@ GWs gm_ws(const GLayout& lo, long R) {
     w.sk_ntile[net] = t;
     if (t + 1 > w.sk_maxT1) w.sk_maxT1 = t + 1;
   }
+  w.slot_stride = 0;
+  for (int net = 0; net < 3; ++net) {
+    const GNet& n = lo.n[net];
+    int c = 0;
+    w.oslab[net] = 0;
+    w.ts[net] = 0;
+    for (int l = 0; l < GM_MAXL; ++l) {
+      w.ylin[net][l] = w.gram[net][l] = 0;
+      w.fs[net][l] = w.ds[net][l] = 0;
+      if (l + 1 >= n.L || R > GS_MAX_ROWS) continue;  // (layers below the top layer)
+      w.ylin[net][l] = take((size_t)R * n.ldh[l]);
+      w.gram[net][l] = take(64 * 64);
+      const int tiles = (n.ldh[l] + 15) / 16;
+      w.fs[net][l] = c; c += tiles;
+      w.ds[net][l] = c; c += tiles;
+    }
+    if (n.L >= 2 && R <= GS_MAX_ROWS) {
+      const int tiles = (n.ldh[n.L - 2] + 15) / 16;
+      w.ts[net] = c; c += tiles;
+      w.oslab[net] = take((size_t)tiles * 64 * n.ldh[n.L - 1]);
+    }
+    w.nslot[net] = c;
+    if (c > w.slot_stride) w.slot_stride = c;
+  }
+  w.slots = take((size_t)3 * w.slot_stride * 4);
   w.npart = take((size_t)3 * (w.nb > w.sk_maxT1 ? w.nb : w.sk_maxT1) * 2);
   w.fin = take(3 * 8);
   w.dws = take(2 * 4 * 1024);
@@ -561,7 +590,10 @@ __global__ __launch_bounds__(256) void gm_loss_kernel(GLossArgs a) {
   __shared__ float red[4];
   const int net = blockIdx.y;
   if (!((a.nets_mask >> net) & 1)) return;
-  gm_loss_body(a, net, (long)blockIdx.x * 256 + threadIdx.x, blockIdx.x, red, a.dz[net], a.ldz[net], true);
+  const long b = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = b < a.R ? (a.idx ? a.idx[b] : b) : 0;
+  const GLossMem acc{a, b, row, a.out[net] + b * a.ldo[net], a.dz[net] + b * a.ldz[net]};
+  gm_loss_body<false>(a, net, b, blockIdx.x, red, a.ldz[net], true, acc, nullptr, row);
 }
 
 struct GRedArgs {
@@ -888,6 +920,19 @@ void gm_fill_ext(GLossArgs& la, const osa_surrogate_ext* ext, const long* idx, f
   la.stats = stats;
 }
 
+// the one-dimensional grid of a skinny launch: tiles of 16 output columns, problem after problem (GSArgs.tile0)
+unsigned gs_grid(GSArgs& g, bool at_least_one) {
+  int t = 0;
+  for (int y = 0; y < g.nprob; ++y) {
+    g.tile0[y] = t;
+    int n = (g.p[y].ldy + 15) / 16;
+    if (at_least_one && n < 1) n = 1;
+    t += n;
+  }
+  for (int y = g.nprob; y <= GS_MAXPROB; ++y) g.tile0[y] = t;
+  return (unsigned)t;
+}
+
 bool gs_enabled() {  // (A/B and test switch: OSA_GMLP_SKINNY=0 keeps small minibatches on the tiled GEMM)
   const char* v = getenv("OSA_GMLP_SKINNY");
   return !(v != nullptr && v[0] == '0' && v[1] == 0);
@@ -905,8 +950,26 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
                         int loss_kind, int mode, int mask, float* ws, float* step_stats, const osa_surrogate_ext* ext,
                         hipStream_t st) {
   int maxL = 0;
-  for (int net = 0; net < 3; ++net)
-    if (((mask >> net) & 1) && lo.n[net].L > maxL) maxL = lo.n[net].L;
+  // (round 6) mode 0: the clip norm comes out of the forward / top / backward launches (gs_gram_norm) and the top layer's
+  // forward pass rides in the launch below it -- 2 L - 1 launches instead of 2 L + 1.  Every active network needs a
+  // hidden layer and a top layer of at most 32 outputs; OSA_GMLP_NORM_FUSE=0 keeps round 5's launches (A/B, tests).
+  static const bool norm_fuse_on = [] {
+    const char* v = getenv("OSA_GMLP_NORM_FUSE");
+    return !(v != nullptr && v[0] == '0' && v[1] == 0);
+  }();
+  bool fusedn = mode == 0 && norm_fuse_on;
+  for (int net = 0; net < 3; ++net) {
+    if (!((mask >> net) & 1)) continue;
+    const GNet& n = lo.n[net];
+    if (n.L > maxL) maxL = n.L;
+    if (n.L < 2 || n.ldh[n.L - 1] > 32) fusedn = false;
+  }
+  {
+    const char* v = getenv("OSA_GMLP_TOP_FUSE");
+    if (v != nullptr && v[0] == '0' && v[1] == 0) fusedn = false;
+  }
+  const float c2 = hp->use_critic_norm ? 2.f * hp->critic_norm_coef : 0.f;
+  auto top_in_fwd = [&](const GNet& n) { return fusedn && n.ldh[n.L - 1] <= 8; };  // the top layer's forward pass fused
   // ---- forward, layer by layer (the networks of a layer in one launch).  No gather launch: layer 0 reads the caller's
   // observation rows through the minibatch's indices, the loss its scalars and action rows likewise
   for (int l = 0; l < maxL; ++l) {
@@ -914,10 +977,12 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
     g.R = (int)B;
     g.xrows = l == 0;
     g.xidx = idx;
+    g.fused = fusedn;
     int maxN = 0;
     for (int net = 0; net < 3; ++net) {
       const GNet& n = lo.n[net];
       if (!((mask >> net) & 1) || l >= n.L) continue;
+      if (l == n.L - 1 && top_in_fwd(n)) continue;  // (its outputs: partial slabs of the launch below)
       GSProb& p = g.p[g.nprob++];
       const float* pn = params + (long)net * lo.P;
       p.X = l == 0 ? obs : ws + w.h[net][l - 1];
@@ -929,11 +994,33 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
       p.act = l + 1 < n.L ? n.act : -1;
       p.net = net;
       if (p.N > maxN) maxN = p.N;
+      if (fusedn && l + 1 < n.L) {
+        if (net != 0 && c2 != 0.f) p.Ylin = ws + w.ylin[net][l];
+        p.slot = ws + w.slots + ((size_t)net * w.slot_stride + w.fs[net][l]) * 4;
+        if (l == n.L - 2 && top_in_fwd(n)) {
+          p.W2 = pn + n.oW[l + 1]; p.ldw2 = n.ld[l + 1]; p.N2 = n.out[l + 1]; p.ldo2 = n.ldh[l + 1];
+          p.oslab = ws + w.oslab[net];
+        }
+        // the Gram matrix of this layer's input rows, for the norm of its weight gradient
+        GSProb& q = g.p[g.nprob++];
+        q.X = p.X; q.ldx = p.ldx; q.W = p.X; q.ldw = p.ldx; q.wrows = l == 0;
+        q.Y = ws + w.gram[net][l]; q.ldy = 64; q.N = (int)B; q.K = n.in[l]; q.act = -1; q.net = net;
+        if (64 > maxN) maxN = 64;
+      }
     }
+    if (g.nprob == 0) continue;
+    if (fusedn && l == 0) {  // Adam's bias corrections of this step, the step counters
+      g.fin = ws + w.fin; g.adam_step = adam_step; g.lr_dev = hp->lr_device; g.lr_actor = hp->lr_actor;
+      g.lr_critic = hp->lr_critic; g.beta1 = hp->beta1; g.beta2 = hp->beta2; g.fin_mask = mask;
+      g.sp[0] = logp; g.sp[1] = adv_r; g.sp[2] = adv_c; g.sp[3] = target_value_r; g.sp[4] = target_value_c;
+      g.act = act; g.ld_act = ld_act; g.act_dim = lo.act_dim; g.lda = lo.lda;
+      g.scal = ws + w.scal; g.actg = ws + w.actg;
+    }
+    const unsigned nwg = gs_grid(g, false) + (fusedn && l == 0 ? 1 : 0);  // (+ the auxiliary workgroup)
     if (l == 0)
-      hipLaunchKernelGGL(gs_fwd_kernel<true>, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+      hipLaunchKernelGGL(gs_fwd_kernel<true>, dim3(nwg), dim3(64 * GS_WAVES), 0, st, g);
     else
-      hipLaunchKernelGGL(gs_fwd_kernel<false>, dim3((maxN + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+      hipLaunchKernelGGL(gs_fwd_kernel<false>, dim3(nwg), dim3(64 * GS_WAVES), 0, st, g);
   }
   // ---- loss and dL/d(output)
   const GNet& an = lo.n[0];
@@ -952,6 +1039,7 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
   la.clip = hp->clip; la.loss_kind = loss_kind; la.nets_mask = mask;
   la.dls = ws + w.dls; la.lpart = ws + w.lpart; la.nblk = w.nblk;
   la.direct = 1; la.ld_act = ld_act; la.act = act; la.idx = idx;
+  la.scal = ws + w.scal; la.actg = ws + w.actg;  // (fused: gathered by the first launch)
   la.sp[0] = logp; la.sp[1] = adv_r; la.sp[2] = adv_c; la.sp[3] = target_value_r; la.sp[4] = target_value_c;
   gm_fill_ext(la, ext, idx, step_stats);
   static const bool fuse_on = [] {  // (A/B switch: OSA_GMLP_TOP_FUSE=0 keeps the loss a launch of its own)
@@ -978,9 +1066,25 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
         p.act = n.act;
         if (p.ldy > maxld) maxld = p.ldy;
       }
+      if (fusedn) {  // (l >= 1 for every active network)
+        const float* pn = params + (long)net * lo.P;
+        float* sl = ws + w.slots + (size_t)net * w.slot_stride * 4;
+        p.c2 = net != 0 ? c2 : 0.f;
+        p.btop = pn + n.ob[l];
+        p.tslot = sl + (size_t)w.ts[net] * 4;
+        p.nslot = sl + (size_t)w.ds[net][l - 1] * 4;
+        p.G = ws + w.gram[net][l - 1];
+        p.Zlin = net != 0 && c2 != 0.f ? ws + w.ylin[net][l - 1] : nullptr;
+        p.bvec = pn + n.ob[l - 1];
+        if (top_in_fwd(n)) {
+          p.oslab = ws + w.oslab[net]; p.ldo2 = n.ldh[l]; p.nbo = (n.ldh[l - 1] + 15) / 16;
+        }
+      }
     }
-    if (g.nprob > 0)
-      hipLaunchKernelGGL(gs_top_kernel, dim3(maxld > 0 ? (maxld + 15) / 16 : 1, g.nprob), dim3(256), 0, st, g, la);
+    g.fused = fusedn;
+    GSTopFin tf = {};
+    tf.stats = step_stats; tf.entropy_coef = hp->entropy_coef; tf.loss_kind = loss_kind; tf.act_dim = lo.act_dim;
+    if (g.nprob > 0) hipLaunchKernelGGL(gs_top_kernel, dim3(gs_grid(g, true)), dim3(256), 0, st, g, la, tf);
   } else {
     hipLaunchKernelGGL(gm_loss_kernel, dim3(w.nblk, 3), dim3(256), 0, st, la);
   }
@@ -1002,8 +1106,17 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
       p.act = n.act;
       p.net = net;
       if (p.K > maxK) maxK = p.K;
+      if (fusedn) {  // the norm of layer l - 1's weight gradient, whose dZ this launch produces
+        const float* pn = params + (long)net * lo.P;
+        p.c2 = net != 0 ? c2 : 0.f;
+        p.nslot = ws + w.slots + ((size_t)net * w.slot_stride + w.ds[net][l - 1]) * 4;
+        p.G = ws + w.gram[net][l - 1];
+        p.Zlin = net != 0 && c2 != 0.f ? ws + w.ylin[net][l - 1] : nullptr;
+        p.bvec = pn + n.ob[l - 1];
+      }
     }
-    if (g.nprob > 0) hipLaunchKernelGGL(gs_bwd_kernel, dim3((maxK + 15) / 16, g.nprob), dim3(64 * GS_WAVES), 0, st, g);
+    g.fused = fusedn;
+    if (g.nprob > 0) hipLaunchKernelGGL(gs_bwd_kernel, dim3(gs_grid(g, false)), dim3(64 * GS_WAVES), 0, st, g);
   }
   // ---- weight gradients of all layers: norm partials (+ the gradient itself for modes 1 / 2)
   GSWArgs wa = {};
@@ -1030,7 +1143,12 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
   wa.adam_step = adam_step; wa.lr_dev = hp->lr_device; wa.lr_actor = hp->lr_actor; wa.lr_critic = hp->lr_critic;
   // (four workgroups per compute unit -- 35 KB of LDS each -- is the best occupancy measured: capped at 3 / 2 / 1 the
   // two launches take 41 / 43 / 62 us instead of 33 at 1024 x 1024, profiles/HISTORY.md)
-  hipLaunchKernelGGL(gs_wgrad_kernel<0>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
+  if (fusedn) {
+    wa.fold = 2; wa.slots = ws + w.slots; wa.slot_stride = w.slot_stride;
+    for (int net = 0; net < 3; ++net) wa.nslot[net] = w.nslot[net];
+  } else {
+    hipLaunchKernelGGL(gs_wgrad_kernel<0>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
+  }
   if (mode == 0) {
     hipLaunchKernelGGL(gs_wgrad_kernel<1>, dim3(w.sk_maxT1, 3), dim3(256), 0, st, wa);
     OSA_CHECK_LAUNCH();

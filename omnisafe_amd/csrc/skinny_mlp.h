@@ -88,37 +88,79 @@ struct GLossArgs {
 // (a device function of 256 threads: gm_loss_kernel = one block per 256 rows and network; gs_top_kernel calls it for the
 // <= 64 rows of a skinny step in EVERY workgroup of the top layer's backward launch -- dzp / ldzp then is an LDS image and
 // only the `writer` workgroup leaves the block partials and statistics)
+// The per-sample operands come through an accessor: GLossMem reads everything through GLossArgs (tiled path, round 5's
+// top launch); GLossLds is round 6's top launch, whose operands the caller has staged in LDS and registers -- explicit
+// LDS pointers, because a float* that MAY point to LDS is a flat access (~10 x an LDS read, and the loop over the
+// action dimensions re-reads log_std from memory every iteration).
+// WAVE: called by wave 0 alone for <= 64 rows, the sums are wave sums (no __syncthreads).
+// sums != nullptr: thread 0 leaves {loss sum, ratio sum, dL/d(log_std)[0 .. act_dim)} of the block there.
+typedef __attribute__((address_space(3))) float lds_f;
+struct GLossMem {
+  const GLossArgs& a;
+  long b, row;
+  const float* outp;
+  float* dzp;
+  __device__ __forceinline__ float sc(int k) const { return a.direct ? a.sp[k][row] : a.scal[(long)k * a.R + b]; }
+  __device__ __forceinline__ float act(int d) const { return a.direct ? a.act[row * a.ld_act + d] : a.actg[b * a.lda + d]; }
+  __device__ __forceinline__ float out(int d) const { return outp[d]; }
+  __device__ __forceinline__ float ls(int d) const { return a.log_std[d]; }
+  __device__ __forceinline__ float sd(int d) const { return expf(a.log_std[d]); }
+  __device__ __forceinline__ float logsd(int d) const { return logf(sd(d)); }
+  __device__ __forceinline__ float iv(int d) const { const float s_ = sd(d); return 1.f / (s_ * s_); }
+  __device__ __forceinline__ float lam() const { return a.lagrange ? *a.lagrange : 0.f; }
+  __device__ __forceinline__ void dz(int d, float v) const { dzp[d] = v; }
+};
+struct GLossLds {
+  float sc_[5], lam_;
+  const lds_f *act_, *out_, *ls_;  // this row's actions and outputs; log_std [0 .. 32), then the tables (the same
+                                   // float32 expressions, evaluated once per workgroup instead of per row and loop):
+                                   // exp(log_std) [32 .. 64), log(exp(log_std)) [64 .. 96), 1 / sd^2 [96 .. 128)
+  lds_f* dz_;                      // this row of the dL/d(output) image
+  __device__ __forceinline__ float sc(int k) const {
+    return k == 0 ? sc_[0] : (k == 1 ? sc_[1] : (k == 2 ? sc_[2] : (k == 3 ? sc_[3] : sc_[4])));
+  }
+  __device__ __forceinline__ float act(int d) const { return act_[d]; }
+  __device__ __forceinline__ float out(int d) const { return out_[d]; }
+  __device__ __forceinline__ float ls(int d) const { return ls_[d]; }
+  __device__ __forceinline__ float sd(int d) const { return ls_[32 + d]; }
+  __device__ __forceinline__ float logsd(int d) const { return ls_[64 + d]; }
+  __device__ __forceinline__ float iv(int d) const { return ls_[96 + d]; }
+  __device__ __forceinline__ float lam() const { return lam_; }
+  __device__ __forceinline__ void dz(int d, float v) const { dz_[d] = v; }
+};
+template <bool WAVE, typename ACC>
 __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, const long b, const int blk, float* red,
-                                             float* __restrict__ dzp, const int ldzp, const bool writer) {
+                                             const int ldzp, const bool writer, const ACC& acc, float* sums,
+                                             const long row) {
   const bool valid = b < a.R;
-  const long row = valid ? (a.idx ? a.idx[b] : b) : 0;  // the sample's row in the caller's arrays
-  auto SC = [&](int k) -> float { return a.direct ? a.sp[k][row] : a.scal[(long)k * a.R + b]; };
-  auto ACT = [&](int d) -> float { return a.direct ? a.act[row * a.ld_act + d] : a.actg[b * a.lda + d]; };
+  auto SC = [&](int k) -> float { return acc.sc(k); };
+  auto ACT = [&](int d) -> float { return acc.act(d); };
+  auto BSUM = [&](float v) -> float { return WAVE ? osa_wave_sum_dpp(v) : gm_block_sum(v, red); };
   const float invB = 1.f / (float)a.R;
   float loss = 0.f, ratio_s = 0.f;
   if (net != 0) {
     if (valid) {
-      const float diff = a.out[net][b * a.ldo[net]] - SC(net == 1 ? 3 : 4);
+      const float diff = acc.out(0) - SC(net == 1 ? 3 : 4);
       loss = diff * diff;
-      dzp[b * ldzp] = 2.f * diff * invB;
-      for (int d = 1; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;  // (row padding: the skinny kernels' 16-byte loads)
+      acc.dz(0, 2.f * diff * invB);
+      for (int d = 1; d < ldzp; ++d) acc.dz(d, 0.f);  // (row padding: the skinny kernels' 16-byte loads)
     }
   } else if (a.loss_kind == 2) {
     if (valid)
       for (int d = 0; d < a.act_dim; ++d) {
-        const float sd = expf(a.log_std[d]);
-        dzp[b * ldzp + d] = a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale;
+        const float sd = acc.sd(d);
+        acc.dz(d, a.tmean[b * a.ldt + d] / (sd * sd) * a.fvp_scale);
       }
     if (valid)
-      for (int d = a.act_dim; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;
+      for (int d = a.act_dim; d < ldzp; ++d) acc.dz(d, 0.f);
   } else {
-    const float lam = a.lagrange ? *a.lagrange : 0.f;
+    const float lam = acc.lam();
     float lp = 0.f;
     if (valid)
       for (int d = 0; d < a.act_dim; ++d) {
-        const float sd = expf(a.log_std[d]);
-        const float z = ACT(d) - a.out[0][b * a.ldo[0] + d];
-        lp += -(z * z) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+        const float sd = acc.sd(d);
+        const float z = ACT(d) - acc.out(d);
+        lp += -(z * z) / (2.f * (sd * sd)) - acc.logsd(d) - 0.91893853320467274178f;
       }
     const float ratio = valid ? expf(lp - SC(0)) : 0.f;
     // ---- extended surrogates: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
@@ -130,15 +172,15 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
     if (a.ext_on) {
       if (valid)
         for (int d = 0; d < a.act_dim; ++d) {
-          const float ls = a.log_std[d], ls0 = a.old_log_std[d], dl = ls - ls0;
+          const float ls = acc.ls(d), ls0 = a.old_log_std[d], dl = ls - ls0;
           const float q = expf(dl), isd0 = expf(-ls0);
-          const float u = (a.out[0][b * a.ldo[0] + d] - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
+          const float u = (acc.out(d) - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
           kl += 0.5f * (q * q + u * u - 1.f - 2.f * dl);
         }
       if (a.ext_mask_eta >= 0.f || a.ext_cost_kappa > 0.f) {  // block-uniform
         mask = (a.ext_mask_eta < 0.f || (valid && kl <= a.ext_mask_eta)) ? 1.f : 0.f;
-        const float tm = gm_block_sum(valid ? mask : 0.f, red);
-        const float tc = gm_block_sum(valid ? ratio * SC(2) : 0.f, red);
+        const float tm = BSUM(valid ? mask : 0.f);
+        const float tc = BSUM(valid ? ratio * SC(2) : 0.f);
         if (a.ext_mask_eta >= 0.f) mask_mean = tm * invB;
         if (a.ext_cost_kappa > 0.f) {
           const float pen = tc * invB + a.ext_cost_excess;
@@ -175,32 +217,36 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
     for (int d = 0; d < a.act_dim; ++d) {
       float dl = 0.f;
       if (valid) {
-        const float sd = expf(a.log_std[d]);
-        const float iv = 1.f / (sd * sd);
-        const float mu = a.out[0][b * a.ldo[0] + d];
+        const float iv = acc.iv(d);
+        const float mu = acc.out(d);
         const float z = ACT(d) - mu;
         float dmu = dlogp * z * iv;
         dl = dlogp * (z * z * iv - 1.f);
         if (a.ext_on) {  // d KL / d mu = (mu - mu0) / var0;  d KL / d log_std = var / var0 - 1
-          const float ls0 = a.old_log_std[d], q = expf(a.log_std[d] - ls0), isd0 = expf(-ls0);
+          const float ls0 = a.old_log_std[d], q = expf(acc.ls(d) - ls0), isd0 = expf(-ls0);
           const float u = (mu - a.old_mean[orow * a.ld_old_mean + d]) * isd0;
           dmu += dklw * (u * isd0);
           dl += dklw * (q * q - 1.f);
         }
-        dzp[b * ldzp + d] = dmu;
+        acc.dz(d, dmu);
       }
-      dl = gm_block_sum(dl, red);
+      dl = BSUM(dl);
       if (threadIdx.x == 0 && writer) a.dls[(long)blk * a.lda + d] = dl;
+      if (threadIdx.x == 0 && sums) sums[2 + d] = dl;
     }
     if (valid)
-      for (int d = a.act_dim; d < ldzp; ++d) dzp[b * ldzp + d] = 0.f;  // (row padding)
+      for (int d = a.act_dim; d < ldzp; ++d) acc.dz(d, 0.f);  // (row padding)
   }
-  loss = gm_block_sum(loss, red);
-  ratio_s = gm_block_sum(ratio_s, red);
+  loss = BSUM(loss);
+  ratio_s = BSUM(ratio_s);
   if (threadIdx.x == 0 && writer) {
     float* lp_ = a.lpart + ((long)net * a.nblk + blk) * 4;
     lp_[0] = loss;
     lp_[1] = ratio_s;
+  }
+  if (threadIdx.x == 0 && sums) {
+    sums[0] = loss;
+    sums[1] = ratio_s;
   }
 }
 
@@ -237,15 +283,71 @@ struct GSProb {
   int N, K;           // W is N x K
   int act;            // fwd: activation, or -1;  bwd: activation whose derivative multiplies, or -1
   int net;            // the network this problem belongs to (gs_top_kernel)
+  // ---- round 6: the clip norm without a weight-gradient launch of its own (GSArgs.fused != 0; see gs_gram_norm)
+  float* Ylin;        // fwd: the layer's outputs before bias and activation [R][ldy] (critics with the L2 term), or null
+  float* slot;        // fwd: norm slots of the tile [tiles][4] = {0, sum b^2, sum w^2, 0} of its 16 weight rows, or null
+  const float* W2;    // fwd: the network's TOP layer fused into this launch: its weights [N2][ldw2] ...
+  float* oslab;       //      ... and the partial outputs of the tile's 16 columns [tiles][64][ldo2]; top: the same slabs
+  int ldw2, N2, ldo2, nbo;   // (nbo: tiles that wrote a slab)
+  int wrows;          // fwd<true>: W's rows are gathered like X's (Gram matrix of the observation rows)
+  const float* G;     // bwd / top: Gram matrix [64][64] of the input rows of the layer whose dZ this launch produces
+  const float* Zlin;  // bwd / top: that layer's Ylin, or null
+  const float* bvec;  // bwd / top: that layer's bias
+  float* nslot;       // bwd / top: norm slots [tiles][4] = {partial squared gradient norm, 0, 0, 0}
+  const float* btop;  // top: the top layer's bias
+  float* tslot;       // top: norm slots of the top layer [tiles + 1][4] = {squared gradient norm, sum w^2 + b^2, 0, 0}
+  float c2;           // 2 critic_norm_coef for a critic with the L2 term, else 0
 };
+#define GS_MAXPROB 6
 struct GSArgs {
-  GSProb p[3];
+  GSProb p[GS_MAXPROB];
   int nprob, R;
   // != 0 (forward of layer 0, round 5: no gather launch): X is the CALLER's observation array -- any row stride, any
   // alignment -- and row r of the minibatch is X[(xidx ? xidx[r] : r) * ldx ..]: four-byte loads, K = obs_dim is small
   int xrows;
   const long* xidx;
+  int fused;          // round 6: norm partials, fused top layer (mode 0 only)
+  // round 6: ONE grid dimension -- workgroup b serves tile b - tile0[y] of problem y (tile0[y] <= b < tile0[y + 1]).  A
+  // (tiles, problems) grid whose problems differ in size is padded with workgroups that exit at once, and a launch
+  // with more workgroups than compute units runs as TWO rounds even so (18 v 10 us with three 4-tile Gram problems)
+  int tile0[GS_MAXPROB + 1];
+  // round 6 (fused, the step's FIRST launch): one thread advances the step counters and leaves Adam's bias corrections
+  // in fin[net][1 .. 2] (float64 pow / sqrt like torch: ~2000 cycles that sat on the top launch's critical path)
+  float* fin;          // [3][8], or nullptr
+  int* adam_step;
+  const float* lr_dev;
+  float lr_actor, lr_critic, beta1, beta2;
+  int fin_mask;
+  // ... and gathers the loss's per-sample operands (they hang on the row index: a second memory round trip in the top
+  // launch) into the tiled path's layout: scal[k][R] (logp, adv_r, adv_c, target_value_r, target_value_c), actg[R][lda]
+  const float* sp[5];
+  const float* act;
+  float* scal;
+  float* actg;
+  int ld_act, act_dim, lda;
 };
+__device__ __forceinline__ int gs_locate(const GSArgs& a, int& tile, int& tiles) {
+  const int b = blockIdx.x;
+  int y = 0;
+#pragma unroll
+  for (int q = 1; q < GS_MAXPROB; ++q)
+    if (q < a.nprob && b >= a.tile0[q]) y = q;
+  int lo = a.tile0[0], hi = a.tile0[1];
+#pragma unroll
+  for (int q = 1; q < GS_MAXPROB; ++q)
+    if (q == y) { lo = a.tile0[q]; hi = a.tile0[q + 1]; }
+  tile = b - lo;
+  tiles = hi - lo;
+  return y;
+}
+__device__ __forceinline__ GSProb gs_pick(const GSArgs& a, int y) {
+  // (selected with scalar compares: a run-time index into the by-value argument would go through scratch memory)
+  GSProb p = a.p[0];
+#pragma unroll
+  for (int q = 1; q < GS_MAXPROB; ++q)
+    if (q == y) p = a.p[q];
+  return p;
+}
 
 #ifndef GS_WAVES
 #define GS_WAVES 8
@@ -288,12 +390,96 @@ __device__ __forceinline__ f32x4 gs_sum_waves(const float* red, int t, int ln) {
   return v;
 }
 
-// grid (ceil(maxN / 16), nprob), 64 GS_WAVES threads.   XI: the rows come from the caller's array (GSArgs.xrows)
+// deterministic sum over the first 256 threads of a workgroup of 256 or 64 GS_WAVES threads (result in thread 0; every
+// thread of the workgroup must call): wave sums in wave order
+__device__ __forceinline__ float gs_sum256(float v, float* red4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = osa_wave_sum_dpp(v);
+  __syncthreads();
+  if (lane == 0 && wave < 4) red4[wave] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+#define GS_TLD 20  // leading dimension of a [64 rows][16 columns] tile in LDS
+
+// Squared norm of rows n0 .. n0 + 15 of a layer's weight gradient dW = dZ^T H WITHOUT forming it (round 6: no
+// weight-gradient launch for the clip norm).  With the tile T = dZ[:, n0 .. n0 + 15] in LDS and G = H H^T (64 x 64,
+// written by a Gram problem of the layer's forward launch):
+//     sum_{n, k} dW[n][k]^2 = sum_n T[:, n]^T G T[:, n] = sum_{n, c} D[n][c] T[c][n],   D = T^T G  (64 MFMAs),
+// the critics' L2 term g = dW + c2 W adds 2 c2 <dW, W> + c2^2 |W|^2 with <dW, W> = sum_{r, n} dZ[r][n] Zlin[r][n]
+// (Zlin = H W^T, the forward pass's product before the bias: `cross` is the calling thread's share of that sum) and
+// |W|^2 from the forward launch's slots; the bias gradient (column sums of T, + c2 b) is formed directly.  The same
+// quantity as gs_wgrad_kernel<0>'s, up to float32 summation order.  Waves 0 .. 3 work.
+// (this thread's share of the sum; b4 = the layer's bias n0 + 4 g .. + 3, used by wave 0's lanes j == 0: the bias
+// gradient = column sums of T come from one more MFMA chain against a matrix of ones, not from a serial LDS loop)
+__device__ __forceinline__ float gs_gram_norm(const float* sT, const float (&gv)[16], const float cross, const f32x4 b4,
+                                              const int n0, const int out, const float c2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  float tot = 0.f;
+  if (wave < 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, ones = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float av = sT[(4 * s + g) * GS_TLD + j];
+      acc = OSA_MFMA(av, gv[s], acc);
+      if (wave == 0) ones = OSA_MFMA(av, 1.f, ones);  // wave-uniform
+    }
+    // D[n = 4 g + i][c = 16 wave + j] = acc[i];  ones[i] = sum_r T[r][4 g + i] in every column j
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(sT + (16 * wave + j) * GS_TLD + 4 * g);
+    tot = (acc[0] * tv[0] + acc[1] * tv[1]) + (acc[2] * tv[2] + acc[3] * tv[3]);
+    tot += 2.f * c2 * cross;
+    if (wave == 0 && j == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n0 + 4 * g + i < out) {
+          const float gb = ones[i] + c2 * b4[i];
+          tot += gb * gb;
+        }
+    }
+  }
+  return tot;
+}
+// the Gram operand of gs_gram_norm for this lane: gv[s] = G[4 s + g][16 wave + j] (rows beyond R: zero), waves 0 .. 3
+__device__ __forceinline__ void gs_gram_load(float (&gv)[16], const float* __restrict__ G, const int R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const bool ok = G != nullptr && wave < 4 && 4 * s + g < R;
+    const float v = G[ok ? (4 * s + g) * 64 + 16 * wave + j : 0];
+    gv[s] = ok ? v : 0.f;
+  }
+}
+
+// grid (sum of the problems' tiles: GSArgs.tile0), 64 GS_WAVES threads.   XI: the rows come from the caller's array
+// (GSArgs.xrows)
 template <bool XI>
 __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
   __shared__ __attribute__((aligned(16))) float red[GS_WAVES * 4 * 64 * 4];
-  const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
-  const int n0 = blockIdx.x * 16;
+  __shared__ __attribute__((aligned(16))) float gs_stage[XI ? 4 : GS_WAVES * 80 * 32];
+  __shared__ float wred[GS_WAVES + 1];
+  int tile, tiles;
+  const GSProb p = gs_pick(a, gs_locate(a, tile, tiles));
+  const int n0 = tile * 16;
+  if (XI && a.fin && blockIdx.x == a.tile0[GS_MAXPROB]) {  // the auxiliary workgroup behind the last tile
+    const int t = threadIdx.x;
+    if (t < a.R) {
+      const long row = a.xidx ? a.xidx[t] : t;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) a.scal[q * a.R + t] = a.sp[q] ? a.sp[q][row] : 0.f;
+      if (a.act)
+        for (int d = 0; d < a.lda; ++d) a.actg[t * a.lda + d] = d < a.act_dim ? a.act[row * a.ld_act + d] : 0.f;
+    }
+    if (t >= 64 && t < 67 && ((a.fin_mask >> (t - 64)) & 1)) {
+      const int net = t - 64;
+      const int step = a.adam_step[net] + 1;
+      const float lr = a.lr_dev ? a.lr_dev[net ? 1 : 0] : (net ? a.lr_critic : a.lr_actor);
+      a.fin[net * 8 + 1] = (float)((double)lr / (1.0 - pow((double)a.beta1, (double)step)));
+      a.fin[net * 8 + 2] = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, (double)step)));
+      a.adam_step[net] = step;
+    }
+    return;
+  }
   if (n0 >= p.ldy) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int R = a.R, K = p.K;
@@ -305,7 +491,9 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool wok = n0 + j < p.N;
-  const float* __restrict__ wrow = p.W + (long)(wok ? n0 + j : 0) * p.ldw;
+  long wr = wok ? n0 + j : 0;
+  if (XI && p.wrows && a.xidx) wr = a.xidx[wr];
+  const float* __restrict__ wrow = p.W + wr * p.ldw;
   const float* __restrict__ xrow[4];
   bool xok[4];
 #pragma unroll
@@ -315,16 +503,93 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
     if (XI && a.xidx) r = a.xidx[r];
     xrow[t] = p.X + r * p.ldx;
   }
+  f32x4 wsq4 = {0.f, 0.f, 0.f, 0.f};  // squares of the tile's weights (this lane's share)
+  // the epilogue's operands are requested NOW (a load behind the contraction is a memory round trip of its own):
+  // bias of the thread's four output columns, the fused top layer's weights of those columns, the tile's 16 biases
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, w2pre[4];
+  float bsq = 0.f;
+  {
+    const int n = n0 + 4 * g;
+    if (tid < 256 && p.bias && n < p.ldy) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      w2pre[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tid < 256 && p.oslab && o < p.N2 && n < p.ldy) w2pre[o] = *reinterpret_cast<const f32x4*>(p.W2 + (long)o * p.ldw2 + n);
+    }
+    if (p.slot && p.bias && tid < 16 && n0 + tid < p.N) bsq = p.bias[n0 + tid];
+  }
+#if !defined(GS_NO_STAGE) && GS_KB == 16 && GS_PF == 8
+  if constexpr (!XI) {
+    // Round 6: the operands reach their MFMA lanes through LDS.  An MFMA operand register holds one ROW per lane (lane =
+    // 16 g + j: row j): loaded straight from memory, the 64 lanes of an instruction touch 64 separate 16-byte pieces in
+    // 16 rows and the texture unit spends ~65 cycles per instruction on them (tools/skinny_probe.hip: one workgroup ALONE
+    // takes as long as the whole grid).  Staged, an instruction covers 8 rows x 128 contiguous bytes (eight lanes per
+    // line), each wave writes its sub-chunk of [64 + 16 rows] x [32 columns] to its own LDS buffer and reads the
+    // fragments back in operand layout (XOR-swizzled 16-byte pieces: no bank conflicts either way).  Same operand
+    // values in the same MFMA order as the direct form: bit-identical.
+    float* __restrict__ stg = gs_stage + wave * (80 * 32);
+    const int lrow = lane >> 3, lp = lane & 7;
+    for (int bb = b0; bb < b1; bb += 8) {
+      f32x4 xr[4][8], wr[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = 16 * (bb + 2 * c) + 4 * (lp ^ lrow);  // (rows 8 i + lrow: (row & 7) == lrow)
+        const bool cok = bb + 2 * c + ((lp ^ lrow) >> 2) < b1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int n = n0 + 8 * i + lrow;
+          wr[c][i] = gs_load4(p.W + (long)(n < p.N ? n : 0) * p.ldw, col, p.ldw, cok && n < p.N);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = 8 * i + lrow;
+          xr[c][i] = gs_load4(p.X + (long)(r < R ? r : 0) * p.ldx, col, p.ldx, cok && r < R);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (bb + 2 * c < b1) {  // wave-uniform
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(stg + (8 * i + lrow) * 32 + 4 * lp) = xr[c][i];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(stg + (64 + 8 * i + lrow) * 32 + 4 * lp) = wr[c][i];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (bb + 2 * c + u < b1) {  // wave-uniform
+              const int pc = 4 * (((4 * u + g) ^ j) & 7);
+              const f32x4 wf = *reinterpret_cast<const f32x4*>(stg + (64 + j) * 32 + pc);
+              f32x4 xf[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const f32x4*>(stg + (16 * t + j) * 32 + pc);
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[s], xf[t][s], acc[t]);
+              wsq4 = wsq4 + wf * wf;
+            }
+          }
+        }
+      }
+    }
+  }
+#endif
   // (XI: layer 0 -- obs_dim columns, a block or two per wave: no window of clamped loads)
   constexpr int PFW = XI ? 1 : GS_PF;
+#if !defined(GS_NO_STAGE) && GS_KB == 16 && GS_PF == 8
+  if constexpr (XI)
+#endif
   for (int bb = b0; bb < b1; bb += PFW) {
     // every load of the window is issued before the first MFMA: the weights come from HBM, the rows from L2
     f32x4 wf[PFW][GS_NQ], xf[PFW][GS_NQ][4];
 #pragma unroll
     for (int u = 0; u < PFW; ++u)
 #pragma unroll
-      for (int q = 0; q < GS_NQ; ++q)
-        wf[u][q] = gs_load4(wrow, GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q, p.ldw, wok && bb + u < b1);
+      for (int q = 0; q < GS_NQ; ++q) {
+        const int c = GS_KB * (bb + u) + 4 * GS_NQ * g + 4 * q;
+        wf[u][q] = (XI && p.wrows) ? gs_load4u(wrow, c, K, wok && bb + u < b1) : gs_load4(wrow, c, p.ldw, wok && bb + u < b1);
+      }
 #pragma unroll
     for (int u = 0; u < PFW; ++u)
 #pragma unroll
@@ -337,47 +602,87 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_fwd_kernel(GSArgs a) {
     for (int u = 0; u < PFW; ++u) {
       if (bb + u < b1) {  // wave-uniform
 #pragma unroll
-        for (int q = 0; q < GS_NQ; ++q)
+        for (int q = 0; q < GS_NQ; ++q) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[u][q][s], xf[u][q][t][s], acc[t]);
+          wsq4 = wsq4 + wf[u][q] * wf[u][q];
+        }
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(red + ((wave * 4 + t) * 64 + lane) * 4) = acc[t];
+  if (p.slot) {  // block-uniform
+    const float ws_ = osa_wave_sum_dpp((wsq4.x + wsq4.y) + (wsq4.z + wsq4.w));
+    if (lane == 0) wred[wave] = ws_;
+    if (wave == 0) {
+      const float bq = osa_wave_sum_dpp(bsq * bsq);
+      if (lane == 0) wred[GS_WAVES] = bq;
+    }
+  }
   __syncthreads();
+  if (p.slot && tid == 0) {
+    float wq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; ++w) wq += wred[w];
+    *reinterpret_cast<f32x4*>(p.slot + 4 * tile) = (f32x4){0.f, wred[GS_WAVES], wq, 0.f};
+  }
   if (tid < 256) {
     // D[m = 4 g + r][n = j] of row tile t: output columns n0 + 4 g + r of row 16 t + j
     const int t = tid >> 6, row = 16 * t + j, n = n0 + 4 * g;
     f32x4 v = gs_sum_waves(red, t, lane);
-    if (row < R && n < p.ldy) {
+    const bool ok = row < R && n < p.ldy;
+    f32x4 lin = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y = 0.f;  // (padding columns of the row: zero, the next layer's 16-byte loads run over them)
-        if (n + r < p.N) {
-          y = v[r];
-          if (p.bias) y += p.bias[n + r];
-          if (p.act >= 0) y = gm_act(y, p.act);
-        }
-        v[r] = y;
+    for (int r = 0; r < 4; ++r) {
+      float y = 0.f;  // (padding columns of the row: zero, the next layer's 16-byte loads run over them)
+      if (ok && n + r < p.N) {
+        y = v[r];
+        lin[r] = y;
+        y += bias4[r];
+        if (p.act >= 0) y = gm_act(y, p.act);
       }
+      v[r] = y;
+    }
+    if (ok) {
       *reinterpret_cast<f32x4*>(p.Y + (long)row * p.ldy + n) = v;
+      if (p.Ylin) *reinterpret_cast<f32x4*>(p.Ylin + (long)row * p.ldy + n) = lin;
+    }
+    if (p.oslab) {  // block-uniform: the top layer's partial outputs from this tile's 16 columns (sum over g by shuffles)
+      for (int o = 0; o < p.ldo2; ++o) {
+        float part = 0.f;
+        if (ok && o < p.N2) {
+          f32x4 w2 = w2pre[0];
+          if (o == 1) w2 = w2pre[1];
+          if (o == 2) w2 = w2pre[2];
+          if (o == 3) w2 = w2pre[3];
+          if (o >= 4) w2 = *reinterpret_cast<const f32x4*>(p.W2 + (long)o * p.ldw2 + n);
+          part = (v[0] * w2[0] + v[1] * w2[1]) + (v[2] * w2[2] + v[3] * w2[3]);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (g == 0 && row < R) p.oslab[((long)tile * 64 + row) * p.ldo2 + o] = part;
+      }
     }
   }
 }
 
-// grid (ceil(maxK / 16), nprob), 64 GS_WAVES threads
+// grid (sum of the problems' tiles), 64 GS_WAVES threads
 __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
   __shared__ __attribute__((aligned(16))) float red[GS_WAVES * 4 * 64 * 4];
-  const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
+  __shared__ __attribute__((aligned(16))) float sT[64 * GS_TLD];
+  __shared__ __attribute__((aligned(16))) float gs_stage[GS_WAVES * 64 * 32];
+  __shared__ float red4[4];
+  int tile, tiles;
+  const GSProb p = gs_pick(a, gs_locate(a, tile, tiles));
   // Column tiles 2 m and 2 m + 1 read the two 64-byte halves of the SAME 128-byte lines of every weight row: in dispatch
   // order they land on different XCCs (workgroup i -> XCC i mod 8) and both L2s fetch the line -- the launch then moves
   // 34 MB instead of 21 (profiles/r5_pmc_traffic_general_1024_B64_table.md).  Remapped, the pair shares an XCC.
-  int bx = blockIdx.x;
+  int bx = tile;
 #ifndef GS_BWD_NO_PAIR
-  if ((gridDim.x & 15) == 0) {
+  if ((tiles & 15) == 0 && ((blockIdx.x - tile) & 7) == 0) {
     const int xcd = bx & 7, slot = bx >> 3;
     bx = 2 * ((slot >> 1) * 8 + xcd) + (slot & 1);
   }
@@ -400,6 +705,71 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
     xok[t] = 16 * t + j < R;
     xrow[t] = p.X + (long)(xok[t] ? 16 * t + j : 0) * p.ldx;
   }
+  float gv[16];  // (round 6) this lane's share of the Gram matrix for the norm of the produced rows' weight gradient
+  const bool norm = a.fused && p.nslot;
+  if (norm) gs_gram_load(gv, p.G, R);
+  // the epilogue's operands are requested now (see gs_fwd_kernel)
+  f32x4 hpre = {0.f, 0.f, 0.f, 0.f}, zpre = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bpre = {0.f, 0.f, 0.f, 0.f};
+  if (norm && wave == 0 && j == 0 && k0 + 4 * g < p.ldy) bpre = *reinterpret_cast<const f32x4*>(p.bvec + k0 + 4 * g);
+  if (tid < 256) {
+    const int row = 16 * (tid >> 6) + j, k = k0 + 4 * g;
+    if (row < R && k < p.ldy) {
+      if (p.act >= 0) hpre = *reinterpret_cast<const f32x4*>(p.aux + (long)row * p.ldaux + k);
+      if (norm && p.Zlin) zpre = *reinterpret_cast<const f32x4*>(p.Zlin + (long)row * p.ldy + k);
+    }
+  }
+#if !defined(GS_NO_STAGE) && GS_PF == 8
+  // (round 6) the dZ rows reach their MFMA lanes through LDS -- coalesced 8 rows x 128 bytes per instruction, see
+  // gs_fwd_kernel; the weight fragments are 4-byte loads of 16 consecutive columns per row already
+  float* __restrict__ stg = gs_stage + wave * (64 * 32);
+  const int lrow = lane >> 3, lp = lane & 7;
+  for (int bb = b0; bb < b1; bb += 8) {
+    float wf[8][4];
+    f32x4 xr[4][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int n = 16 * (bb + u) + 4 * g + s;
+        const bool ok = kok && bb + u < b1 && n < N;
+        const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
+        wf[u][s] = ok ? wv : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 16 * (bb + 2 * c) + 4 * (lp ^ lrow);
+      const bool cok = bb + 2 * c + ((lp ^ lrow) >> 2) < b1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * i + lrow;
+        xr[c][i] = gs_load4(p.X + (long)(r < R ? r : 0) * p.ldx, col, p.ldx, cok && r < R);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (bb + 2 * c < b1) {  // wave-uniform
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(stg + (8 * i + lrow) * 32 + 4 * lp) = xr[c][i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (bb + 2 * c + u < b1) {  // wave-uniform
+            const int pc = 4 * (((4 * u + g) ^ j) & 7);
+            f32x4 xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const f32x4*>(stg + (16 * t + j) * 32 + pc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[2 * c + u][s], xf[t][s], acc[t]);
+          }
+        }
+      }
+    }
+  }
+#else
   for (int bb = b0; bb < b1; bb += GS_PF) {
     // A fragments: step s of block u contracts n = 16 (bb + u) + 4 g + s (the same permutation for both operands);
     // branch-free (clamped address, value selected), all loads of the window before the first MFMA
@@ -428,15 +798,17 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
       }
     }
   }
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(red + ((wave * 4 + t) * 64 + lane) * 4) = acc[t];
   __syncthreads();
+  float cross = 0.f;
   if (tid < 256) {
     const int t = tid >> 6, row = 16 * t + j, k = k0 + 4 * g;
     f32x4 v = gs_sum_waves(red, t, lane);
-    if (row < R && k < p.ldy) {
-      f32x4 h = {0.f, 0.f, 0.f, 0.f};
-      if (p.act >= 0) h = *reinterpret_cast<const f32x4*>(p.aux + (long)row * p.ldaux + k);
+    const bool ok = row < R && k < p.ldy;
+    if (ok) {
+      const f32x4 h = hpre;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float y = 0.f;
@@ -447,7 +819,18 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
         v[r] = y;
       }
       *reinterpret_cast<f32x4*>(p.Y + (long)row * p.ldy + k) = v;
+    } else {
+      v = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (norm) {
+      *reinterpret_cast<f32x4*>(sT + row * GS_TLD + 4 * g) = v;
+      cross = (v[0] * zpre[0] + v[1] * zpre[1]) + (v[2] * zpre[2] + v[3] * zpre[3]);
+    }
+  }
+  if (norm) {  // block-uniform
+    __syncthreads();
+    const float gq = gs_sum256(gs_gram_norm(sT, gv, cross, bpre, k0, p.K, p.c2), red4);
+    if (tid == 0) *reinterpret_cast<f32x4*>(p.nslot + 4 * bx) = (f32x4){gq, 0.f, 0.f, 0.f};
   }
 }
 
@@ -457,48 +840,226 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
 // once.  Workgroup 0 of a network is the writer: dL/d(output) rows for the weight-gradient launch, block partials of
 // dL/d(log_std), loss statistics.  Networks without a hidden layer take part with zero output columns (loss only).
 #define GS_TOP_LDZ 36  // leading dimension of the dL/d(output) image in LDS (top layers up to 32 wide)
-// grid (max(1, ceil(maxK / 16)), nprob), 256 threads (wave = row tile)
-__global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la) {
+#ifdef GS_CLOCKS  // (tools/skinny_probe.hip: phase stamps of one workgroup)
+__device__ long long gs_clk[2][16];
+#define GS_STAMP(i) do { if (threadIdx.x == 0 && tile < 2 && p.net == 0) gs_clk[tile][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GS_STAMP(i) do { } while (0)
+#endif
+struct GSTopFin {  // (round 6) what gs_wgrad_kernel<0>'s tail workgroup did: the writer workgroups of the top launch do it
+  float* stats;
+  float entropy_coef;
+  int loss_kind, act_dim;
+};
+// grid (sum over the problems of max(1, tiles)), 256 threads (wave = row tile)
+// a.fused (round 6, mode 0): (1) the top layer's OUTPUT is the sum of the partial slabs the forward launch of the layer
+// below left (GSProb.oslab; no launch for a 1024 -> 2 layer), (2) norm slots: the top layer's weight-gradient block of
+// this workgroup's 16 input columns directly (dZ is <= 32 wide), the rows k0 .. k0 + 15 of the layer below through its
+// Gram matrix (gs_gram_norm), (3) the writer workgroup: log_std, Adam's bias corrections, loss statistics.
+__global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GSTopFin tf) {
   __shared__ __attribute__((aligned(16))) float sDZ[64 * GS_TOP_LDZ];
+  __shared__ __attribute__((aligned(16))) float sOut[64 * GS_TOP_LDZ];
+  __shared__ __attribute__((aligned(16))) float sT[64 * GS_TLD];
+  __shared__ __attribute__((aligned(16))) float sA[64 * GS_TLD];
+  __shared__ float sAct[64 * 32];
+  __shared__ float sLS[4 * 32];  // the actor's log_std and its tables (GLossLds)
+  __shared__ float sLam;         // the Lagrange multiplier
+  __shared__ float sBT[8];       // the fused top layer's bias
+  __shared__ __attribute__((aligned(16))) float sPart[4 * 64 * 8];
+  __shared__ float sums[2 + 32];
   __shared__ float red[4];
-  const GSProb p = blockIdx.y == 0 ? a.p[0] : (blockIdx.y == 1 ? a.p[1] : a.p[2]);
-  const int k0 = blockIdx.x * 16;
-  const bool writer = blockIdx.x == 0;
+  __shared__ float red3[4 * 3];
+  int tile, tiles;
+  const GSProb p = gs_pick(a, gs_locate(a, tile, tiles));
+  const int k0 = tile * 16;
+  const bool writer = tile == 0;
   if (!writer && k0 >= p.ldy) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int net = p.net, R = a.R, ldz = la.ldz[net];
+  const bool fused = a.fused != 0;
+  GS_STAMP(0);
+  // ---- every operand that depends on nothing is requested before the first dependent step (each load issued later is
+  // a memory round trip of its own on the critical path of this latency-bound launch)
+  const long lrow = tid < R && (!fused || la.ext_on) ? (la.idx ? la.idx[tid] : tid) : 0;  // (fused: only FOCOPS / P3O's old_mean)
+  float gv[16];
+  if (fused) gs_gram_load(gv, p.G, R);
+  const int N = p.N;
+  const bool cols = k0 < p.ldy;
+  const bool kok = cols && k0 + j < p.K;
+  const float* __restrict__ wcol = p.W + (kok ? k0 + j : 0);
+  float wf[2][4];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = 16 * bb + 4 * g + s;
+      const bool ok = kok && n < N;
+      const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
+      wf[bb][s] = ok ? wv : 0.f;
+    }
+  const int row = 16 * wave + j, k = k0 + 4 * g;
+  const bool ok = cols && row < R && k < p.ldy;
+  f32x4 h = {0.f, 0.f, 0.f, 0.f}, zl = {0.f, 0.f, 0.f, 0.f}, bpre = {0.f, 0.f, 0.f, 0.f};
+  f32x4 btop4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (ok && (p.act >= 0 || fused)) h = *reinterpret_cast<const f32x4*>(p.aux + (long)row * p.ldaux + k);
+  if (ok && fused && p.Zlin) zl = *reinterpret_cast<const f32x4*>(p.Zlin + (long)row * p.ldy + k);
+  if (fused) {
+    if (cols && wave == 0 && j == 0 && k < p.ldy) bpre = *reinterpret_cast<const f32x4*>(p.bvec + k);
+    if (writer && wave == 3 && j == 0) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+        if (16 * hb + 4 * g < (N + 3) / 4 * 4) btop4[hb] = *reinterpret_cast<const f32x4*>(p.btop + 16 * hb + 4 * g);
+    }
+  }
+  // the top layer's weights of this workgroup's block in the layout of the norm's MFMA result (waves 1, 2)
+  float wdir[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fused && (wave == 1 || wave == 2)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = 16 * (wave - 1) + 4 * g + i;
+      if (kok && n < N) wdir[i] = p.W[(long)n * p.ldw + k0 + j];
+    }
+  }
+  // the fused top layer's partial outputs: lane = row, wave w sums the slabs w, w + 4, ... (16-byte pieces of the row, all
+  // of them requested at once), the four partial sums meet in LDS
+  const bool ofuse = fused && p.oslab != nullptr && p.ldo2 <= 8 && p.nbo <= 64;
+  f32x4 osum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (ofuse) {
+    const long ne = 64 * p.ldo2;
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      if (4 * q4 < p.ldo2) {  // block-uniform
+        f32x4 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int b = wave + 4 * i;
+          const bool bok = lane < R && b < p.nbo;
+          const f32x4 x = *reinterpret_cast<const f32x4*>(p.oslab + (bok ? b * ne + lane * p.ldo2 + 4 * q4 : 0));
+          t[i] = bok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) osum[q4] = osum[q4] + t[i];
+      }
+    }
+  }
+  // the loss's per-sample operands, gathered by the step's first launch (GSArgs.scal / actg): scalars in registers of
+  // wave 0 (lane = row); action rows, log_std with its tables and the Lagrange multiplier in LDS
+  float scv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (fused) {
+    if (tid < la.act_dim) {
+      const float ls = la.log_std[tid], sd = expf(ls);
+      sLS[tid] = ls;
+      sLS[32 + tid] = sd;
+      sLS[64 + tid] = logf(sd);
+      sLS[96 + tid] = 1.f / (sd * sd);
+    }
+    if (tid == 32) sLam = la.lagrange ? *la.lagrange : 0.f;
+    if (ofuse && tid >= 64 && tid < 64 + p.ldo2) sBT[tid - 64] = tid - 64 < N ? p.btop[tid - 64] : 0.f;
+    if (tid < R) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) scv[q] = la.scal[q * R + tid];
+      if (net == 0)
+        for (int d = 0; d < la.act_dim; ++d) sAct[tid * 32 + d] = la.actg[tid * la.lda + d];
+    }
+  }
+  GS_STAMP(1);
+  const float* outp = la.out[net];
+  int ldop = la.ldo[net];
+  if (ofuse) {  // block-uniform
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4)
+      if (4 * q4 < p.ldo2) *reinterpret_cast<f32x4*>(sPart + (wave * 64 + lane) * 8 + 4 * q4) = osum[q4];
+    outp = sOut;
+    ldop = GS_TOP_LDZ;
+  } else if (fused && p.oslab) {
+    const int ne = 64 * p.ldo2;
+    for (int e = tid; e < ne; e += 256) {
+      const int orow = e / p.ldo2, o = e - orow * p.ldo2;
+      float v = 0.f;
+      if (orow < R) {
+        const float* __restrict__ sl = p.oslab + e;
+        for (int b = 0; b < p.nbo; ++b) v += sl[(long)b * ne];
+        if (o < N) v += p.btop[o];
+        if (writer) const_cast<float*>(la.out[net])[(long)orow * la.ldo[net] + o] = v;
+      }
+      sOut[orow * GS_TOP_LDZ + o] = v;
+    }
+    outp = sOut;
+    ldop = GS_TOP_LDZ;
+  }
+  GS_STAMP(2);
+  if (fused && !p.oslab) {  // (a top layer wider than 8 outputs ran as a launch of its own: its rows into the LDS image)
+    for (int e = tid; e < R * ldop; e += 256) sOut[(e / ldop) * GS_TOP_LDZ + e % ldop] = outp[e];
+  }
   for (int e = tid; e < 64 * GS_TOP_LDZ; e += 256) sDZ[e] = 0.f;
   __syncthreads();
-  gm_loss_body(la, net, tid, 0, red, sDZ, GS_TOP_LDZ, writer);  // (rows beyond R: nothing written, the image stays zero)
+  // (rows beyond R: nothing written, the image stays zero)
+  if (fused) {
+    if (wave == 0) {  // <= 64 rows: wave 0 alone, wave sums
+      if (ofuse && tid < R) {  // this row's outputs = bias + the four partial sums, in wave order
+        for (int o = 0; o < p.ldo2; ++o) {
+          float v = (sPart[(0 * 64 + tid) * 8 + o] + sPart[(1 * 64 + tid) * 8 + o]) +
+                    (sPart[(2 * 64 + tid) * 8 + o] + sPart[(3 * 64 + tid) * 8 + o]);
+          if (o < N) v += sBT[o];
+          sOut[tid * GS_TOP_LDZ + o] = v;
+          if (writer) const_cast<float*>(la.out[net])[(long)tid * la.ldo[net] + o] = v;
+        }
+      }
+      GLossLds acc;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) acc.sc_[q] = scv[q];
+      acc.lam_ = sLam;
+      acc.act_ = (const lds_f*)sAct + tid * 32;
+      acc.out_ = (const lds_f*)sOut + tid * GS_TOP_LDZ;
+      acc.ls_ = (const lds_f*)sLS;
+      acc.dz_ = (lds_f*)sDZ + tid * GS_TOP_LDZ;
+      gm_loss_body<true>(la, net, tid, 0, red, GS_TOP_LDZ, writer, acc, sums, lrow);
+    }
+  } else {
+    const GLossMem acc{la, tid, lrow, outp + (long)tid * ldop, sDZ + tid * GS_TOP_LDZ};
+    gm_loss_body<false>(la, net, tid, 0, red, GS_TOP_LDZ, writer, acc, nullptr, lrow);
+  }
   __syncthreads();
+  GS_STAMP(3);
   if (writer)
     for (int e = tid; e < R * ldz; e += 256) la.dz[net][e] = sDZ[(e / ldz) * GS_TOP_LDZ + e % ldz];
-  if (k0 >= p.ldy) return;
+  float tq = 0.f, tp = 0.f;  // the top layer's slot of this workgroup
+  if (fused && writer) {
+    // ---- the actor's log_std, statistics (gs_wgrad_kernel<0>'s tail; the bias corrections: the step's first launch)
+    const bool critic = net != 0;
+    if (!critic && tid < tf.act_dim && tf.loss_kind != 2) {
+      const float g_ = sums[2 + tid] - tf.entropy_coef / (float)tf.act_dim;
+      tq += g_ * g_;
+    }
+    if (tid == 0) {
+      if (tf.stats && tf.loss_kind != 2) {
+        const float invB = 1.f / (float)R;
+        if (net == 0) {
+          float ent = 0.f;
+          for (int d = 0; d < tf.act_dim; ++d) ent += 1.41893853320467274178f + sLS[d];
+          ent /= (float)tf.act_dim;
+          tf.stats[2] = sums[0] * invB - tf.entropy_coef * ent;
+          tf.stats[3] = sums[1] * invB;
+          tf.stats[4] = ent;
+        } else {
+          tf.stats[net - 1] = sums[0] * invB;
+        }
+      }
+    }
+  }
+  if (!cols) return;  // (a writer without columns: never with a.fused, whose networks have a hidden layer)
+  GS_STAMP(4);
   // ---- dZ'[r][k] = (sum_n dZ[r][n] W[n][k]) act'(H[r][k]) for the 16 columns k0 .., row tile = wave
-  const int N = p.N;
-  const bool kok = k0 + j < p.K;
-  const float* __restrict__ wcol = p.W + (kok ? k0 + j : 0);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
     if (16 * bb < N) {  // block-uniform
-      float wf[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int n = 16 * bb + 4 * g + s;
-        const bool ok = kok && n < N;
-        const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
-        wf[s] = ok ? wv : 0.f;
-      }
       const f32x4 xf = *reinterpret_cast<const f32x4*>(sDZ + (16 * wave + j) * GS_TOP_LDZ + 16 * bb + 4 * g);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = OSA_MFMA(wf[s], xf[s], acc);
+      for (int s = 0; s < 4; ++s) acc = OSA_MFMA(wf[bb][s], xf[s], acc);
     }
   }
-  const int row = 16 * wave + j, k = k0 + 4 * g;
-  if (row < R && k < p.ldy) {
-    f32x4 h = {0.f, 0.f, 0.f, 0.f};
-    if (p.act >= 0) h = *reinterpret_cast<const f32x4*>(p.aux + (long)row * p.ldaux + k);
+  if (ok) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y = 0.f;
@@ -509,7 +1070,70 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la) {
       acc[r] = y;
     }
     *reinterpret_cast<f32x4*>(p.Y + (long)row * p.ldy + k) = acc;
+  } else {
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  if (!fused) return;
+  *reinterpret_cast<f32x4*>(sT + row * GS_TLD + 4 * g) = acc;
+  *reinterpret_cast<f32x4*>(sA + row * GS_TLD + 4 * g) = h;
+  const float cross = (acc[0] * zl[0] + acc[1] * zl[1]) + (acc[2] * zl[2] + acc[3] * zl[3]);
+  __syncthreads();
+  GS_STAMP(5);
+  // ---- norm of the top layer's weight gradient for the input columns k0 .. k0 + 15, formed directly (the layer is at most
+  // 32 outputs wide): dW[n][k] = sum_r dZ[r][n] H[r][k] as one MFMA chain per 16 outputs (waves 1, 2); its bias
+  // gradient = column sums of dZ against a matrix of ones (writer, wave 3)
+  if (wave == 1 || wave == 2) {
+    const int hb = wave - 1;
+    if (16 * hb < N) {  // wave-uniform
+      f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        dw = OSA_MFMA(sDZ[(4 * s + g) * GS_TOP_LDZ + 16 * hb + j], sA[(4 * s + g) * GS_TLD + j], dw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (kok && 16 * hb + 4 * g + i < N) {  // D[n = 16 hb + 4 g + i][k = k0 + j]
+          const float w = wdir[i], gg = dw[i] + p.c2 * w;
+          tq += gg * gg;
+          if (net != 0) tp += w * w;
+        }
+    }
+  }
+  if (writer && wave == 3) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+      if (16 * hb < N) {  // block-uniform
+        f32x4 ones = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) ones = OSA_MFMA(sDZ[(4 * s + g) * GS_TOP_LDZ + 16 * hb + j], 1.f, ones);
+        if (j == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (16 * hb + 4 * g + i < N) {
+              const float bw = btop4[hb][i], gb = ones[i] + p.c2 * bw;
+              tq += gb * gb;
+              if (net != 0) tp += bw * bw;
+            }
+        }
+      }
+  }
+  // ---- rows k0 .. k0 + 15 of the layer below through its input rows' Gram matrix
+  float gq = gs_gram_norm(sT, gv, cross, bpre, k0, p.K, p.c2);
+  GS_STAMP(6);
+  tq = osa_wave_sum_dpp(tq);
+  tp = osa_wave_sum_dpp(tp);
+  gq = osa_wave_sum_dpp(gq);
+  if (lane == 0) {
+    red3[wave * 3 + 0] = tq;
+    red3[wave * 3 + 1] = tp;
+    red3[wave * 3 + 2] = gq;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *reinterpret_cast<f32x4*>(p.tslot + 4 * tile) =
+        (f32x4){(red3[0] + red3[3]) + (red3[6] + red3[9]), (red3[1] + red3[4]) + (red3[7] + red3[10]), 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(p.nslot + 4 * tile) = (f32x4){(red3[2] + red3[5]) + (red3[8] + red3[11]), 0.f, 0.f, 0.f};
+  }
+  GS_STAMP(7);
 }
 
 struct GSWLayer {
@@ -527,7 +1151,10 @@ struct GSWArgs {
   int R, P, maxT1, act_dim, lda, nblk, nets_mask, loss_kind, write_grads, use_critic_norm;
   // fold != 0 (mode 0): no gm_final_kernel -- phase 0's tail workgroup advances the step counter and leaves Adam's
   // bias corrections in fin, every workgroup of phase 1 sums the norm partials itself (gm_final_kernel's order)
+  // fold == 2 (round 6): no phase 0 at all -- the partials are the norm slots of the other launches (gs_gram_norm)
   int fold, use_max_grad_norm;
+  const float* slots;  // [3][slot_stride][4]
+  int slot_stride, nslot[3];
   float* params;
   float* adam_m;
   float* adam_v;
@@ -604,6 +1231,15 @@ __global__ __launch_bounds__(256) void gs_wgrad_kernel(GSWArgs a) {
     ibc2 = a.fin[net * 8 + 2];
     if (a.fold) {
       float gq = 0.f, pq = 0.f;
+      if (a.fold == 2) {  // (round 6) the slots of the forward / top / backward launches: {g^2 part, b^2, w^2, -}
+        const float cc = l2 ? c2 * c2 : 0.f;
+        const f32x4* __restrict__ sl = reinterpret_cast<const f32x4*>(a.slots) + (long)net * a.slot_stride;
+        for (int k = tid; k < a.nslot[net]; k += 256) {
+          const f32x4 v = sl[k];
+          gq += v[0] + cc * v[2];
+          pq += v[1] + v[2];
+        }
+      } else
       for (int k = tid; k < a.maxT1; k += 256) {
         gq += a.npart[((long)net * a.maxT1 + k) * 2 + 0];
         pq += a.npart[((long)net * a.maxT1 + k) * 2 + 1];
