@@ -953,11 +953,8 @@ int gm_minibatch_skinny(const GLayout& lo, const GWs& w, float* params, float* a
   // (round 6) mode 0: the clip norm comes out of the forward / top / backward launches (gs_gram_norm) and the top layer's
   // forward pass rides in the launch below it -- 2 L - 1 launches instead of 2 L + 1.  Every active network needs a
   // hidden layer and a top layer of at most 32 outputs; OSA_GMLP_NORM_FUSE=0 keeps round 5's launches (A/B, tests).
-  static const bool norm_fuse_on = [] {
-    const char* v = getenv("OSA_GMLP_NORM_FUSE");
-    return !(v != nullptr && v[0] == '0' && v[1] == 0);
-  }();
-  bool fusedn = mode == 0 && norm_fuse_on;
+  const char* nf = getenv("OSA_GMLP_NORM_FUSE");  // (read per call: the tests switch it inside one process)
+  bool fusedn = mode == 0 && !(nf != nullptr && nf[0] == '0' && nf[1] == 0);
   for (int net = 0; net < 3; ++net) {
     if (!((mask >> net) & 1)) continue;
     const GNet& n = lo.n[net];

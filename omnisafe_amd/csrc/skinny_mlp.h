@@ -95,6 +95,12 @@ struct GLossArgs {
 // WAVE: called by wave 0 alone for <= 64 rows, the sums are wave sums (no __syncthreads).
 // sums != nullptr: thread 0 leaves {loss sum, ratio sum, dL/d(log_std)[0 .. act_dim)} of the block there.
 typedef __attribute__((address_space(3))) float lds_f;
+#ifdef GS_CLOCKS  // (tools/skinny_probe.hip: phase stamps inside the loss of workgroup 1)
+__device__ long long gs_lclk[16];
+#define GS_LSTAMP(i) do { if (WAVE && threadIdx.x == 0 && blockIdx.x == 1) gs_lclk[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GS_LSTAMP(i) do { } while (0)
+#endif
 struct GLossMem {
   const GLossArgs& a;
   long b, row;
@@ -138,6 +144,7 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
   auto BSUM = [&](float v) -> float { return WAVE ? osa_wave_sum_dpp(v) : gm_block_sum(v, red); };
   const float invB = 1.f / (float)a.R;
   float loss = 0.f, ratio_s = 0.f;
+    GS_LSTAMP(0);
   if (net != 0) {
     if (valid) {
       const float diff = acc.out(0) - SC(net == 1 ? 3 : 4);
@@ -163,6 +170,7 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
         lp += -(z * z) / (2.f * (sd * sd)) - acc.logsd(d) - 0.91893853320467274178f;
       }
     const float ratio = valid ? expf(lp - SC(0)) : 0.f;
+    GS_LSTAMP(1);
     // ---- extended surrogates: per-sample KL(pi_theta || pi_old) (torch.distributions.kl._kl_normal_normal), FOCOPS'
     // trust mask with the reference's broadcast semantics (focops.py:84-88: the surrogate term sees the minibatch MEAN
     // of the mask), P3O's kappa * relu(mean(ratio * A_c) + excess) -- the arithmetic of osa_mb_grad_kernel's EXT form.
@@ -213,6 +221,7 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
       ratio_s = ratio;
       dlogp = dratio * ratio * invB;
     }
+    GS_LSTAMP(2);
     // d logp / d mu = z / var;  d logp / d log_std = z^2 / var - 1; block sums of the latter, dimension by dimension
     for (int d = 0; d < a.act_dim; ++d) {
       float dl = 0.f;
@@ -234,11 +243,14 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
       if (threadIdx.x == 0 && writer) a.dls[(long)blk * a.lda + d] = dl;
       if (threadIdx.x == 0 && sums) sums[2 + d] = dl;
     }
+    GS_LSTAMP(3);
     if (valid)
       for (int d = a.act_dim; d < ldzp; ++d) acc.dz(d, 0.f);  // (row padding)
   }
+    GS_LSTAMP(4);
   loss = BSUM(loss);
   ratio_s = BSUM(ratio_s);
+    GS_LSTAMP(5);
   if (threadIdx.x == 0 && writer) {
     float* lp_ = a.lpart + ((long)net * a.nblk + blk) * 4;
     lp_[0] = loss;
@@ -248,6 +260,7 @@ __device__ __forceinline__ void gm_loss_body(const GLossArgs& a, const int net, 
     sums[0] = loss;
     sums[1] = ratio_s;
   }
+  GS_LSTAMP(6);
 }
 
 
@@ -421,7 +434,7 @@ __device__ __forceinline__ float gs_gram_norm(const float* sT, const float (&gv)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, ones = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float av = sT[(4 * s + g) * GS_TLD + j];
+      const float av = sT[(16 * (s >> 2) + 4 * g + (s & 3)) * GS_TLD + j];  // (row r(s, g) of gs_gram_load)
       acc = OSA_MFMA(av, gv[s], acc);
       if (wave == 0) ones = OSA_MFMA(av, 1.f, ones);  // wave-uniform
     }
@@ -440,14 +453,19 @@ __device__ __forceinline__ float gs_gram_norm(const float* sT, const float (&gv)
   }
   return tot;
 }
-// the Gram operand of gs_gram_norm for this lane: gv[s] = G[4 s + g][16 wave + j] (rows beyond R: zero), waves 0 .. 3
+// the Gram operand of gs_gram_norm for this lane, waves 0 .. 3.  MFMA step s of lane group g contracts row
+// r(s, g) = 16 (s >> 2) + 4 g + (s & 3) (any permutation serves as long as both operands use it): the four steps of a
+// quarter then need G[r .. r + 3][c], which by symmetry is the 16-byte piece G[c][r .. r + 3] -- four loads instead of 16
 __device__ __forceinline__ void gs_gram_load(float (&gv)[16], const float* __restrict__ G, const int R) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int c = 16 * wave + j;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const bool ok = G != nullptr && wave < 4 && 4 * s + g < R;
-    const float v = G[ok ? (4 * s + g) * 64 + 16 * wave + j : 0];
-    gv[s] = ok ? v : 0.f;
+  for (int q = 0; q < 4; ++q) {
+    const int r = 16 * q + 4 * g;
+    const bool ok = G != nullptr && wave < 4 && c < R;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(G + (ok ? c * 64 + r : 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[4 * q + i] = ok && r + i < R ? v[i] : 0.f;
   }
 }
 
@@ -843,7 +861,13 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
 #ifdef GS_CLOCKS  // (tools/skinny_probe.hip: phase stamps of one workgroup)
 __device__ long long gs_clk[2][16];
 #define GS_STAMP(i) do { if (threadIdx.x == 0 && tile < 2 && p.net == 0) gs_clk[tile][i] = __builtin_readcyclecounter(); } while (0)
+#ifdef GS_CLOCKS_WAIT  // every group of loads waited for: what each costs alone
+#define GS_WSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 64 && tile == 1 && p.net == 0) gs_clk[0][8 + i] = __builtin_readcyclecounter(); } while (0)
 #else
+#define GS_WSTAMP(i) do { } while (0)
+#endif
+#else
+#define GS_WSTAMP(i) do { } while (0)
 #define GS_STAMP(i) do { } while (0)
 #endif
 struct GSTopFin {  // (round 6) what gs_wgrad_kernel<0>'s tail workgroup did: the writer workgroups of the top launch do it
@@ -878,11 +902,13 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
   const int net = p.net, R = a.R, ldz = la.ldz[net];
   const bool fused = a.fused != 0;
   GS_STAMP(0);
+  GS_WSTAMP(0);
   // ---- every operand that depends on nothing is requested before the first dependent step (each load issued later is
   // a memory round trip of its own on the critical path of this latency-bound launch)
   const long lrow = tid < R && (!fused || la.ext_on) ? (la.idx ? la.idx[tid] : tid) : 0;  // (fused: only FOCOPS / P3O's old_mean)
   float gv[16];
   if (fused) gs_gram_load(gv, p.G, R);
+  GS_WSTAMP(1);
   const int N = p.N;
   const bool cols = k0 < p.ldy;
   const bool kok = cols && k0 + j < p.K;
@@ -897,6 +923,7 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
       const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
       wf[bb][s] = ok ? wv : 0.f;
     }
+  GS_WSTAMP(2);
   const int row = 16 * wave + j, k = k0 + 4 * g;
   const bool ok = cols && row < R && k < p.ldy;
   f32x4 h = {0.f, 0.f, 0.f, 0.f}, zl = {0.f, 0.f, 0.f, 0.f}, bpre = {0.f, 0.f, 0.f, 0.f};
@@ -920,6 +947,7 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
       if (kok && n < N) wdir[i] = p.W[(long)n * p.ldw + k0 + j];
     }
   }
+  GS_WSTAMP(3);
   // the fused top layer's partial outputs: lane = row, wave w sums the slabs w, w + 4, ... (16-byte pieces of the row, all
   // of them requested at once), the four partial sums meet in LDS
   const bool ofuse = fused && p.oslab != nullptr && p.ldo2 <= 8 && p.nbo <= 64;
@@ -942,6 +970,7 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
       }
     }
   }
+  GS_WSTAMP(4);
   // the loss's per-sample operands, gathered by the step's first launch (GSArgs.scal / actg): scalars in registers of
   // wave 0 (lane = row); action rows, log_std with its tables and the Lagrange multiplier in LDS
   float scv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -962,6 +991,7 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
         for (int d = 0; d < la.act_dim; ++d) sAct[tid * 32 + d] = la.actg[tid * la.lda + d];
     }
   }
+  GS_WSTAMP(5);
   GS_STAMP(1);
   const float* outp = la.out[net];
   int ldop = la.ldo[net];
@@ -1013,7 +1043,8 @@ __global__ __launch_bounds__(256) void gs_top_kernel(GSArgs a, GLossArgs la, GST
       acc.out_ = (const lds_f*)sOut + tid * GS_TOP_LDZ;
       acc.ls_ = (const lds_f*)sLS;
       acc.dz_ = (lds_f*)sDZ + tid * GS_TOP_LDZ;
-      gm_loss_body<true>(la, net, tid, 0, red, GS_TOP_LDZ, writer, acc, sums, lrow);
+      // (ldzp = the layer's width: the image is zero already, no padding loop)
+      gm_loss_body<true>(la, net, tid, 0, red, net == 0 ? la.act_dim : 1, writer, acc, sums, lrow);
     }
   } else {
     const GLossMem acc{la, tid, lrow, outp + (long)tid * ldop, sDZ + tid * GS_TOP_LDZ};
@@ -1221,8 +1252,9 @@ __global__ __launch_bounds__(256) void gs_wgrad_kernel(GSWArgs a) {
     w4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (PHASE == 1 || critic) w4[r] = *reinterpret_cast<const f32x4*>(P_ + ro[r]);
     if (PHASE == 1) {
-      m4[r] = *reinterpret_cast<const f32x4*>(M_ + ro[r]);
-      v4[r] = *reinterpret_cast<const f32x4*>(V_ + ro[r]);
+      // (the moments are read and written once per step and by nobody else: non-temporal)
+      m4[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(M_ + ro[r]));
+      v4[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(V_ + ro[r]));
     }
   }
   float coef = 1.f, step_size = 0.f, ibc2 = 0.f, total_norm = 0.f, total_psq = 0.f;
@@ -1357,8 +1389,8 @@ __global__ __launch_bounds__(256) void gs_wgrad_kernel(GSWArgs a) {
         f32x4 m = m4[r], v = v4[r];
         const f32x4 wn = osa_adam_update4(gv * coef, m, v, w, a.beta1, a.beta2, step_size, ibc2, a.eps);
         *reinterpret_cast<f32x4*>(P_ + ro[r]) = wn;
-        *reinterpret_cast<f32x4*>(M_ + ro[r]) = m;
-        *reinterpret_cast<f32x4*>(V_ + ro[r]) = v;
+        __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(M_ + ro[r]));
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(V_ + ro[r]));
       }
     }
   }

@@ -526,3 +526,60 @@ def test_skinny_step_with_network_masks_equals_the_tiled_step(monkeypatch, mask_
             x, y = pa[net].cpu().numpy(), pb[net].cpu().numpy()
             bad = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
             assert bad.mean() < 2e-3 and np.abs(x - y).max() < 1e-3, (net, bad.mean(), np.abs(x - y).max())
+
+
+@pytest.mark.parametrize('B', [64, 41])
+@pytest.mark.parametrize('obs_dim,act_dim,a_h,c_h,a_act,c_act,max_norm', [
+    (60, 2, [256, 128], [256, 128], 'tanh', 'tanh', 0.05),       # clip active in every network, L2 term on
+    (376, 17, [160, 96], [96], 'tanh', 'relu', 0.3),             # wide observations; a 17-wide top layer (own launch)
+    (27, 8, [64, 80, 48, 33], [50, 1, 9], 'sigmoid', 'tanh', 40.0),  # deeper actor than critics, widths off multiples of 4
+    (33, 5, [1100], [70], 'tanh', 'tanh', 0.2)])                 # more than 64 column tiles of partial outputs
+def test_fused_clip_norm_equals_the_weight_gradient_launch(monkeypatch, obs_dim, act_dim, a_h, c_h, a_act, c_act,
+                                                           max_norm, B):
+    """Round 6: in mode 0 the clip norm of a skinny step comes out of the forward / top / backward launches
+    (skinny_mlp.h: gs_gram_norm -- |dZ^T H|^2 = <dZ dZ^T, H H^T> per 16 rows of every layer, the critics' L2 cross term
+    from the pre-bias outputs, |W|^2 from the forward launches) and the top layer's forward pass rides in the launch below
+    it; OSA_GMLP_NORM_FUSE=0 keeps round 5's launches, whose gs_wgrad_kernel<0> forms every gradient tile for the norm.
+    Same inputs, four chained steps with the clip ACTIVE (small max_grad_norm) and the critics' L2 term on: the logged
+    norms (stats 7..9), the critics' |W|^2 (stats 5, 6), losses, parameters and moments agree to float32 summation
+    order (reference: torch.nn.utils.clip_grad_norm_ over the same gradients, policy_gradient.py:437-442)."""
+    from omnisafe_amd.update import PPOUpdater
+
+    monkeypatch.setenv('OSA_FORCE_GENERAL_MLP', '1')
+    M = 400
+    g = torch.Generator().manual_seed(11)
+    cpu = {'obs': torch.randn(M, obs_dim, generator=g), 'act': torch.randn(M, act_dim, generator=g),
+           'logp': -1.0 + 0.3 * torch.randn(M, generator=g), 'target_value_r': torch.randn(M, generator=g),
+           'target_value_c': torch.randn(M, generator=g), 'adv_r': torch.randn(M, generator=g),
+           'adv_c': torch.randn(M, generator=g)}
+    dev = {k: v.to(DEV).contiguous() for k, v in cpu.items()}
+    idxs = [torch.randperm(M, generator=g)[:B].to(DEV) for _ in range(4)]
+    lam = torch.tensor([0.4], device=DEV)
+    out = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('OSA_GMLP_NORM_FUSE', fuse)
+        torch.manual_seed(6)
+        ac, _ = make(obs_dim, act_dim, a_h, c_h, a_act, c_act)
+        up = PPOUpdater(ac, batch_size=B, update_iters=1, target_kl=0.02, kl_early_stop=False, entropy_coef=0.01)
+        up.hp.lr_actor, up.hp.lr_critic = 3e-4, 1e-3
+        up.hp.max_grad_norm = max_norm
+        up.hp.use_critic_norm, up.hp.critic_norm_coef = 1, 0.01
+        stats = torch.zeros(4, 16, device=DEV)
+        for k in range(4):
+            up.minibatch(dev, idxs[k], B, lam, stats[k])
+        out[fuse] = {'params': ac.params.clone(), 'm': ac.adam_m.clone(), 'v': ac.adam_v.clone(),
+                     'step': ac.adam_step.clone(), 'stats': stats.clone()}
+    a, b = out['1'], out['0']
+    assert a['step'].tolist() == [4, 4, 4] == b['step'].tolist()
+    sa, sb = a['stats'].cpu().numpy(), b['stats'].cpu().numpy()
+    assert (sb[:, 8:10] > max_norm).all() or max_norm >= 40.0    # the clip is active (critics) where the case says so
+    np.testing.assert_allclose(sa[:, 7:10], sb[:, 7:10], rtol=2e-5)    # total gradient norms
+    np.testing.assert_allclose(sa[:, 5:7], sb[:, 5:7], rtol=2e-5)      # the critics' sum of squared parameters
+    np.testing.assert_allclose(sa[:, :5], sb[:, :5], rtol=2e-4, atol=1e-6)
+    for key in ('m', 'v'):
+        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
+        scale = np.abs(y).max() + 1e-30
+        assert np.abs(x - y).max() <= 1e-4 * scale, (key, np.abs(x - y).max(), scale)
+    x, y = a['params'].cpu().numpy(), b['params'].cpu().numpy()
+    bad = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
+    assert bad.mean() < 2e-3 and np.abs(x - y).max() < 1e-3, (bad.mean(), np.abs(x - y).max())

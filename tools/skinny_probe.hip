@@ -131,6 +131,20 @@ int main(int argc, char** argv) {
 #ifdef GS_CLOCKS
       long long clk[2][16];
       CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(gs_clk), sizeof(clk)));
+#ifdef GS_CLOCKS_WAIT
+      if (fused) {
+        printf("  loads waited for group by group (wave 1 of tile 1), cycles:");
+        for (int q = 1; q < 6; ++q) printf(" %lld", clk[0][8 + q] - clk[0][8 + q - 1]);
+        printf("   (Gram 16 x 4 B, top weights 8 x 4 B, h / Zlin / biases, slabs 16 x 16 B, gathered operands)\n");
+      }
+#endif
+      if (fused) {
+        long long lc[16];
+        CK(hipMemcpyFromSymbol(lc, HIP_SYMBOL(gs_lclk), sizeof(lc)));
+        printf("  loss of tile 1, cycles since its entry:");
+        for (int q = 1; q < 7; ++q) printf(" %lld", lc[q] - lc[0]);
+        printf("   (1 log-prob + ratio, 2 surrogate, 3 gradient rows + log_std sums, 4 padding, 5 loss sums, 6 end)\n");
+      }
       for (int t = 0; t < 2; ++t) {
         printf("  tile %d cycles since entry:", t);
         for (int q = 1; q < 8; ++q) printf(" %lld", clk[t][q] - clk[t][0]);
