@@ -692,6 +692,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
   __shared__ __attribute__((aligned(16))) float red[GS_WAVES * 4 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float sT[64 * GS_TLD];
   __shared__ __attribute__((aligned(16))) float gs_stage[GS_WAVES * 64 * 32];
+  __shared__ __attribute__((aligned(16))) float gs_stage_w[GS_WAVES * 32 * GS_TLD];
   __shared__ float red4[4];
   int tile, tiles;
   const GSProb p = gs_pick(a, gs_locate(a, tile, tiles));
@@ -740,20 +741,24 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
 #if !defined(GS_NO_STAGE) && GS_PF == 8
   // (round 6) the dZ rows reach their MFMA lanes through LDS -- coalesced 8 rows x 128 bytes per instruction, see
   // gs_fwd_kernel; the weight fragments are 4-byte loads of 16 consecutive columns per row already
+  // ... and so do the weights: W[n][k0 .. k0 + 15] of a block's 16 rows n as one instruction of 16-byte pieces (16 rows x
+  // 64 bytes) instead of four 4-byte loads per lane; the fragments a[n = 4 g + s][k0 + j] are read back as scalars from a
+  // [32 rows][20] tile (row stride 20: the four lane groups hit disjoint banks)
   float* __restrict__ stg = gs_stage + wave * (64 * 32);
+  float* __restrict__ stw = gs_stage_w + wave * (32 * GS_TLD);
+  (void)wcol;
+  (void)kok;
   const int lrow = lane >> 3, lp = lane & 7;
+  const int wrow_ = lane >> 2, wp = lane & 3;
   for (int bb = b0; bb < b1; bb += 8) {
-    float wf[8][4];
+    f32x4 wr[8];
     f32x4 xr[4][8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int n = 16 * (bb + u) + 4 * g + s;
-        const bool ok = kok && bb + u < b1 && n < N;
-        const float wv = wcol[(long)(ok ? n : 0) * p.ldw];
-        wf[u][s] = ok ? wv : 0.f;
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int n = 16 * (bb + u) + wrow_;
+      const bool ok = bb + u < b1 && n < N && k0 + 4 * wp < p.ldw;
+      wr[u] = gs_load4(p.W + (long)(ok ? n : 0) * p.ldw, k0 + 4 * wp, p.ldw, ok);
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = 16 * (bb + 2 * c) + 4 * (lp ^ lrow);
@@ -770,18 +775,23 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gs_bwd_kernel(GSArgs a) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(stg + (8 * i + lrow) * 32 + 4 * lp) = xr[c][i];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(stw + (16 * u + wrow_) * GS_TLD + 4 * wp) = wr[2 * c + u];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (bb + 2 * c + u < b1) {  // wave-uniform
             const int pc = 4 * (((4 * u + g) ^ j) & 7);
             f32x4 xf[4];
+            float wf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wf[s] = stw[(16 * u + 4 * g + s) * GS_TLD + j];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const f32x4*>(stg + (16 * t + j) * 32 + pc);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[2 * c + u][s], xf[t][s], acc[t]);
+              for (int t = 0; t < 4; ++t) acc[t] = OSA_MFMA(wf[s], xf[t][s], acc[t]);
           }
         }
       }

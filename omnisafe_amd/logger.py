@@ -53,6 +53,7 @@ class Logger:  # pylint: disable=too-many-instance-attributes
                 pass
 
         atexit.register(_flush_at_exit)
+        self._atexit_hook = _flush_at_exit  # (unregistered by close(): one closure per Logger otherwise piles up)
         # Optional sinks of the reference (logger.py:130-150, 312-318): the epoch row goes to TensorBoard
         # (`<log_dir>/tb`) and / or Weights & Biases when their packages are importable; when one is asked for and
         # missing, the run continues on csv alone and SAYS so (a drop-in must not silently ignore a config key).
@@ -256,6 +257,11 @@ class Logger:  # pylint: disable=too-many-instance-attributes
 
     def close(self) -> None:
         self.flush()
+        hook = self.__dict__.pop('_atexit_hook', None)
+        if hook is not None:
+            import atexit
+
+            atexit.unregister(hook)
         if self._maste_proc:
             self._output_file.close()
             if self._tb_writer is not None:
