@@ -55,6 +55,8 @@ PEAK_HBM_GBPS = 8000.0                                         # MI355X_MICROARC
 # networks run concurrently on three CUs.  The B = 64 chain cannot go below this however the rest is scheduled.
 MFMA_PER_STEP, MFMA_CYCLES, ENGINE_GHZ = 320, 32, 2.4
 W_PI_RUN, W_V_RUN = W_PI, W_V  # (set from --hidden-sizes in main)
+GENERAL_WEIGHTS = (0, 0)       # (all weights of the three networks, those above layer 0): set with --hidden-sizes
+GENERAL_IS_1024 = False
 
 
 def weights_of(hidden):
@@ -273,12 +275,33 @@ def roofline_from_events(events, batch_size):
         out['note'] = (f'persistent pass: {steps} dependent {batch_size}-row optimiser steps per launch on 3 '
                        'workgroups (one per network) of a 256-CU chip -- latency-bound by the reference\'s '
                        'batch_size=64 chain, not by MFMA throughput; see throughput_variant')
-    elif name == 'gm_gemm_kernel':
+    elif name == 'gm_gemm_kernel' and batch_size > 64:
         steps = max(1, rows // len(events) // batch_size)
         out['us_per_optimiser_step'] = round(us / steps, 3)
         out['kernel'] = 'gm_gemm_kernel (csrc/general_mlp.hip: forward / backward-data / backward-weight GEMMs) + loss / reduce / Adam'
         out['note'] = ('general networks, layer-wise: ~13 launches per optimiser step on one float32-MFMA GEMM kernel '
                        '(v_mfma_f32_32x32x2_f32), three networks per launch; the timed unit is a whole step (or captured pass)')
+    elif name == 'gm_gemm_kernel' and batch_size <= 64:
+        # general networks at the YAML batch: the skinny kernels (csrc/skinny_mlp.h) -- a 64-row step is bandwidth work.
+        # Algorithmic HBM bytes per optimiser step: every weight read by the forward pass, every weight above layer 0 by
+        # the backward-data pass, weights and both Adam moments read and written once: 4 (7 W + W_above_0) bytes.
+        steps = max(1, rows // len(events) // batch_size)
+        w_all, w_up = GENERAL_WEIGHTS
+        alg_bytes = 4 * (7 * w_all + w_up)
+        us_step = us / steps
+        gbs = alg_bytes / (us_step * 1e-6) / 1e9
+        traffic = pmc_traffic(['gs_fwd_kernel<true>', 'gs_fwd_kernel<false>', 'gs_top_kernel', 'gs_bwd_kernel',
+                               'gs_wgrad_kernel<1>'], 'general_1024_B64') if GENERAL_IS_1024 else None
+        out = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+               'frac': round(gbs / PEAK_HBM_GBPS, 5), 'traffic': traffic,
+               'kernel': 'gs_fwd_kernel x (L - 1) + gs_top_kernel + gs_bwd_kernel x (L - 2) + gs_wgrad_kernel<1> '
+                         '(csrc/skinny_mlp.h; L linear layers, three networks per launch)',
+               'launches_timed': len(events), 'us_per_optimiser_step': round(us_step, 3),
+               'algorithmic_bytes_per_step': alg_bytes, 'traffic_per': 'optimiser step (sum of the five launches)',
+               'flops_per_step': flops // len(events) // steps,
+               'note': ('general networks, minibatches of <= 64 rows: 2 L - 1 launches per optimiser step (clip norm from '
+                        'Gram matrices inside the forward / top / backward launches, top layer fused into the launch '
+                        'below); bound by streaming the weights and the Adam state, not by the matrix pipe')}
     else:
         steps = max(1, rows // len(events) // batch_size)  # (a captured pass of several steps is one timed event)
         out['us_per_optimiser_step'] = round(us / steps, 3)
@@ -453,8 +476,11 @@ def main():
     torch.cuda.set_device(dev)
     import tempfile
 
-    global W_PI_RUN, W_V_RUN
+    global W_PI_RUN, W_V_RUN, GENERAL_WEIGHTS, GENERAL_IS_1024
     W_PI_RUN, W_V_RUN = weights_of(args.hidden_sizes)
+    _first = OBS_DIM * args.hidden_sizes[0] if args.hidden_sizes else 0
+    GENERAL_WEIGHTS = (W_PI_RUN + 2 * W_V_RUN, W_PI_RUN + 2 * W_V_RUN - 3 * _first)
+    GENERAL_IS_1024 = list(args.hidden_sizes) == [1024, 1024] and args.batch_size == 64
     general = list(args.hidden_sizes) != [64, 64]
     hid = 'x'.join(str(h) for h in args.hidden_sizes)
     log_dir = tempfile.mkdtemp(prefix='osa_bench_')

@@ -26,6 +26,27 @@
 
 #define OFV_NSTAT 16  // OSA_NSTAT of mlp_kernels.hip: statistics slots behind the P gradient entries of a slab
 
+// Phase clocks of a chunk (tools/build_variant_lib.sh fvpclocks fvp_kernel.hip -DOFV_CLOCKS; tools/fvp_phase_clocks.py):
+// thread 0 of workgroup 0 accumulates the shader cycles between the marks over its chunks.  Not in the product build.
+#ifdef OFV_CLOCKS
+__device__ long long ofv_clk[16];
+#define OFV_MARK(k)                                                         \
+  do {                                                                      \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();         \
+    ofv_acc_[k] += now_ - ofv_t_;  /* (registers: a memory update here would wait for every load in flight) */ \
+    ofv_t_ = now_;                                                          \
+  } while (0)
+extern "C" int osa_debug_fvp_clocks(long long* out16, int reset) {
+  if (reset) {
+    long long z[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(ofv_clk), z, sizeof(z)) == hipSuccess ? 0 : 1;
+  }
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ofv_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#else
+#define OFV_MARK(k) do { } while (0)
+#endif
+
 struct OsaFvpArgs {
   OsaNet nd;
   const float* params;  // actor block [P]
@@ -205,24 +226,59 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
   // this lane's row of the chunk as S-layout fragments (zero past the end and past obs_dim); the NEXT chunk's are
   // requested as soon as the forward and tangent passes have consumed the current ones (one wave per SIMD: nothing
   // else would hide the first touch of the rows in HBM)
+  // Round 6: the request is RAW -- 16-byte loads from clamped addresses, nothing computed on the values: osa_load_x
+  // zeroes the columns past obs_dim with selects on the loaded data, and a select is a use: the wave sat out the whole
+  // memory round trip right behind the request (1 600 of a chunk's 28 000 cycles by the phase clocks, profiles/
+  // r6_fvp_phase_clocks.txt).  The masks are applied where the fragments are taken over at the top of the next chunk.
   f32x4 xn[KBT];
-  {
-    const int pos0 = blockIdx.x * SPC + 16 * wave + j;
-    const float* xr0 = pos0 < a.M ? a.obs + (long)pos0 * a.ld_obs : nullptr;
+  bool xn_ok = false;
+  auto request_rows = [&](int pos, bool have) {
+    xn_ok = have && pos < a.M;
+    const float* xr = xn_ok ? a.obs + (long)pos * a.ld_obs : nullptr;
+    if (vec_ok) {
 #pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) xn[kb] = osa_load_x(xr0, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
-  }
+      for (int kb = 0; kb < KBT; ++kb) {
+        const int col0 = 16 * kb + 4 * g;
+        const bool ok = xn_ok && col0 < nd.obs_dim;  // (ld % 4 == 0 and col0 < obs_dim <= ld: the piece lies inside the row)
+        xn[kb] = *reinterpret_cast<const f32x4*>(ok ? xr + col0 : a.obs);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < KBT; ++kb) xn[kb] = osa_load_x(xr, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, false);
+    }
+  };
+  auto take_rows = [&](f32x4 (&xf)[KBT]) {  // osa_load_x's values
+#pragma unroll
+    for (int kb = 0; kb < KBT; ++kb) {
+      f32x4 x = xn[kb];
+      if (vec_ok) {
+        const int col0 = 16 * kb + 4 * g;
+        if (!(xn_ok && col0 < nd.obs_dim)) x.x = 0.f;
+        if (!(xn_ok && col0 + 1 < nd.obs_dim)) x.y = 0.f;
+        if (!(xn_ok && col0 + 2 < nd.obs_dim)) x.z = 0.f;
+        if (!(xn_ok && col0 + 3 < nd.obs_dim)) x.w = 0.f;
+      }
+      xf[kb] = x;
+    }
+  };
+  request_rows(blockIdx.x * SPC + 16 * wave + j, true);
+#ifdef OFV_CLOCKS
+  long long ofv_acc_[12] = {};
+  long long ofv_t_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (int chunk = blockIdx.x; chunk < nchunk; chunk += a.nblk, first = false) {
+    OFV_MARK(0);  // (loop overhead, the previous chunk's tail)
     const int pos = chunk * SPC + 16 * wave + j;
     const bool valid = pos < a.M;
     f32x4 xf[KBT];
-#pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) xf[kb] = xn[kb];
+    take_rows(xf);
     __syncthreads();  // previous chunk's tiles fully consumed
+    OFV_MARK(1);
 
     f32x4 h1[HT], h2[HT], out[OT];
     ofv_forward<OT, KBT>(nl, p, xf, OSA_ACT_TANH, h1, h2, out);  // (tanh only: a run-time activation switch is a branch,
     // i.e. a scheduling barrier, between the MFMA groups of every layer; other activations keep the general kernel)
+    OFV_MARK(2);
     // ---- JVP: t = d(mean) along v
     f32x4 dO[OT];
 #pragma unroll
@@ -299,12 +355,11 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
         }
       }
     }
+    OFV_MARK(3);
     {  // the next chunk's rows (the loads ride under the backward pass and the contractions)
-      const int posn = (chunk + a.nblk) * SPC + 16 * wave + j;
-      const float* xrn = (chunk + a.nblk < nchunk && posn < a.M) ? a.obs + (long)posn * a.ld_obs : nullptr;
-#pragma unroll
-      for (int kb = 0; kb < KBT; ++kb) xn[kb] = osa_load_x(xrn, 16 * kb + 4 * g, nd.obs_dim, a.ld_obs, vec_ok);
+      request_rows((chunk + a.nblk) * SPC + 16 * wave + j, chunk + a.nblk < nchunk);
     }
+    OFV_MARK(4);
     // ---- backward through the hidden layers (S layout, activations stay in registers)
     const float* __restrict__ W2 = p + nl.oW2;
     const float* __restrict__ W3 = p + nl.oW3;
@@ -341,6 +396,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
             if (kb == HT - 1) z1[t] = acc * osa_dact4(h1[t], OSA_ACT_TANH);
           });
     }
+    OFV_MARK(5);
     // ---- S layout -> F layout through LDS: element (feature f, sample c) at [f * SLD + c]
     const int c = 16 * wave + j;
 #pragma unroll
@@ -360,6 +416,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       for (int r = 0; r < 4; ++r) sDO[(16 * o + 4 * g + r) * SLD + c] = dO[o][r];
     }
     __syncthreads();
+    OFV_MARK(6);
     // ---- weight gradients: contraction over the 64 samples of the chunk.  D tile: lane (cc = l & 15, g) holds
     // dW[row 4g + r][col cc]; wave w owns row tile w of dW2 and dW1 (all column tiles) and column tile w of dW3
     f32x4 a1[NSB];
@@ -389,6 +446,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
             });
       }
     }
+    OFV_MARK(7);
     {  // dW3: output tiles o x column tile `wave`
       const int ct = wave;
       {
@@ -410,6 +468,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
             });
       }
     }
+    OFV_MARK(8);
     // bias gradients: one thread per feature sums its LDS row over the 64 samples
     if ((int)threadIdx.x < 2 * H + OUTP) {
       const int tid = threadIdx.x;
@@ -425,6 +484,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       }
       gB = first ? s : gB + s;
     }
+    OFV_MARK(9);
     // dW1's second operand -- the chunk's rows, element (input feature f, sample c) -- takes the place of the h1 / h2
     // tiles once dW2 and dW3 have consumed them (the general kernel gathers these values from global memory again, 64 scalar loads per
     // lane; the 155 KB of parameters and tiles leave no room for a fifth tile): same values, same MFMA order
@@ -436,6 +496,7 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
       for (int r = 0; r < 4; ++r) sX[(16 * kb + 4 * g + r) * SLD + c] = xf[kb][r];
     }
     __syncthreads();
+    OFV_MARK(10);
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       ofv_pipe<KBT * NSB, OFV_D>(
@@ -453,7 +514,12 @@ __global__ __launch_bounds__(256) void osa_fvp_kernel(OsaFvpArgs a) {
             if (sb == NSB - 1) gW1[kb] = first ? acc : gW1[kb] + acc;
           });
     }
+    OFV_MARK(11);
   }  // chunks
+#ifdef OFV_CLOCKS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int k = 0; k < 12; ++k) ofv_clk[k] += ofv_acc_[k];
+#endif
   // ---- this workgroup's slab
   float* __restrict__ gout = a.slabs + (long)blockIdx.x * (P + OFV_NSTAT);
   const int cc = j;

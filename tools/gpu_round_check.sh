@@ -10,7 +10,7 @@
 #   stage 6  per-step all-reduce mode over RCCL at world 1 (eager v graph, kernel split), every algorithm's epoch time
 # Everything lands under gpurun_out/<ROUND>_*; copy what is to be judged into profiles/.
 set -x
-T=${1:-r5}
+T=${1:-r6}
 STAGES=${2:-123456}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -62,6 +62,11 @@ OSA_GMLP_SKINNY=0 timeout 300 python tools/general_mlp_timing.py --shapes 1024x1
 cd /tmp; rm -rf $O/${T}_prof_gm $O/${T}_pmc_sq_gm
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_gm -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:64 --reps 10 > /dev/null 2>&1
 f=$(find $O/${T}_prof_gm -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_general_1024_B64.csv; rm -rf $O/${T}_prof_gm
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${T}_pmc_gm_$c -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:64 --reps 3 > /dev/null 2>&1
+done
+python $R/tools/pmc_summary.py $O/${T}_pmc_gm_FETCH_SIZE $O/${T}_pmc_gm_WRITE_SIZE $O/${T}_pmc_traffic_general_1024_B64 | head -12
+rm -rf $O/${T}_pmc_gm_FETCH_SIZE $O/${T}_pmc_gm_WRITE_SIZE
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_gm -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:16384 --reps 5 > /dev/null 2>&1
 f=$(find $O/${T}_prof_gm -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats_general_1024_B16384.csv; rm -rf $O/${T}_prof_gm
 timeout 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${T}_pmc_sq_gm -- python $R/tools/general_mlp_timing.py --shapes 1024x1024:16384 --reps 2 > /dev/null 2>&1
