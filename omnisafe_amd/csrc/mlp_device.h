@@ -186,6 +186,26 @@ __device__ __forceinline__ f32x4 osa_load_x(const float* __restrict__ row, int c
   return x;
 }
 
+// The same fragment in two steps (round 6): osa_load_x zeroes the columns past obs_dim with selects ON THE LOADED DATA, and
+// a select is a use -- behind a prefetch it makes the wave sit out the memory round trip at once (one trip per K block
+// of the first layer instead of one for all; 1 600 cycles per chunk of the Fisher-vector product,
+// profiles/r6_fvp_phase_clocks.txt).  osa_load_x_raw only REQUESTS (vec_ok: one 16-byte load from a clamped address,
+// `safe` = any readable 16-byte aligned address for masked lanes), osa_mask_x turns the raw value into osa_load_x's.
+__device__ __forceinline__ f32x4 osa_load_x_raw(const float* __restrict__ row, int col0, int obs_dim, int ld, bool vec_ok,
+                                                const float* __restrict__ safe) {
+  if (!vec_ok) return osa_load_x(row, col0, obs_dim, ld, false);
+  // (ld % 4 == 0, col0 % 4 == 0 and col0 < obs_dim <= ld: the piece lies inside the row)
+  const bool ok = row != nullptr && col0 < obs_dim;
+  return *reinterpret_cast<const f32x4*>(ok ? row + col0 : safe);
+}
+__device__ __forceinline__ f32x4 osa_mask_x(f32x4 x, bool have_row, int col0, int obs_dim) {
+  if (!(have_row && col0 < obs_dim)) x.x = 0.f;
+  if (!(have_row && col0 + 1 < obs_dim)) x.y = 0.f;
+  if (!(have_row && col0 + 2 < obs_dim)) x.z = 0.f;
+  if (!(have_row && col0 + 3 < obs_dim)) x.w = 0.f;
+  return x;
+}
+
 // Forward pass of one network for the 16 samples owned by this wave.
 //   xrow : this lane's sample row (lane l -> sample l&15), nullptr if masked
 //   h1,h2: hidden activations, S layout, HT tiles of 16 features
@@ -204,17 +224,17 @@ __device__ __forceinline__ void osa_mlp_forward(const OsaNet& nd, const float* _
   // software-pipelined over the input K blocks: the x chunk and the four weight fragments of block kb+1 are
   // requested before the MFMAs of block kb issue (wide inputs -- Humanoid has 24 blocks -- otherwise pay one
   // L2 round trip per block)
-  f32x4 xn = osa_load_x(xrow, 4 * g, nd.obs_dim, ld, vec_ok);
+  f32x4 xn = osa_load_x_raw(xrow, 4 * g, nd.obs_dim, ld, vec_ok, p);
   f32x4 wn[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 4 * g);
   for (int kb = 0; kb < nd.KB; ++kb) {
-    const f32x4 x = xn;
+    const f32x4 x = osa_mask_x(xn, xrow != nullptr, 16 * kb + 4 * g, nd.obs_dim);
     f32x4 w[HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) w[t] = wn[t];
     if (kb + 1 < nd.KB) {
-      xn = osa_load_x(xrow, 16 * (kb + 1) + 4 * g, nd.obs_dim, ld, vec_ok);
+      xn = osa_load_x_raw(xrow, 16 * (kb + 1) + 4 * g, nd.obs_dim, ld, vec_ok, p);
 #pragma unroll
       for (int t = 0; t < HT; ++t)
         wn[t] = *reinterpret_cast<const f32x4*>(W1 + (long)(16 * t + i) * INP + 16 * (kb + 1) + 4 * g);
