@@ -1,4 +1,4 @@
-# End-of-round measurement set on one MI355X (run through gpurun; ROUND tag as first argument, default r5).
+# End-of-round measurement set on one MI355X (run through gpurun; ROUND tag as first argument, default r6).
 #   stage 1  GPU suite, default bench, 2-rank code-path check (both ranks on the one GPU over gloo; incl. the
 #            large-batch variant under data parallelism)
 #   stage 2  rocprofv3 kernel stats of the bench command; FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace
@@ -8,10 +8,11 @@
 #   stage 4  general networks: bench line at hidden 1024 x 1024, kernel stats, SQ pass, timing table
 #   stage 5  buffer kernels (GAE bandwidth), BASELINE configs on one GPU, pass timings
 #   stage 6  per-step all-reduce mode over RCCL at world 1 (eager v graph, kernel split), every algorithm's epoch time
+#   stage 7  one-shot peer exchange at 1 / 2 / 4 / 8 ranks on the one device, skinny-kernel probe, FVP phase clocks
 # Everything lands under gpurun_out/<ROUND>_*; copy what is to be judged into profiles/.
 set -x
 T=${1:-r6}
-STAGES=${2:-123456}
+STAGES=${2:-1234567}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd $R
@@ -90,4 +91,13 @@ cp $O/rccl_world1_timing.json $O/${T}_rccl_world1_timing.json 2>/dev/null
 cd $R; timeout 900 python tools/algo_sweep.py > $O/${T}_algo_sweep.txt 2>&1; tail -25 $O/${T}_algo_sweep.txt
 # the unmodified reference with ALL 40 passes on this box's host (the bench line's cpu_baseline extrapolates from 4)
 timeout 400 python oracle/ref_cpu_baseline.py --envs 4096 --steps-per-env 16 --batch-size 64 --update-iters 40 --sample-iters 40 --threads 16 2>/dev/null | tail -1 > $O/${T}_reference_full_epoch_config2.json; cat $O/${T}_reference_full_epoch_config2.json | cut -c1-300
+fi
+if [[ $STAGES == *7* ]]; then
+# round 6: one-shot peer exchange (ranks on the one device), probes of the skinny kernels, phase clocks of the FVP chunk
+# (build first, here on the CPU:  hipcc ... tools/skinny_probe.hip -DGS_CLOCKS -o tools/_probe/skinny_probe ;
+#  tools/build_variant_lib.sh fvpclocks fvp_kernel.hip -DOFV_CLOCKS)
+cd $R
+timeout 600 python tools/p2p_timing.py --out $O/${T}_p2p_timing.json 2>&1 | grep '^{"shape' | cut -c1-240
+[ -x tools/_probe/skinny_probe ] && tools/_probe/skinny_probe > $O/${T}_skinny_probe.txt 2>&1; tail -12 $O/${T}_skinny_probe.txt
+[ -f omnisafe_amd/lib/libomnisafe_amd_fvpclocks.so ] && OSA_LIB_PATH=$R/omnisafe_amd/lib/libomnisafe_amd_fvpclocks.so timeout 300 python tools/fvp_phase_clocks.py --out $O/${T}_fvp_phase_clocks.txt 2>&1 | grep -v amdgpu | tail -15
 fi
