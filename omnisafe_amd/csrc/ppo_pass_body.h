@@ -272,6 +272,29 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
 #endif
   const int i = j, cc = j;
+  // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
+  // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
+  const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
+  const bool strided = part;
+  const int cstride = part ? (contig ? 1 : a.part_stride) : 1;
+  const int cfirst = part ? (contig ? pc0 : rk) : (chunked ? cchunk : 0);
+  const int nchunk = strided ? (contig ? pn : (nchunk_all - cfirst + cstride - 1) / cstride) : nchunk_all;
+  auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
+    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
+    const long inb = ch * 64 + 16 * wave + j;
+    return (mb < a.mb0 + a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
+  };
+  auto row_of = [&](long cidx) -> long {  // raw (unconsumed) load of the permutation entry
+    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
+    const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
+    return perm_p ? perm_p[pc] : pc;
+  };
+  // Round 6: the first two permutation entries are requested BEFORE the parameter loads -- the gather's first hop (a cold
+  // trip to HBM for the index, then the rows) used to start only after the workgroup's own start-up and weight requests
+  // (2 400 + 2 700 cycles per segment of the large-batch step by the part kernel's phase marks)
+  const long cidx_first = (long)a.mb0 * nchunk;
+  const long r0_first = row_of(cidx_first);
+  const long r1_first = row_of(cidx_first + 1);
   // serial per-step chores (entropy, statistics) go to the first thread of wave 3: waves 0-2 also own the
   // bias-like parameters, so wave 3 is the one with slack before every barrier
   const bool leader = tid == 192;
@@ -299,20 +322,37 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
 #else
   constexpr bool VPRO = DPS;
 #endif
-  f32x4 w1v_[VPRO ? KB : 1];
+  // Round 6 (VPRO): EVERY parameter load of the prologue is requested here, into registers, and nothing is done with the
+  // values until the first minibatch's gather has been issued: an LDS store of a loaded bias right behind the W1
+  // request made the workgroup sit out that round trip (3 200 cycles by the part kernel's phase marks), the gather's two
+  // hops came after it (2 500) and W2 / W3 after those (900) -- three dependent trips per segment of the large-batch step
+  f32x4 w1v_[VPRO ? KB : 1], w2v_[VPRO ? 4 : 1], w3v_[VPRO ? OT : 1];
+  float b1v_ = 0.f, b2v_ = 0.f, b3v_ = 0.f, lsv_ = 0.f;
   if constexpr (VPRO) {
 #pragma unroll
     for (int q = 0; q < KB; ++q) w1v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW1 + 4 * (tid + 256 * q));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w2v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW2 + 4 * (tid + 256 * q));
+#pragma unroll
+    for (int q = 0; q < OT; ++q) w3v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW3 + 4 * (tid + 256 * q));
+    if (tid < H) {
+      b1v_ = gp[nd.ob1 + tid];
+      b2v_ = gp[nd.ob2 + tid];
+    }
+    if (tid < OUTP) {
+      b3v_ = gp[nd.ob3 + tid];
+      lsv_ = gp[nd.oLS + tid];
+    }
   } else {
     for (int e = tid; e < H * INP; e += 256) sW1[(e / INP) * W1LD + (e % INP)] = gp[nd.oW1 + e];
-  }
-  if (tid < H) {
-    sB1[tid] = gp[nd.ob1 + tid];
-    sB2[tid] = gp[nd.ob2 + tid];
-  }
-  if (tid < OUTP) {
-    sB3[tid] = gp[nd.ob3 + tid];
-    sLS[tid] = gp[nd.oLS + tid];
+    if (tid < H) {
+      sB1[tid] = gp[nd.ob1 + tid];
+      sB2[tid] = gp[nd.ob2 + tid];
+    }
+    if (tid < OUTP) {
+      sB3[tid] = gp[nd.ob3 + tid];
+      sLS[tid] = gp[nd.oLS + tid];
+    }
   }
   // (W2 / W3 are loaded after the first minibatch's gather has been issued, see below)
   OSA_PART_MARK(8);
@@ -397,23 +437,6 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     float old[EXT ? 4 * OT : 1];  // behaviour-policy mean of this lane's action dimensions (EXT)
     bool valid;
   };
-  // 64-row chunks per (full) minibatch; compile-time 1 for B <= 64 (the reference's default batch)
-  // (partial mode: this workgroup's chunks are rk, rk + stride, ... of the minibatch's ceil(B/64))
-  const int nchunk_all = MULTI ? (a.B + 63) / 64 : 1;
-  const bool strided = part;
-  const int cstride = part ? (contig ? 1 : a.part_stride) : 1;
-  const int cfirst = part ? (contig ? pc0 : rk) : (chunked ? cchunk : 0);
-  const int nchunk = strided ? (contig ? pn : (nchunk_all - cfirst + cstride - 1) / cstride) : nchunk_all;
-  auto pos_ok = [&](long cidx) -> bool {  // global chunk counter -> (minibatch, chunk)
-    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
-    const long inb = ch * 64 + 16 * wave + j;
-    return (mb < a.mb0 + a.nmb) && (inb < a.B) && (mb * a.B + inb < a.M);
-  };
-  auto row_of = [&](long cidx) -> long {  // raw (unconsumed) load of the permutation entry
-    const long mb = cidx / nchunk, ch = cfirst + (cidx - mb * nchunk) * cstride;
-    const long pc = pos_ok(cidx) ? mb * a.B + ch * 64 + 16 * wave + j : 0;
-    return perm_p ? perm_p[pc] : pc;
-  };
   // The gather of the NEXT chunk lands in the SAME registers as the current one: the observation part is
   // re-issued as soon as layer 1 has consumed it, the per-sample scalars as soon as the loss has (no second
   // buffer: the kernel is register-bound -- 256 + ~250 AGPR in use -- and every spilled value costs VALU
@@ -476,22 +499,25 @@ __device__ __forceinline__ void osa_ppo_pass_body(const OsaPassArgs& a, const in
     for (int r = 0; r < 4; ++r) dm[o][r] = (16 * o + 4 * g + r) < nd.act_dim ? 1.f : 0.f;
   OSA_PART_MARK(10);
   Pre cur;
-  long cidx = (long)a.mb0 * nchunk;
+  long cidx = cidx_first;
   {
-    const long r0 = row_of(cidx);
+    const long r0 = r0_first;
     fetch_x(r0, cur);  // first gather in flight ...
     fetch_s(r0, cur);
     cur.valid = pos_ok(cidx);
   }
-  long row_nxt = row_of(cidx + 1);
+  long row_nxt = r1_first;
   OSA_PART_MARK(11);
   // ... while the remaining weights stream into LDS (matters for the one-step-per-launch dp mode)
   if constexpr (VPRO) {
-    f32x4 w2v_[4], w3v_[OT];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w2v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW2 + 4 * (tid + 256 * q));
-#pragma unroll
-    for (int q = 0; q < OT; ++q) w3v_[q] = *reinterpret_cast<const f32x4*>(gp + nd.oW3 + 4 * (tid + 256 * q));
+    if (tid < H) {
+      sB1[tid] = b1v_;
+      sB2[tid] = b2v_;
+    }
+    if (tid < OUTP) {
+      sB3[tid] = b3v_;
+      sLS[tid] = lsv_;
+    }
 #pragma unroll
     for (int q = 0; q < KB; ++q) {  // float4 index e4 = tid + 256 q of W1[H][INP]: row e4 / (INP / 4), columns 4 (e4 % (INP / 4)) ..
       const int e4 = tid + 256 * q;
