@@ -722,11 +722,40 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
   const int step = a.adam_step[net] + 1;  // read before anybody can advance it (the last finisher does)
   float* __restrict__ p = a.params + (long)net * P;
   float gval = 0.f, pval = 0.f, gsq = 0.f, psq = 0.f;
+  float mv0 = 0.f, vv0 = 0.f, step_size = 0.f, inv_bc2_sqrt = 0.f;
+  bool pre_done = false;
   if (e < W) {
     const float* s = a.slabs + (long)net * a.nblk * W + e;
     const int ns = a.nslab[0] < 0 ? a.nblk : a.nslab[net];
     float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same association as osa_slab_reduce_kernel
     int b = 0;
+    // Round 6 (phase clocks of this launch: slab sum 8 700 cycles, then 3 300 for the float64 bias corrections, 3 300 for
+    // two block sums, 5 300 barrier, 2 600 for the totals): the first 64 slabs are REQUESTED, then everything of the Adam
+    // step that does not depend on them is computed while they travel -- the moments, two pow, a sqrt, two divisions
+    if (ns >= 64) {
+      float t[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) t[u] = s[(long)u * W];
+      __builtin_amdgcn_sched_barrier(0);
+      if (e < P && a.mode == 0) {
+        mv0 = a.adam_m[(long)net * P + e];
+        vv0 = a.adam_v[(long)net * P + e];
+        const double b1 = a.hp.beta1, b2 = a.hp.beta2;
+        const float lr = a.hp.lr_dev ? a.hp.lr_dev[critic ? 1 : 0] : (critic ? a.hp.lr_critic : a.hp.lr_actor);
+        step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
+        inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
+        pre_done = true;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 64; v += 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += t[v + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += t[v + 8 + u];
+      }
+      b = 64;
+    }
     for (; b + 64 <= ns; b += 64) {  // 64 slabs' loads in flight (ONE round trip for the large-batch step's 64
       // slabs instead of four: the loop is latency-bound, 99 workgroups x 256 threads x 4 bytes per load); the
       // additions keep the order of the 16-slab loop below
@@ -789,8 +818,7 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
   // everything of the Adam step that does not depend on the clip factor is requested / computed BEFORE the grid barrier
   // (round 4): the moments of this thread's element and the float64 bias corrections (two pow, a sqrt and two divisions
   // per thread) used to sit behind it, on the critical path of every large-batch step
-  float mv0 = 0.f, vv0 = 0.f, step_size = 0.f, inv_bc2_sqrt = 0.f;
-  if (e < P && a.mode == 0) {
+  if (e < P && a.mode == 0 && !pre_done) {
     mv0 = a.adam_m[(long)net * P + e];
     vv0 = a.adam_v[(long)net * P + e];
     const double b1 = a.hp.beta1, b2 = a.hp.beta2;
@@ -798,8 +826,18 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
     step_size = (float)((double)lr / (1.0 - pow(b1, (double)step)));
     inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
   }
-  gsq = osa_block_sum_f(gsq, red);
-  psq = osa_block_sum_f(psq, red);
+  // (one pass for both sums: DPP wave sums, one barrier -- osa_block_sum_f twice was six barriers and twelve
+  // ds_bpermute rounds)
+  {
+    const float wg_ = osa_wave_sum_dpp(gsq), wp_ = osa_wave_sum_dpp(psq);
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6] = wg_;
+      red[4 + (threadIdx.x >> 6)] = wp_;
+    }
+    __syncthreads();
+    gsq = (red[0] + red[1]) + (red[2] + red[3]);
+    psq = (red[4] + red[5]) + (red[6] + red[7]);
+  }
   float* part = partials + ((long)net * nblk + blockIdx.x) * 2;
   if (threadIdx.x == 0) {
     // (agent-scope accesses for the two partial sums instead of an agent-scope release / acquire fence pair around
@@ -824,28 +862,29 @@ __global__ __launch_bounds__(256) void osa_slab_reduce_finalize_kernel(OsaMbArgs
   }
   __syncthreads();
   {
-    // every partial is fetched by its own thread (one round trip for all), then added in block order: identical
-    // totals in every workgroup
-    __shared__ float s_part[2][256];
+    // every partial is fetched by its own thread (one round trip for all); tiles of 256 partials summed by DPP wave sums
+    // and a fixed cross-wave order, tile after tile: identical totals in every workgroup (round 6: thread 0 used to add
+    // them one by one out of LDS, 2 600 cycles behind the barrier)
+    __shared__ float s_w[2][4];
     float* pp = partials + (long)net * nblk * 2;
-    float tg = 0.f, tp = 0.f;  // (thread 0's running totals)
-    // tiles of 256 partials (one tile for every network up to ~940 inputs; wider ones take more trips instead of
-    // writing past the staging array), added in block order across the tiles
+    float tg = 0.f, tp = 0.f;
     for (int k0 = 0; k0 < nblk; k0 += 256) {
       const int k = k0 + threadIdx.x;
+      float pg = 0.f, ppv = 0.f;
       if (k < nblk) {
-        s_part[0][threadIdx.x] = __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_part[1][threadIdx.x] = __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pg = __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ppv = __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      pg = osa_wave_sum_dpp(pg);
+      ppv = osa_wave_sum_dpp(ppv);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) {
+        s_w[0][threadIdx.x >> 6] = pg;
+        s_w[1][threadIdx.x >> 6] = ppv;
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        const int n = min(256, nblk - k0);
-        for (int q = 0; q < n; ++q) {
-          tg += s_part[0][q];
-          tp += s_part[1][q];
-        }
-      }
-      __syncthreads();
+      tg += (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
+      tp += (s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3]);
     }
     if (threadIdx.x == 0) {
       s_tot[0] = tg;
