@@ -573,117 +573,149 @@ def main():
                                                                       (dt / args.steps * 1e3), 5)
     headline_mode = os.environ.get('OSA_DP_MODE', 'replicated')
     if world > 1 and not args.no_allreduce_leg and headline_mode != 'allreduce' and args.algo == 'PPOLag':
-        # the same workload in the reference's own structure: per optimiser step gradient kernel -> ONE flat RCCL
-        # all-reduce of the three networks' clipped gradients -> Adam (policy_gradient.py:437-443 with 1 message for 19);
-        # every rank runs only its own 64-row minibatch.  A few epochs: a step waits for the collective's latency.
-        del algo
-        torch.cuda.empty_cache()
-        os.environ['OSA_DP_MODE'] = 'allreduce'
-        a_iters = min(args.update_iters, args.allreduce_update_iters)
-        a_algo = make_algo(args, world, args.batch_size, a_iters, args.allreduce_steps + 3, log_dir)
-        run_epochs(a_algo, 2, lambda: torch.cuda.synchronize(dev))
-        a_dt = timed(a_algo, args.allreduce_steps, 0, world, dev)  # (no per-step events: 40 960 steps per epoch)
-        a_val = world * per_gpu_steps * args.allreduce_steps / a_dt
-        n_steps = a_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
-        out['allreduce_mode'] = {
-            'workload': (f'same shapes, update_iters={a_iters} (NOT the headline\'s {args.update_iters}: bounded run), '
-                         'dp_mode=allreduce (gradient kernel -> flat all-reduce -> Adam per optimiser step)'),
-            'update_iters': a_iters,
-            'value': round(a_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
-            'ms_per_step': round(a_dt / args.allreduce_steps * 1e3, 3), 'steps': args.allreduce_steps, 'warmup': 2,
-            'update_path': a_algo._updater.last_path,
-            'us_per_optimiser_step_incl_collective': round(a_dt / args.allreduce_steps * 1e6 / n_steps, 3),
-            'message_bytes': (4 * int(a_algo._updater.lib.osa_ppo_dp_ws_floats(OBS_DIM, ACT_DIM, HIDDEN, 1))
-                              if not general else None)}
-        if args.n1_value and a_iters == args.update_iters:
-            # (a ratio of throughputs is a scaling efficiency only at the SAME update_iters as the N = 1 headline)
-            out['allreduce_mode']['efficiency_vs_n1'] = round(a_val / (world * args.n1_value), 4)
-        os.environ['OSA_DP_MODE'] = headline_mode
-        algo = a_algo
-    if world > 1 and not args.no_p2p_leg and headline_mode != 'p2p' and args.algo == 'PPOLag' and not general:
-        # the same workload with the one-shot peer exchange (round 6): each rank runs the single-GPU persistent pass on
-        # its own rows, the clipped gradients travel by peer writes into hipIpc-mapped buffers -- no collective and no
-        # W-fold recomputation on the step path; FULL update_iters (a pass is one launch per rank)
-        del algo
-        torch.cuda.empty_cache()
-        os.environ['OSA_DP_MODE'] = 'p2p'
-        p_algo = make_algo(args, world, args.batch_size, args.update_iters, args.steps + 3, log_dir)
-        run_epochs(p_algo, 2, lambda: torch.cuda.synchronize(dev))
-        p_dt = timed(p_algo, args.steps, 0, world, dev)
-        p_val = world * per_gpu_steps * args.steps / p_dt
-        n_steps = args.update_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
-        out['p2p_mode'] = {
-            'workload': 'same shapes and update_iters, dp_mode=p2p (osa_ppo_p2p_pass)',
-            'value': round(p_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
-            'ms_per_step': round(p_dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': 2,
-            'update_path': p_algo._updater.last_path,
-            'us_per_optimiser_step_incl_rollout': round(p_dt / args.steps * 1e6 / n_steps, 3)}
-        if args.n1_value:
-            out['p2p_mode']['efficiency_vs_n1'] = round(p_val / (world * args.n1_value), 4)
-        os.environ['OSA_DP_MODE'] = headline_mode
-        algo = p_algo
-    if world == 1 and not args.no_early_stop_leg and args.algo == 'PPOLag' and not args.kl_early_stop and not general:
-        # the YAML default `kl_early_stop: true` (PPOLag.yaml; SURVEY 8d's parity variant): one full-batch KL pass AND
-        # one host synchronisation per pass.  (a) target_kl at the YAML's 0.02: the update stops where the reference's
-        # would (passes_executed < update_iters: less work per epoch, not comparable with the headline); (b) a target
-        # nothing reaches: all passes, i.e. the headline's work + update_iters - 1 KL passes + update_iters host syncs
-        del algo
-        torch.cuda.empty_cache()
-        es = {}
-        for tag, tkl in (('yaml_target_kl_0.02', None), ('never_stops', 1e30)):
-            args.kl_early_stop = True
-            e_algo = make_algo(args, world, args.batch_size, args.update_iters, 8, log_dir)
-            args.kl_early_stop = False
-            if tkl is not None:
-                e_algo._updater.target_kl = tkl
-            run_epochs(e_algo, 2, lambda: torch.cuda.synchronize(dev))
-            passes = []
-            t0 = time.perf_counter()
-            for _ in range(3):
-                run_epochs(e_algo, 1, lambda: torch.cuda.synchronize(dev))
-                passes.append(int(getattr(e_algo, '_last_update_steps', 0)) // ((per_gpu_steps + args.batch_size - 1) // args.batch_size))
-            e_dt = (time.perf_counter() - t0) / 3
-            es[tag] = {'value': round(per_gpu_steps / e_dt, 1), 'ms_per_step': round(e_dt * 1e3, 3),
-                       'passes_executed': passes, 'target_kl': float(e_algo._updater.target_kl)}
-            del e_algo
+        try:
+            # the same workload in the reference's own structure: per optimiser step gradient kernel -> ONE flat RCCL
+            # all-reduce of the three networks' clipped gradients -> Adam (policy_gradient.py:437-443 with 1 message for 19);
+            # every rank runs only its own 64-row minibatch.  A few epochs: a step waits for the collective's latency.
+            del algo
             torch.cuda.empty_cache()
-        es['note'] = ('kl_early_stop on (PPOLag.yaml default): a KL pass + a host read per pass; `never_stops` = every pass '
-                      'executed = the headline workload + the 39 skipped KL passes + 40 syncs')
-        out['kl_early_stop_epoch'] = es
-        algo = None
+            os.environ['OSA_DP_MODE'] = 'allreduce'
+            a_iters = min(args.update_iters, args.allreduce_update_iters)
+            a_algo = make_algo(args, world, args.batch_size, a_iters, args.allreduce_steps + 3, log_dir)
+            run_epochs(a_algo, 2, lambda: torch.cuda.synchronize(dev))
+            a_dt = timed(a_algo, args.allreduce_steps, 0, world, dev)  # (no per-step events: 40 960 steps per epoch)
+            a_val = world * per_gpu_steps * args.allreduce_steps / a_dt
+            n_steps = a_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
+            out['allreduce_mode'] = {
+                'workload': (f'same shapes, update_iters={a_iters} (NOT the headline\'s {args.update_iters}: bounded run), '
+                             'dp_mode=allreduce (gradient kernel -> flat all-reduce -> Adam per optimiser step)'),
+                'update_iters': a_iters,
+                'value': round(a_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+                'ms_per_step': round(a_dt / args.allreduce_steps * 1e3, 3), 'steps': args.allreduce_steps, 'warmup': 2,
+                'update_path': a_algo._updater.last_path,
+                'us_per_optimiser_step_incl_collective': round(a_dt / args.allreduce_steps * 1e6 / n_steps, 3),
+                'message_bytes': (4 * int(a_algo._updater.lib.osa_ppo_dp_ws_floats(OBS_DIM, ACT_DIM, HIDDEN, 1))
+                                  if not general else None)}
+            if args.n1_value and a_iters == args.update_iters:
+                # (a ratio of throughputs is a scaling efficiency only at the SAME update_iters as the N = 1 headline)
+                out['allreduce_mode']['efficiency_vs_n1'] = round(a_val / (world * args.n1_value), 4)
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = a_algo
+        except Exception as exc:  # noqa: BLE001 -- a secondary leg must never cost the headline its JSON line
+            out['allreduce_mode'] = {'error': repr(exc)[:400]}
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = None
+    if world > 1 and not args.no_p2p_leg and headline_mode != 'p2p' and args.algo == 'PPOLag' and not general:
+        try:
+            # the same workload with the one-shot peer exchange (round 6): each rank runs the single-GPU persistent pass on
+            # its own rows, the clipped gradients travel by peer writes into hipIpc-mapped buffers -- no collective and no
+            # W-fold recomputation on the step path; FULL update_iters (a pass is one launch per rank)
+            del algo
+            torch.cuda.empty_cache()
+            os.environ['OSA_DP_MODE'] = 'p2p'
+            # (a peer that never arrives costs every step this long before the sticky time-out word ends the waiting:
+            # seconds, not the library's default 20 s per step, in a leg that has never seen two real devices)
+            os.environ.setdefault('OSA_P2P_TIMEOUT_S', '3')
+            shared = bool(os.environ.get('OSA_SINGLE_DEVICE_RANKS'))
+            # ranks that SHARE a device (the 1-GPU code-path check) are time-sliced, not concurrent: a rank's persistent
+            # pass spins through its slice until the peer's gets one -- milliseconds per optimiser step, nothing to do
+            # with the exchange (tools/p2p_timing.py starts the ranks behind a barrier and takes the best pass).  One pass
+            # and one epoch there: the launch, the mapping and the bits are what the check is for
+            p_iters, p_steps = (1, 1) if shared else (args.update_iters, args.steps)
+            p_algo = make_algo(args, world, args.batch_size, p_iters, p_steps + 3, log_dir)
+            run_epochs(p_algo, 1 if shared else 2, lambda: torch.cuda.synchronize(dev))
+            p_dt = timed(p_algo, p_steps, 0, world, dev)
+            p_val = world * per_gpu_steps * p_steps / p_dt
+            n_steps = p_iters * ((per_gpu_steps + args.batch_size - 1) // args.batch_size)
+            out['p2p_mode'] = {
+                'workload': f'same shapes, update_iters={p_iters}, dp_mode=p2p (osa_ppo_p2p_pass)',
+                'value': round(p_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+                'ms_per_step': round(p_dt / p_steps * 1e3, 3), 'steps': p_steps, 'warmup': 1 if shared else 2,
+                'update_path': p_algo._updater.last_path,
+                'us_per_optimiser_step_incl_rollout': round(p_dt / p_steps * 1e6 / n_steps, 3)}
+            if shared:
+                out['p2p_mode']['note'] = ('ranks share ONE device: their persistent passes are time-sliced, the figure '
+                                           'says nothing about the exchange (profiles/r6_p2p_timing.json does)')
+            if args.n1_value and not shared:
+                out['p2p_mode']['efficiency_vs_n1'] = round(p_val / (world * args.n1_value), 4)
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = p_algo
+        except Exception as exc:  # noqa: BLE001 -- a secondary leg must never cost the headline its JSON line
+            out['p2p_mode'] = {'error': repr(exc)[:400]}
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = None
+    if world == 1 and not args.no_early_stop_leg and args.algo == 'PPOLag' and not args.kl_early_stop and not general:
+        try:
+            # the YAML default `kl_early_stop: true` (PPOLag.yaml; SURVEY 8d's parity variant): one full-batch KL pass AND
+            # one host synchronisation per pass.  (a) target_kl at the YAML's 0.02: the update stops where the reference's
+            # would (passes_executed < update_iters: less work per epoch, not comparable with the headline); (b) a target
+            # nothing reaches: all passes, i.e. the headline's work + update_iters - 1 KL passes + update_iters host syncs
+            del algo
+            torch.cuda.empty_cache()
+            es = {}
+            for tag, tkl in (('yaml_target_kl_0.02', None), ('never_stops', 1e30)):
+                args.kl_early_stop = True
+                e_algo = make_algo(args, world, args.batch_size, args.update_iters, 8, log_dir)
+                args.kl_early_stop = False
+                if tkl is not None:
+                    e_algo._updater.target_kl = tkl
+                run_epochs(e_algo, 2, lambda: torch.cuda.synchronize(dev))
+                passes = []
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    run_epochs(e_algo, 1, lambda: torch.cuda.synchronize(dev))
+                    passes.append(int(getattr(e_algo, '_last_update_steps', 0)) // ((per_gpu_steps + args.batch_size - 1) // args.batch_size))
+                e_dt = (time.perf_counter() - t0) / 3
+                es[tag] = {'value': round(per_gpu_steps / e_dt, 1), 'ms_per_step': round(e_dt * 1e3, 3),
+                           'passes_executed': passes, 'target_kl': float(e_algo._updater.target_kl)}
+                del e_algo
+                torch.cuda.empty_cache()
+            es['note'] = ('kl_early_stop on (PPOLag.yaml default): a KL pass + a host read per pass; `never_stops` = every pass '
+                          'executed = the headline workload + the 39 skipped KL passes + 40 syncs')
+            out['kl_early_stop_epoch'] = es
+            algo = None
+        except Exception as exc:  # noqa: BLE001 -- a secondary leg must never cost the headline its JSON line
+            out['kl_early_stop_epoch'] = {'error': repr(exc)[:400]}
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = None
     if not args.no_variant and args.algo == 'PPOLag':
-        # the large-batch setting on EVERY rank (round 4): under world_size > 1 the update is the data-parallel
-        # large-batch pass -- partial gradients, local clip, ONE flat RCCL all-reduce, Adam per step, the whole pass
-        # incl. its collectives one captured hipGraph (`dp-large-batch-graph`)
-        algo = None
-        torch.cuda.empty_cache()
-        vb = args.variant_batch
-        v_algo = make_algo(args, world, vb, 8, 14, log_dir)
-        v_steps = 10 if not general else 3
-        v_events = []
-        run_epochs(v_algo, 3, lambda: torch.cuda.synchronize(dev))  # eager epoch, capture epoch, one replay
-        v_algo._updater.profile_events = v_events
-        v_dt = timed(v_algo, v_steps, 0, world, dev)
-        v_algo._updater.profile_events = None
-        v_val = world * per_gpu_steps * v_steps / v_dt
-        out['throughput_variant'] = {
-            'workload': f'same shapes, batch_size={vb}, update_iters=8 (large-batch setting of PPOLag.yaml '
-                        'GPU-env blocks)',
-            'value': round(v_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
-            'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
-            'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
-            'rollout_path': getattr(v_algo._env, 'last_rollout_path', 'launches'),
-            'update_path': v_algo._updater.last_path,
-            'roofline': roofline_from_events(v_events, vb),
-            'whole_path': whole_path(args, v_val, world, 8, 1)}
-        if args.n1_variant_value:
-            out['throughput_variant']['efficiency_vs_n1'] = round(v_val / (world * args.n1_variant_value), 4)
-        if world > 1:
-            # per-step exchange time = what a step costs beyond the single-GPU step measured on the same kernels
-            # (profiles/r4_dp_large_batch_world1_rccl.json: +8.9 us at world 1, no wire time)
-            out['throughput_variant']['note'] = (
-                'data-parallel large-batch pass: us_per_optimiser_step includes the flat RCCL all-reduce of '
-                f'{3 * 8448 * 4} bytes and osa_adam_apply of every step; compare with the N = 1 line')
+        try:
+            # the large-batch setting on EVERY rank (round 4): under world_size > 1 the update is the data-parallel
+            # large-batch pass -- partial gradients, local clip, ONE flat RCCL all-reduce, Adam per step, the whole pass
+            # incl. its collectives one captured hipGraph (`dp-large-batch-graph`)
+            algo = None
+            torch.cuda.empty_cache()
+            vb = args.variant_batch
+            v_algo = make_algo(args, world, vb, 8, 14, log_dir)
+            v_steps = 10 if not general else 3
+            v_events = []
+            run_epochs(v_algo, 3, lambda: torch.cuda.synchronize(dev))  # eager epoch, capture epoch, one replay
+            v_algo._updater.profile_events = v_events
+            v_dt = timed(v_algo, v_steps, 0, world, dev)
+            v_algo._updater.profile_events = None
+            v_val = world * per_gpu_steps * v_steps / v_dt
+            out['throughput_variant'] = {
+                'workload': f'same shapes, batch_size={vb}, update_iters=8 (large-batch setting of PPOLag.yaml '
+                            'GPU-env blocks)',
+                'value': round(v_val, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+                'ms_per_step': round(v_dt / v_steps * 1e3, 3), 'steps': v_steps, 'warmup': 3,
+                'rollout_graphed': bool(getattr(v_algo._env, 'last_rollout_graphed', False)),
+                'rollout_path': getattr(v_algo._env, 'last_rollout_path', 'launches'),
+                'update_path': v_algo._updater.last_path,
+                'roofline': roofline_from_events(v_events, vb),
+                'whole_path': whole_path(args, v_val, world, 8, 1)}
+            if args.n1_variant_value:
+                out['throughput_variant']['efficiency_vs_n1'] = round(v_val / (world * args.n1_variant_value), 4)
+            if world > 1:
+                # per-step exchange time = what a step costs beyond the single-GPU step measured on the same kernels
+                # (profiles/r4_dp_large_batch_world1_rccl.json: +8.9 us at world 1, no wire time)
+                out['throughput_variant']['note'] = (
+                    'data-parallel large-batch pass: us_per_optimiser_step includes the flat RCCL all-reduce of '
+                    f'{3 * 8448 * 4} bytes and osa_adam_apply of every step; compare with the N = 1 line')
+        except Exception as exc:  # noqa: BLE001 -- a secondary leg must never cost the headline its JSON line
+            out['throughput_variant'] = {'error': repr(exc)[:400]}
+            os.environ['OSA_DP_MODE'] = headline_mode
+            algo = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         port = cpu_baseline(args)
         ref = cpu_baseline_reference(args)
