@@ -345,6 +345,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out['allreduce_mode']['update_path'] == ('allreduce-graph' if real else 'per-step')
     assert out['allreduce_mode']['value'] > 0
     assert out['throughput_variant']['update_path'].startswith('dp-large-batch')
+    # (round 6) the one-shot peer exchange leg: ran, through osa_ppo_p2p_pass, and no guarded leg swallowed an exception
+    assert out['p2p_mode'].get('update_path') == 'p2p' and out['p2p_mode']['value'] > 0, out['p2p_mode']
+    assert not [k for k in ('allreduce_mode', 'p2p_mode', 'throughput_variant') if 'error' in out[k]]
     # refused, loudly, when the box has fewer GPUs and the hook is not set
     if not real:
         env.pop('OSA_SINGLE_DEVICE_RANKS')
